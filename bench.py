@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- rating-updates/sec of the rank-64 SGD hot path on synthetic ML-20M-shape CSR.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one SGD epoch (device-side reshuffle + Hogwild update kernel, modelMF.cpp:1739-1767)
+over the rank's train ratings.  N > 1: one process per GPU (torch.distributed.run), the rating
+matrix is sharded by user-row blocks (every rank owns a full ML-20M-shape block of users over the
+SAME item catalogue: weak scaling) and the item factors are all-reduced over RCCL after every
+local epoch.  Rank 0 prints ONE JSON line (see the driver contract in the task statement).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="C2")
+    ap.add_argument("--rank-k", type=int, default=64, dest="K")
+    ap.add_argument("--scale", type=float, default=1.0, help="scale nnz (debug only)")
+    ap.add_argument("--arith", default="f32", choices=["f32", "ref64"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=float, default=1.0, help="epochs of the CPU baseline sample")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    N = args.gpus
+    if N != world:
+        if world == 1 and N > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % N)
+        N = world
+
+    import numpy as np
+
+    dist = None
+    if N > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from matfac_amd import Ctx, mfx, synth
+
+    K = args.K
+    shape = dict(synth.SHAPES[args.workload])
+    # the NAMED shape is the training matrix: generate train/val/test = 80/10/10 around it
+    shape["nnz"] = int(shape["nnz"] * args.scale / 0.8)
+    t0 = time.time()
+    d = synth.make(shape, seed=1, shard=rank)
+    tr, va = d["train"], d["val"]
+    nU, nI = d["nUsers"], shape["nI"]
+    gen_s = time.time() - t0
+
+    ctx = Ctx(local_rank)
+    cp, ci, cv = tr.col_view() if False else (None, None, None)
+    ctx.set_csr(mfx.MAT_TRAIN, tr.nrows, nI, tr.rowptr, tr.rowind, tr.rowval, cp, ci, cv)
+    ctx.set_csr(mfx.MAT_VAL, va.nrows, nI, va.rowptr, va.rowind, va.rowval)
+    ctx.set_model(nU, nI, K)
+    U0, _ = synth.init_factors(1 + rank, nU, nI, K, want_v=False)   # U shard: per-rank stream
+    _, V0 = synth.init_factors(1, 1, nI, K, want_u=False)            # V replica: identical everywhere
+    ctx.set_factors(U0, V0)
+    ctx.compute_invalid()
+    if N > 1:
+        import torch
+        uid = [Ctx.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(N, rank, uid[0])
+        ctx.comm_mark_synced()
+
+    lr, ureg, ireg = 0.005, 0.01, 0.01   # main.cpp:29-31 defaults
+    arith = mfx.ARITH_F32 if args.arith == "f32" else mfx.ARITH_REF64
+    nnz = tr.nnz
+
+    def step(ep):
+        ctx.sgd_epoch(lr, ureg, ireg, mode=mfx.SGD_HOGWILD, order=mfx.ORDER_DEVICE, arith=arith, seed=1, epoch=ep)
+        if N > 1:
+            ctx.allreduce_item_factors(mfx.REDUCE_DELTA_SUM)
+
+    def barrier():
+        ctx.synchronize()
+        if N > 1:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for ep in range(args.warmup):
+        step(ep)
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for ep in range(args.warmup, args.warmup + args.steps):
+        step(ep)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ctx.prof_enable(False)
+    sgd_ms, sgd_launches = ctx.prof_get(mfx.K_SGD)
+    perm_ms, _ = ctx.prof_get(mfx.K_PERMUTE)
+    val_rmse = ctx.rmse(mfx.MAT_VAL)
+    tr_rmse = ctx.rmse(mfx.MAT_TRAIN)
+
+    total_nnz = nnz
+    if N > 1:
+        import torch
+        t = torch.tensor([elapsed, float(nnz)], dtype=torch.float64, device="cuda")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0])
+        total_nnz = int(t[1])
+
+    out = None
+    if rank == 0:
+        value = total_nnz * args.steps / elapsed
+        avg_ms = sgd_ms / max(1, sgd_launches)
+        alg_bytes = (16 * K + 12) * nnz               # B_sgd(K) per update x updates per launch
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "rating-updates/sec @ rank=%d" % K, "value": value, "unit": "updates/s",
+            "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: ML-20M-shape synthetic CSR %dx%d per GPU, train nnz=%d per GPU, rank=%d, "
+                                   "Hogwild SGD epoch (device reshuffle + update kernel%s)"
+                                   % (args.workload, nU, nI, nnz, K, ", RCCL item-factor all-reduce" if N > 1 else ""),
+                       "learnrate": lr, "ureg": ureg, "ireg": ireg, "arith": args.arith,
+                       "parallelism": "user-block x%d" % N},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "sgd_hogwild_kernel", "avg_launch_ms": avg_ms, "launches": sgd_launches,
+                         "algorithmic_bytes_per_launch": alg_bytes},
+            "permute_ms_per_step": perm_ms / max(1, args.steps),
+            "val_rmse_after": val_rmse, "train_rmse_after": tr_rmse,
+            "datagen_s": gen_s,
+        }
+        if N == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(np, tr, nU, nI, K, lr, ureg, ireg, args.cpu_sample)
+    if N > 1:
+        ctx.comm_destroy()
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+def cpu_baseline(np, tr, nU, nI, K, lr, ureg, ireg, epochs):
+    """The oracle's OpenMP Hogwild loop (restatement of modelMF.cpp:1746-1767) on the host cores:
+    reported baseline only.  Sample = `epochs` epoch(s) over the first part of the same train list."""
+    from oracle import binding as orc
+    from matfac_amd import synth
+    threads = orc.max_threads()
+    n = int(tr.nnz * min(1.0, epochs))
+    rng = np.random.default_rng(1)
+    sel = rng.permutation(tr.nnz)[:n]
+    u = tr.rowids()[sel].astype(np.int32)
+    i = tr.rowind[sel].astype(np.int32)
+    r = tr.rowval[sel].astype(np.float32)
+    U, V = synth.init_factors(1, nU, nI, K)
+    res = {}
+    for name, colmajor in (("rowmajor", 0), ("colmajor", 1)):
+        Uc = np.ascontiguousarray(U.T if colmajor else U).copy()
+        Vc = np.ascontiguousarray(V.T if colmajor else V).copy()
+        orc.time_hogwild(Uc, Vc, u[: n // 20], i[: n // 20], r[: n // 20], nU, nI, K, lr, ureg, ireg, threads, colmajor)
+        s = orc.time_hogwild(Uc, Vc, u, i, r, nU, nI, K, lr, ureg, ireg, threads, colmajor)
+        res[name] = n / s
+    return {"value": res["rowmajor"], "unit": "updates/s", "cores": threads, "kind": "port",
+            "sample": "%d shuffled train ratings (%.2f epoch) of the same workload, OpenMP Hogwild "
+                      "(modelMF.cpp:1746-1767 restated), row-major factors" % (n, n / tr.nnz),
+            "value_colmajor_reference_layout": res["colmajor"]}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,187 @@
+/*
+ * mfx.h -- C ABI of the MI355X (gfx950) matrix-completion hot path.
+ *
+ * This is the drop-in boundary for the training loops of mohit-shrma/matfac's
+ * ModelMF (reference: modelMF.cpp / model.cpp).  The reference has no FFI layer:
+ * its boundary is the C++ class API `void ModelMF::trainX(const Data&, Model&
+ * bestModel, unordered_set<int>& invalidUsers, unordered_set<int>& invalidItems)`
+ * (modelMF.h:30-56) over GKlib `gk_csr_t` matrices and Eigen factor matrices.
+ * The host classes in matfac_amd/host/ keep that class API; each of their inner
+ * loops is one call below.  Every entry point cites the reference loop it replaces.
+ *
+ * Conventions
+ *  - plain C types only; no exceptions cross this boundary; nothing calls exit().
+ *  - every function returns MFX_OK (0) or a negative mfx_status; the message is
+ *    available from mfx_last_error().  (The reference prints to cerr and exit()s:
+ *    model.cpp:1481-1484, main.cpp:62-64.)
+ *  - host pointers are borrowed for the duration of the call only.
+ *  - one mfx_ctx <-> one device <-> one HIP stream; calls on a ctx are serialised
+ *    by the caller.  Different ctxs may be driven from different threads/processes.
+ *  - there is NO CPU fallback: without a HIP device mfx_create() fails with
+ *    MFX_E_NODEVICE.
+ *
+ * Device layout (DESIGN.md "Data layout in HBM"): factors are row-major
+ * float[n][ld], ld = 4*L*C >= K, zero padded, where L lanes of a wavefront own
+ * one rating and each lane owns 4 consecutive floats per chunk:
+ *      K <= 16: L=4,C=1   K <= 32: L=8,C=1   else L=16, C=ceil(K/64).
+ * The fp32 dot product is evaluated as: per-lane fma chain over the lane's
+ * elements (chunk-major) starting from 0, then an xor butterfly (L/2,...,1)
+ * over the L lanes.  (Eigen's order for row.dot(row) is unspecified; the CPU
+ * oracle can evaluate either order.)
+ */
+#ifndef MFX_H_
+#define MFX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mfx_ctx mfx_ctx;
+
+typedef enum {
+  MFX_OK = 0,
+  MFX_E_ARG = -1,      /* bad argument / shape mismatch            */
+  MFX_E_HIP = -2,      /* HIP runtime error                        */
+  MFX_E_COMM = -3,     /* RCCL error / librccl not loadable        */
+  MFX_E_OOM = -4,      /* device or host allocation failed         */
+  MFX_E_STATE = -5,    /* call sequence error (e.g. no train matrix) */
+  MFX_E_NODEVICE = -6  /* no HIP device: there is no CPU fallback  */
+} mfx_status;
+
+enum { MFX_MAT_TRAIN = 0, MFX_MAT_VAL = 1, MFX_MAT_TEST = 2 };
+enum { MFX_ROWMAJOR = 0, MFX_COLMAJOR = 1 };   /* host layout; Eigen::MatrixXf is COLMAJOR */
+enum { MFX_SNAP_CURRENT = 0, MFX_SNAP_BEST = 1 };
+enum { MFX_SIDE_USERS = 0, MFX_SIDE_ITEMS = 1 };
+
+/* ---- lifetime ----------------------------------------------------------- */
+int mfx_version(void);
+int mfx_device_count(int* n);
+int mfx_create(int device, mfx_ctx** out);
+void mfx_destroy(mfx_ctx* ctx);
+/* message of the last failing call on ctx (ctx may be NULL: last mfx_create error) */
+const char* mfx_last_error(const mfx_ctx* ctx);
+int mfx_synchronize(mfx_ctx* ctx);
+
+/* ---- data: replaces Data / gk_csr_t (datastruct.h:72-136, datastruct.cpp:3-120) */
+/* Upload one rating matrix.  rowptr has nrows+1 entries (GKlib ssize_t), indices
+ * are 0-based int32, values float.  The column view (gk_csr_CreateIndex(COL),
+ * datastruct.cpp:18) may be NULL: it is then built here by a stable counting sort
+ * (users ascending inside a column).  Only TRAIN needs a column view.          */
+int mfx_set_csr(mfx_ctx* ctx, int which, int32_t nrows, int32_t ncols,
+                const int64_t* rowptr, const int32_t* rowind, const float* rowval,
+                const int64_t* colptr, const int32_t* colind, const float* colval);
+
+/* ---- model: replaces Model's factor storage (model.h:36-37, model.cpp:2315-2366) */
+/* nUsers/nItems are Data::nUsers / Data::nItems (nItems = 1 + max item index over
+ * train, test and val: datastruct.cpp:91).  Allocates U, V and the best snapshot. */
+int mfx_set_model(mfx_ctx* ctx, int32_t nUsers, int32_t nItems, int32_t K);
+int mfx_set_factors(mfx_ctx* ctx, const float* U, const float* V, int layout);
+int mfx_get_factors(mfx_ctx* ctx, int snapshot, float* U, float* V, int layout);
+/* getInvalidUsersItems (util.cpp:511-544) + modelMF.cpp:40-45: users/items with no
+ * train rating (or beyond the train matrix) are invalid.  Computes the masks on
+ * the device, keeps them for the evaluation kernels and returns them (1 = invalid);
+ * the outputs may be NULL.                                                       */
+int mfx_compute_invalid(mfx_ctx* ctx, uint8_t* invalidUsers, uint8_t* invalidItems);
+/* bestModel = *this (model.cpp:1500-1504) / *this = bestModel (model.cpp:1492),
+ * factor matrices only; learnRate bookkeeping stays with the host Model.        */
+int mfx_snapshot_best(mfx_ctx* ctx);
+int mfx_restore_best(mfx_ctx* ctx);
+
+/* ---- SGD: replaces modelMF.cpp:83-105 (train), :1747-1763 (hogTrain),
+ *      :637-659 (trainUShuffle), :273-304 (trainSGDPar)                          */
+enum {
+  MFX_SGD_HOGWILD = 0,  /* all ratings of the epoch list in flight, lock-free (a5)     */
+  MFX_SGD_SERIAL = 1,   /* one rating at a time in list order: bit-exact a4 / a7 order  */
+  MFX_SGD_USERS = 2     /* one wave-group per user row, items in CSR order, users in
+                           the (shuffled) user list: parallel trainUShuffle (a7)      */
+};
+enum {
+  MFX_ORDER_DEVICE = 0,  /* fresh device-side pseudo-random permutation per (seed, epoch) */
+  MFX_ORDER_HOST = 1,    /* the permutation last given to mfx_sgd_set_order()             */
+  MFX_ORDER_NATURAL = 2  /* CSR order                                                     */
+};
+enum {
+  MFX_ARITH_REF64 = 0,   /* modelMF.cpp:91-103: double diff, double bracket, one rounding */
+  MFX_ARITH_REF64F = 1,  /* modelMF.cpp:288-299: float diff, double bracket              */
+  MFX_ARITH_F32 = 2      /* modelMF.cpp:1755-1762: scalars narrowed to float, fp32 axpy  */
+};
+typedef struct {
+  int32_t mode, order, arith;
+  float learnRate, uReg, iReg;
+  uint32_t seed;       /* MFX_ORDER_DEVICE: permutation key (with epoch)        */
+  int32_t epoch;
+  int64_t first, count; /* sub-range of the epoch list; count <= 0: everything  */
+} mfx_sgd_opts;
+/* Permutation of the train ratings (indices into the CSR-order rating list with
+ * invalid users/items removed -- on a train matrix that is every rating), as
+ * std::vector<size_t> uiRatingInds in modelMF.cpp:67-68; for MFX_SGD_USERS the
+ * list is the shuffled valid-user list (modelMF.cpp:620-635).                   */
+int mfx_sgd_set_order(mfx_ctx* ctx, const uint64_t* perm, int64_t n);
+int mfx_sgd_epoch(mfx_ctx* ctx, const mfx_sgd_opts* opts);
+/* test hook: the (u,i,r) list the last epoch visited, in visiting order */
+int mfx_debug_epoch_list(mfx_ctx* ctx, int32_t* u, int32_t* i, float* r, int64_t cap,
+                         int64_t* n);
+
+/* ---- evaluation: replaces Model::objective (model.cpp:1770-1815) and
+ *      Model::RMSE (model.cpp:214-251)                                          */
+typedef struct {
+  double sse;      /* sum over valid (u,i) of (r - p.q)^2             */
+  int64_t n;       /* ratings counted                                 */
+  double unorm2;   /* sum over valid users of ||p_u||^2 (TRAIN only)  */
+  double inorm2;   /* sum over valid items of ||q_i||^2 (TRAIN only)  */
+} mfx_eval_out;
+/* objective = sse + uReg*unorm2 + iReg*inorm2 ; RMSE = sqrt(sse/n).
+ * with_norms != 0 also fills unorm2/inorm2.                                     */
+int mfx_eval(mfx_ctx* ctx, int which, int snapshot, int with_norms, mfx_eval_out* out);
+
+/* ---- ALS: replaces modelMF.cpp:805-841 (users) / :844-880 (items) ----------- */
+int mfx_als_half_sweep(mfx_ctx* ctx, int side, float reg);
+
+/* ---- CCD++: replaces modelMF.cpp:1013-1121 (trainCCDPP) and :1258-1360
+ *      (trainCCDPPFreqAdap)                                                     */
+/* begin: res = gk_csr_Dup(trainMat) on both views, uFac.fill(0) (:1013,:1020)    */
+int mfx_ccdpp_begin(mfx_ctx* ctx);
+/* one factor k: optional add-back (iter > 0), `inner` sweeps of {row pass, column
+ * pass}, subtract, write the columns back.  freq_thresh < 0: plain CCD++;
+ * otherwise items with train frequency < freq_thresh get v_k = 0 for k > 0.     */
+int mfx_ccdpp_rank1(mfx_ctx* ctx, int32_t k, int32_t inner, float uReg, float iReg,
+                    int32_t add_back, float freq_thresh);
+int mfx_ccdpp_end(mfx_ctx* ctx);
+/* test hook: the two residual views */
+int mfx_debug_residuals(mfx_ctx* ctx, float* res_row, float* res_col);
+
+/* ---- multi-GPU: user-row-block sharding, item-factor exchange over RCCL ------ */
+/* The reference is single-process; this is new.  Each rank owns a
+ * user block (its CSR rows + U shard) and a replica of V.  After local work,
+ * V <- V_sync + sum_over_ranks (V - V_sync)   (MFX_REDUCE_DELTA_SUM)   or
+ * V <- mean_over_ranks V                       (MFX_REDUCE_AVERAGE).              */
+enum { MFX_REDUCE_DELTA_SUM = 0, MFX_REDUCE_AVERAGE = 1 };
+#define MFX_UNIQUE_ID_BYTES 128
+int mfx_comm_unique_id(void* id128);
+int mfx_comm_init(mfx_ctx* ctx, int nranks, int rank, const void* id128);
+int mfx_comm_destroy(mfx_ctx* ctx);
+/* declare the current V identical on all ranks (call after mfx_set_factors, before
+ * the first local epoch): V_sync <- V                                             */
+int mfx_comm_mark_synced(mfx_ctx* ctx);
+int mfx_allreduce_item_factors(mfx_ctx* ctx, int op);
+/* sum a few doubles over ranks (objective / RMSE partials) */
+int mfx_allreduce_f64(mfx_ctx* ctx, double* vals, int n);
+
+/* ---- measurement ------------------------------------------------------------ */
+/* HIP-event timing of the hot kernels on the ctx stream (bench.py roofline).    */
+enum {
+  MFX_K_SGD = 0, MFX_K_PERMUTE = 1, MFX_K_EVAL = 2, MFX_K_ALS_GRAM = 3,
+  MFX_K_ALS_SOLVE = 4, MFX_K_CCD_ROW = 5, MFX_K_CCD_COL = 6, MFX_K_CCD_RESID = 7,
+  MFX_K_COUNT = 8
+};
+int mfx_prof_enable(mfx_ctx* ctx, int on);
+int mfx_prof_reset(mfx_ctx* ctx);
+int mfx_prof_get(mfx_ctx* ctx, int kernel, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MFX_H_ */

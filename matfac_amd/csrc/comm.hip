@@ -1,0 +1,201 @@
+// comm.hip -- multi-GPU item-factor exchange over RCCL (xGMI inside a node).
+//
+// The reference is single-process OpenMP: nothing to cite.  Design:
+// rank g owns a user-row block (its CSR rows and its U shard, never communicated)
+// and a full replica of V.  After a local (sub-)epoch every rank holds
+// V_g = V_sync + D_g.  MFX_REDUCE_DELTA_SUM forms V <- V_sync + sum_g D_g with ONE
+// all-reduce of nItems*ld floats; MFX_REDUCE_AVERAGE forms V <- mean_g V_g.
+//
+// librccl is loaded lazily with dlopen so that single-GPU use has no RCCL
+// dependency; inside a process that already loaded RCCL (e.g. through
+// torch.distributed) the same library instance is reused (same SONAME).
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstring>
+
+#include "mfx_internal.h"
+
+namespace {
+struct UniqueId { char internal[128]; };
+typedef int (*fn_get_uid)(UniqueId*);
+typedef int (*fn_init_rank)(void**, int, UniqueId, int);
+typedef int (*fn_destroy)(void*);
+typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef const char* (*fn_errstr)(int);
+struct Rccl {
+  void* h = nullptr;
+  fn_get_uid get_uid = nullptr;
+  fn_init_rank init_rank = nullptr;
+  fn_destroy destroy = nullptr;
+  fn_allreduce allreduce = nullptr;
+  fn_errstr errstr = nullptr;
+  std::string err;
+};
+Rccl g_rccl;
+constexpr int kNcclFloat = 7, kNcclDouble = 8, kNcclSum = 0;
+
+bool load_rccl() {
+  if (g_rccl.h) return true;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char* n : names) {
+    g_rccl.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (g_rccl.h) break;
+  }
+  if (!g_rccl.h) { g_rccl.err = dlerror() ? dlerror() : "dlopen(librccl) failed"; return false; }
+  g_rccl.get_uid = (fn_get_uid)dlsym(g_rccl.h, "ncclGetUniqueId");
+  g_rccl.init_rank = (fn_init_rank)dlsym(g_rccl.h, "ncclCommInitRank");
+  g_rccl.destroy = (fn_destroy)dlsym(g_rccl.h, "ncclCommDestroy");
+  g_rccl.allreduce = (fn_allreduce)dlsym(g_rccl.h, "ncclAllReduce");
+  g_rccl.errstr = (fn_errstr)dlsym(g_rccl.h, "ncclGetErrorString");
+  if (!g_rccl.get_uid || !g_rccl.init_rank || !g_rccl.destroy || !g_rccl.allreduce) {
+    g_rccl.err = "librccl lacks a required symbol";
+    dlclose(g_rccl.h);
+    g_rccl.h = nullptr;
+    return false;
+  }
+  return true;
+}
+const char* rccl_err(int rc) { return g_rccl.errstr ? g_rccl.errstr(rc) : "rccl error"; }
+}  // namespace
+
+__global__ void delta_kernel(const float* __restrict__ v, const float* __restrict__ vsync,
+                             float* __restrict__ d, int64_t n4) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n4; t += stride)
+    ((f4*)d)[t] = ((const f4*)v)[t] - ((const f4*)vsync)[t];
+}
+__global__ void apply_delta_kernel(float* __restrict__ v, float* __restrict__ vsync,
+                                   const float* __restrict__ dsum, int64_t n4) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n4; t += stride) {
+    const f4 x = ((const f4*)vsync)[t] + ((const f4*)dsum)[t];
+    ((f4*)v)[t] = x;
+    ((f4*)vsync)[t] = x;
+  }
+}
+__global__ void scale_copy_kernel(float* __restrict__ v, float* __restrict__ vsync, float s, int64_t n4) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n4; t += stride) {
+    const f4 x = ((const f4*)v)[t] * s;
+    ((f4*)v)[t] = x;
+    ((f4*)vsync)[t] = x;
+  }
+}
+
+int mfx_comm_free_internal(mfx_ctx* ctx) {
+  if (ctx->comm && g_rccl.destroy) g_rccl.destroy(ctx->comm);
+  ctx->comm = nullptr;
+  ctx->nranks = 1;
+  ctx->rank = 0;
+  dev_free(ctx->comm_tmp);
+  return MFX_OK;
+}
+
+extern "C" int mfx_comm_unique_id(void* id128) {
+  mfx_ctx* ctx = nullptr;
+  NEED(id128, MFX_E_ARG, "mfx_comm_unique_id: NULL");
+  NEED(load_rccl(), MFX_E_COMM, "mfx_comm_unique_id: %s", g_rccl.err.c_str());
+  UniqueId id;
+  int rc = g_rccl.get_uid(&id);
+  NEED(rc == 0, MFX_E_COMM, "ncclGetUniqueId: %s", rccl_err(rc));
+  memcpy(id128, &id, sizeof id);
+  return MFX_OK;
+}
+
+extern "C" int mfx_comm_init(mfx_ctx* ctx, int nranks, int rank, const void* id128) {
+  if (!ctx) return MFX_E_ARG;
+  NEED(nranks >= 1 && rank >= 0 && rank < nranks && id128, MFX_E_ARG, "mfx_comm_init: nranks=%d rank=%d", nranks, rank);
+  NEED(load_rccl(), MFX_E_COMM, "mfx_comm_init: %s", g_rccl.err.c_str());
+  HIPCHK(hipSetDevice(ctx->device));
+  mfx_comm_free_internal(ctx);
+  UniqueId id;
+  memcpy(&id, id128, sizeof id);
+  void* comm = nullptr;
+  int rc = g_rccl.init_rank(&comm, nranks, id, rank);
+  NEED(rc == 0, MFX_E_COMM, "ncclCommInitRank: %s", rccl_err(rc));
+  ctx->comm = comm;
+  ctx->nranks = nranks;
+  ctx->rank = rank;
+  return MFX_OK;
+}
+
+extern "C" int mfx_comm_destroy(mfx_ctx* ctx) {
+  if (!ctx) return MFX_E_ARG;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  return mfx_comm_free_internal(ctx);
+}
+
+// V_sync tracks the last agreed item factors; it is (re)initialised from V the first
+// time and after every exchange.
+static int ensure_sync_buffers(mfx_ctx* ctx) {
+  const size_t n = (size_t)ctx->nI * ctx->ld;
+  int rc;
+  if (!ctx->comm_tmp && (rc = dev_alloc(ctx, &ctx->comm_tmp, n))) return rc;
+  if (!ctx->Vsync) {
+    if ((rc = dev_alloc(ctx, &ctx->Vsync, n))) return rc;
+    HIPCHK(hipMemcpyAsync(ctx->Vsync, ctx->V, n * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  return MFX_OK;
+}
+
+// Call once after mfx_set_factors on every rank (V identical on all ranks) and
+// before the first local epoch: snapshots V into V_sync.
+extern "C" int mfx_comm_mark_synced(mfx_ctx* ctx) {
+  if (!ctx) return MFX_E_ARG;
+  NEED(ctx->V, MFX_E_STATE, "mfx_comm_mark_synced: no model");
+  HIPCHK(hipSetDevice(ctx->device));
+  dev_free(ctx->Vsync);
+  return ensure_sync_buffers(ctx);
+}
+
+extern "C" int mfx_allreduce_item_factors(mfx_ctx* ctx, int op) {
+  if (!ctx) return MFX_E_ARG;
+  NEED(ctx->V, MFX_E_STATE, "mfx_allreduce_item_factors: no model");
+  NEED(op == MFX_REDUCE_DELTA_SUM || op == MFX_REDUCE_AVERAGE, MFX_E_ARG, "mfx_allreduce_item_factors: op=%d", op);
+  HIPCHK(hipSetDevice(ctx->device));
+  if (ctx->nranks == 1 || !ctx->comm) return MFX_OK;  // single rank: V is already the sum
+  int rc;
+  if ((rc = ensure_sync_buffers(ctx))) return rc;
+  const int64_t n = (int64_t)ctx->nI * ctx->ld, n4 = n / 4;
+  const int blocks = (int)std::min<int64_t>((n4 + 255) / 256, 4096);
+  if (op == MFX_REDUCE_DELTA_SUM) {
+    hipLaunchKernelGGL(delta_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ctx->V, ctx->Vsync, ctx->comm_tmp, n4);
+    HIPCHK(hipGetLastError());
+    int r = g_rccl.allreduce(ctx->comm_tmp, ctx->comm_tmp, (size_t)n, kNcclFloat, kNcclSum, ctx->comm, ctx->stream);
+    NEED(r == 0, MFX_E_COMM, "ncclAllReduce: %s", rccl_err(r));
+    hipLaunchKernelGGL(apply_delta_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ctx->V, ctx->Vsync, ctx->comm_tmp, n4);
+  } else {
+    int r = g_rccl.allreduce(ctx->V, ctx->V, (size_t)n, kNcclFloat, kNcclSum, ctx->comm, ctx->stream);
+    NEED(r == 0, MFX_E_COMM, "ncclAllReduce: %s", rccl_err(r));
+    hipLaunchKernelGGL(scale_copy_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ctx->V, ctx->Vsync,
+                       1.0f / (float)ctx->nranks, n4);
+  }
+  HIPCHK(hipGetLastError());
+  return MFX_OK;
+}
+
+extern "C" int mfx_allreduce_f64(mfx_ctx* ctx, double* vals, int n) {
+  if (!ctx) return MFX_E_ARG;
+  NEED(vals && n > 0 && n <= 8, MFX_E_ARG, "mfx_allreduce_f64: n must be in [1,8]");
+  if (ctx->nranks == 1 || !ctx->comm) return MFX_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (ctx->red_blocks < 1) {
+    int rc;
+    dev_free(ctx->red_d); dev_free(ctx->red_i);
+    if ((rc = dev_alloc(ctx, &ctx->red_d, (size_t)16))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->red_i, (size_t)8))) return rc;
+    ctx->red_blocks = 8;
+  }
+  HIPCHK(hipMemcpyAsync(ctx->red_d, vals, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+  int r = g_rccl.allreduce(ctx->red_d, ctx->red_d, (size_t)n, kNcclDouble, kNcclSum, ctx->comm, ctx->stream);
+  NEED(r == 0, MFX_E_COMM, "ncclAllReduce(f64): %s", rccl_err(r));
+  HIPCHK(hipMemcpyAsync(ctx->red_out, ctx->red_d, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  for (int k = 0; k < n; k++) vals[k] = ctx->red_out[k];
+  return MFX_OK;
+}

@@ -1,0 +1,205 @@
+// eval.hip -- objective / RMSE pass.
+//
+// Replaces Model::objective (model.cpp:1770-1815) and Model::RMSE (model.cpp:214-251),
+// which the reference runs after EVERY iteration (OBJ_ITER = 1, const.h:4): one fp32
+// dot per rating, (r - est)^2 accumulated in double.  Same L-lane group per rating and
+// the same dot order as the SGD kernel; partial sums are combined in a fixed order
+// (per-lane -> wave -> block -> one finishing block), so the result is reproducible
+// run to run (the reference's OpenMP reduction order is thread-dependent).
+#include <algorithm>
+
+#include "mfx_internal.h"
+
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+template <int L>
+__device__ __forceinline__ float group_sum_f(float s) {
+#pragma unroll
+  for (int m = L / 2; m >= 1; m >>= 1) s = s + __shfl_xor(s, m, 64);
+  return s;
+}
+
+template <int L, int C>
+__device__ __forceinline__ float row_dot(const float* __restrict__ a, const float* __restrict__ b) {
+  float s = 0.0f;
+#pragma unroll
+  for (int c = 0; c < C; c++) {
+    const float4v x = *(const float4v*)(a + c * 4 * L);
+    const float4v y = *(const float4v*)(b + c * 4 * L);
+    s = __builtin_fmaf(x.x, y.x, s);
+    s = __builtin_fmaf(x.y, y.y, s);
+    s = __builtin_fmaf(x.z, y.z, s);
+    s = __builtin_fmaf(x.w, y.w, s);
+  }
+  return group_sum_f<L>(s);
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+__device__ __forceinline__ long long wave_sum_ll(long long v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+// block-level fixed-order combine; result valid in thread 0
+template <typename T>
+__device__ __forceinline__ T block_combine(T wave_val, T* sh) {
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) sh[w] = wave_val;
+  __syncthreads();
+  T tot = 0;
+  if (threadIdx.x == 0)
+    for (int k = 0; k < (int)(blockDim.x >> 6); k++) tot += sh[k];
+  __syncthreads();
+  return tot;
+}
+
+template <int L, int C>
+__global__ __launch_bounds__(256) void eval_sse_kernel(const int32_t* __restrict__ ru,
+                                                       const int32_t* __restrict__ ri,
+                                                       const float* __restrict__ rr, int64_t n,
+                                                       const float* __restrict__ U, const float* __restrict__ V,
+                                                       const uint8_t* __restrict__ invU,
+                                                       const uint8_t* __restrict__ invI, int32_t nU, int32_t nI,
+                                                       double* __restrict__ part_d, int64_t* __restrict__ part_i) {
+  constexpr int G = 64 / L;
+  constexpr int LD = 4 * L * C;
+  __shared__ double shd[4];
+  __shared__ long long shi[4];
+  const int lane = threadIdx.x & 63;
+  const int g = lane / L, j = lane % L;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  double acc = 0.0;
+  long long cnt = 0;
+  for (int64_t base = wave * 64; base < n; base += nwaves * 64) {
+    const bool ok = base + lane < n;
+    const int mu = ok ? ru[base + lane] : 0;
+    const int mi = ok ? ri[base + lane] : 0;
+    const float mr = ok ? rr[base + lane] : 0.0f;
+    const int nvalid = (int)(n - base < 64 ? n - base : 64);
+#pragma unroll 1
+    for (int s = 0; s < L; s++) {
+      const int e = s * G + g;
+      const int u = __shfl(mu, e, 64);
+      const int it = __shfl(mi, e, 64);
+      const float r = __shfl(mr, e, 64);
+      // Model::RMSE: u < nUsers, user valid, item < nItems and valid (model.cpp:223-237)
+      bool use = e < nvalid && u < nU && it < nI;
+      if (use) use = !invU[u] && !invI[it];
+      if (use) {
+        const float est = row_dot<L, C>(U + (int64_t)u * LD + 4 * j, V + (int64_t)it * LD + 4 * j);
+        const double diff = (double)r - (double)est;
+        if (j == 0) { acc += diff * diff; cnt++; }
+      }
+    }
+  }
+  const double wd = wave_sum_d(acc);
+  const long long wi = wave_sum_ll(cnt);
+  const double bd = block_combine<double>(wd, shd);
+  const long long bi = block_combine<long long>(wi, shi);
+  if (threadIdx.x == 0) { part_d[blockIdx.x] = bd; part_i[blockIdx.x] = bi; }
+}
+
+// sum over valid rows of ||x||^2 (fp32 dot in device order, double sum)
+template <int L, int C>
+__global__ __launch_bounds__(256) void eval_norm_kernel(const float* __restrict__ X, int32_t n,
+                                                        const uint8_t* __restrict__ inv,
+                                                        double* __restrict__ part_d) {
+  constexpr int G = 64 / L;
+  constexpr int LD = 4 * L * C;
+  __shared__ double shd[4];
+  const int lane = threadIdx.x & 63;
+  const int g = lane / L, j = lane % L;
+  const int64_t grp = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * G + g;
+  const int64_t ngrp = (((int64_t)gridDim.x * blockDim.x) >> 6) * G;
+  double acc = 0.0;
+  for (int64_t r = grp; r < n; r += ngrp) {
+    if (inv[r]) continue;
+    const float* x = X + r * LD + 4 * j;
+    const float d = row_dot<L, C>(x, x);
+    if (j == 0) acc += (double)d;
+  }
+  const double bd = block_combine<double>(wave_sum_d(acc), shd);
+  if (threadIdx.x == 0) part_d[blockIdx.x] = bd;
+}
+
+__global__ void eval_finish_kernel(const double* __restrict__ p0, int n0, const int64_t* __restrict__ pi,
+                                   const double* __restrict__ p1, int n1, const double* __restrict__ p2, int n2,
+                                   double* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double s = 0;
+  long long c = 0;
+  for (int k = 0; k < n0; k++) { s += p0[k]; c += pi[k]; }
+  double a = 0, b = 0;
+  for (int k = 0; k < n1; k++) a += p1[k];
+  for (int k = 0; k < n2; k++) b += p2[k];
+  out[0] = s;
+  out[1] = (double)c;
+  out[2] = a;
+  out[3] = b;
+}
+
+template <int L, int C>
+static int eval_lc(mfx_ctx* ctx, const DevCSR& m, const float* U, const float* V, int with_norms, int nb,
+                   int nbu, int nbi) {
+  ProfScope ps(ctx, MFX_K_EVAL);
+  double* pd = ctx->red_d;
+  hipLaunchKernelGGL((eval_sse_kernel<L, C>), dim3(nb), dim3(256), 0, ctx->stream, m.rowid, m.rowind, m.rowval,
+                     m.nnz, U, V, ctx->invU, ctx->invI, ctx->nU, ctx->nI, pd, ctx->red_i);
+  if (with_norms) {
+    hipLaunchKernelGGL((eval_norm_kernel<L, C>), dim3(nbu), dim3(256), 0, ctx->stream, U, ctx->nU, ctx->invU,
+                       pd + nb);
+    hipLaunchKernelGGL((eval_norm_kernel<L, C>), dim3(nbi), dim3(256), 0, ctx->stream, V, ctx->nI, ctx->invI,
+                       pd + nb + nbu);
+  }
+  HIPCHK(hipGetLastError());
+  return MFX_OK;
+}
+
+int mfx_launch_eval(mfx_ctx* ctx, const DevCSR& m, const float* U, const float* V, int with_norms,
+                    mfx_eval_out* out) {
+  const int L = ctx->L, C = ctx->C;
+  const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(((m.nnz + 63) / 64 + 3) / 4, 2048));
+  const int G = 64 / L;
+  const int nbu = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)ctx->nU + 4 * G - 1) / (4 * G), 1024));
+  const int nbi = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)ctx->nI + 4 * G - 1) / (4 * G), 1024));
+  const int need = nb + nbu + nbi;
+  if (ctx->red_blocks < need) {
+    dev_free(ctx->red_d);
+    dev_free(ctx->red_i);
+    int rc;
+    if ((rc = dev_alloc(ctx, &ctx->red_d, (size_t)need + 8))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->red_i, (size_t)need))) return rc;
+    ctx->red_blocks = need;
+  }
+  int rc = MFX_E_ARG;
+  if (L == 4) rc = eval_lc<4, 1>(ctx, m, U, V, with_norms, nb, nbu, nbi);
+  else if (L == 8) rc = eval_lc<8, 1>(ctx, m, U, V, with_norms, nb, nbu, nbi);
+  else switch (C) {
+    case 1: rc = eval_lc<16, 1>(ctx, m, U, V, with_norms, nb, nbu, nbi); break;
+    case 2: rc = eval_lc<16, 2>(ctx, m, U, V, with_norms, nb, nbu, nbi); break;
+    case 3: rc = eval_lc<16, 3>(ctx, m, U, V, with_norms, nb, nbu, nbi); break;
+    case 4: rc = eval_lc<16, 4>(ctx, m, U, V, with_norms, nb, nbu, nbi); break;
+    case 5: rc = eval_lc<16, 5>(ctx, m, U, V, with_norms, nb, nbu, nbi); break;
+    case 6: rc = eval_lc<16, 6>(ctx, m, U, V, with_norms, nb, nbu, nbi); break;
+    case 7: rc = eval_lc<16, 7>(ctx, m, U, V, with_norms, nb, nbu, nbi); break;
+    case 8: rc = eval_lc<16, 8>(ctx, m, U, V, with_norms, nb, nbu, nbi); break;
+  }
+  if (rc) return rc;
+  double* dout = ctx->red_d + need;  // 4 doubles of the +8 tail
+  hipLaunchKernelGGL(eval_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->red_d, nb, ctx->red_i,
+                     ctx->red_d + nb, with_norms ? nbu : 0, ctx->red_d + nb + nbu, with_norms ? nbi : 0, dout);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(ctx->red_out, dout, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  out->sse = ctx->red_out[0];
+  out->n = (int64_t)ctx->red_out[1];
+  out->unorm2 = ctx->red_out[2];
+  out->inorm2 = ctx->red_out[3];
+  return MFX_OK;
+}

@@ -1,0 +1,568 @@
+// mfx_api.hip -- context lifetime, data/model upload, epoch-list construction.
+// Replaces the state handling of Data (datastruct.cpp:3-120) and Model
+// (model.cpp:2315-2366, :1492, :1500-1504) on the device.
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mfx_internal.h"
+
+static thread_local std::string g_create_err;
+
+int mfx_fail(mfx_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf; else g_create_err = buf;
+  return code;
+}
+
+ProfScope::ProfScope(mfx_ctx* c, int kernel) : ctx(c), k(kernel) {
+  if (!ctx->prof_on) return;
+  ProfSlot& s = ctx->prof[k];
+  if (!s.pool.empty()) { a = s.pool.back().first; b = s.pool.back().second; s.pool.pop_back(); }
+  else {
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+  }
+  (void)hipEventRecord(a, ctx->stream);
+}
+ProfScope::~ProfScope() {
+  if (!a) return;
+  (void)hipEventRecord(b, ctx->stream);
+  ctx->prof[k].pending.emplace_back(a, b);
+}
+
+extern "C" {
+
+int mfx_version(void) { return 100; }
+
+int mfx_device_count(int* n) {
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) c = 0;
+  if (n) *n = c;
+  return MFX_OK;
+}
+
+const char* mfx_last_error(const mfx_ctx* ctx) {
+  return ctx ? ctx->err.c_str() : g_create_err.c_str();
+}
+
+int mfx_create(int device, mfx_ctx** out) {
+  mfx_ctx* ctx = nullptr;
+  if (!out) return mfx_fail(nullptr, MFX_E_ARG, "mfx_create: out is NULL");
+  *out = nullptr;
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess || c <= 0)
+    return mfx_fail(nullptr, MFX_E_NODEVICE,
+                    "mfx_create: no HIP device (%s); this library has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+  if (device < 0 || device >= c)
+    return mfx_fail(nullptr, MFX_E_ARG, "mfx_create: device %d out of range [0,%d)", device, c);
+  e = hipSetDevice(device);
+  if (e != hipSuccess) return mfx_fail(nullptr, MFX_E_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+  ctx = new mfx_ctx;
+  ctx->device = device;
+  e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete ctx;
+    return mfx_fail(nullptr, MFX_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+  }
+  e = hipHostMalloc((void**)&ctx->red_out, 8 * sizeof(double));
+  if (e != hipSuccess) {
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return mfx_fail(nullptr, MFX_E_OOM, "hipHostMalloc: %s", hipGetErrorString(e));
+  }
+  *out = ctx;
+  return MFX_OK;
+}
+
+static void free_csr(DevCSR& m) {
+  dev_free(m.rowptr); dev_free(m.rowind); dev_free(m.rowval); dev_free(m.rowid);
+  dev_free(m.colptr); dev_free(m.colind); dev_free(m.colval);
+  m = DevCSR();
+}
+
+static void free_model(mfx_ctx* ctx) {
+  dev_free(ctx->U); dev_free(ctx->V); dev_free(ctx->Ubest); dev_free(ctx->Vbest);
+  dev_free(ctx->Vsync); dev_free(ctx->invU); dev_free(ctx->invI);
+  ctx->have_invalid = false;
+}
+
+void mfx_destroy(mfx_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  mfx_comm_free_internal(ctx);
+  mfx_ccd_free_internal(ctx);
+  for (auto& m : ctx->mat) free_csr(m);
+  free_model(ctx);
+  dev_free(ctx->eu); dev_free(ctx->ei); dev_free(ctx->er); dev_free(ctx->order);
+  dev_free(ctx->ulist); dev_free(ctx->red_d); dev_free(ctx->red_i); dev_free(ctx->als_A);
+  if (ctx->red_out) (void)hipHostFree(ctx->red_out);
+  for (auto& s : ctx->prof) {
+    for (auto& p : s.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    for (auto& p : s.pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+  }
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int mfx_synchronize(mfx_ctx* ctx) {
+  if (!ctx) return MFX_E_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return MFX_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// CSR upload
+// ---------------------------------------------------------------------------
+__global__ void expand_rowid_kernel(const int64_t* __restrict__ rowptr, int32_t nrows,
+                                    int32_t* __restrict__ rowid) {
+  // one wave per row, grid-stride; rows are short on average and this runs once
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t u = wave; u < nrows; u += nwaves) {
+    const int64_t b = rowptr[u], e = rowptr[u + 1];
+    for (int64_t t = b + lane; t < e; t += 64) rowid[t] = (int32_t)u;
+  }
+}
+
+extern "C" int mfx_set_csr(mfx_ctx* ctx, int which, int32_t nrows, int32_t ncols,
+                           const int64_t* rowptr, const int32_t* rowind, const float* rowval,
+                           const int64_t* colptr, const int32_t* colind, const float* colval) {
+  if (!ctx) return MFX_E_ARG;
+  NEED(which >= 0 && which < 3, MFX_E_ARG, "mfx_set_csr: which=%d", which);
+  NEED(nrows >= 0 && ncols >= 0 && rowptr, MFX_E_ARG, "mfx_set_csr: bad shape/pointers");
+  const int64_t nnz = rowptr[nrows];
+  NEED(rowptr[0] == 0 && nnz >= 0, MFX_E_ARG, "mfx_set_csr: rowptr[0] must be 0");
+  NEED(nnz == 0 || (rowind && rowval), MFX_E_ARG, "mfx_set_csr: rowind/rowval NULL");
+  // the kernels index factor rows with these: validate once on the host
+  for (int32_t u = 0; u < nrows; u++)
+    NEED(rowptr[u + 1] >= rowptr[u], MFX_E_ARG, "mfx_set_csr: rowptr not monotone at row %d", u);
+  for (int64_t e = 0; e < nnz; e++)
+    NEED(rowind[e] >= 0 && rowind[e] < ncols, MFX_E_ARG,
+         "mfx_set_csr: column index %d out of [0,%d) at entry %lld", rowind[e], ncols, (long long)e);
+  HIPCHK(hipSetDevice(ctx->device));
+  DevCSR& m = ctx->mat[which];
+  free_csr(m);
+  if (which == MFX_MAT_TRAIN) mfx_ccd_free_internal(ctx);
+  int rc;
+  if ((rc = dev_alloc(ctx, &m.rowptr, (size_t)nrows + 1))) return rc;
+  if ((rc = dev_alloc(ctx, &m.rowind, (size_t)nnz))) return rc;
+  if ((rc = dev_alloc(ctx, &m.rowval, (size_t)nnz))) return rc;
+  if ((rc = dev_alloc(ctx, &m.rowid, (size_t)nnz))) return rc;
+  HIPCHK(hipMemcpyAsync(m.rowptr, rowptr, sizeof(int64_t) * ((size_t)nrows + 1), hipMemcpyHostToDevice, ctx->stream));
+  if (nnz) {
+    HIPCHK(hipMemcpyAsync(m.rowind, rowind, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(m.rowval, rowval, sizeof(float) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream));
+  }
+  m.nrows = nrows; m.ncols = ncols; m.nnz = nnz;
+  if (nrows > 0) {
+    int blocks = (int)std::min<int64_t>(((int64_t)nrows + 3) / 4, 4096);
+    hipLaunchKernelGGL(expand_rowid_kernel, dim3(blocks), dim3(256), 0, ctx->stream, m.rowptr, nrows, m.rowid);
+    HIPCHK(hipGetLastError());
+  }
+  // column view: given, or built here (stable counting sort == gk_csr_CreateIndex(COL))
+  std::vector<int64_t> cp;
+  std::vector<int32_t> ci;
+  std::vector<float> cv;
+  if (!colptr && which == MFX_MAT_TRAIN) {
+    cp.assign((size_t)ncols + 1, 0);
+    ci.resize((size_t)nnz);
+    cv.resize((size_t)nnz);
+    for (int64_t e = 0; e < nnz; e++) cp[rowind[e] + 1]++;
+    for (int32_t j = 0; j < ncols; j++) cp[j + 1] += cp[j];
+    std::vector<int64_t> pos(cp.begin(), cp.end() - 1);
+    for (int32_t u = 0; u < nrows; u++)
+      for (int64_t e = rowptr[u]; e < rowptr[u + 1]; e++) {
+        int64_t d = pos[rowind[e]]++;
+        ci[d] = u;
+        cv[d] = rowval[e];
+      }
+    colptr = cp.data(); colind = ci.data(); colval = cv.data();
+  }
+  if (colptr) {
+    NEED(colptr[0] == 0 && colptr[ncols] == nnz, MFX_E_ARG, "mfx_set_csr: colptr inconsistent with nnz");
+    for (int64_t e = 0; e < nnz; e++)
+      NEED(colind[e] >= 0 && colind[e] < nrows, MFX_E_ARG, "mfx_set_csr: row index out of range in column view");
+    if ((rc = dev_alloc(ctx, &m.colptr, (size_t)ncols + 1))) return rc;
+    if ((rc = dev_alloc(ctx, &m.colind, (size_t)nnz))) return rc;
+    if ((rc = dev_alloc(ctx, &m.colval, (size_t)nnz))) return rc;
+    HIPCHK(hipMemcpyAsync(m.colptr, colptr, sizeof(int64_t) * ((size_t)ncols + 1), hipMemcpyHostToDevice, ctx->stream));
+    if (nnz) {
+      HIPCHK(hipMemcpyAsync(m.colind, colind, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(hipMemcpyAsync(m.colval, colval, sizeof(float) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream));
+    }
+    m.has_col = true;
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));  // host buffers are borrowed for this call only
+  m.present = true;
+  if (which == MFX_MAT_TRAIN) ctx->have_invalid = false;
+  return MFX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// model
+// ---------------------------------------------------------------------------
+extern "C" int mfx_set_model(mfx_ctx* ctx, int32_t nUsers, int32_t nItems, int32_t K) {
+  if (!ctx) return MFX_E_ARG;
+  NEED(nUsers > 0 && nItems > 0 && K > 0 && K <= 512, MFX_E_ARG,
+       "mfx_set_model: need nUsers>0, nItems>0, 0<K<=512 (got %d,%d,%d)", nUsers, nItems, K);
+  HIPCHK(hipSetDevice(ctx->device));
+  free_model(ctx);
+  mfx_ccd_free_internal(ctx);
+  ctx->nU = nUsers; ctx->nI = nItems; ctx->K = K;
+  mfx_tree_shape(K, &ctx->L, &ctx->C);
+  ctx->ld = 4 * ctx->L * ctx->C;
+  const size_t su = (size_t)nUsers * ctx->ld, si = (size_t)nItems * ctx->ld;
+  int rc;
+  if ((rc = dev_alloc(ctx, &ctx->U, su))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->V, si))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->Ubest, su))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->Vbest, si))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->invU, (size_t)nUsers))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->invI, (size_t)nItems))) return rc;
+  HIPCHK(hipMemsetAsync(ctx->U, 0, su * sizeof(float), ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->V, 0, si * sizeof(float), ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->Ubest, 0, su * sizeof(float), ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->Vbest, 0, si * sizeof(float), ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->invU, 0, (size_t)nUsers, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->invI, 0, (size_t)nItems, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return MFX_OK;
+}
+
+// host [n][K] (row- or column-major) <-> device [n][ld] zero padded
+static void pack_rows(const float* src, float* dst, int64_t n, int K, int ld, int layout) {
+  for (int64_t r = 0; r < n; r++) {
+    float* d = dst + r * ld;
+    if (layout == MFX_ROWMAJOR) memcpy(d, src + r * K, sizeof(float) * K);
+    else for (int k = 0; k < K; k++) d[k] = src[(int64_t)k * n + r];
+    for (int k = K; k < ld; k++) d[k] = 0.0f;
+  }
+}
+static void unpack_rows(const float* src, float* dst, int64_t n, int K, int ld, int layout) {
+  for (int64_t r = 0; r < n; r++) {
+    const float* s = src + r * ld;
+    if (layout == MFX_ROWMAJOR) memcpy(dst + r * K, s, sizeof(float) * K);
+    else for (int k = 0; k < K; k++) dst[(int64_t)k * n + r] = s[k];
+  }
+}
+
+static int upload_mat(mfx_ctx* ctx, const float* host, float* dev, int64_t n, int layout) {
+  const int K = ctx->K, ld = ctx->ld;
+  const int64_t chunk = std::max<int64_t>(1, (64ll << 20) / (ld * 4));
+  std::vector<float> stage((size_t)std::min(chunk, n) * ld);
+  for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+    const int64_t m = std::min(chunk, n - r0);
+    if (layout == MFX_ROWMAJOR) pack_rows(host + r0 * K, stage.data(), m, K, ld, layout);
+    else
+      for (int64_t r = 0; r < m; r++) {
+        float* d = stage.data() + r * ld;
+        for (int k = 0; k < K; k++) d[k] = host[(int64_t)k * n + r0 + r];
+        for (int k = K; k < ld; k++) d[k] = 0.0f;
+      }
+    HIPCHK(hipMemcpy(dev + r0 * ld, stage.data(), sizeof(float) * (size_t)m * ld, hipMemcpyHostToDevice));
+  }
+  return MFX_OK;
+}
+static int download_mat(mfx_ctx* ctx, const float* dev, float* host, int64_t n, int layout) {
+  const int K = ctx->K, ld = ctx->ld;
+  const int64_t chunk = std::max<int64_t>(1, (64ll << 20) / (ld * 4));
+  std::vector<float> stage((size_t)std::min(chunk, n) * ld);
+  for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+    const int64_t m = std::min(chunk, n - r0);
+    HIPCHK(hipMemcpy(stage.data(), dev + r0 * ld, sizeof(float) * (size_t)m * ld, hipMemcpyDeviceToHost));
+    if (layout == MFX_ROWMAJOR) unpack_rows(stage.data(), host + r0 * K, m, K, ld, layout);
+    else
+      for (int64_t r = 0; r < m; r++)
+        for (int k = 0; k < K; k++) host[(int64_t)k * n + r0 + r] = stage[(size_t)r * ld + k];
+  }
+  return MFX_OK;
+}
+
+extern "C" int mfx_set_factors(mfx_ctx* ctx, const float* U, const float* V, int layout) {
+  if (!ctx) return MFX_E_ARG;
+  NEED(ctx->U, MFX_E_STATE, "mfx_set_factors: call mfx_set_model first");
+  NEED(layout == MFX_ROWMAJOR || layout == MFX_COLMAJOR, MFX_E_ARG, "mfx_set_factors: layout");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  int rc;
+  if (U && (rc = upload_mat(ctx, U, ctx->U, ctx->nU, layout))) return rc;
+  if (V && (rc = upload_mat(ctx, V, ctx->V, ctx->nI, layout))) return rc;
+  return MFX_OK;
+}
+
+extern "C" int mfx_get_factors(mfx_ctx* ctx, int snapshot, float* U, float* V, int layout) {
+  if (!ctx) return MFX_E_ARG;
+  NEED(ctx->U, MFX_E_STATE, "mfx_get_factors: call mfx_set_model first");
+  NEED(layout == MFX_ROWMAJOR || layout == MFX_COLMAJOR, MFX_E_ARG, "mfx_get_factors: layout");
+  NEED(snapshot == MFX_SNAP_CURRENT || snapshot == MFX_SNAP_BEST, MFX_E_ARG, "mfx_get_factors: snapshot");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  int rc;
+  if (U && (rc = download_mat(ctx, snapshot ? ctx->Ubest : ctx->U, U, ctx->nU, layout))) return rc;
+  if (V && (rc = download_mat(ctx, snapshot ? ctx->Vbest : ctx->V, V, ctx->nI, layout))) return rc;
+  return MFX_OK;
+}
+
+__global__ void invalid_kernel(const int64_t* __restrict__ ptr, int32_t nmat, int32_t n,
+                               uint8_t* __restrict__ inv) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) inv[t] = (t >= nmat) || (ptr[t + 1] == ptr[t]);
+}
+
+extern "C" int mfx_compute_invalid(mfx_ctx* ctx, uint8_t* invalidUsers, uint8_t* invalidItems) {
+  if (!ctx) return MFX_E_ARG;
+  const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
+  NEED(m.present && m.has_col, MFX_E_STATE, "mfx_compute_invalid: train matrix with column view needed");
+  NEED(ctx->U, MFX_E_STATE, "mfx_compute_invalid: call mfx_set_model first");
+  HIPCHK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(invalid_kernel, dim3((ctx->nU + 255) / 256), dim3(256), 0, ctx->stream,
+                     m.rowptr, m.nrows, ctx->nU, ctx->invU);
+  hipLaunchKernelGGL(invalid_kernel, dim3((ctx->nI + 255) / 256), dim3(256), 0, ctx->stream,
+                     m.colptr, m.ncols, ctx->nI, ctx->invI);
+  HIPCHK(hipGetLastError());
+  if (invalidUsers) HIPCHK(hipMemcpyAsync(invalidUsers, ctx->invU, (size_t)ctx->nU, hipMemcpyDeviceToHost, ctx->stream));
+  if (invalidItems) HIPCHK(hipMemcpyAsync(invalidItems, ctx->invI, (size_t)ctx->nI, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->have_invalid = true;
+  return MFX_OK;
+}
+
+extern "C" int mfx_snapshot_best(mfx_ctx* ctx) {
+  if (!ctx) return MFX_E_ARG;
+  NEED(ctx->U, MFX_E_STATE, "mfx_snapshot_best: no model");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipMemcpyAsync(ctx->Ubest, ctx->U, sizeof(float) * (size_t)ctx->nU * ctx->ld, hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->Vbest, ctx->V, sizeof(float) * (size_t)ctx->nI * ctx->ld, hipMemcpyDeviceToDevice, ctx->stream));
+  return MFX_OK;
+}
+extern "C" int mfx_restore_best(mfx_ctx* ctx) {
+  if (!ctx) return MFX_E_ARG;
+  NEED(ctx->U, MFX_E_STATE, "mfx_restore_best: no model");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipMemcpyAsync(ctx->U, ctx->Ubest, sizeof(float) * (size_t)ctx->nU * ctx->ld, hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->V, ctx->Vbest, sizeof(float) * (size_t)ctx->nI * ctx->ld, hipMemcpyDeviceToDevice, ctx->stream));
+  return MFX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// epoch list: replaces std::shuffle(uiRatingInds) (modelMF.cpp:76-81, 1739-1744)
+// ---------------------------------------------------------------------------
+// Bijection on [0,n): alternating (unbalanced) Feistel network on ceil(log2 n) bits
+// keyed by (seed, epoch), cycle-walked into range.  Documented in DESIGN.md; the
+// python tests re-implement it to check the device list is that permutation.
+__host__ __device__ inline uint32_t mfx_mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__host__ __device__ inline uint64_t mfx_feistel(uint64_t x, int abits, int bbits, uint32_t k0, uint32_t k1) {
+  const uint32_t maskA = (abits >= 32) ? 0xffffffffU : ((1U << abits) - 1U);
+  const uint32_t maskB = (bbits >= 32) ? 0xffffffffU : ((1U << bbits) - 1U);
+  uint32_t Lh = (uint32_t)(x >> bbits) & maskA, Rh = (uint32_t)x & maskB;
+#pragma unroll
+  for (int r = 0; r < 6; r++) {
+    if ((r & 1) == 0) Lh ^= mfx_mix32(Rh * 0x9e3779b1U + k0 + (uint32_t)r * 0x85ebca6bU) & maskA;
+    else Rh ^= mfx_mix32(Lh * 0xc2b2ae35U + k1 + (uint32_t)r * 0x27d4eb2fU) & maskB;
+  }
+  return ((uint64_t)Lh << bbits) | Rh;
+}
+__host__ __device__ inline int64_t mfx_perm_index(int64_t t, int64_t n, int abits, int bbits, uint32_t k0, uint32_t k1) {
+  uint64_t y = mfx_feistel((uint64_t)t, abits, bbits, k0, k1);
+  while (y >= (uint64_t)n) y = mfx_feistel(y, abits, bbits, k0, k1);
+  return (int64_t)y;
+}
+
+template <int MODE>  // 0: feistel, 1: order[] array
+__global__ void build_epoch_list_kernel(const int32_t* __restrict__ cu, const int32_t* __restrict__ ci,
+                                        const float* __restrict__ cr, int64_t nsrc,
+                                        const uint64_t* __restrict__ order, int64_t n, int abits, int bbits,
+                                        uint32_t k0, uint32_t k1, int32_t* __restrict__ eu,
+                                        int32_t* __restrict__ ei, float* __restrict__ er) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
+    int64_t s;
+    if (MODE == 0) s = mfx_perm_index(t, n, abits, bbits, k0, k1);
+    else { s = (int64_t)order[t]; if (s < 0 || s >= nsrc) s = 0; }
+    eu[t] = cu[s]; ei[t] = ci[s]; er[t] = cr[s];
+  }
+}
+
+static int ensure_elist(mfx_ctx* ctx, int64_t n) {
+  if (ctx->elist_cap >= n && ctx->eu) return MFX_OK;
+  dev_free(ctx->eu); dev_free(ctx->ei); dev_free(ctx->er);
+  int rc;
+  if ((rc = dev_alloc(ctx, &ctx->eu, (size_t)n))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->ei, (size_t)n))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->er, (size_t)n))) return rc;
+  ctx->elist_cap = n;
+  return MFX_OK;
+}
+
+extern "C" int mfx_sgd_set_order(mfx_ctx* ctx, const uint64_t* perm, int64_t n) {
+  if (!ctx) return MFX_E_ARG;
+  NEED(perm && n >= 0, MFX_E_ARG, "mfx_sgd_set_order: perm NULL or n<0");
+  HIPCHK(hipSetDevice(ctx->device));
+  if (ctx->order_cap < n || !ctx->order) {
+    dev_free(ctx->order);
+    int rc;
+    if ((rc = dev_alloc(ctx, &ctx->order, (size_t)n))) return rc;
+    ctx->order_cap = n;
+  }
+  if (n) HIPCHK(hipMemcpyAsync(ctx->order, perm, sizeof(uint64_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->order_n = n;
+  return MFX_OK;
+}
+
+__global__ void build_user_list_kernel(const uint64_t* __restrict__ order, int64_t n, int32_t nU,
+                                       int32_t* __restrict__ ulist) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) { uint64_t u = order ? order[t] : (uint64_t)t; ulist[t] = u < (uint64_t)nU ? (int32_t)u : 0; }
+}
+
+extern "C" int mfx_sgd_epoch(mfx_ctx* ctx, const mfx_sgd_opts* o) {
+  if (!ctx) return MFX_E_ARG;
+  NEED(o, MFX_E_ARG, "mfx_sgd_epoch: opts NULL");
+  const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
+  NEED(m.present, MFX_E_STATE, "mfx_sgd_epoch: no train matrix");
+  NEED(ctx->U, MFX_E_STATE, "mfx_sgd_epoch: no model");
+  NEED(m.nrows <= ctx->nU && m.ncols <= ctx->nI, MFX_E_ARG,
+       "mfx_sgd_epoch: train matrix %dx%d exceeds model %dx%d", m.nrows, m.ncols, ctx->nU, ctx->nI);
+  NEED(o->mode >= MFX_SGD_HOGWILD && o->mode <= MFX_SGD_USERS, MFX_E_ARG, "mfx_sgd_epoch: mode=%d", o->mode);
+  NEED(o->order >= MFX_ORDER_DEVICE && o->order <= MFX_ORDER_NATURAL, MFX_E_ARG, "mfx_sgd_epoch: order=%d", o->order);
+  NEED(o->arith >= MFX_ARITH_REF64 && o->arith <= MFX_ARITH_F32, MFX_E_ARG, "mfx_sgd_epoch: arith=%d", o->arith);
+  HIPCHK(hipSetDevice(ctx->device));
+
+  if (o->mode == MFX_SGD_USERS) {
+    // user list: host order (shuffled valid users) or 0..nrows-1
+    int64_t nu = o->order == MFX_ORDER_HOST ? ctx->order_n : m.nrows;
+    NEED(o->order != MFX_ORDER_DEVICE, MFX_E_ARG, "mfx_sgd_epoch: MFX_SGD_USERS needs HOST or NATURAL order");
+    if (nu == 0) return MFX_OK;
+    if (ctx->ulist_cap < nu || !ctx->ulist) {
+      dev_free(ctx->ulist);
+      int rc;
+      if ((rc = dev_alloc(ctx, &ctx->ulist, (size_t)nu))) return rc;
+      ctx->ulist_cap = nu;
+    }
+    hipLaunchKernelGGL(build_user_list_kernel, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, ctx->stream,
+                       o->order == MFX_ORDER_HOST ? ctx->order : nullptr, nu, m.nrows, ctx->ulist);
+    HIPCHK(hipGetLastError());
+    return mfx_launch_sgd_users(ctx, o, nu);
+  }
+
+  int64_t n = m.nnz;
+  if (o->order == MFX_ORDER_HOST) {
+    NEED(ctx->order && ctx->order_n > 0, MFX_E_STATE, "mfx_sgd_epoch: MFX_ORDER_HOST without mfx_sgd_set_order");
+    n = ctx->order_n;
+  }
+  if (n == 0) return MFX_OK;
+  int rc;
+  if ((rc = ensure_elist(ctx, n))) return rc;
+  {
+    ProfScope ps(ctx, MFX_K_PERMUTE);
+    const int blocks = (int)std::min<int64_t>((n + 255) / 256, 8192);
+    if (o->order == MFX_ORDER_DEVICE) {
+      int bits = 1;
+      while (((int64_t)1 << bits) < n) bits++;
+      if (bits < 2) bits = 2;
+      const int abits = bits / 2, bbits = bits - abits;
+      const uint32_t k0 = mfx_mix32(o->seed ^ 0x3c6ef372U) + (uint32_t)o->epoch * 0x9e3779b9U;
+      const uint32_t k1 = mfx_mix32(o->seed * 0x85ebca6bU + 0xdaa66d2bU) ^ mfx_mix32((uint32_t)o->epoch + 0x1b873593U);
+      hipLaunchKernelGGL(build_epoch_list_kernel<0>, dim3(blocks), dim3(256), 0, ctx->stream, m.rowid, m.rowind,
+                         m.rowval, m.nnz, (const uint64_t*)nullptr, n, abits, bbits, k0, k1, ctx->eu, ctx->ei, ctx->er);
+    } else if (o->order == MFX_ORDER_HOST) {
+      hipLaunchKernelGGL(build_epoch_list_kernel<1>, dim3(blocks), dim3(256), 0, ctx->stream, m.rowid, m.rowind,
+                         m.rowval, m.nnz, ctx->order, n, 0, 0, 0u, 0u, ctx->eu, ctx->ei, ctx->er);
+    } else {
+      HIPCHK(hipMemcpyAsync(ctx->eu, m.rowid, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+      HIPCHK(hipMemcpyAsync(ctx->ei, m.rowind, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+      HIPCHK(hipMemcpyAsync(ctx->er, m.rowval, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    HIPCHK(hipGetLastError());
+  }
+  ctx->elist_n = n;
+  int64_t first = o->count > 0 ? o->first : 0;
+  int64_t count = o->count > 0 ? o->count : n;
+  NEED(first >= 0 && first + count <= n, MFX_E_ARG, "mfx_sgd_epoch: sub-range [%lld,+%lld) outside list of %lld",
+       (long long)first, (long long)count, (long long)n);
+  return mfx_launch_sgd(ctx, o, first, count);
+}
+
+extern "C" int mfx_debug_epoch_list(mfx_ctx* ctx, int32_t* u, int32_t* i, float* r, int64_t cap, int64_t* n) {
+  if (!ctx) return MFX_E_ARG;
+  NEED(n, MFX_E_ARG, "mfx_debug_epoch_list: n NULL");
+  *n = ctx->elist_n;
+  if (!u && !i && !r) return MFX_OK;
+  NEED(cap >= ctx->elist_n, MFX_E_ARG, "mfx_debug_epoch_list: cap too small");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const size_t k = (size_t)ctx->elist_n;
+  if (k == 0) return MFX_OK;
+  if (u) HIPCHK(hipMemcpy(u, ctx->eu, sizeof(int32_t) * k, hipMemcpyDeviceToHost));
+  if (i) HIPCHK(hipMemcpy(i, ctx->ei, sizeof(int32_t) * k, hipMemcpyDeviceToHost));
+  if (r) HIPCHK(hipMemcpy(r, ctx->er, sizeof(float) * k, hipMemcpyDeviceToHost));
+  return MFX_OK;
+}
+
+extern "C" int mfx_eval(mfx_ctx* ctx, int which, int snapshot, int with_norms, mfx_eval_out* out) {
+  if (!ctx) return MFX_E_ARG;
+  NEED(out, MFX_E_ARG, "mfx_eval: out NULL");
+  NEED(which >= 0 && which < 3, MFX_E_ARG, "mfx_eval: which=%d", which);
+  NEED(ctx->mat[which].present, MFX_E_STATE, "mfx_eval: matrix %d not set", which);
+  NEED(ctx->U, MFX_E_STATE, "mfx_eval: no model");
+  NEED(ctx->have_invalid, MFX_E_STATE, "mfx_eval: call mfx_compute_invalid first");
+  NEED(snapshot == MFX_SNAP_CURRENT || snapshot == MFX_SNAP_BEST, MFX_E_ARG, "mfx_eval: snapshot");
+  HIPCHK(hipSetDevice(ctx->device));
+  return mfx_launch_eval(ctx, ctx->mat[which], snapshot ? ctx->Ubest : ctx->U, snapshot ? ctx->Vbest : ctx->V,
+                         with_norms, out);
+}
+
+// ---------------------------------------------------------------------------
+// measurement
+// ---------------------------------------------------------------------------
+extern "C" int mfx_prof_enable(mfx_ctx* ctx, int on) {
+  if (!ctx) return MFX_E_ARG;
+  ctx->prof_on = on != 0;
+  return MFX_OK;
+}
+static int prof_resolve(mfx_ctx* ctx) {
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  for (auto& s : ctx->prof) {
+    for (auto& p : s.pending) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) { s.ms += ms; s.launches++; }
+      s.pool.push_back(p);
+    }
+    s.pending.clear();
+  }
+  return MFX_OK;
+}
+extern "C" int mfx_prof_reset(mfx_ctx* ctx) {
+  if (!ctx) return MFX_E_ARG;
+  int rc = prof_resolve(ctx);
+  if (rc) return rc;
+  for (auto& s : ctx->prof) { s.ms = 0; s.launches = 0; }
+  return MFX_OK;
+}
+extern "C" int mfx_prof_get(mfx_ctx* ctx, int kernel, double* total_ms, int64_t* launches) {
+  if (!ctx) return MFX_E_ARG;
+  NEED(kernel >= 0 && kernel < MFX_K_COUNT, MFX_E_ARG, "mfx_prof_get: kernel=%d", kernel);
+  int rc = prof_resolve(ctx);
+  if (rc) return rc;
+  if (total_ms) *total_ms = ctx->prof[kernel].ms;
+  if (launches) *launches = ctx->prof[kernel].launches;
+  return MFX_OK;
+}

@@ -1,0 +1,131 @@
+// mfx_internal.h -- context and helpers shared by the HIP translation units.
+#ifndef MFX_INTERNAL_H_
+#define MFX_INTERNAL_H_
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "mfx.h"
+
+struct DevCSR {
+  int32_t nrows = 0, ncols = 0;
+  int64_t nnz = 0;
+  int64_t* rowptr = nullptr;
+  int32_t* rowind = nullptr;
+  float* rowval = nullptr;
+  int32_t* rowid = nullptr;   // expanded row index per rating (CSR order)
+  int64_t* colptr = nullptr;
+  int32_t* colind = nullptr;
+  float* colval = nullptr;
+  bool present = false, has_col = false;
+};
+
+struct ProfSlot {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+  double ms = 0;
+  int64_t launches = 0;
+};
+
+struct mfx_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  DevCSR mat[3];
+  int32_t nU = 0, nI = 0, K = 0, L = 0, C = 0, ld = 0;
+  float *U = nullptr, *V = nullptr, *Ubest = nullptr, *Vbest = nullptr, *Vsync = nullptr;
+  uint8_t *invU = nullptr, *invI = nullptr;
+  bool have_invalid = false;
+
+  // epoch rating list (visiting order) and host-provided permutation
+  int32_t *eu = nullptr, *ei = nullptr;
+  float* er = nullptr;
+  int64_t elist_n = 0, elist_cap = 0;
+  uint64_t* order = nullptr;
+  int64_t order_n = 0, order_cap = 0;
+  int32_t* ulist = nullptr;  // user list for MFX_SGD_USERS
+  int64_t ulist_cap = 0;
+
+  // reduction scratch
+  double* red_d = nullptr;   // [blocks][4]
+  int64_t* red_i = nullptr;  // [blocks]
+  int red_blocks = 0;
+  double* red_out = nullptr; // pinned host [8]
+
+  // CCD++ state
+  float *res_row = nullptr, *res_col = nullptr, *uk = nullptr, *vk = nullptr;
+  bool ccd_active = false;
+
+  // ALS scratch
+  float* als_A = nullptr;    // [rows_in_batch][K*K] Gramians + rhs
+  int64_t als_cap = 0;
+
+  // comm
+  void* comm = nullptr;      // ncclComm_t
+  int nranks = 1, rank = 0;
+  float* comm_tmp = nullptr;
+
+  bool prof_on = false;
+  ProfSlot prof[MFX_K_COUNT];
+};
+
+int mfx_fail(mfx_ctx* ctx, int code, const char* fmt, ...);
+
+#define HIPCHK(expr)                                                                   \
+  do {                                                                                 \
+    hipError_t e_ = (expr);                                                            \
+    if (e_ != hipSuccess)                                                              \
+      return mfx_fail(ctx, e_ == hipErrorOutOfMemory ? MFX_E_OOM : MFX_E_HIP, "%s: %s", \
+                      #expr, hipGetErrorString(e_));                                   \
+  } while (0)
+
+#define NEED(cond, code, ...)                            \
+  do {                                                   \
+    if (!(cond)) return mfx_fail(ctx, code, __VA_ARGS__); \
+  } while (0)
+
+// Records a start/stop HIP event pair around a launch on ctx->stream when
+// profiling is on; mfx_prof_get() resolves the pairs.
+struct ProfScope {
+  mfx_ctx* ctx;
+  int k;
+  hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(mfx_ctx* c, int kernel);
+  ~ProfScope();
+};
+
+template <typename T>
+static inline int dev_alloc(mfx_ctx* ctx, T** p, size_t n) {
+  *p = nullptr;
+  if (n == 0) n = 1;
+  HIPCHK(hipMalloc((void**)p, n * sizeof(T)));
+  return MFX_OK;
+}
+template <typename T>
+static inline void dev_free(T*& p) {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+}
+
+static inline void mfx_tree_shape(int K, int* L, int* C) {
+  if (K <= 16) { *L = 4; *C = 1; }
+  else if (K <= 32) { *L = 8; *C = 1; }
+  else { *L = 16; *C = (K + 63) / 64; }
+}
+
+// kernels launched from other translation units
+int mfx_launch_sgd(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_t count);
+int mfx_launch_sgd_users(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t nusers);
+int mfx_launch_eval(mfx_ctx* ctx, const DevCSR& m, const float* U, const float* V,
+                    int with_norms, mfx_eval_out* out);
+int mfx_comm_free_internal(mfx_ctx* ctx);
+void mfx_ccd_free_internal(mfx_ctx* ctx);
+
+#endif

@@ -1,0 +1,225 @@
+"""ctypes view of include/mfx.h.  One method per C entry point; arrays are numpy."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+OK = 0
+MAT_TRAIN, MAT_VAL, MAT_TEST = 0, 1, 2
+ROWMAJOR, COLMAJOR = 0, 1
+SNAP_CURRENT, SNAP_BEST = 0, 1
+SIDE_USERS, SIDE_ITEMS = 0, 1
+SGD_HOGWILD, SGD_SERIAL, SGD_USERS = 0, 1, 2
+ORDER_DEVICE, ORDER_HOST, ORDER_NATURAL = 0, 1, 2
+ARITH_REF64, ARITH_REF64F, ARITH_F32 = 0, 1, 2
+REDUCE_DELTA_SUM, REDUCE_AVERAGE = 0, 1
+K_SGD, K_PERMUTE, K_EVAL, K_ALS_GRAM, K_ALS_SOLVE, K_CCD_ROW, K_CCD_COL, K_CCD_RESID = range(8)
+E_NODEVICE = -6
+
+
+class MfxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("mfx error %d: %s" % (code, msg))
+        self.code = code
+
+
+class SgdOpts(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("order", C.c_int32), ("arith", C.c_int32),
+                ("learnRate", C.c_float), ("uReg", C.c_float), ("iReg", C.c_float),
+                ("seed", C.c_uint32), ("epoch", C.c_int32),
+                ("first", C.c_int64), ("count", C.c_int64)]
+
+
+class EvalOut(C.Structure):
+    _fields_ = [("sse", C.c_double), ("n", C.c_int64), ("unorm2", C.c_double), ("inorm2", C.c_double)]
+
+
+def _p(a, dtype):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype)
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+def tree_shape(K):
+    if K <= 16:
+        return 4, 1
+    if K <= 32:
+        return 8, 1
+    return 16, (K + 63) // 64
+
+
+class Ctx:
+    """One mfx_ctx (one device, one stream)."""
+
+    def __init__(self, device=0):
+        self.lib = _lib.load()
+        self.lib.mfx_last_error.restype = C.c_char_p
+        self.h = C.c_void_p()
+        rc = self.lib.mfx_create(int(device), C.byref(self.h))
+        if rc != OK:
+            msg = self.lib.mfx_last_error(None).decode()
+            self.h = None
+            raise MfxError(rc, msg)
+        self.nU = self.nI = self.K = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mfx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise MfxError(rc, self.lib.mfx_last_error(self.h).decode())
+
+    # ---- data / model -------------------------------------------------------
+    def set_csr(self, which, nrows, ncols, rowptr, rowind, rowval, colptr=None, colind=None, colval=None):
+        keep = [_p(rowptr, np.int64), _p(rowind, np.int32), _p(rowval, np.float32),
+                _p(colptr, np.int64), _p(colind, np.int32), _p(colval, np.float32)]
+        ptrs = [k[1] if k else None for k in keep]
+        self._chk(self.lib.mfx_set_csr(self.h, which, C.c_int32(nrows), C.c_int32(ncols), *ptrs))
+
+    def set_model(self, nUsers, nItems, K):
+        self._chk(self.lib.mfx_set_model(self.h, C.c_int32(nUsers), C.c_int32(nItems), C.c_int32(K)))
+        self.nU, self.nI, self.K = nUsers, nItems, K
+
+    def set_factors(self, U, V, layout=ROWMAJOR):
+        ku, kv = _p(U, np.float32), _p(V, np.float32)
+        if ku is not None:
+            assert ku[0].size == self.nU * self.K
+        if kv is not None:
+            assert kv[0].size == self.nI * self.K
+        self._chk(self.lib.mfx_set_factors(self.h, ku[1] if ku else None, kv[1] if kv else None, layout))
+
+    def get_factors(self, snapshot=SNAP_CURRENT, layout=ROWMAJOR):
+        shape_u = (self.nU, self.K) if layout == ROWMAJOR else (self.K, self.nU)
+        shape_v = (self.nI, self.K) if layout == ROWMAJOR else (self.K, self.nI)
+        U = np.empty(shape_u, np.float32)
+        V = np.empty(shape_v, np.float32)
+        self._chk(self.lib.mfx_get_factors(self.h, snapshot, U.ctypes.data_as(C.c_void_p),
+                                           V.ctypes.data_as(C.c_void_p), layout))
+        return U, V
+
+    def compute_invalid(self):
+        invU = np.empty(self.nU, np.uint8)
+        invI = np.empty(self.nI, np.uint8)
+        self._chk(self.lib.mfx_compute_invalid(self.h, invU.ctypes.data_as(C.c_void_p),
+                                               invI.ctypes.data_as(C.c_void_p)))
+        return invU, invI
+
+    def snapshot_best(self):
+        self._chk(self.lib.mfx_snapshot_best(self.h))
+
+    def restore_best(self):
+        self._chk(self.lib.mfx_restore_best(self.h))
+
+    def synchronize(self):
+        self._chk(self.lib.mfx_synchronize(self.h))
+
+    # ---- SGD ----------------------------------------------------------------
+    def sgd_set_order(self, perm):
+        k = _p(perm, np.uint64)
+        self._chk(self.lib.mfx_sgd_set_order(self.h, k[1], C.c_int64(k[0].size)))
+
+    def sgd_epoch(self, lr, uReg, iReg, mode=SGD_HOGWILD, order=ORDER_DEVICE, arith=ARITH_F32, seed=1,
+                  epoch=0, first=0, count=0):
+        o = SgdOpts(mode, order, arith, lr, uReg, iReg, seed, epoch, first, count)
+        self._chk(self.lib.mfx_sgd_epoch(self.h, C.byref(o)))
+
+    def debug_epoch_list(self):
+        n = C.c_int64()
+        self._chk(self.lib.mfx_debug_epoch_list(self.h, None, None, None, C.c_int64(0), C.byref(n)))
+        u = np.empty(n.value, np.int32)
+        i = np.empty(n.value, np.int32)
+        r = np.empty(n.value, np.float32)
+        self._chk(self.lib.mfx_debug_epoch_list(self.h, u.ctypes.data_as(C.c_void_p), i.ctypes.data_as(C.c_void_p),
+                                                r.ctypes.data_as(C.c_void_p), C.c_int64(n.value), C.byref(n)))
+        return u, i, r
+
+    # ---- evaluation -----------------------------------------------------------
+    def eval(self, which, snapshot=SNAP_CURRENT, with_norms=False):
+        out = EvalOut()
+        self._chk(self.lib.mfx_eval(self.h, which, snapshot, int(with_norms), C.byref(out)))
+        return out
+
+    def objective(self, uReg, iReg, snapshot=SNAP_CURRENT):
+        """Model::objective (model.cpp:1770-1815) from the device sums."""
+        o = self.eval(MAT_TRAIN, snapshot, True)
+        return o.sse + float(np.float32(uReg)) * o.unorm2 + float(np.float32(iReg)) * o.inorm2
+
+    def rmse(self, which, snapshot=SNAP_CURRENT):
+        o = self.eval(which, snapshot, False)
+        return float(np.sqrt(o.sse / o.n)) if o.n else float("nan")
+
+    # ---- ALS / CCD++ ----------------------------------------------------------
+    def als_half_sweep(self, side, reg):
+        self._chk(self.lib.mfx_als_half_sweep(self.h, side, C.c_float(reg)))
+
+    def ccdpp_begin(self):
+        self._chk(self.lib.mfx_ccdpp_begin(self.h))
+
+    def ccdpp_rank1(self, k, uReg, iReg, add_back, inner=5, freq_thresh=-1.0):
+        self._chk(self.lib.mfx_ccdpp_rank1(self.h, C.c_int32(k), C.c_int32(inner), C.c_float(uReg),
+                                           C.c_float(iReg), C.c_int32(int(add_back)), C.c_float(freq_thresh)))
+
+    def ccdpp_end(self):
+        self._chk(self.lib.mfx_ccdpp_end(self.h))
+
+    def debug_residuals(self, nnz):
+        a = np.empty(nnz, np.float32)
+        b = np.empty(nnz, np.float32)
+        self._chk(self.lib.mfx_debug_residuals(self.h, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)))
+        return a, b
+
+    # ---- multi-GPU ------------------------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        lib = _lib.load()
+        buf = C.create_string_buffer(128)
+        rc = lib.mfx_comm_unique_id(buf)
+        if rc != OK:
+            lib.mfx_last_error.restype = C.c_char_p
+            raise MfxError(rc, lib.mfx_last_error(None).decode())
+        return bytes(buf.raw)
+
+    def comm_init(self, nranks, rank, uid):
+        self._chk(self.lib.mfx_comm_init(self.h, nranks, rank, C.c_char_p(uid)))
+
+    def comm_mark_synced(self):
+        self._chk(self.lib.mfx_comm_mark_synced(self.h))
+
+    def comm_destroy(self):
+        self._chk(self.lib.mfx_comm_destroy(self.h))
+
+    def allreduce_item_factors(self, op=REDUCE_DELTA_SUM):
+        self._chk(self.lib.mfx_allreduce_item_factors(self.h, op))
+
+    def allreduce_f64(self, vals):
+        a = np.ascontiguousarray(vals, np.float64).copy()
+        self._chk(self.lib.mfx_allreduce_f64(self.h, a.ctypes.data_as(C.c_void_p), a.size))
+        return a
+
+    # ---- measurement ----------------------------------------------------------
+    def prof_enable(self, on=True):
+        self._chk(self.lib.mfx_prof_enable(self.h, int(on)))
+
+    def prof_reset(self):
+        self._chk(self.lib.mfx_prof_reset(self.h))
+
+    def prof_get(self, kernel):
+        ms, n = C.c_double(), C.c_int64()
+        self._chk(self.lib.mfx_prof_get(self.h, kernel, C.byref(ms), C.byref(n)))
+        return ms.value, n.value

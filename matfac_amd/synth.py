@@ -1,0 +1,100 @@
+"""Synthetic rating matrices of the BASELINE.md shapes (no MovieLens/Netflix files offline).
+
+Mirrors the reference's own synthetic workflow -- ground-truth low-rank factors
+(python/genLatFacs.py:17-37), a CSR sampled from them (io.cpp:726-787) and a per-rating
+train/test/val split (io.cpp:410-459) -- with the power-law degree/popularity skew that
+SURVEY.md 8(d) asks for.  Host-side data preparation only; nothing here is on the hot path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+SHAPES = {
+    "C1": dict(nU=943, nI=1682, nnz=100_000, K=10),             # MovieLens-100K shape
+    "C2": dict(nU=138_493, nI=26_744, nnz=20_000_263, K=64),    # MovieLens-20M shape
+    "C4": dict(nU=480_189, nI=17_770, nnz=100_000_000, K=128),  # Netflix shape
+}
+
+
+class CSR:
+    __slots__ = ("nrows", "ncols", "rowptr", "rowind", "rowval")
+
+    def __init__(self, nrows, ncols, rowptr, rowind, rowval):
+        self.nrows, self.ncols = int(nrows), int(ncols)
+        self.rowptr = np.ascontiguousarray(rowptr, np.int64)
+        self.rowind = np.ascontiguousarray(rowind, np.int32)
+        self.rowval = np.ascontiguousarray(rowval, np.float32)
+
+    @property
+    def nnz(self):
+        return int(self.rowptr[-1])
+
+    def rowids(self):
+        return np.repeat(np.arange(self.nrows, dtype=np.int32), np.diff(self.rowptr)).astype(np.int32)
+
+    def col_view(self):
+        """gk_csr_CreateIndex(COL): stable, users ascending inside a column."""
+        order = np.argsort(self.rowind, kind="stable")
+        colptr = np.zeros(self.ncols + 1, np.int64)
+        np.cumsum(np.bincount(self.rowind, minlength=self.ncols), out=colptr[1:])
+        return colptr, self.rowids()[order].astype(np.int32), self.rowval[order]
+
+
+_lib = None
+
+
+def _host():
+    global _lib
+    if _lib is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmfhost.so")
+        if not os.path.exists(path):
+            raise ImportError("matfac_amd: %s not found; build it with `make -C matfac_amd/host`" % path)
+        _lib = C.CDLL(path)
+        _lib.mfh_synth_create.restype = C.c_void_p
+        _lib.mfh_synth_create.argtypes = [C.c_int32, C.c_int32, C.c_int64, C.c_uint32, C.c_double, C.c_double,
+                                          C.c_double, C.c_int32, C.c_double, C.c_double, C.c_uint32]
+        _lib.mfh_synth_free.argtypes = [C.c_void_p]
+        _lib.mfh_synth_shape.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.mfh_synth_copy.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.mfh_synth_nitems.argtypes = [C.c_void_p]
+        _lib.mfh_init_factors.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    return _lib
+
+
+def make(shape="C2", seed=1, scale=1.0, alpha_u=0.9, alpha_i=1.0, noise=0.5, K0=16, frac=(0.8, 0.1), shard=0):
+    """Generate + split with the C++ generator (matfac_amd/host/synth.cpp).  Returns a dict
+    with full/train/val/test CSR (all with nUsers rows), nUsers, nItems (datastruct.cpp:91), K."""
+    s = SHAPES[shape] if isinstance(shape, str) else shape
+    lib = _host()
+    nnz = max(int(s["nnz"] * scale), s["nU"])
+    h = lib.mfh_synth_create(s["nU"], s["nI"], nnz, seed, alpha_u, alpha_i, noise, K0, frac[0], frac[1], shard)
+    if not h:
+        raise ValueError("mfh_synth_create rejected the shape %r" % (s,))
+    try:
+        out = {}
+        for which, name in ((0, "full"), (1, "train"), (2, "val"), (3, "test")):
+            nr, nc, nz = C.c_int32(), C.c_int32(), C.c_int64()
+            lib.mfh_synth_shape(h, which, C.byref(nr), C.byref(nc), C.byref(nz))
+            rp = np.empty(nr.value + 1, np.int64)
+            ri = np.empty(nz.value, np.int32)
+            rv = np.empty(nz.value, np.float32)
+            lib.mfh_synth_copy(h, which, rp.ctypes.data_as(C.c_void_p), ri.ctypes.data_as(C.c_void_p),
+                               rv.ctypes.data_as(C.c_void_p))
+            out[name] = CSR(nr.value, nc.value, rp, ri, rv)
+        out["nUsers"] = s["nU"]
+        out["nItems"] = int(lib.mfh_synth_nitems(h))
+        out["K"] = s.get("K", 0)
+        return out
+    finally:
+        lib.mfh_synth_free(h)
+
+
+def init_factors(seed, nUsers, nItems, K, want_u=True, want_v=True):
+    """Model::Model(const Params&) initialisation (model.cpp:2331-2341), host library."""
+    lib = _host()
+    U = np.empty((nUsers, K), np.float32) if want_u else None
+    V = np.empty((nItems, K), np.float32) if want_v else None
+    lib.mfh_init_factors(seed, nUsers, nItems, K, U.ctypes.data_as(C.c_void_p) if want_u else None,
+                         V.ctypes.data_as(C.c_void_p) if want_v else None)
+    return U, V

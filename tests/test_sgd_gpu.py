@@ -1,0 +1,188 @@
+"""GPU parity of the SGD kernels (through the C ABI) against the CPU oracle.
+
+Tolerances: bit-exact (np.array_equal) wherever the visiting order is defined --
+conflict-free batches and the serial kernel; the oracle evaluates the fp32 dot in the
+device order (ORC_DOT_TREE), everything else is the reference's arithmetic."""
+import numpy as np
+import pytest
+
+from matfac_amd import Ctx, mfx, synth
+from oracle import binding as orc
+from tests.util import load_ctx, small
+
+pytestmark = pytest.mark.gpu
+
+ARITHS = [(mfx.ARITH_REF64, orc.ARITH_REF64), (mfx.ARITH_REF64F, orc.ARITH_REF64F), (mfx.ARITH_F32, orc.ARITH_F32)]
+
+
+def _conflict_free_matrix(n, K, seed):
+    """n ratings with pairwise distinct users and items: any schedule equals the serial one."""
+    rng = np.random.default_rng(seed)
+    items = rng.permutation(n).astype(np.int32)
+    rowptr = np.arange(n + 1, dtype=np.int64)
+    vals = (rng.integers(1, 11, n) * 0.5).astype(np.float32)
+    return synth.CSR(n, n, rowptr, items, vals)
+
+
+@pytest.mark.parametrize("K", [5, 10, 16, 20, 32, 64, 100, 128, 200, 256, 320])
+@pytest.mark.parametrize("arith", ARITHS)
+def test_hogwild_conflict_free_batch_bit_exact(K, arith):
+    n = 1000
+    tr = _conflict_free_matrix(n, K, seed=K)
+    rng = np.random.default_rng(100 + K)
+    U0 = rng.normal(0, 0.3, (n, K)).astype(np.float32)
+    V0 = rng.normal(0, 0.3, (n, K)).astype(np.float32)
+    with Ctx(0) as ctx:
+        ctx.set_csr(mfx.MAT_TRAIN, n, n, tr.rowptr, tr.rowind, tr.rowval)
+        ctx.set_model(n, n, K)
+        ctx.set_factors(U0, V0)
+        ctx.sgd_epoch(0.01, 0.05, 0.02, mode=mfx.SGD_HOGWILD, order=mfx.ORDER_DEVICE, arith=arith[0], seed=7, epoch=3)
+        U, V = ctx.get_factors()
+    Uo, Vo = U0.copy(), V0.copy()
+    orc.sgd_pass(Uo, Vo, tr.rowids(), tr.rowind, tr.rowval, None, 0.01, 0.05, 0.02, arith[1], orc.DOT_TREE)
+    assert np.array_equal(U, Uo)
+    assert np.array_equal(V, Vo)
+
+
+@pytest.mark.parametrize("K", [10, 64, 128])
+@pytest.mark.parametrize("arith", ARITHS)
+def test_serial_epochs_bit_exact(K, arith):
+    """ModelMF::train order (std::shuffle of the rating indices, modelMF.cpp:76-81) replayed by the
+    serial kernel: bit-identical factors after 3 epochs."""
+    d = small(nU=200, nI=150, nnz=4000, K=K, seed=5)
+    tr = d["train"]
+    nU, nI = d["nUsers"], d["nItems"]
+    U0, V0 = orc.init_factors(1, nU, nI, K)
+    U0 *= 30  # make the updates large enough to matter
+    V0 *= 30
+    ru = tr.rowids()
+    mt = orc.MT(1)
+    order = np.arange(tr.nnz, dtype=np.uint64)
+    Uo, Vo = U0.copy(), V0.copy()
+    with Ctx(0) as ctx:
+        load_ctx(ctx, d, K, U0, V0)
+        for ep in range(3):
+            mt.shuffle_u64(order)
+            ctx.sgd_set_order(order)
+            ctx.sgd_epoch(0.005, 0.01, 0.01, mode=mfx.SGD_SERIAL, order=mfx.ORDER_HOST, arith=arith[0])
+            orc.sgd_pass(Uo, Vo, ru, tr.rowind, tr.rowval, order, 0.005, 0.01, 0.01, arith[1], orc.DOT_TREE)
+            u, i, r = ctx.debug_epoch_list()
+            assert np.array_equal(u, ru[order.astype(np.int64)])
+            assert np.array_equal(i, tr.rowind[order.astype(np.int64)])
+        U, V = ctx.get_factors()
+    assert np.array_equal(U, Uo)
+    assert np.array_equal(V, Vo)
+
+
+def test_device_permutation_is_a_bijection_and_changes_per_epoch():
+    d = small(nU=500, nI=400, nnz=20000, K=16, seed=9)
+    tr = d["train"]
+    K = 16
+    U0, V0 = orc.init_factors(1, d["nUsers"], d["nItems"], K)
+    key = tr.rowids().astype(np.int64) * tr.ncols + tr.rowind
+    seen = []
+    with Ctx(0) as ctx:
+        load_ctx(ctx, d, K, U0, V0)
+        for ep in range(3):
+            ctx.sgd_epoch(0.0, 0.0, 0.0, order=mfx.ORDER_DEVICE, seed=1, epoch=ep)
+            u, i, r = ctx.debug_epoch_list()
+            k = u.astype(np.int64) * tr.ncols + i
+            assert np.array_equal(np.sort(k), np.sort(key))          # every rating exactly once
+            pos = np.searchsorted(key, k)
+            assert np.array_equal(r, tr.rowval[pos])
+            seen.append(k)
+    assert not np.array_equal(seen[0], seen[1]) and not np.array_equal(seen[1], seen[2])
+    # far from the CSR order: few ratings stay next to their CSR neighbour
+    assert np.mean(np.abs(np.diff(np.searchsorted(key, seen[0]))) == 1) < 0.01
+
+
+def test_lr_zero_is_identity_and_natural_order():
+    d = small(K=64)
+    K = 64
+    U0, V0 = orc.init_factors(2, d["nUsers"], d["nItems"], K)
+    with Ctx(0) as ctx:
+        load_ctx(ctx, d, K, U0, V0)
+        ctx.sgd_epoch(0.0, 0.0, 0.0, order=mfx.ORDER_NATURAL)
+        U, V = ctx.get_factors()
+        u, i, r = ctx.debug_epoch_list()
+    assert np.array_equal(U, U0) and np.array_equal(V, V0)
+    assert np.array_equal(u, d["train"].rowids()) and np.array_equal(i, d["train"].rowind)
+
+
+@pytest.mark.parametrize("K", [10, 64, 256])
+def test_eval_matches_oracle(K):
+    d = small(nU=400, nI=300, nnz=12000, K=K, seed=11)
+    tr, va = d["train"], d["val"]
+    nU, nI = d["nUsers"], d["nItems"]
+    rng = np.random.default_rng(K)
+    U0 = rng.normal(0, 0.4, (nU, K)).astype(np.float32)
+    V0 = rng.normal(0, 0.4, (nI, K)).astype(np.float32)
+    with Ctx(0) as ctx:
+        invU, invI = load_ctx(ctx, d, K, U0, V0)
+        e_tr = ctx.eval(mfx.MAT_TRAIN, with_norms=True)
+        e_va = ctx.eval(mfx.MAT_VAL)
+        obj = ctx.objective(0.01, 0.02)
+    oinvU, oinvI = orc.invalid(tr.nrows, tr.ncols, tr.rowptr, tr.rowind, nU, nI)
+    assert np.array_equal(invU, oinvU) and np.array_equal(invI, oinvI)
+    oobj, osse, oun, oin = orc.objective(U0, V0, nU, nI, tr.nrows, tr.rowptr, tr.rowind, tr.rowval, oinvU, oinvI,
+                                         0.01, 0.02, orc.DOT_TREE)
+    ormse, ovsse, ocnt = orc.rmse(U0, V0, nU, nI, va.nrows, va.rowptr, va.rowind, va.rowval, oinvU, oinvI,
+                                  orc.DOT_TREE)
+    # identical per-rating terms, double sums in a different order: 1e-12 relative
+    assert abs(e_tr.sse - osse) <= 1e-12 * osse
+    assert abs(e_tr.unorm2 - oun) <= 1e-12 * oun and abs(e_tr.inorm2 - oin) <= 1e-12 * oin
+    assert abs(obj - oobj) <= 1e-12 * oobj
+    assert e_va.n == ocnt and abs(e_va.sse - ovsse) <= 1e-12 * ovsse
+    # and the reference's sequential dot order agrees to fp32 round-off
+    sobj, *_ = orc.objective(U0, V0, nU, nI, tr.nrows, tr.rowptr, tr.rowind, tr.rowval, oinvU, oinvI, 0.01, 0.02,
+                             orc.DOT_SEQ)
+    assert abs(obj - sobj) <= 1e-5 * sobj
+
+
+def test_colmajor_factor_roundtrip():
+    K, nU, nI = 10, 37, 23
+    rng = np.random.default_rng(0)
+    U = rng.normal(size=(nU, K)).astype(np.float32)
+    V = rng.normal(size=(nI, K)).astype(np.float32)
+    with Ctx(0) as ctx:
+        ctx.set_model(nU, nI, K)
+        ctx.set_factors(np.asfortranarray(U).T.copy(), np.asfortranarray(V).T.copy(), layout=mfx.COLMAJOR)
+        U1, V1 = ctx.get_factors()
+        U2, V2 = ctx.get_factors(layout=mfx.COLMAJOR)
+        ctx.snapshot_best()
+        ctx.set_factors(V[:0].reshape(0, K) if False else U * 0, V * 0)
+        Ub, Vb = ctx.get_factors(snapshot=mfx.SNAP_BEST)
+        ctx.restore_best()
+        U3, V3 = ctx.get_factors()
+    assert np.array_equal(U1, U) and np.array_equal(V1, V)
+    assert np.array_equal(U2, U.T) and np.array_equal(V2, V.T)
+    assert np.array_equal(Ub, U) and np.array_equal(U3, U) and np.array_equal(V3, V)
+
+
+def test_hogwild_convergence_tracks_sequential_oracle():
+    """Hogwild on the device vs ModelMF::train's sequential loop on the CPU: same data, same
+    hyper-parameters, 30 epochs.  The trajectories are different random schedules of the same
+    algorithm; the validation RMSE they reach must agree closely."""
+    d = synth.make(dict(nU=2000, nI=1500, nnz=200_000, K=32), seed=4)
+    tr, va = d["train"], d["val"]
+    nU, nI, K = d["nUsers"], d["nItems"], 32
+    U0, V0 = orc.init_factors(1, nU, nI, K)
+    lr, reg, epochs = 0.005, 0.01, 30
+    with Ctx(0) as ctx:
+        invU, invI = load_ctx(ctx, d, K, U0, V0)
+        for ep in range(epochs):
+            ctx.sgd_epoch(lr, reg, reg, mode=mfx.SGD_HOGWILD, order=mfx.ORDER_DEVICE, arith=mfx.ARITH_F32, seed=1, epoch=ep)
+        gpu_val = ctx.rmse(mfx.MAT_VAL)
+        gpu_tr = ctx.rmse(mfx.MAT_TRAIN)
+    Uo, Vo = U0.copy(), V0.copy()
+    ru = tr.rowids()
+    mt = orc.MT(1)
+    order = np.arange(tr.nnz, dtype=np.uint64)
+    for ep in range(epochs):
+        mt.shuffle_u64(order)
+        orc.sgd_pass(Uo, Vo, ru, tr.rowind, tr.rowval, order, lr, reg, reg, orc.ARITH_REF64, orc.DOT_SEQ)
+    cpu_val, _, _ = orc.rmse(Uo, Vo, nU, nI, va.nrows, va.rowptr, va.rowind, va.rowval, invU, invI)
+    cpu_tr, _, _ = orc.rmse(Uo, Vo, nU, nI, tr.nrows, tr.rowptr, tr.rowind, tr.rowval, invU, invI)
+    print("val RMSE gpu %.5f cpu %.5f | train RMSE gpu %.5f cpu %.5f" % (gpu_val, cpu_val, gpu_tr, cpu_tr))
+    assert abs(gpu_val - cpu_val) < 5e-3
+    assert abs(gpu_tr - cpu_tr) < 5e-3
