@@ -95,8 +95,15 @@ int mfx_restore_best(mfx_ctx* ctx);
 enum {
   MFX_SGD_HOGWILD = 0,  /* all ratings of the epoch list in flight, lock-free (a5)     */
   MFX_SGD_SERIAL = 1,   /* one rating at a time in list order: bit-exact a4 / a7 order  */
-  MFX_SGD_USERS = 2     /* one wave-group per user row, items in CSR order, users in
+  MFX_SGD_USERS = 2,    /* one wave-group per user row, items in CSR order, users in
                            the (shuffled) user list: parallel trainUShuffle (a7)      */
+  MFX_SGD_TILED = 3     /* Hogwild scheduled in 8x8 (user-block x item-block) tiles: in
+                           round r the workgroups running on XCD x visit tile
+                           (x, (x+r) mod 8) only, so every factor row has ONE XCD (one
+                           coherent L2) reading and writing it at a time; the order
+                           inside a tile is the per-epoch device permutation.  This is
+                           the stratification of trainSGDPar (modelMF.cpp:229-304) mapped
+                           onto the chip's 8 L2 domains; MFX_ORDER_DEVICE only.        */
 };
 enum {
   MFX_ORDER_DEVICE = 0,  /* fresh device-side pseudo-random permutation per (seed, epoch) */
@@ -175,7 +182,8 @@ int mfx_allreduce_f64(mfx_ctx* ctx, double* vals, int n);
 enum {
   MFX_K_SGD = 0, MFX_K_PERMUTE = 1, MFX_K_EVAL = 2, MFX_K_ALS_GRAM = 3,
   MFX_K_ALS_SOLVE = 4, MFX_K_CCD_ROW = 5, MFX_K_CCD_COL = 6, MFX_K_CCD_RESID = 7,
-  MFX_K_COUNT = 8
+  MFX_K_SGD_SWEEP = 8, /* MFX_SGD_TILED: the placement-independent leftover sweep */
+  MFX_K_COUNT = 9
 };
 int mfx_prof_enable(mfx_ctx* ctx, int on);
 int mfx_prof_reset(mfx_ctx* ctx);

@@ -52,6 +52,13 @@ struct mfx_ctx {
   int64_t order_n = 0, order_cap = 0;
   int32_t* ulist = nullptr;  // user list for MFX_SGD_USERS
   int64_t ulist_cap = 0;
+  // MFX_SGD_TILED: train ratings bucketed by (user block, item block), 64 tiles
+  int32_t *tu = nullptr, *ti = nullptr;
+  float* tr = nullptr;
+  int64_t* tile_start = nullptr;          // device [65]
+  unsigned long long* tile_ctr = nullptr; // device [64] work counters
+  int64_t tile_start_h[65] = {0};
+  bool have_tiles = false;
 
   // reduction scratch
   double* red_d = nullptr;   // [blocks][4]
@@ -114,6 +121,15 @@ static inline void dev_free(T*& p) {
   p = nullptr;
 }
 
+// user / item block of the 8x8 tiling (MFX_SGD_TILED): a hash of the index, so the
+// blocks are balanced in expectation and need no table.
+__host__ __device__ static inline uint32_t mfx_mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__host__ __device__ static inline int mfx_user_block(int32_t u) { return (int)(mfx_mix32((uint32_t)u * 0x9e3779b1U + 0x1234567U) & 7U); }
+__host__ __device__ static inline int mfx_item_block(int32_t i) { return (int)(mfx_mix32((uint32_t)i * 0x85ebca6bU + 0x89abcdeU) & 7U); }
+
 static inline void mfx_tree_shape(int K, int* L, int* C) {
   if (K <= 16) { *L = 4; *C = 1; }
   else if (K <= 32) { *L = 8; *C = 1; }
@@ -123,6 +139,7 @@ static inline void mfx_tree_shape(int K, int* L, int* C) {
 // kernels launched from other translation units
 int mfx_launch_sgd(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_t count);
 int mfx_launch_sgd_users(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t nusers);
+int mfx_launch_sgd_tiled(mfx_ctx* ctx, const mfx_sgd_opts* o);
 int mfx_launch_eval(mfx_ctx* ctx, const DevCSR& m, const float* U, const float* V,
                     int with_norms, mfx_eval_out* out);
 int mfx_comm_free_internal(mfx_ctx* ctx);

@@ -115,36 +115,86 @@ __device__ __forceinline__ void sgd_visit(const Rows<POL>& Um, const Rows<POL>& 
   }
 }
 
-// Hogwild: every wave streams 64-rating chunks of the epoch list (coalesced SoA
-// reads), then walks the chunk G ratings at a time.
+// One 64-rating chunk of the epoch list: coalesced SoA read by the whole wave, then the
+// chunk is walked G ratings at a time (group g takes entries g, G+g, 2G+g, ...).
+template <int L, int C, int ARITH, int POL>
+__device__ __forceinline__ void sgd_chunk(const Rows<POL>& Um, const Rows<POL>& Vm,
+                                          const int32_t* __restrict__ eu, const int32_t* __restrict__ ei,
+                                          const float* __restrict__ er, int64_t idx0, int nvalid, int lane,
+                                          float lr, float uReg, float iReg) {
+  constexpr int G = 64 / L;
+  constexpr int LD = 4 * L * C;
+  const int g = lane / L, j = lane % L;
+  const bool ok = lane < nvalid;
+  const int mu = ok ? eu[idx0 + lane] : 0;
+  const int mi = ok ? ei[idx0 + lane] : 0;
+  const float mr = ok ? er[idx0 + lane] : 0.0f;
+#pragma unroll 1
+  for (int s = 0; s < L; s++) {
+    const int e = s * G + g;
+    const int u = __shfl(mu, e, 64);
+    const int it = __shfl(mi, e, 64);
+    const float r = __shfl(mr, e, 64);
+    if (e < nvalid)
+      sgd_visit<L, C, ARITH, POL>(Um, Vm, (int64_t)u * LD + 4 * j, (int64_t)it * LD + 4 * j, r, lr, uReg, iReg);
+  }
+}
+
+// Hogwild: every wave streams 64-rating chunks of the epoch list, grid-stride.
 template <int L, int C, int ARITH, int POL>
 __global__ __launch_bounds__(256) void sgd_hogwild_kernel(const int32_t* __restrict__ eu,
                                                           const int32_t* __restrict__ ei,
                                                           const float* __restrict__ er, int64_t first,
                                                           int64_t count, float* U, float* V, uint32_t ubytes,
                                                           uint32_t vbytes, float lr, float uReg, float iReg) {
-  constexpr int G = 64 / L;
-  constexpr int LD = 4 * L * C;
   const Rows<POL> Um(U, ubytes), Vm(V, vbytes);
   const int lane = threadIdx.x & 63;
-  const int g = lane / L, j = lane % L;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t base = wave * 64; base < count; base += nwaves * 64) {
-    const int64_t idx = first + base + lane;
-    const bool ok = base + lane < count;
-    const int mu = ok ? eu[idx] : 0;
-    const int mi = ok ? ei[idx] : 0;
-    const float mr = ok ? er[idx] : 0.0f;
     const int nvalid = (int)(count - base < 64 ? count - base : 64);
+    sgd_chunk<L, C, ARITH, POL>(Um, Vm, eu, ei, er, first + base, nvalid, lane, lr, uReg, iReg);
+  }
+}
+
+// Tiled Hogwild (MFX_SGD_TILED).  The epoch list is stored tile by tile (tile =
+// user block x item block, 8 x 8).  In round r a workgroup that runs on XCD x works
+// only on tile (x, (x + r) & 7): during a round every user row and every item row is
+// touched from ONE XCD, i.e. through one coherent L2 (the per-XCD L2s are not coherent
+// with each other: MI355X_MICROARCH.md).  Loads bypass the CU's L1 (sc1) and are served
+// by that L2; stores are plain (write-back into the same L2); the kernel boundary
+// between rounds publishes them chip-wide.  Waves pull 64*PULL-rating pieces of their
+// tile from a per-tile counter, so the result does not depend on how many workgroups
+// the dispatcher put on each XCD; round = -1 sweeps whatever is left in ANY tile, which
+// makes "every rating exactly once per epoch" independent of placement altogether.
+template <int L, int C, int ARITH, bool SWEEP>
+__global__ __launch_bounds__(256) void sgd_tiled_kernel(const int32_t* __restrict__ eu,
+                                                        const int32_t* __restrict__ ei,
+                                                        const float* __restrict__ er,
+                                                        const int64_t* __restrict__ tile_start,
+                                                        unsigned long long* tile_ctr, int round, float* U,
+                                                        float* V, uint32_t ubytes, uint32_t vbytes, float lr,
+                                                        float uReg, float iReg) {
+  constexpr int PULL = 4;
+  const Rows<3> Um(U, ubytes), Vm(V, vbytes);
+  const int lane = threadIdx.x & 63;
+  const int xcc = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7);  // HW_REG_XCC_ID[3:0]
+  const int t_first = SWEEP ? 0 : xcc * 8 + ((xcc + round) & 7);
+  const int t_last = SWEEP ? 63 : t_first;
+  for (int tile = t_first; tile <= t_last; tile++) {
+    const int64_t b = tile_start[tile], sz = tile_start[tile + 1] - b;
+    for (;;) {
+      unsigned long long got = 0;
+      if (lane == 0) got = atomicAdd(&tile_ctr[tile], (unsigned long long)(64 * PULL));
+      const int64_t base = (int64_t)__shfl(got, 0, 64);
+      if (base >= sz) break;
 #pragma unroll 1
-    for (int s = 0; s < L; s++) {
-      const int e = s * G + g;
-      const int u = __shfl(mu, e, 64);
-      const int it = __shfl(mi, e, 64);
-      const float r = __shfl(mr, e, 64);
-      if (e < nvalid)
-        sgd_visit<L, C, ARITH, POL>(Um, Vm, (int64_t)u * LD + 4 * j, (int64_t)it * LD + 4 * j, r, lr, uReg, iReg);
+      for (int c = 0; c < PULL; c++) {
+        const int64_t cb = base + (int64_t)c * 64;
+        if (cb >= sz) break;
+        const int nvalid = (int)(sz - cb < 64 ? sz - cb : 64);
+        sgd_chunk<L, C, ARITH, 3>(Um, Vm, eu, ei, er, b + cb, nvalid, lane, lr, uReg, iReg);
+      }
     }
   }
 }
@@ -197,6 +247,17 @@ __global__ __launch_bounds__(256) void sgd_users_kernel(const int32_t* __restric
 // ---------------------------------------------------------------------------
 // dispatch
 // ---------------------------------------------------------------------------
+// experiment knob: number of 256-thread workgroups of the Hogwild kernels (in-flight ratings
+// = blocks * 4 waves * 64/L); default fills the chip (256 CUs x 8 blocks).
+static int sgd_blocks(int dflt) {
+  static int b = -1;
+  if (b < 0) {
+    const char* e = getenv("MFX_SGD_BLOCKS");
+    b = e ? atoi(e) : 0;
+    if (b < 0) b = 0;
+  }
+  return b > 0 ? b : dflt;
+}
 static int sgd_policy() {
   static int pol = -1;
   if (pol < 0) {
@@ -208,6 +269,27 @@ static int sgd_policy() {
 }
 template <int L, int C, int ARITH>
 static int launch_lca(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_t count, int64_t nusers) {
+  if (o->mode == MFX_SGD_TILED) {
+    const uint64_t ub = (uint64_t)ctx->nU * ctx->ld * 4, vb = (uint64_t)ctx->nI * ctx->ld * 4;
+    if (ub >= (1ull << 32) || vb >= (1ull << 32))
+      return mfx_fail(ctx, MFX_E_ARG, "MFX_SGD_TILED: a factor matrix exceeds 4 GiB (buffer addressing)");
+    HIPCHK(hipMemsetAsync(ctx->tile_ctr, 0, 64 * sizeof(unsigned long long), ctx->stream));
+    const int blocks = sgd_blocks(2048);
+    for (int round = 0; round < 8; round++) {   // 8 XCD-local rounds
+      ProfScope ps(ctx, MFX_K_SGD);
+      hipLaunchKernelGGL((sgd_tiled_kernel<L, C, ARITH, false>), dim3(blocks), dim3(256), 0, ctx->stream, ctx->eu,
+                         ctx->ei, ctx->er, ctx->tile_start, ctx->tile_ctr, round, ctx->U, ctx->V, (uint32_t)ub,
+                         (uint32_t)vb, o->learnRate, o->uReg, o->iReg);
+    }
+    {  // placement-independent sweep of whatever the rounds left
+      ProfScope ps(ctx, MFX_K_SGD_SWEEP);
+      hipLaunchKernelGGL((sgd_tiled_kernel<L, C, ARITH, true>), dim3(256), dim3(256), 0, ctx->stream, ctx->eu,
+                         ctx->ei, ctx->er, ctx->tile_start, ctx->tile_ctr, -1, ctx->U, ctx->V, (uint32_t)ub,
+                         (uint32_t)vb, o->learnRate, o->uReg, o->iReg);
+    }
+    HIPCHK(hipGetLastError());
+    return MFX_OK;
+  }
   ProfScope ps(ctx, MFX_K_SGD);
   if (o->mode == MFX_SGD_SERIAL) {
     hipLaunchKernelGGL((sgd_serial_kernel<L, C, ARITH>), dim3(1), dim3(64), 0, ctx->stream, ctx->eu, ctx->ei,
@@ -221,7 +303,7 @@ static int launch_lca(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_
                        nusers, m.rowptr, m.rowind, m.rowval, ctx->U, ctx->V, o->learnRate, o->uReg, o->iReg);
   } else {
     int64_t waves = (count + 63) / 64;
-    int blocks = (int)std::min<int64_t>((waves + 3) / 4, 2048);  // 256 CUs x 8 blocks x 4 waves
+    int blocks = (int)std::min<int64_t>((waves + 3) / 4, sgd_blocks(2048));  // 256 CUs x 8 blocks x 4 waves
     const uint64_t ub = (uint64_t)ctx->nU * ctx->ld * 4, vb = (uint64_t)ctx->nI * ctx->ld * 4;
     int pol = sgd_policy();
     if (ub >= (1ull << 32) || vb >= (1ull << 32)) pol = 0;  // buffer descriptors address 4 GiB
@@ -274,3 +356,4 @@ int mfx_launch_sgd(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_t c
 int mfx_launch_sgd_users(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t nusers) {
   return launch_any(ctx, o, 0, 0, nusers);
 }
+int mfx_launch_sgd_tiled(mfx_ctx* ctx, const mfx_sgd_opts* o) { return launch_any(ctx, o, 0, 0, 0); }

@@ -11,7 +11,8 @@ extern "C" {
 typedef struct mfh_synth mfh_synth;
 mfh_synth* mfh_synth_create(int32_t nUsers, int32_t nItems, int64_t nnz, uint32_t seed, double alpha_u,
                             double alpha_i, double noise, int32_t K0, double frac_train, double frac_val,
-                            uint32_t shard /* user-block id: items depend on seed only */);
+                            uint32_t shard /* user-block id: items depend on seed only */,
+                            double r0_u, double r0_i /* Zipf-Mandelbrot rank offsets */);
 void mfh_synth_free(mfh_synth* s);
 int mfh_synth_shape(const mfh_synth* s, int which, int32_t* nrows, int32_t* ncols, int64_t* nnz);
 int mfh_synth_copy(const mfh_synth* s, int which, int64_t* rowptr, int32_t* rowind, float* rowval);

@@ -47,13 +47,16 @@ struct Csr {
   std::vector<float> rowval;
 };
 
-// power-law weights over a random ranking of n objects
-std::vector<double> powerlaw(int64_t n, double alpha, uint64_t seed) {
+// Zipf-Mandelbrot weights (rank + r0)^-alpha over a random ranking of n objects.  The
+// defaults in matfac_amd/synth.py are fitted to MovieLens-20M's published marginals
+// (most-rated movie ~0.34 % of the ratings, median movie ~18 ratings; users 20..9254,
+// median 68), so that the Hogwild conflict pattern is the real one.
+std::vector<double> powerlaw(int64_t n, double alpha, double r0, uint64_t seed) {
   std::vector<std::pair<uint64_t, int64_t>> key(n);
   for (int64_t i = 0; i < n; i++) key[i] = {hash2(seed, (uint64_t)i), i};
   std::sort(key.begin(), key.end());
   std::vector<double> w(n);
-  for (int64_t r = 0; r < n; r++) w[key[r].second] = 1.0 / std::pow((double)(r + 1), alpha);
+  for (int64_t r = 0; r < n; r++) w[key[r].second] = 1.0 / std::pow((double)(r + 1) + r0, alpha);
   return w;
 }
 }  // namespace
@@ -65,21 +68,30 @@ struct mfh_synth {
 
 extern "C" mfh_synth* mfh_synth_create(int32_t nU, int32_t nI, int64_t nnz, uint32_t seed, double alpha_u,
                                        double alpha_i, double noise, int32_t K0, double frac_train,
-                                       double frac_val, uint32_t shard) {
+                                       double frac_val, uint32_t shard, double r0_u, double r0_i) {
   if (nU <= 0 || nI <= 1 || nnz < nU || K0 <= 0) return nullptr;
   const int64_t dmax = std::max<int64_t>(1, nI / 2);
   nnz = std::min<int64_t>(nnz, (int64_t)nU * dmax);
   mfh_synth* S = new mfh_synth;
 
-  // ---- user degrees: power law, every user >= 1, exact total ----------------
+  // ---- user degrees: floor + log-normal, exact total --------------------------
+  // MovieLens-20M users: min 20, median 68, mean 144, max 9254  ==  20 + lognormal with
+  // sigma ~1.38; alpha_u is that sigma, r0_u the floor as a fraction of the mean degree.
   const uint64_t useed = hash2(seed, 0x1000ULL + shard);  // per-user streams: (seed, shard)
-  std::vector<double> wu = powerlaw(nU, alpha_u, hash2(useed, 11));
+  const double mean_deg = (double)nnz / (double)nU;
+  const int64_t dmin = std::max<int64_t>(1, (int64_t)std::floor(r0_u * mean_deg));
+  std::vector<double> wu(nU);
   double W = 0;
-  for (double x : wu) W += x;
+  for (int32_t u = 0; u < nU; u++) {
+    Rng r(hash2(useed, 11ULL * 1315423911ULL + (uint64_t)u));
+    wu[u] = std::exp(alpha_u * r.normal());
+    W += wu[u];
+  }
   std::vector<int64_t> deg(nU);
   int64_t tot = 0;
+  const double spare = std::max(0.0, (double)nnz - (double)dmin * nU);
   for (int32_t u = 0; u < nU; u++) {
-    int64_t d = (int64_t)std::floor(wu[u] / W * (double)nnz);
+    int64_t d = dmin + (int64_t)std::floor(wu[u] / W * spare);
     d = std::min(std::max<int64_t>(d, 1), dmax);
     deg[u] = d;
     tot += d;
@@ -100,7 +112,7 @@ extern "C" mfh_synth* mfh_synth_create(int32_t nU, int32_t nI, int64_t nnz, uint
     }
   }
   // ---- item popularity cdf ---------------------------------------------------
-  std::vector<double> wi = powerlaw(nI, alpha_i, hash2(seed, 23));
+  std::vector<double> wi = powerlaw(nI, alpha_i, r0_i, hash2(seed, 23));
   std::vector<double> cdf(nI);
   {
     double c = 0, Wi = 0;

@@ -10,11 +10,11 @@ MAT_TRAIN, MAT_VAL, MAT_TEST = 0, 1, 2
 ROWMAJOR, COLMAJOR = 0, 1
 SNAP_CURRENT, SNAP_BEST = 0, 1
 SIDE_USERS, SIDE_ITEMS = 0, 1
-SGD_HOGWILD, SGD_SERIAL, SGD_USERS = 0, 1, 2
+SGD_HOGWILD, SGD_SERIAL, SGD_USERS, SGD_TILED = 0, 1, 2, 3
 ORDER_DEVICE, ORDER_HOST, ORDER_NATURAL = 0, 1, 2
 ARITH_REF64, ARITH_REF64F, ARITH_F32 = 0, 1, 2
 REDUCE_DELTA_SUM, REDUCE_AVERAGE = 0, 1
-K_SGD, K_PERMUTE, K_EVAL, K_ALS_GRAM, K_ALS_SOLVE, K_CCD_ROW, K_CCD_COL, K_CCD_RESID = range(8)
+K_SGD, K_PERMUTE, K_EVAL, K_ALS_GRAM, K_ALS_SOLVE, K_CCD_ROW, K_CCD_COL, K_CCD_RESID, K_SGD_SWEEP = range(9)
 E_NODEVICE = -6
 
 

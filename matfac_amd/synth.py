@@ -53,7 +53,7 @@ def _host():
         _lib = C.CDLL(path)
         _lib.mfh_synth_create.restype = C.c_void_p
         _lib.mfh_synth_create.argtypes = [C.c_int32, C.c_int32, C.c_int64, C.c_uint32, C.c_double, C.c_double,
-                                          C.c_double, C.c_int32, C.c_double, C.c_double, C.c_uint32]
+                                          C.c_double, C.c_int32, C.c_double, C.c_double, C.c_uint32, C.c_double, C.c_double]
         _lib.mfh_synth_free.argtypes = [C.c_void_p]
         _lib.mfh_synth_shape.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.mfh_synth_copy.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -62,13 +62,17 @@ def _host():
     return _lib
 
 
-def make(shape="C2", seed=1, scale=1.0, alpha_u=0.9, alpha_i=1.0, noise=0.5, K0=16, frac=(0.8, 0.1), shard=0):
+def make(shape="C2", seed=1, scale=1.0, alpha_u=1.38, alpha_i=2.3, noise=0.5, K0=16, frac=(0.8, 0.1), shard=0,
+         r0_u=0.1385, r0_i=0.01):
     """Generate + split with the C++ generator (matfac_amd/host/synth.cpp).  Returns a dict
-    with full/train/val/test CSR (all with nUsers rows), nUsers, nItems (datastruct.cpp:91), K."""
+    with full/train/val/test CSR (all with nUsers rows), nUsers, nItems (datastruct.cpp:91), K.
+    User degrees are floor + log-normal (sigma alpha_u, floor r0_u * mean), item popularity is
+    Zipf-Mandelbrot (rank + r0_i*nItems)^-alpha_i, both fitted to the MovieLens-20M marginals (see matfac_amd/host/synth.cpp)."""
     s = SHAPES[shape] if isinstance(shape, str) else shape
     lib = _host()
     nnz = max(int(s["nnz"] * scale), s["nU"])
-    h = lib.mfh_synth_create(s["nU"], s["nI"], nnz, seed, alpha_u, alpha_i, noise, K0, frac[0], frac[1], shard)
+    h = lib.mfh_synth_create(s["nU"], s["nI"], nnz, seed, alpha_u, alpha_i, noise, K0, frac[0], frac[1], shard,
+                             r0_u, r0_i * s["nI"])
     if not h:
         raise ValueError("mfh_synth_create rejected the shape %r" % (s,))
     try:

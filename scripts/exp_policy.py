@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def child(policy, epochs, scale, K):
+def child(policy, epochs, scale, K, mode=0, lr=0.0025):
     import numpy as np
     from matfac_amd import Ctx, mfx, synth
     shape = dict(synth.SHAPES["C2"])
@@ -28,13 +28,13 @@ def child(policy, epochs, scale, K):
     ctx.prof_enable(True)
     traj = []
     for ep in range(epochs):
-        ctx.sgd_epoch(0.005, 0.01, 0.01, seed=1, epoch=ep)
+        ctx.sgd_epoch(lr, 0.01, 0.01, mode=mode, seed=1, epoch=ep)
         traj.append((ctx.rmse(mfx.MAT_TRAIN), ctx.rmse(mfx.MAT_VAL)))
     ms, n = ctx.prof_get(mfx.K_SGD)
     pms, _ = ctx.prof_get(mfx.K_PERMUTE)
     ems, en = ctx.prof_get(mfx.K_EVAL)
-    print(json.dumps(dict(policy=policy, nnz=tr.nnz, sgd_ms=ms / n, perm_ms=pms / n, eval_ms=ems / en,
-                          gups=tr.nnz / (ms / n) / 1e6, traj=traj)))
+    print(json.dumps(dict(policy=policy, mode=mode, blocks=os.environ.get('MFX_SGD_BLOCKS',''), nnz=tr.nnz, sgd_ms=ms / n, perm_ms=pms / n, eval_ms=ems / en,
+                          gups=tr.nnz * epochs / ms / 1e6, traj=traj)))
 
 
 def cpu(epochs, scale, K):
@@ -55,7 +55,7 @@ def cpu(epochs, scale, K):
     t0 = time.time()
     for ep in range(epochs):
         mt.shuffle_u64(order)
-        orc.sgd_pass(U, V, ru, tr.rowind, tr.rowval, order, 0.005, 0.01, 0.01, orc.ARITH_REF64, orc.DOT_SEQ)
+        orc.sgd_pass(U, V, ru, tr.rowind, tr.rowval, order, float(os.environ.get('LR', '0.0025')), 0.01, 0.01, orc.ARITH_REF64, orc.DOT_SEQ)
         a, _, _ = orc.rmse(U, V, nU, nI, tr.nrows, tr.rowptr, tr.rowind, tr.rowval, invU, invI)
         b, _, _ = orc.rmse(U, V, nU, nI, va.nrows, va.rowptr, va.rowind, va.rowval, invU, invI)
         traj.append((a, b))
@@ -64,14 +64,17 @@ def cpu(epochs, scale, K):
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "child":
-        child(int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]), int(sys.argv[5]))
+        child(int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), float(sys.argv[7]))
     elif len(sys.argv) > 1 and sys.argv[1] == "cpu":
         cpu(int(sys.argv[2]), float(sys.argv[3]), int(sys.argv[4]))
     else:
         epochs, scale, K = int(os.environ.get("EPOCHS", 12)), float(os.environ.get("SCALE", 1.0)), 64
-        for pol in os.environ.get("POLICIES", "0,1,2,3,4").split(","):
-            env = dict(os.environ, MFX_SGD_POLICY=pol)
-            subprocess.run([sys.executable, __file__, "child", pol, str(epochs), str(scale), str(K)], env=env, check=False)
+        lr = os.environ.get("LR", "0.0025")
+        # CONFIGS: mode:policy:blocks triples
+        for cfg in os.environ.get("CONFIGS", "0:0:2048,0:1:2048,3:0:2048").split(","):
+            mode, pol, blocks = cfg.split(":")
+            env = dict(os.environ, MFX_SGD_POLICY=pol, MFX_SGD_BLOCKS=blocks)
+            subprocess.run([sys.executable, __file__, "child", pol, str(epochs), str(scale), str(K), mode, lr], env=env, check=False)
             sys.stdout.flush()
         if os.environ.get("CPU", "1") == "1":
             subprocess.run([sys.executable, __file__, "cpu", str(epochs), str(scale), str(K)], check=False)

@@ -44,6 +44,56 @@ def test_hogwild_conflict_free_batch_bit_exact(K, arith):
     assert np.array_equal(V, Vo)
 
 
+@pytest.mark.parametrize("K", [10, 64, 256])
+def test_tiled_conflict_free_batch_bit_exact(K):
+    n = 3000
+    tr = _conflict_free_matrix(n, K, seed=K + 1)
+    rng = np.random.default_rng(200 + K)
+    U0 = rng.normal(0, 0.3, (n, K)).astype(np.float32)
+    V0 = rng.normal(0, 0.3, (n, K)).astype(np.float32)
+    with Ctx(0) as ctx:
+        ctx.set_csr(mfx.MAT_TRAIN, n, n, tr.rowptr, tr.rowind, tr.rowval)
+        ctx.set_model(n, n, K)
+        ctx.set_factors(U0, V0)
+        ctx.sgd_epoch(0.01, 0.05, 0.02, mode=mfx.SGD_TILED, order=mfx.ORDER_DEVICE, arith=mfx.ARITH_REF64, seed=3, epoch=1)
+        U, V = ctx.get_factors()
+        u, i, r = ctx.debug_epoch_list()
+    Uo, Vo = U0.copy(), V0.copy()
+    orc.sgd_pass(Uo, Vo, tr.rowids(), tr.rowind, tr.rowval, None, 0.01, 0.05, 0.02, orc.ARITH_REF64, orc.DOT_TREE)
+    assert np.array_equal(U, Uo) and np.array_equal(V, Vo)     # every rating visited exactly once
+    assert np.array_equal(np.sort(u), np.arange(n))
+
+
+def test_tiled_epoch_list_is_tile_grouped_permutation():
+    d = small(nU=700, nI=500, nnz=30000, K=16, seed=2)
+    tr = d["train"]
+    K = 16
+    U0, V0 = orc.init_factors(1, d["nUsers"], d["nItems"], K)
+    key = tr.rowids().astype(np.int64) * tr.ncols + tr.rowind
+    lists = []
+    with Ctx(0) as ctx:
+        load_ctx(ctx, d, K, U0, V0)
+        for ep in range(2):
+            ctx.sgd_epoch(0.0, 0.0, 0.0, mode=mfx.SGD_TILED, order=mfx.ORDER_DEVICE, seed=5, epoch=ep)
+            u, i, r = ctx.debug_epoch_list()
+            k = u.astype(np.int64) * tr.ncols + i
+            assert np.array_equal(np.sort(k), np.sort(key))
+            lists.append((u, i))
+        U, V = ctx.get_factors()
+    assert np.array_equal(U, U0) and np.array_equal(V, V0)
+    assert not np.array_equal(lists[0][0], lists[1][0])
+    # inside the list the (user block, item block) tile id is non-decreasing: 64 contiguous tiles
+    def mix(x):
+        x = x.astype(np.uint64) & 0xffffffff
+        x ^= x >> 16; x = (x * 0x7feb352d) & 0xffffffff; x ^= x >> 15; x = (x * 0x846ca68b) & 0xffffffff; x ^= x >> 16
+        return x
+    u, i = lists[0]
+    bu = mix((u.astype(np.uint64) * 0x9e3779b1 + 0x1234567) & 0xffffffff) & 7
+    bi = mix((i.astype(np.uint64) * 0x85ebca6b + 0x89abcde) & 0xffffffff) & 7
+    tile = (bu * 8 + bi).astype(np.int64)
+    assert np.all(np.diff(tile) >= 0)
+
+
 @pytest.mark.parametrize("K", [10, 64, 128])
 @pytest.mark.parametrize("arith", ARITHS)
 def test_serial_epochs_bit_exact(K, arith):
