@@ -120,6 +120,11 @@ typedef struct {
   float learnRate, uReg, iReg;
   uint32_t seed;       /* MFX_ORDER_DEVICE: permutation key (with epoch)        */
   int32_t epoch;
+  int32_t blocks;      /* HOGWILD/TILED: 256-thread workgroups in flight (each keeps
+                          4*64/L ratings in flight); 0 = auto: min(nUsers,nItems)/64
+                          clamped to [8,2048] -- lock-free SGD loses updates when the
+                          ratings in flight are not << min(nUsers,nItems)            */
+  int32_t reserved;
   int64_t first, count; /* sub-range of the epoch list; count <= 0: everything  */
 } mfx_sgd_opts;
 /* Permutation of the train ratings (indices into the CSR-order rating list with

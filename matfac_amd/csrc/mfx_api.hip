@@ -530,6 +530,11 @@ extern "C" int mfx_sgd_epoch(mfx_ctx* ctx, const mfx_sgd_opts* o) {
       const uint32_t k0 = mfx_mix32(o->seed ^ 0x3c6ef372U) + (uint32_t)o->epoch * 0x9e3779b9U;
       const uint32_t k1 = mfx_mix32(o->seed * 0x85ebca6bU + 0xdaa66d2bU) ^ mfx_mix32((uint32_t)o->epoch + 0x1b873593U);
       const int blocks = (int)std::min<int64_t>((n + 255) / 256, 8192);
+      if (tiled_variant() & 1) {  // experiment: keep the tile lists in their stored (user-major) order
+        HIPCHK(hipMemcpyAsync(ctx->eu, ctx->tu, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->ei, ctx->ti, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->er, ctx->tr, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+      } else
       hipLaunchKernelGGL(build_tiled_epoch_list_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ctx->tu, ctx->ti,
                          ctx->tr, ctx->tile_start, n, k0, k1, ctx->eu, ctx->ei, ctx->er);
       HIPCHK(hipGetLastError());

@@ -140,6 +140,7 @@ static inline void mfx_tree_shape(int K, int* L, int* C) {
 int mfx_launch_sgd(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_t count);
 int mfx_launch_sgd_users(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t nusers);
 int mfx_launch_sgd_tiled(mfx_ctx* ctx, const mfx_sgd_opts* o);
+int tiled_variant();  // experiment knob MFX_TILED_VARIANT
 int mfx_launch_eval(mfx_ctx* ctx, const DevCSR& m, const float* U, const float* V,
                     int with_norms, mfx_eval_out* out);
 int mfx_comm_free_internal(mfx_ctx* ctx);

@@ -73,14 +73,15 @@ __device__ __forceinline__ float upd_f32(float x, float y, float c1, float c2, f
   return x - lr * (c1 * y + c2 * x);
 }
 
-template <int L, int C, int ARITH, int POL>
+template <int L, int C, int ARITH, int POL, bool QATOM = false>
 __device__ __forceinline__ void sgd_visit(const Rows<POL>& Um, const Rows<POL>& Vm, int64_t pe, int64_t qe,
                                           float r, float lr, float uReg, float iReg) {
-  float4v p[C], q[C];
+  float4v p[C], q[C], q0[C];
 #pragma unroll
   for (int c = 0; c < C; c++) {
     p[c] = Um.ld(pe + c * 4 * L);
     q[c] = Vm.ld(qe + c * 4 * L);
+    q0[c] = q[c];
   }
   const float est = group_dot<L, C>(p, q);
   if (ARITH == MFX_ARITH_F32) {
@@ -111,13 +112,17 @@ __device__ __forceinline__ void sgd_visit(const Rows<POL>& Um, const Rows<POL>& 
 #pragma unroll
   for (int c = 0; c < C; c++) {
     Um.st(pe + c * 4 * L, p[c]);
-    Vm.st(qe + c * 4 * L, q[c]);
+    if (!QATOM) Vm.st(qe + c * 4 * L, q[c]);
+    else {
+#pragma unroll
+      for (int e = 0; e < 4; e++) atomicAdd(Vm.base + qe + c * 4 * L + e, q[c][e] - q0[c][e]);
+    }
   }
 }
 
 // One 64-rating chunk of the epoch list: coalesced SoA read by the whole wave, then the
 // chunk is walked G ratings at a time (group g takes entries g, G+g, 2G+g, ...).
-template <int L, int C, int ARITH, int POL>
+template <int L, int C, int ARITH, int POL, int VAR = 0>
 __device__ __forceinline__ void sgd_chunk(const Rows<POL>& Um, const Rows<POL>& Vm,
                                           const int32_t* __restrict__ eu, const int32_t* __restrict__ ei,
                                           const float* __restrict__ er, int64_t idx0, int nvalid, int lane,
@@ -131,12 +136,13 @@ __device__ __forceinline__ void sgd_chunk(const Rows<POL>& Um, const Rows<POL>& 
   const float mr = ok ? er[idx0 + lane] : 0.0f;
 #pragma unroll 1
   for (int s = 0; s < L; s++) {
-    const int e = s * G + g;
+    const int e = (VAR & 4) ? g * L + s : s * G + g;
     const int u = __shfl(mu, e, 64);
     const int it = __shfl(mi, e, 64);
     const float r = __shfl(mr, e, 64);
     if (e < nvalid)
-      sgd_visit<L, C, ARITH, POL>(Um, Vm, (int64_t)u * LD + 4 * j, (int64_t)it * LD + 4 * j, r, lr, uReg, iReg);
+      sgd_visit<L, C, ARITH, POL, (VAR & 2) != 0>(Um, Vm, (int64_t)u * LD + 4 * j, (int64_t)it * LD + 4 * j, r, lr,
+                                                  uReg, iReg);
   }
 }
 
@@ -167,7 +173,7 @@ __global__ __launch_bounds__(256) void sgd_hogwild_kernel(const int32_t* __restr
 // tile from a per-tile counter, so the result does not depend on how many workgroups
 // the dispatcher put on each XCD; round = -1 sweeps whatever is left in ANY tile, which
 // makes "every rating exactly once per epoch" independent of placement altogether.
-template <int L, int C, int ARITH, bool SWEEP>
+template <int L, int C, int ARITH, bool SWEEP, int VAR = 0>
 __global__ __launch_bounds__(256) void sgd_tiled_kernel(const int32_t* __restrict__ eu,
                                                         const int32_t* __restrict__ ei,
                                                         const float* __restrict__ er,
@@ -193,7 +199,7 @@ __global__ __launch_bounds__(256) void sgd_tiled_kernel(const int32_t* __restric
         const int64_t cb = base + (int64_t)c * 64;
         if (cb >= sz) break;
         const int nvalid = (int)(sz - cb < 64 ? sz - cb : 64);
-        sgd_chunk<L, C, ARITH, 3>(Um, Vm, eu, ei, er, b + cb, nvalid, lane, lr, uReg, iReg);
+        sgd_chunk<L, C, ARITH, 3, VAR>(Um, Vm, eu, ei, er, b + cb, nvalid, lane, lr, uReg, iReg);
       }
     }
   }
@@ -249,14 +255,21 @@ __global__ __launch_bounds__(256) void sgd_users_kernel(const int32_t* __restric
 // ---------------------------------------------------------------------------
 // experiment knob: number of 256-thread workgroups of the Hogwild kernels (in-flight ratings
 // = blocks * 4 waves * 64/L); default fills the chip (256 CUs x 8 blocks).
-static int sgd_blocks(int dflt) {
+static int sgd_blocks(const mfx_ctx* ctx, const mfx_sgd_opts* o) {
   static int b = -1;
   if (b < 0) {
     const char* e = getenv("MFX_SGD_BLOCKS");
     b = e ? atoi(e) : 0;
     if (b < 0) b = 0;
   }
-  return b > 0 ? b : dflt;
+  if (b > 0) return b;
+  if (o->blocks > 0) return std::min(o->blocks, 8192);
+  return std::max(8, std::min(2048, std::min(ctx->nU, ctx->nI) / 64));
+}
+int tiled_variant() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("MFX_TILED_VARIANT"); v = e ? atoi(e) : 0; }
+  return v;
 }
 static int sgd_policy() {
   static int pol = -1;
@@ -274,12 +287,21 @@ static int launch_lca(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_
     if (ub >= (1ull << 32) || vb >= (1ull << 32))
       return mfx_fail(ctx, MFX_E_ARG, "MFX_SGD_TILED: a factor matrix exceeds 4 GiB (buffer addressing)");
     HIPCHK(hipMemsetAsync(ctx->tile_ctr, 0, 64 * sizeof(unsigned long long), ctx->stream));
-    const int blocks = sgd_blocks(2048);
+    const int blocks = sgd_blocks(ctx, o);
+    const int var = tiled_variant();
     for (int round = 0; round < 8; round++) {   // 8 XCD-local rounds
       ProfScope ps(ctx, MFX_K_SGD);
-      hipLaunchKernelGGL((sgd_tiled_kernel<L, C, ARITH, false>), dim3(blocks), dim3(256), 0, ctx->stream, ctx->eu,
-                         ctx->ei, ctx->er, ctx->tile_start, ctx->tile_ctr, round, ctx->U, ctx->V, (uint32_t)ub,
-                         (uint32_t)vb, o->learnRate, o->uReg, o->iReg);
+#define MFX_LAUNCH_TILED(VV)                                                                                     \
+  hipLaunchKernelGGL((sgd_tiled_kernel<L, C, ARITH, false, VV>), dim3(blocks), dim3(256), 0, ctx->stream, ctx->eu, \
+                     ctx->ei, ctx->er, ctx->tile_start, ctx->tile_ctr, round, ctx->U, ctx->V, (uint32_t)ub,      \
+                     (uint32_t)vb, o->learnRate, o->uReg, o->iReg)
+      switch (var & 6) {
+        case 2: MFX_LAUNCH_TILED(2); break;
+        case 4: MFX_LAUNCH_TILED(4); break;
+        case 6: MFX_LAUNCH_TILED(6); break;
+        default: MFX_LAUNCH_TILED(0); break;
+      }
+#undef MFX_LAUNCH_TILED
     }
     {  // placement-independent sweep of whatever the rounds left
       ProfScope ps(ctx, MFX_K_SGD_SWEEP);
@@ -303,7 +325,7 @@ static int launch_lca(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_
                        nusers, m.rowptr, m.rowind, m.rowval, ctx->U, ctx->V, o->learnRate, o->uReg, o->iReg);
   } else {
     int64_t waves = (count + 63) / 64;
-    int blocks = (int)std::min<int64_t>((waves + 3) / 4, sgd_blocks(2048));  // 256 CUs x 8 blocks x 4 waves
+    int blocks = (int)std::min<int64_t>((waves + 3) / 4, sgd_blocks(ctx, o));
     const uint64_t ub = (uint64_t)ctx->nU * ctx->ld * 4, vb = (uint64_t)ctx->nI * ctx->ld * 4;
     int pol = sgd_policy();
     if (ub >= (1ull << 32) || vb >= (1ull << 32)) pol = 0;  // buffer descriptors address 4 GiB

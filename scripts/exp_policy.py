@@ -33,7 +33,7 @@ def child(policy, epochs, scale, K, mode=0, lr=0.0025):
     ms, n = ctx.prof_get(mfx.K_SGD)
     pms, _ = ctx.prof_get(mfx.K_PERMUTE)
     ems, en = ctx.prof_get(mfx.K_EVAL)
-    print(json.dumps(dict(policy=policy, mode=mode, blocks=os.environ.get('MFX_SGD_BLOCKS',''), nnz=tr.nnz, sgd_ms=ms / n, perm_ms=pms / n, eval_ms=ems / en,
+    print(json.dumps(dict(policy=policy, mode=mode, blocks=os.environ.get('MFX_SGD_BLOCKS',''), var=os.environ.get('MFX_TILED_VARIANT',''), nnz=tr.nnz, sgd_ms=ms / n, perm_ms=pms / n, eval_ms=ems / en,
                           gups=tr.nnz * epochs / ms / 1e6, traj=traj)))
 
 
@@ -72,8 +72,9 @@ if __name__ == "__main__":
         lr = os.environ.get("LR", "0.0025")
         # CONFIGS: mode:policy:blocks triples
         for cfg in os.environ.get("CONFIGS", "0:0:2048,0:1:2048,3:0:2048").split(","):
-            mode, pol, blocks = cfg.split(":")
-            env = dict(os.environ, MFX_SGD_POLICY=pol, MFX_SGD_BLOCKS=blocks)
+            mode, pol, blocks = cfg.split(":")[:3]
+            var = cfg.split(":")[3] if cfg.count(":") >= 3 else "0"
+            env = dict(os.environ, MFX_SGD_POLICY=pol, MFX_SGD_BLOCKS=blocks, MFX_TILED_VARIANT=var)
             subprocess.run([sys.executable, __file__, "child", pol, str(epochs), str(scale), str(K), mode, lr], env=env, check=False)
             sys.stdout.flush()
         if os.environ.get("CPU", "1") == "1":

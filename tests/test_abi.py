@@ -42,7 +42,7 @@ def test_header_is_plain_c():
 
 
 def test_struct_layouts_match_ctypes():
-    assert C.sizeof(mfx.SgdOpts) == 48
+    assert C.sizeof(mfx.SgdOpts) == 56
     assert C.sizeof(mfx.EvalOut) == 32
 
 
