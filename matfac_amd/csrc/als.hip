@@ -1,7 +1,329 @@
-// als.hip -- placeholder until the MFMA Gramian + batched solve kernels land.
+// als.hip -- ALS half-sweep for gfx950: per-row gathered Gramian on the f32 MFMA
+// (v_mfma_f32_32x32x2_f32, exact fp32 fma chain) + in-register LDL^T solve.
+//
+// Replaces ModelMF::trainALS' two loops (modelMF.cpp:805-841 users, :844-880 items):
+//   A = sum_{j in row, r>0} y_j y_j^T  (full K x K, both triangles),  b = sum r y_j,
+//   A_jj += reg (not degree-scaled),  x = A^-1 b   (Eigen: YTY.ldlt().solve(b)).
+//
+// One wavefront per row segment.  Two ratings enter each MFMA step (k = 2): lanes 0-31
+// carry y_j of the even rating, lanes 32-63 of the odd one; four 32x32 accumulator
+// tiles hold the 64x64 Gramian (K <= 64, zero padded).  Rows longer than SEG ratings
+// are split into segments whose partial (A,b) go to a slab and are summed in segment
+// order by a second launch, so a 50k-rating item does not serialise the sweep.
+// After accumulation lanes l and l^32 swap half-columns so that lane i owns row i of A
+// (= column i, A is symmetric); the factorisation then runs entirely in registers with
+// v_readlane broadcasts of the pivot row: no LDS, no pivoting (A + reg*I is SPD; Eigen's
+// LDLT pivots on the diagonal, which changes round-off only -- see DESIGN.md).
+#include <algorithm>
+#include <vector>
+
 #include "mfx_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+constexpr int SEG = 1024;         // ratings per segment
+constexpr int SLAB = 66 * 64;     // floats per partial: 4 tiles x 16 regs + 2 rhs, per lane
+
+struct AlsSide {
+  int32_t* seg_row = nullptr;     // row of each segment
+  int64_t* seg_beg = nullptr;
+  int64_t* seg_end = nullptr;
+  int32_t* seg_slab = nullptr;    // slab index, or -1 when the row is a single segment
+  int32_t* mrow = nullptr;        // rows with several segments
+  int32_t* mrow_first = nullptr;  // first slab of such a row
+  int32_t* mrow_n = nullptr;      // number of slabs
+  int64_t nseg = 0, nmrow = 0, nslab = 0;
+  bool built = false;
+};
+struct AlsState {
+  AlsSide side[2];
+  float* slabs = nullptr;
+  int64_t slab_cap = 0;
+};
+}  // namespace
+
+// kept outside mfx_ctx's header to avoid dragging this file's types around
+static AlsState* als_state(mfx_ctx* ctx) { return (AlsState*)ctx->als; }
+
+__device__ __forceinline__ float rdlane(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+struct GramAcc {
+  f32x16 t[2][2];
+  float b0, b1;
+};
+
+__device__ __forceinline__ void gram_zero(GramAcc& g) {
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) g.t[i][j][r] = 0.0f;
+  g.b0 = g.b1 = 0.0f;
+}
+
+// accumulate ratings [beg,end) of one row: ind[] = counterpart index, val[] = rating
+__device__ __forceinline__ void gram_accumulate(GramAcc& g, const float* __restrict__ Y,
+                                                const int32_t* __restrict__ ind,
+                                                const float* __restrict__ val, int64_t beg, int64_t end,
+                                                int lane, int ld) {
+  const int half = lane >> 5, idx = lane & 31;
+  for (int64_t base = beg; base < end; base += 64) {
+    const bool ok = base + lane < end;
+    const int mj = ok ? ind[base + lane] : 0;
+    const float mr = ok ? val[base + lane] : 0.0f;
+    const int n = (int)(end - base < 64 ? end - base : 64);
+#pragma unroll 2
+    for (int s = 0; s < n; s += 2) {
+      const int e = s + half;
+      const int j = __shfl(mj, e, 64);
+      const float r = __shfl(mr, e, 64);
+      // ratings <= 0 are skipped (modelMF.cpp:819,857); a missing odd partner contributes 0
+      const float w = (e < n && r > 0.0f) ? 1.0f : 0.0f;
+      const float* y = Y + (int64_t)j * ld;
+      const float y0 = idx < ld ? y[idx] : 0.0f, y1 = 32 + idx < ld ? y[32 + idx] : 0.0f;
+      const float a0 = w * y0, a1 = w * y1;
+      g.t[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, y0, g.t[0][0], 0, 0, 0);
+      g.t[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, y1, g.t[0][1], 0, 0, 0);
+      g.t[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, y0, g.t[1][0], 0, 0, 0);
+      g.t[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, y1, g.t[1][1], 0, 0, 0);
+      const float wr = w * r;
+      g.b0 = __builtin_fmaf(wr, y0, g.b0);
+      g.b1 = __builtin_fmaf(wr, y1, g.b1);
+    }
+  }
+}
+
+// Turn the tile layout into "lane i owns row i", add reg, solve, return x_i in lane i.
+__device__ __forceinline__ float gram_solve(const GramAcc& g, int K, float reg, int lane) {
+  const int h = lane >> 5;
+  float a[64];
+  // lane l holds, of columns c and 32+c (c = l&31), the rows whose bit 2 equals h; its
+  // partner l^32 holds the other rows.  Keep column 32h+c, trade the rest.
+#pragma unroll
+  for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const float own = h ? g.t[ti][1][r] : g.t[ti][0][r];
+      const float send = h ? g.t[ti][0][r] : g.t[ti][1][r];
+      const float recv = __shfl_xor(send, 32, 64);
+      const int I0 = 32 * ti + (r & 3) + 8 * (r >> 2);  // row with bit 2 clear; I0+4 has it set
+      a[I0] = h ? recv : own;
+      a[I0 + 4] = h ? own : recv;
+    }
+  const float bt0 = g.b0 + __shfl_xor(g.b0, 32, 64);
+  const float bt1 = g.b1 + __shfl_xor(g.b1, 32, 64);
+  float z = h ? bt1 : bt0;
+  // YTY(j,j) += reg for j < K (modelMF.cpp:831-833); padded dimensions become identity rows
+#pragma unroll
+  for (int I = 0; I < 64; I++) {
+    if (I == lane) a[I] = I < K ? a[I] + reg : 1.0f;
+  }
+  // right-looking LDL^T, row i of A in lane i
+  float d = 1.0f;
+#pragma unroll
+  for (int k = 0; k < 64; k++) {
+    const float dk = rdlane(a[k], k);
+    const float lik = a[k] / dk;
+#pragma unroll
+    for (int j = k + 1; j < 64; j++) a[j] = a[j] - lik * rdlane(a[j], k);
+    a[k] = lik;
+    if (lane == k) d = dk;
+  }
+  // L y = b
+#pragma unroll
+  for (int k = 0; k < 64; k++) {
+    const float zk = rdlane(z, k);
+    if (lane > k) z = z - a[k] * zk;
+  }
+  z = z / d;
+  // L^T x = y
+  float x = z;
+#pragma unroll
+  for (int i = 63; i >= 0; i--) {
+    const float t = lane > i ? a[i] * x : 0.0f;
+    const float s = wave_sum_f(t);
+    if (lane == i) x = x - s;
+  }
+  return x;
+}
+
+__global__ __launch_bounds__(64) void als_segment_kernel(const int32_t* __restrict__ seg_row,
+                                                         const int64_t* __restrict__ seg_beg,
+                                                         const int64_t* __restrict__ seg_end,
+                                                         const int32_t* __restrict__ seg_slab, int64_t nseg,
+                                                         const int32_t* __restrict__ ind,
+                                                         const float* __restrict__ val,
+                                                         const float* __restrict__ Y, float* __restrict__ X,
+                                                         float* __restrict__ slabs, int K, int ld, float reg) {
+  const int lane = threadIdx.x;
+  for (int64_t s = blockIdx.x; s < nseg; s += gridDim.x) {
+    GramAcc g;
+    gram_zero(g);
+    gram_accumulate(g, Y, ind, val, seg_beg[s], seg_end[s], lane, ld);
+    const int slab = seg_slab[s];
+    if (slab < 0) {
+      const float x = gram_solve(g, K, reg, lane);
+      if (lane < K) X[(int64_t)seg_row[s] * ld + lane] = x;
+    } else {
+      float* o = slabs + (int64_t)slab * SLAB + lane;
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) o[((i * 2 + j) * 16 + r) * 64] = g.t[i][j][r];
+      o[64 * 64] = g.b0;
+      o[65 * 64] = g.b1;
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void als_reduce_kernel(const int32_t* __restrict__ mrow,
+                                                        const int32_t* __restrict__ mrow_first,
+                                                        const int32_t* __restrict__ mrow_n, int64_t nmrow,
+                                                        const float* __restrict__ slabs, float* __restrict__ X,
+                                                        int K, int ld, float reg) {
+  const int lane = threadIdx.x;
+  for (int64_t m = blockIdx.x; m < nmrow; m += gridDim.x) {
+    GramAcc g;
+    gram_zero(g);
+    const int first = mrow_first[m], n = mrow_n[m];
+    for (int s = 0; s < n; s++) {  // fixed segment order: reproducible
+      const float* o = slabs + (int64_t)(first + s) * SLAB + lane;
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) g.t[i][j][r] += o[((i * 2 + j) * 16 + r) * 64];
+      g.b0 += o[64 * 64];
+      g.b1 += o[65 * 64];
+    }
+    const float x = gram_solve(g, K, reg, lane);
+    if (lane < K) X[(int64_t)mrow[m] * ld + lane] = x;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+template <typename T>
+static int upload_vec(mfx_ctx* ctx, T** dst, const std::vector<T>& v) {
+  int rc = dev_alloc(ctx, dst, v.size());
+  if (rc) return rc;
+  if (!v.empty()) HIPCHK(hipMemcpyAsync(*dst, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice, ctx->stream));
+  return MFX_OK;
+}
+
+static void free_side(AlsSide& s) {
+  dev_free(s.seg_row); dev_free(s.seg_beg); dev_free(s.seg_end); dev_free(s.seg_slab);
+  dev_free(s.mrow); dev_free(s.mrow_first); dev_free(s.mrow_n);
+  s = AlsSide();
+}
+
+void mfx_als_free_internal(mfx_ctx* ctx) {
+  AlsState* st = als_state(ctx);
+  if (!st) return;
+  free_side(st->side[0]);
+  free_side(st->side[1]);
+  dev_free(st->slabs);
+  delete st;
+  ctx->als = nullptr;
+}
+
+// Build the segment lists of one side from the device row pointers (read back once).
+static int build_side(mfx_ctx* ctx, AlsSide& sd, const int64_t* dptr, int32_t n) {
+  std::vector<int64_t> ptr((size_t)n + 1);
+  HIPCHK(hipMemcpy(ptr.data(), dptr, sizeof(int64_t) * ((size_t)n + 1), hipMemcpyDeviceToHost));
+  std::vector<int32_t> rows;
+  rows.reserve(n);
+  for (int32_t r = 0; r < n; r++)
+    if (ptr[r + 1] > ptr[r]) rows.push_back(r);  // rows without ratings are invalid: left untouched
+  std::stable_sort(rows.begin(), rows.end(),
+                   [&](int32_t a, int32_t b) { return ptr[a + 1] - ptr[a] > ptr[b + 1] - ptr[b]; });
+  std::vector<int32_t> seg_row, seg_slab, mrow, mfirst, mn;
+  std::vector<int64_t> seg_beg, seg_end;
+  int32_t nslab = 0;
+  for (int32_t r : rows) {
+    const int64_t b = ptr[r], e = ptr[r + 1], len = e - b;
+    if (len <= SEG) {
+      seg_row.push_back(r); seg_beg.push_back(b); seg_end.push_back(e); seg_slab.push_back(-1);
+    } else {
+      const int nsg = (int)((len + SEG - 1) / SEG);
+      mrow.push_back(r); mfirst.push_back(nslab); mn.push_back(nsg);
+      for (int s = 0; s < nsg; s++) {
+        seg_row.push_back(r);
+        seg_beg.push_back(b + (int64_t)s * SEG);
+        seg_end.push_back(std::min<int64_t>(e, b + (int64_t)(s + 1) * SEG));
+        seg_slab.push_back(nslab++);
+      }
+    }
+  }
+  int rc;
+  if ((rc = upload_vec(ctx, &sd.seg_row, seg_row))) return rc;
+  if ((rc = upload_vec(ctx, &sd.seg_beg, seg_beg))) return rc;
+  if ((rc = upload_vec(ctx, &sd.seg_end, seg_end))) return rc;
+  if ((rc = upload_vec(ctx, &sd.seg_slab, seg_slab))) return rc;
+  if ((rc = upload_vec(ctx, &sd.mrow, mrow))) return rc;
+  if ((rc = upload_vec(ctx, &sd.mrow_first, mfirst))) return rc;
+  if ((rc = upload_vec(ctx, &sd.mrow_n, mn))) return rc;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  sd.nseg = (int64_t)seg_row.size();
+  sd.nmrow = (int64_t)mrow.size();
+  sd.nslab = nslab;
+  sd.built = true;
+  return MFX_OK;
+}
+
 extern "C" int mfx_als_half_sweep(mfx_ctx* ctx, int side, float reg) {
-  (void)side; (void)reg;
   if (!ctx) return MFX_E_ARG;
-  return mfx_fail(ctx, MFX_E_STATE, "mfx_als_half_sweep: not implemented yet");
+  NEED(side == MFX_SIDE_USERS || side == MFX_SIDE_ITEMS, MFX_E_ARG, "mfx_als_half_sweep: side=%d", side);
+  const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
+  NEED(m.present && m.has_col, MFX_E_STATE, "mfx_als_half_sweep: train matrix with column view needed");
+  NEED(ctx->U, MFX_E_STATE, "mfx_als_half_sweep: no model");
+  NEED(ctx->K <= 64, MFX_E_ARG, "mfx_als_half_sweep: this build supports K <= 64 (got %d)", ctx->K);
+  NEED(m.nrows <= ctx->nU && m.ncols <= ctx->nI, MFX_E_ARG, "mfx_als_half_sweep: matrix exceeds model");
+  HIPCHK(hipSetDevice(ctx->device));
+  AlsState* st = als_state(ctx);
+  if (!st) { st = new AlsState; ctx->als = st; }
+  AlsSide& sd = st->side[side];
+  if (!sd.built) {
+    int rc = build_side(ctx, sd, side == MFX_SIDE_USERS ? m.rowptr : m.colptr,
+                        side == MFX_SIDE_USERS ? m.nrows : m.ncols);
+    if (rc) return rc;
+  }
+  if (sd.nslab > st->slab_cap) {
+    dev_free(st->slabs);
+    int rc = dev_alloc(ctx, &st->slabs, (size_t)sd.nslab * SLAB);
+    if (rc) return rc;
+    st->slab_cap = sd.nslab;
+  }
+  const int32_t* ind = side == MFX_SIDE_USERS ? m.rowind : m.colind;
+  const float* val = side == MFX_SIDE_USERS ? m.rowval : m.colval;
+  const float* Y = side == MFX_SIDE_USERS ? ctx->V : ctx->U;
+  float* X = side == MFX_SIDE_USERS ? ctx->U : ctx->V;
+  if (sd.nseg > 0) {
+    ProfScope ps(ctx, MFX_K_ALS_GRAM);
+    const int blocks = (int)std::min<int64_t>(sd.nseg, 256 * 16);
+    hipLaunchKernelGGL(als_segment_kernel, dim3(blocks), dim3(64), 0, ctx->stream, sd.seg_row, sd.seg_beg,
+                       sd.seg_end, sd.seg_slab, sd.nseg, ind, val, Y, X, st->slabs, ctx->K, ctx->ld, reg);
+    HIPCHK(hipGetLastError());
+  }
+  if (sd.nmrow > 0) {
+    ProfScope ps(ctx, MFX_K_ALS_SOLVE);
+    const int blocks = (int)std::min<int64_t>(sd.nmrow, 256 * 16);
+    hipLaunchKernelGGL(als_reduce_kernel, dim3(blocks), dim3(64), 0, ctx->stream, sd.mrow, sd.mrow_first,
+                       sd.mrow_n, sd.nmrow, st->slabs, X, ctx->K, ctx->ld, reg);
+    HIPCHK(hipGetLastError());
+  }
+  return MFX_OK;
 }

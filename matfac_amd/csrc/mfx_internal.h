@@ -70,9 +70,8 @@ struct mfx_ctx {
   float *res_row = nullptr, *res_col = nullptr, *uk = nullptr, *vk = nullptr;
   bool ccd_active = false;
 
-  // ALS scratch
-  float* als_A = nullptr;    // [rows_in_batch][K*K] Gramians + rhs
-  int64_t als_cap = 0;
+  // ALS segment lists + partial-Gramian slabs (als.hip owns the type)
+  void* als = nullptr;
 
   // comm
   void* comm = nullptr;      // ncclComm_t
@@ -145,5 +144,6 @@ int mfx_launch_eval(mfx_ctx* ctx, const DevCSR& m, const float* U, const float* 
                     int with_norms, mfx_eval_out* out);
 int mfx_comm_free_internal(mfx_ctx* ctx);
 void mfx_ccd_free_internal(mfx_ctx* ctx);
+void mfx_als_free_internal(mfx_ctx* ctx);
 
 #endif

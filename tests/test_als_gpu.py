@@ -1,0 +1,112 @@
+"""GPU parity of the ALS half-sweep (MFMA Gramian + in-register LDL^T) against the oracle's
+restatement of modelMF.cpp:805-880 (scalar Gramian + Eigen-style pivoted LDLT).
+
+fp32 tolerance: both sides solve (Q^T Q + reg I) x = Q^T r in fp32 with different but backward
+stable algorithms, so they agree to ~eps * cond(A); the tests bound the row-wise relative error by
+that and check the normal-equation residual of the GPU result in float64."""
+import numpy as np
+import pytest
+
+from matfac_amd import Ctx, mfx, synth
+from oracle import binding as orc
+from tests.util import load_ctx
+
+pytestmark = pytest.mark.gpu
+
+
+def _data(nU, nI, nnz, seed):
+    d = synth.make(dict(nU=nU, nI=nI, nnz=nnz, K=0), seed=seed)
+    tr = d["train"]
+    cp, ci, cv = orc.create_col_index(tr.nrows, tr.ncols, tr.rowptr, tr.rowind, tr.rowval)
+    return d, tr, (cp, ci, cv)
+
+
+@pytest.mark.parametrize("K,reg", [(64, 5.0), (64, 0.5), (64, 0.05), (32, 1.0), (10, 1.0), (48, 2.0)])
+def test_half_sweeps_match_oracle(K, reg):
+    d, tr, (cp, ci, cv) = _data(1500, 400, 60000, seed=K)
+    nU, nI = d["nUsers"], d["nItems"]
+    rng = np.random.default_rng(K)
+    U0 = rng.normal(0, 0.3, (nU, K)).astype(np.float32)
+    V0 = rng.normal(0, 0.3, (nI, K)).astype(np.float32)
+    assert np.bincount(tr.rowind).max() > 1024        # exercises the split-row (slab) path
+    with Ctx(0) as ctx:
+        invU, invI = load_ctx(ctx, d, K, U0, V0)
+        ctx.als_half_sweep(mfx.SIDE_USERS, reg)
+        U1, V1 = ctx.get_factors()
+        ctx.als_half_sweep(mfx.SIDE_ITEMS, reg)
+        U2, V2 = ctx.get_factors()
+    assert np.array_equal(V1, V0) and np.array_equal(U2, U1)
+    Uo, Vo = U0.copy(), V0.copy()
+    orc.als_half(0, Uo, Vo, tr.nrows, tr.rowptr, tr.rowind, tr.rowval, invU, reg, nthreads=4)
+    # users: relative error per row
+    scale = np.maximum(np.linalg.norm(Uo, axis=1), 1e-6)
+    relu = np.linalg.norm(U1 - Uo, axis=1) / scale
+    # cond(A) <= (sigma_max^2 + reg)/reg ; eps = 6e-8 ; generous constant
+    tol = 2e-4 if reg >= 0.5 else 5e-3
+    assert relu.max() < tol, relu.max()
+    orc.als_half(1, Vo, U1, tr.ncols, cp, ci, cv, invI, reg, nthreads=4)   # items from the GPU's users
+    scale = np.maximum(np.linalg.norm(Vo, axis=1), 1e-6)
+    reli = np.linalg.norm(V2[:tr.ncols] - Vo[:tr.ncols], axis=1) / scale[:tr.ncols]
+    assert reli.max() < tol, reli.max()
+    # invalid rows keep their old factors (modelMF.cpp:809-811, 847-849)
+    assert np.array_equal(U1[invU.astype(bool)], U0[invU.astype(bool)])
+    assert np.array_equal(V2[invI.astype(bool)], V0[invI.astype(bool)])
+    # float64 residual of the normal equations for the heaviest and a few random rows
+    deg = np.diff(tr.rowptr)
+    for u in list(np.argsort(deg)[-3:]) + list(rng.integers(0, nU, 5)):
+        if invU[u]:
+            continue
+        sl = slice(tr.rowptr[u], tr.rowptr[u + 1])
+        Q = V0[tr.rowind[sl]].astype(np.float64)
+        r = tr.rowval[sl].astype(np.float64)
+        A = Q.T @ Q + reg * np.eye(K)
+        b = Q.T @ r
+        res = np.linalg.norm(A @ U1[u].astype(np.float64) - b) / np.linalg.norm(b)
+        assert res < 1e-4, (u, res)
+
+
+def test_als_iterations_track_oracle_trajectory():
+    """ModelMF::trainALS for 5 iterations: objective and validation RMSE per iteration."""
+    K, reg = 64, 3.0
+    d, tr, (cp, ci, cv) = _data(1200, 500, 50000, seed=21)
+    va = d["val"]
+    nU, nI = d["nUsers"], d["nItems"]
+    U0, V0 = orc.init_factors(1, nU, nI, K)
+    Uo, Vo = U0.copy(), V0.copy()
+    with Ctx(0) as ctx:
+        invU, invI = load_ctx(ctx, d, K, U0, V0)
+        for it in range(5):
+            ctx.als_half_sweep(mfx.SIDE_USERS, reg)
+            ctx.als_half_sweep(mfx.SIDE_ITEMS, reg)
+            orc.als_half(0, Uo, Vo, tr.nrows, tr.rowptr, tr.rowind, tr.rowval, invU, reg, nthreads=4)
+            orc.als_half(1, Vo, Uo, tr.ncols, cp, ci, cv, invI, reg, nthreads=4)
+            g_obj = ctx.objective(reg, reg)
+            g_val = ctx.rmse(mfx.MAT_VAL)
+            o_obj, *_ = orc.objective(Uo, Vo, nU, nI, tr.nrows, tr.rowptr, tr.rowind, tr.rowval, invU, invI, reg, reg)
+            o_val, _, _ = orc.rmse(Uo, Vo, nU, nI, va.nrows, va.rowptr, va.rowind, va.rowval, invU, invI)
+            assert abs(g_obj - o_obj) <= 1e-4 * o_obj, (it, g_obj, o_obj)
+            assert abs(g_val - o_val) <= 1e-5, (it, g_val, o_val)      # <= 1e-5 abs RMSE
+        U, V = ctx.get_factors()
+    rel = np.abs(U - Uo).max() / np.abs(Uo).max()
+    assert rel < 1e-3
+
+
+def test_nonpositive_ratings_are_skipped():
+    """rating <= 0 contributes nothing (modelMF.cpp:819): flip some ratings to 0 / negative."""
+    K, reg = 64, 1.0
+    d, tr, (cp, ci, cv) = _data(300, 200, 8000, seed=33)
+    tr.rowval[::7] = 0.0
+    tr.rowval[3::11] = -1.5
+    cp, ci, cv = orc.create_col_index(tr.nrows, tr.ncols, tr.rowptr, tr.rowind, tr.rowval)
+    nU, nI = d["nUsers"], d["nItems"]
+    rng = np.random.default_rng(1)
+    U0 = rng.normal(0, 0.3, (nU, K)).astype(np.float32)
+    V0 = rng.normal(0, 0.3, (nI, K)).astype(np.float32)
+    with Ctx(0) as ctx:
+        invU, invI = load_ctx(ctx, d, K, U0, V0)
+        ctx.als_half_sweep(mfx.SIDE_USERS, reg)
+        U1, _ = ctx.get_factors()
+    Uo, Vo = U0.copy(), V0.copy()
+    orc.als_half(0, Uo, Vo, tr.nrows, tr.rowptr, tr.rowind, tr.rowval, invU, reg)
+    rel = np.linalg.norm(U1 - Uo, axis=1) / np.maximum(np.linalg.norm(Uo, axis=1), 1e-6)
+    assert rel.max() < 2e-4
