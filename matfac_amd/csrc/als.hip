@@ -22,29 +22,8 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
-constexpr int SEG = 1024;         // ratings per segment
 constexpr int SLAB = 66 * 64;     // floats per partial: 4 tiles x 16 regs + 2 rhs, per lane
-
-struct AlsSide {
-  int32_t* seg_row = nullptr;     // row of each segment
-  int64_t* seg_beg = nullptr;
-  int64_t* seg_end = nullptr;
-  int32_t* seg_slab = nullptr;    // slab index, or -1 when the row is a single segment
-  int32_t* mrow = nullptr;        // rows with several segments
-  int32_t* mrow_first = nullptr;  // first slab of such a row
-  int32_t* mrow_n = nullptr;      // number of slabs
-  int64_t nseg = 0, nmrow = 0, nslab = 0;
-  bool built = false;
-};
-struct AlsState {
-  AlsSide side[2];
-  float* slabs = nullptr;
-  int64_t slab_cap = 0;
-};
 }  // namespace
-
-// kept outside mfx_ctx's header to avoid dragging this file's types around
-static AlsState* als_state(mfx_ctx* ctx) { return (AlsState*)ctx->als; }
 
 __device__ __forceinline__ float rdlane(float v, int lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
@@ -224,24 +203,24 @@ static int upload_vec(mfx_ctx* ctx, T** dst, const std::vector<T>& v) {
   return MFX_OK;
 }
 
-static void free_side(AlsSide& s) {
+static void free_segs(RowSegs& s) {
   dev_free(s.seg_row); dev_free(s.seg_beg); dev_free(s.seg_end); dev_free(s.seg_slab);
   dev_free(s.mrow); dev_free(s.mrow_first); dev_free(s.mrow_n);
-  s = AlsSide();
+  s = RowSegs();
 }
 
+void mfx_segs_free_internal(mfx_ctx* ctx) {
+  free_segs(ctx->segs[0]);
+  free_segs(ctx->segs[1]);
+}
 void mfx_als_free_internal(mfx_ctx* ctx) {
-  AlsState* st = als_state(ctx);
-  if (!st) return;
-  free_side(st->side[0]);
-  free_side(st->side[1]);
-  dev_free(st->slabs);
-  delete st;
-  ctx->als = nullptr;
+  dev_free(ctx->als_slabs);
+  ctx->als_slab_cap = 0;
 }
 
 // Build the segment lists of one side from the device row pointers (read back once).
-static int build_side(mfx_ctx* ctx, AlsSide& sd, const int64_t* dptr, int32_t n) {
+static int build_side(mfx_ctx* ctx, RowSegs& sd, const int64_t* dptr, int32_t n) {
+  constexpr int SEG = MFX_SEG;
   std::vector<int64_t> ptr((size_t)n + 1);
   HIPCHK(hipMemcpy(ptr.data(), dptr, sizeof(int64_t) * ((size_t)n + 1), hipMemcpyDeviceToHost));
   std::vector<int32_t> rows;
@@ -284,6 +263,17 @@ static int build_side(mfx_ctx* ctx, AlsSide& sd, const int64_t* dptr, int32_t n)
   return MFX_OK;
 }
 
+int mfx_get_segments(mfx_ctx* ctx, int side, RowSegs** out) {
+  const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
+  RowSegs& sd = ctx->segs[side];
+  if (!sd.built) {
+    int rc = build_side(ctx, sd, side == 0 ? m.rowptr : m.colptr, side == 0 ? m.nrows : m.ncols);
+    if (rc) return rc;
+  }
+  *out = &sd;
+  return MFX_OK;
+}
+
 extern "C" int mfx_als_half_sweep(mfx_ctx* ctx, int side, float reg) {
   if (!ctx) return MFX_E_ARG;
   NEED(side == MFX_SIDE_USERS || side == MFX_SIDE_ITEMS, MFX_E_ARG, "mfx_als_half_sweep: side=%d", side);
@@ -293,19 +283,15 @@ extern "C" int mfx_als_half_sweep(mfx_ctx* ctx, int side, float reg) {
   NEED(ctx->K <= 64, MFX_E_ARG, "mfx_als_half_sweep: this build supports K <= 64 (got %d)", ctx->K);
   NEED(m.nrows <= ctx->nU && m.ncols <= ctx->nI, MFX_E_ARG, "mfx_als_half_sweep: matrix exceeds model");
   HIPCHK(hipSetDevice(ctx->device));
-  AlsState* st = als_state(ctx);
-  if (!st) { st = new AlsState; ctx->als = st; }
-  AlsSide& sd = st->side[side];
-  if (!sd.built) {
-    int rc = build_side(ctx, sd, side == MFX_SIDE_USERS ? m.rowptr : m.colptr,
-                        side == MFX_SIDE_USERS ? m.nrows : m.ncols);
+  RowSegs* sdp;
+  int rc0 = mfx_get_segments(ctx, side, &sdp);
+  if (rc0) return rc0;
+  RowSegs& sd = *sdp;
+  if (sd.nslab > ctx->als_slab_cap) {
+    dev_free(ctx->als_slabs);
+    int rc = dev_alloc(ctx, &ctx->als_slabs, (size_t)sd.nslab * SLAB);
     if (rc) return rc;
-  }
-  if (sd.nslab > st->slab_cap) {
-    dev_free(st->slabs);
-    int rc = dev_alloc(ctx, &st->slabs, (size_t)sd.nslab * SLAB);
-    if (rc) return rc;
-    st->slab_cap = sd.nslab;
+    ctx->als_slab_cap = sd.nslab;
   }
   const int32_t* ind = side == MFX_SIDE_USERS ? m.rowind : m.colind;
   const float* val = side == MFX_SIDE_USERS ? m.rowval : m.colval;
@@ -315,14 +301,14 @@ extern "C" int mfx_als_half_sweep(mfx_ctx* ctx, int side, float reg) {
     ProfScope ps(ctx, MFX_K_ALS_GRAM);
     const int blocks = (int)std::min<int64_t>(sd.nseg, 256 * 16);
     hipLaunchKernelGGL(als_segment_kernel, dim3(blocks), dim3(64), 0, ctx->stream, sd.seg_row, sd.seg_beg,
-                       sd.seg_end, sd.seg_slab, sd.nseg, ind, val, Y, X, st->slabs, ctx->K, ctx->ld, reg);
+                       sd.seg_end, sd.seg_slab, sd.nseg, ind, val, Y, X, ctx->als_slabs, ctx->K, ctx->ld, reg);
     HIPCHK(hipGetLastError());
   }
   if (sd.nmrow > 0) {
     ProfScope ps(ctx, MFX_K_ALS_SOLVE);
     const int blocks = (int)std::min<int64_t>(sd.nmrow, 256 * 16);
     hipLaunchKernelGGL(als_reduce_kernel, dim3(blocks), dim3(64), 0, ctx->stream, sd.mrow, sd.mrow_first,
-                       sd.mrow_n, sd.nmrow, st->slabs, X, ctx->K, ctx->ld, reg);
+                       sd.mrow_n, sd.nmrow, ctx->als_slabs, X, ctx->K, ctx->ld, reg);
     HIPCHK(hipGetLastError());
   }
   return MFX_OK;

@@ -1,10 +1,256 @@
-// ccd.hip -- placeholder until the CCD++ kernels land.
+// ccd.hip -- CCD++ rank-one sweeps for gfx950.
+//
+// Replaces ModelMF::trainCCDPP (modelMF.cpp:1013-1121) and trainCCDPPFreqAdap
+// (:1258-1360).  State: the residual R - U V^T on BOTH views (CSR values res_row,
+// CSC values res_col), exactly as the reference keeps gk_csr_Dup(trainMat)'s rowval
+// and colval in lock-step.  All passes are HBM-streaming:
+//   row pass   u_k[u] = sum_i res_ui v_k[i] / (uReg + sum_i v_k[i]^2)   (:1062-1074)
+//   col pass   v_k[i] = sum_u res_ui u_k[u] / (iReg + sum_u u_k[u]^2)   (:1078-1090)
+//   residual   res_ui +-= u_k[u] v_k[i] on both views                   (:1032-1056, :1095-1116)
+// Arithmetic as in the reference: the products are float*float, num/denom accumulate
+// in double, the quotient is rounded to float once.  A 16-lane group reduces one row
+// segment (<= MFX_SEG ratings); rows with several segments are finished in segment
+// order by a second launch, so every sum has a fixed association (reproducible).
+#include <algorithm>
+
 #include "mfx_internal.h"
+
 void mfx_ccd_free_internal(mfx_ctx* ctx) {
   dev_free(ctx->res_row); dev_free(ctx->res_col); dev_free(ctx->uk); dev_free(ctx->vk);
+  dev_free(ctx->ccd_part); dev_free(ctx->colid);
+  ctx->ccd_part_cap = 0;
   ctx->ccd_active = false;
 }
-extern "C" int mfx_ccdpp_begin(mfx_ctx* ctx) { if (!ctx) return MFX_E_ARG; return mfx_fail(ctx, MFX_E_STATE, "not implemented yet"); }
-extern "C" int mfx_ccdpp_rank1(mfx_ctx* ctx, int32_t, int32_t, float, float, int32_t, float) { if (!ctx) return MFX_E_ARG; return mfx_fail(ctx, MFX_E_STATE, "not implemented yet"); }
-extern "C" int mfx_ccdpp_end(mfx_ctx* ctx) { if (!ctx) return MFX_E_ARG; return mfx_fail(ctx, MFX_E_STATE, "not implemented yet"); }
-extern "C" int mfx_debug_residuals(mfx_ctx* ctx, float*, float*) { if (!ctx) return MFX_E_ARG; return mfx_fail(ctx, MFX_E_STATE, "not implemented yet"); }
+
+__global__ void expand_colid_kernel(const int64_t* __restrict__ colptr, int32_t ncols,
+                                    int32_t* __restrict__ colid) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t c = wave; c < ncols; c += nwaves) {
+    const int64_t b = colptr[c], e = colptr[c + 1];
+    for (int64_t t = b + lane; t < e; t += 64) colid[t] = (int32_t)c;
+  }
+}
+
+// column k of a factor matrix <-> dense vector
+__global__ void extract_col_kernel(const float* __restrict__ X, int32_t n, int ld, int k, float* __restrict__ xk) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) xk[t] = X[t * ld + k];
+}
+__global__ void store_col_kernel(float* __restrict__ X, int32_t n, int ld, int k, const float* __restrict__ xk) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) X[t * ld + k] = xk[t];
+}
+
+// res[e] (+/-)= a[rowOf[e]] * b[colOf[e]]   -- float product, then float add/sub
+template <int SIGN>
+__global__ __launch_bounds__(256) void resid_update_kernel(float* __restrict__ res, const int32_t* __restrict__ ia,
+                                                           const int32_t* __restrict__ ib,
+                                                           const float* __restrict__ a, const float* __restrict__ b,
+                                                           int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+    const float prod = a[ia[e]] * b[ib[e]];
+    res[e] = SIGN > 0 ? res[e] + prod : res[e] - prod;
+  }
+}
+
+__device__ __forceinline__ double group16_sum(double v) {
+#pragma unroll
+  for (int m = 8; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+// One 16-lane group per row segment.
+__global__ __launch_bounds__(256) void ccd_pass_kernel(const int32_t* __restrict__ seg_row,
+                                                       const int64_t* __restrict__ seg_beg,
+                                                       const int64_t* __restrict__ seg_end,
+                                                       const int32_t* __restrict__ seg_slab, int64_t nseg,
+                                                       const float* __restrict__ res,
+                                                       const int32_t* __restrict__ ind,
+                                                       const float* __restrict__ other, float reg,
+                                                       float* __restrict__ mine, double* __restrict__ part,
+                                                       const int64_t* __restrict__ ptr, float freq_thresh, int k) {
+  const int lane = threadIdx.x & 63;
+  const int j = lane & 15;
+  const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
+  for (int64_t s = grp; s < nseg; s += ngrp) {
+    const int64_t b = seg_beg[s], e = seg_end[s];
+    double num = 0.0, den = 0.0;
+    for (int64_t t = b + j; t < e; t += 16) {
+      const float o = other[ind[t]];
+      const float p = res[t] * o;   // float product (modelMF.cpp:1069)
+      const float q = o * o;        // (modelMF.cpp:1070)
+      num += (double)p;
+      den += (double)q;
+    }
+    num = group16_sum(num);
+    den = group16_sum(den);
+    if (j == 0) {
+      const int slab = seg_slab[s];
+      if (slab < 0) {
+        const int row = seg_row[s];
+        float v = (float)(num / ((double)reg + den));
+        if (freq_thresh >= 0.0f) {  // modelMF.cpp:1336-1342: itemFreq = ratings of the item in train
+          const double freq = (double)(ptr[row + 1] - ptr[row]);
+          if (freq < (double)freq_thresh && k > 0) v = 0.0f;
+        }
+        mine[row] = v;
+      } else {
+        part[2 * (int64_t)slab] = num;
+        part[2 * (int64_t)slab + 1] = den;
+      }
+    }
+  }
+}
+
+__global__ void ccd_finish_kernel(const int32_t* __restrict__ mrow, const int32_t* __restrict__ mrow_first,
+                                  const int32_t* __restrict__ mrow_n, int64_t nmrow,
+                                  const double* __restrict__ part, float reg, float* __restrict__ mine,
+                                  const int64_t* __restrict__ ptr, float freq_thresh, int k) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= nmrow) return;
+  double num = 0.0, den = 0.0;
+  const int first = mrow_first[m], n = mrow_n[m];
+  for (int s = 0; s < n; s++) {
+    num += part[2 * (int64_t)(first + s)];
+    den += part[2 * (int64_t)(first + s) + 1];
+  }
+  const int row = mrow[m];
+  float v = (float)(num / ((double)reg + den));
+  if (freq_thresh >= 0.0f) {
+    const double freq = (double)(ptr[row + 1] - ptr[row]);
+    if (freq < (double)freq_thresh && k > 0) v = 0.0f;
+  }
+  mine[row] = v;
+}
+
+extern "C" int mfx_ccdpp_begin(mfx_ctx* ctx) {
+  if (!ctx) return MFX_E_ARG;
+  const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
+  NEED(m.present && m.has_col, MFX_E_STATE, "mfx_ccdpp_begin: train matrix with column view needed");
+  NEED(ctx->U, MFX_E_STATE, "mfx_ccdpp_begin: no model");
+  NEED(m.nrows <= ctx->nU && m.ncols <= ctx->nI, MFX_E_ARG, "mfx_ccdpp_begin: matrix exceeds model");
+  HIPCHK(hipSetDevice(ctx->device));
+  mfx_ccd_free_internal(ctx);
+  int rc;
+  const size_t nnz = (size_t)m.nnz;
+  if ((rc = dev_alloc(ctx, &ctx->res_row, nnz))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->res_col, nnz))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->colid, nnz))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->uk, (size_t)ctx->nU))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->vk, (size_t)ctx->nI))) return rc;
+  // res = gk_csr_Dup(trainMat) (modelMF.cpp:1013): both value arrays
+  if (nnz) {
+    HIPCHK(hipMemcpyAsync(ctx->res_row, m.rowval, sizeof(float) * nnz, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->res_col, m.colval, sizeof(float) * nnz, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  if (m.ncols > 0) {
+    const int blocks = (int)std::min<int64_t>(((int64_t)m.ncols + 3) / 4, 4096);
+    hipLaunchKernelGGL(expand_colid_kernel, dim3(blocks), dim3(256), 0, ctx->stream, m.colptr, m.ncols, ctx->colid);
+    HIPCHK(hipGetLastError());
+  }
+  // uFac.fill(0) (modelMF.cpp:1020)
+  HIPCHK(hipMemsetAsync(ctx->U, 0, sizeof(float) * (size_t)ctx->nU * ctx->ld, ctx->stream));
+  RowSegs* sg;
+  for (int side = 0; side < 2; side++) {
+    if ((rc = mfx_get_segments(ctx, side, &sg))) return rc;
+    if (sg->nslab > ctx->ccd_part_cap) {
+      dev_free(ctx->ccd_part);
+      if ((rc = dev_alloc(ctx, &ctx->ccd_part, (size_t)sg->nslab * 2))) return rc;
+      ctx->ccd_part_cap = sg->nslab;
+    }
+  }
+  ctx->ccd_active = true;
+  return MFX_OK;
+}
+
+static int run_pass(mfx_ctx* ctx, int side, float reg, float freq_thresh, int k) {
+  const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
+  RowSegs* sg;
+  int rc = mfx_get_segments(ctx, side, &sg);
+  if (rc) return rc;
+  const float* res = side == 0 ? ctx->res_row : ctx->res_col;
+  const int32_t* ind = side == 0 ? m.rowind : m.colind;
+  const float* other = side == 0 ? ctx->vk : ctx->uk;
+  float* mine = side == 0 ? ctx->uk : ctx->vk;
+  const int64_t* ptr = side == 0 ? m.rowptr : m.colptr;
+  if (sg->nseg > 0) {
+    ProfScope ps(ctx, side == 0 ? MFX_K_CCD_ROW : MFX_K_CCD_COL);
+    const int blocks = (int)std::min<int64_t>((sg->nseg + 15) / 16, 256 * 8);
+    hipLaunchKernelGGL(ccd_pass_kernel, dim3(blocks), dim3(256), 0, ctx->stream, sg->seg_row, sg->seg_beg,
+                       sg->seg_end, sg->seg_slab, sg->nseg, res, ind, other, reg, mine, ctx->ccd_part, ptr,
+                       freq_thresh, k);
+    HIPCHK(hipGetLastError());
+  }
+  if (sg->nmrow > 0) {
+    hipLaunchKernelGGL(ccd_finish_kernel, dim3((unsigned)((sg->nmrow + 255) / 256)), dim3(256), 0, ctx->stream,
+                       sg->mrow, sg->mrow_first, sg->mrow_n, sg->nmrow, ctx->ccd_part, reg, mine, ptr,
+                       freq_thresh, k);
+    HIPCHK(hipGetLastError());
+  }
+  return MFX_OK;
+}
+
+template <int SIGN>
+static int run_resid(mfx_ctx* ctx) {
+  const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
+  if (m.nnz == 0) return MFX_OK;
+  ProfScope ps(ctx, MFX_K_CCD_RESID);
+  const int blocks = (int)std::min<int64_t>((m.nnz + 255) / 256, 256 * 16);
+  // row view: res_row[e] +-= u_k[rowid[e]] * v_k[rowind[e]]; column view likewise
+  hipLaunchKernelGGL(resid_update_kernel<SIGN>, dim3(blocks), dim3(256), 0, ctx->stream, ctx->res_row, m.rowid,
+                     m.rowind, ctx->uk, ctx->vk, m.nnz);
+  hipLaunchKernelGGL(resid_update_kernel<SIGN>, dim3(blocks), dim3(256), 0, ctx->stream, ctx->res_col, m.colind,
+                     ctx->colid, ctx->uk, ctx->vk, m.nnz);
+  HIPCHK(hipGetLastError());
+  return MFX_OK;
+}
+
+extern "C" int mfx_ccdpp_rank1(mfx_ctx* ctx, int32_t k, int32_t inner, float uReg, float iReg, int32_t add_back,
+                               float freq_thresh) {
+  if (!ctx) return MFX_E_ARG;
+  NEED(ctx->ccd_active, MFX_E_STATE, "mfx_ccdpp_rank1: call mfx_ccdpp_begin first");
+  NEED(k >= 0 && k < ctx->K, MFX_E_ARG, "mfx_ccdpp_rank1: k=%d outside [0,%d)", k, ctx->K);
+  NEED(inner >= 0, MFX_E_ARG, "mfx_ccdpp_rank1: inner=%d", inner);
+  HIPCHK(hipSetDevice(ctx->device));
+  const int bu = (ctx->nU + 255) / 256, bi = (ctx->nI + 255) / 256;
+  // u_k = uFac.col(k); v_k = iFac.col(k)  (modelMF.cpp:1028-1029)
+  hipLaunchKernelGGL(extract_col_kernel, dim3(bu), dim3(256), 0, ctx->stream, ctx->U, ctx->nU, ctx->ld, k, ctx->uk);
+  hipLaunchKernelGGL(extract_col_kernel, dim3(bi), dim3(256), 0, ctx->stream, ctx->V, ctx->nI, ctx->ld, k, ctx->vk);
+  HIPCHK(hipGetLastError());
+  int rc;
+  if (add_back && (rc = run_resid<+1>(ctx))) return rc;     // :1032-1056
+  for (int it = 0; it < inner; it++) {                      // :1058-1092
+    if ((rc = run_pass(ctx, 0, uReg, -1.0f, k))) return rc;
+    if ((rc = run_pass(ctx, 1, iReg, freq_thresh, k))) return rc;
+  }
+  if ((rc = run_resid<-1>(ctx))) return rc;                 // :1095-1116
+  // uFac.col(k) = u_k; iFac.col(k) = v_k  (:1119-1120)
+  hipLaunchKernelGGL(store_col_kernel, dim3(bu), dim3(256), 0, ctx->stream, ctx->U, ctx->nU, ctx->ld, k, ctx->uk);
+  hipLaunchKernelGGL(store_col_kernel, dim3(bi), dim3(256), 0, ctx->stream, ctx->V, ctx->nI, ctx->ld, k, ctx->vk);
+  HIPCHK(hipGetLastError());
+  return MFX_OK;
+}
+
+extern "C" int mfx_ccdpp_end(mfx_ctx* ctx) {
+  if (!ctx) return MFX_E_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  mfx_ccd_free_internal(ctx);
+  return MFX_OK;
+}
+
+extern "C" int mfx_debug_residuals(mfx_ctx* ctx, float* res_row, float* res_col) {
+  if (!ctx) return MFX_E_ARG;
+  NEED(ctx->ccd_active, MFX_E_STATE, "mfx_debug_residuals: CCD++ not active");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const size_t nnz = (size_t)ctx->mat[MFX_MAT_TRAIN].nnz;
+  if (nnz == 0) return MFX_OK;
+  if (res_row) HIPCHK(hipMemcpy(res_row, ctx->res_row, sizeof(float) * nnz, hipMemcpyDeviceToHost));
+  if (res_col) HIPCHK(hipMemcpy(res_col, ctx->res_col, sizeof(float) * nnz, hipMemcpyDeviceToHost));
+  return MFX_OK;
+}

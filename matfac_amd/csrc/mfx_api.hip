@@ -101,6 +101,7 @@ void mfx_destroy(mfx_ctx* ctx) {
   mfx_comm_free_internal(ctx);
   mfx_ccd_free_internal(ctx);
   mfx_als_free_internal(ctx);
+  mfx_segs_free_internal(ctx);
   for (auto& m : ctx->mat) free_csr(m);
   free_model(ctx);
   dev_free(ctx->eu); dev_free(ctx->ei); dev_free(ctx->er); dev_free(ctx->order);
@@ -157,7 +158,7 @@ extern "C" int mfx_set_csr(mfx_ctx* ctx, int which, int32_t nrows, int32_t ncols
   HIPCHK(hipSetDevice(ctx->device));
   DevCSR& m = ctx->mat[which];
   free_csr(m);
-  if (which == MFX_MAT_TRAIN) { mfx_ccd_free_internal(ctx); mfx_als_free_internal(ctx); }
+  if (which == MFX_MAT_TRAIN) { mfx_ccd_free_internal(ctx); mfx_als_free_internal(ctx); mfx_segs_free_internal(ctx); }
   int rc;
   if ((rc = dev_alloc(ctx, &m.rowptr, (size_t)nrows + 1))) return rc;
   if ((rc = dev_alloc(ctx, &m.rowind, (size_t)nnz))) return rc;

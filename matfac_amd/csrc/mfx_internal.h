@@ -26,6 +26,22 @@ struct DevCSR {
   bool present = false, has_col = false;
 };
 
+// Rows of the train matrix cut into segments of <= MFX_SEG ratings (rows sorted by
+// length, longest first): the unit of work of the ALS and CCD++ row kernels, so that a
+// 50k-rating item does not serialise a sweep.  side 0 = row view, 1 = column view.
+constexpr int MFX_SEG = 1024;
+struct RowSegs {
+  int32_t* seg_row = nullptr;     // row of each segment
+  int64_t* seg_beg = nullptr;
+  int64_t* seg_end = nullptr;
+  int32_t* seg_slab = nullptr;    // partial-result slot, or -1 when the row is a single segment
+  int32_t* mrow = nullptr;        // rows with several segments
+  int32_t* mrow_first = nullptr;  // first slot of such a row
+  int32_t* mrow_n = nullptr;      // number of slots
+  int64_t nseg = 0, nmrow = 0, nslab = 0;
+  bool built = false;
+};
+
 struct ProfSlot {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
@@ -70,8 +86,14 @@ struct mfx_ctx {
   float *res_row = nullptr, *res_col = nullptr, *uk = nullptr, *vk = nullptr;
   bool ccd_active = false;
 
-  // ALS segment lists + partial-Gramian slabs (als.hip owns the type)
-  void* als = nullptr;
+  RowSegs segs[2];
+  // ALS partial-Gramian slabs
+  float* als_slabs = nullptr;
+  int64_t als_slab_cap = 0;
+  // CCD++ partial (num, denom) slots and expanded column ids
+  double* ccd_part = nullptr;
+  int64_t ccd_part_cap = 0;
+  int32_t* colid = nullptr;
 
   // comm
   void* comm = nullptr;      // ncclComm_t
@@ -145,5 +167,7 @@ int mfx_launch_eval(mfx_ctx* ctx, const DevCSR& m, const float* U, const float* 
 int mfx_comm_free_internal(mfx_ctx* ctx);
 void mfx_ccd_free_internal(mfx_ctx* ctx);
 void mfx_als_free_internal(mfx_ctx* ctx);
+void mfx_segs_free_internal(mfx_ctx* ctx);
+int mfx_get_segments(mfx_ctx* ctx, int side, RowSegs** out);
 
 #endif

@@ -274,9 +274,12 @@ int tiled_variant() {
 static int sgd_policy() {
   static int pol = -1;
   if (pol < 0) {
+    // default 1: the flat Hogwild kernel touches every row from all 8 XCDs, whose L2s are
+    // not coherent with each other; plain write-back stores leave 8 diverging copies of
+    // the hot rows (measured: much slower convergence), sc1 keeps one copy at the memory side
     const char* e = getenv("MFX_SGD_POLICY");
-    pol = e ? atoi(e) : 0;
-    if (pol < 0 || pol > 4) pol = 0;
+    pol = e ? atoi(e) : 1;
+    if (pol < 0 || pol > 4) pol = 1;
   }
   return pol;
 }
