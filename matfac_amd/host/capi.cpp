@@ -1,0 +1,53 @@
+// capi.cpp -- C entry point that drives the host classes on in-memory matrices, so that the
+// parity tests (Python) can run ModelMF::train* exactly as main() would, without text files.
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "mf_model.h"
+#include "mfhost.h"
+
+extern "C" int mfh_train(const char* method, int32_t nrows, const int64_t* tr_ptr, const int32_t* tr_ind,
+                         const float* tr_val, int32_t tr_ncols, const int64_t* va_ptr, const int32_t* va_ind,
+                         const float* va_val, int32_t va_ncols, const int64_t* te_ptr, const int32_t* te_ind,
+                         const float* te_val, int32_t te_ncols, int32_t K, int32_t maxIter, int32_t seed,
+                         float learnRate, float uReg, float iReg, const char* prefix, float* Ulast, float* Vlast,
+                         float* Ubest, float* Vbest, double* stats, uint8_t* invU, uint8_t* invI) {
+  std::string e, pfx = prefix ? prefix : "";
+  if (!prefix) setenv("MFX_NO_SAVE", "1", 1);
+  Params params(K, maxIter, K, seed, uReg, iReg, learnRate, 0.0f, 0.0f, e, e, e, e, e, e, e, e, pfx);
+  Data data(csr_from_arrays(nrows, tr_ncols, tr_ptr, tr_ind, tr_val),
+            csr_from_arrays(nrows, te_ncols, te_ptr, te_ind, te_val),
+            csr_from_arrays(nrows, va_ncols, va_ptr, va_ind, va_val), pfx.c_str());
+  params.nUsers = data.nUsers;
+  params.nItems = data.nItems;
+  ModelMF model(params, params.seed), best(params, params.seed);
+  std::unordered_set<int> iu, ii;
+  const std::string m = method;
+  if (m == "ccd++") model.trainCCDPPFreqAdap(data, best, iu, ii);
+  else if (m == "ccdpp") model.trainCCDPP(data, best, iu, ii);
+  else if (m == "als") model.trainALS(data, best, iu, ii);
+  else if (m == "hogsgd") model.hogTrain(data, best, iu, ii);
+  else if (m == "sgdu") model.trainUShuffle(data, best, iu, ii);
+  else if (m == "sgdpar") model.trainSGDPar(data, best, iu, ii);
+  else if (m == "sgd") model.train(data, best, iu, ii);
+  else return -1;
+  const size_t su = sizeof(float) * (size_t)data.nUsers * K, si = sizeof(float) * (size_t)data.nItems * K;
+  if (Ulast) memcpy(Ulast, model.uFac.data(), su);
+  if (Vlast) memcpy(Vlast, model.iFac.data(), si);
+  if (Ubest) memcpy(Ubest, best.uFac.data(), su);
+  if (Vbest) memcpy(Vbest, best.iFac.data(), si);
+  if (stats) {
+    stats[0] = best.RMSE(data.trainMat, iu, ii);   // main.cpp:1377-1382
+    stats[1] = best.RMSE(data.testMat, iu, ii);
+    stats[2] = best.RMSE(data.valMat, iu, ii);
+    stats[3] = model.learnRate;
+    stats[4] = best.learnRate;
+    stats[5] = data.nItems;
+  }
+  if (invU) for (int u = 0; u < data.nUsers; u++) invU[u] = iu.count(u) ? 1 : 0;
+  if (invI) for (int i = 0; i < data.nItems; i++) invI[i] = ii.count(i) ? 1 : 0;
+  if (!prefix) unsetenv("MFX_NO_SAVE");
+  return 0;
+}

@@ -1,0 +1,496 @@
+// mf_model.cpp -- Model / ModelMF on top of the C ABI (include/mfx.h).
+//
+// What stays on the host is what the reference keeps in its control flow: the
+// hyper-parameters, the RNG (std::mt19937 / std::shuffle exactly as modelMF.cpp uses them),
+// the termination rules of Model::isTerminateModel, logging and the factor files.  Every loop
+// over ratings, rows or columns is a device call.
+#include "mf_model.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <numeric>
+#include <random>
+
+// ---------------------------------------------------------------------------
+// device session
+// ---------------------------------------------------------------------------
+MfxSession::~MfxSession() {
+  if (ctx) mfx_destroy(ctx);
+}
+
+void MfxSession::check(int rc, const char* what) const {
+  if (rc == MFX_OK) return;
+  std::cerr << "\nmfx error " << rc << " in " << what << ": " << mfx_last_error(ctx) << std::endl;
+  exit(-2);
+}
+
+static void upload(MfxSession& s, int which, const csr_t* m, int nItems) {
+  if (!m) return;
+  // ncols is declared as the model's nItems so that every index is in range for the kernels
+  s.check(mfx_set_csr(s.ctx, which, m->nrows, std::max(m->ncols, 0), m->rowptr, m->rowind, m->rowval,
+                      which == MFX_MAT_TRAIN ? m->colptr : nullptr, which == MFX_MAT_TRAIN ? m->colind : nullptr,
+                      which == MFX_MAT_TRAIN ? m->colval : nullptr),
+          "mfx_set_csr");
+  s.mats[which] = m;
+  (void)nItems;
+}
+
+std::shared_ptr<MfxSession> MfxSession::open(const Data& data, int nUsers, int nItems, int K) {
+  auto s = std::make_shared<MfxSession>();
+  const char* dv = getenv("MFX_DEVICE");
+  int rc = mfx_create(dv ? atoi(dv) : 0, &s->ctx);
+  if (rc != MFX_OK) {
+    std::cerr << "\nmfx_create failed (" << rc << "): " << mfx_last_error(nullptr) << std::endl;
+    exit(-2);
+  }
+  s->nUsers = nUsers; s->nItems = nItems; s->K = K;
+  upload(*s, MFX_MAT_TRAIN, data.trainMat, nItems);
+  upload(*s, MFX_MAT_VAL, data.valMat, nItems);
+  upload(*s, MFX_MAT_TEST, data.testMat, nItems);
+  s->check(mfx_set_model(s->ctx, nUsers, nItems, K), "mfx_set_model");
+  return s;
+}
+
+int MfxSession::which(const csr_t* m) const {
+  for (int w = 0; w < 3; w++)
+    if (mats[w] == m && m) return w;
+  return -1;
+}
+
+// ---------------------------------------------------------------------------
+// factor files (io.cpp:83-154): one row per line, "v " per value, default precision
+// ---------------------------------------------------------------------------
+void writeMat(const DenseF32& mat, int nrows, int ncols, const char* fileName) {
+  std::ofstream op(fileName);
+  if (!op.is_open()) return;
+  for (int i = 0; i < nrows; i++) {
+    for (int j = 0; j < ncols; j++) op << mat(i, j) << " ";
+    op << std::endl;
+  }
+}
+
+bool readMat(DenseF32& mat, int nrows, int ncols, const char* fileName) {
+  std::cout << "\nReading ... " << fileName << " nrows: " << nrows << " ncols: " << ncols << std::endl;
+  std::ifstream in(fileName);
+  if (!in.is_open()) {
+    std::cout << "\nCan't open file: " << fileName << std::endl;
+    return false;
+  }
+  mat = DenseF32(nrows, ncols);
+  std::string line;
+  int i = 0;
+  while (std::getline(in, line) && i < nrows) {
+    int j = 0;
+    size_t b = 0;
+    while (b < line.size()) {
+      size_t e = line.find(' ', b);
+      if (e == std::string::npos) e = line.size();
+      if (e > b) {
+        if (j >= ncols) return false;
+        mat(i, j++) = (float)std::stod(line.substr(b, e - b));
+      }
+      b = e + 1;
+    }
+    if (j != ncols) return false;   // the reference asserts j == ncols (io.cpp:110)
+    i++;
+  }
+  return i == nrows;
+}
+
+bool isFileExist(const char* fileName) {
+  std::ifstream f(fileName);
+  return f.good();
+}
+
+// ---------------------------------------------------------------------------
+// Model
+// ---------------------------------------------------------------------------
+Model::Model(int nUsers, int nItems, int facDim) : nUsers(nUsers), nItems(nItems), facDim(facDim) {}
+
+Model::Model(const Params& params) {
+  nUsers = params.nUsers;
+  nItems = params.nItems;
+  facDim = params.facDim;
+  uReg = params.uReg;
+  iReg = params.iReg;
+  sing_a = params.uReg;
+  sing_b = params.iReg;
+  learnRate = params.learnRate;
+  origLearnRate = params.learnRate;
+  rhoRMS = params.rhoRMS;
+  alpha = params.alpha;
+  maxIter = params.maxIter;
+  trainSeed = -1;
+  // one minstd_rand0 stream, U(-0.01f, 0.01f) drawn as double: uFac, iFac, uBias, iBias
+  std::default_random_engine generator(params.seed);
+  const float lb = -0.01, ub = 0.01;
+  std::uniform_real_distribution<double> dist(lb, ub);
+  std::cout << "lb = " << lb << " ub = " << ub << std::endl;
+  uFac = DenseF32(nUsers, facDim);
+  for (float& x : uFac.a) x = (float)dist(generator);
+  iFac = DenseF32(nItems, facDim);
+  for (float& x : iFac.a) x = (float)dist(generator);
+  uBias.resize(nUsers);
+  for (float& x : uBias) x = (float)dist(generator);
+  iBias.resize(nItems);
+  for (float& x : iBias) x = (float)dist(generator);
+}
+
+Model::Model(const Params& params, int seed) : Model(params) { trainSeed = seed; }
+
+Model::Model(const Params& params, const char* uFacName, const char* iFacName, int seed) : Model(params, seed) {
+  std::cout << "\nLoading user factors: " << uFacName;
+  readMat(uFac, nUsers, facDim, uFacName);
+  std::cout << "\nLoading item factors: " << iFacName;
+  readMat(iFac, nItems, facDim, iFacName);
+}
+
+void Model::notInBase(const char* what) { std::cerr << "\n" << what << ": method not in base class" << std::endl; }
+
+void Model::copyScalarsFrom(const Model& o) {
+  nUsers = o.nUsers; nItems = o.nItems; facDim = o.facDim; trainSeed = o.trainSeed;
+  origLearnRate = o.origLearnRate; learnRate = o.learnRate; rhoRMS = o.rhoRMS; alpha = o.alpha;
+  maxIter = o.maxIter; uReg = o.uReg; iReg = o.iReg; sing_a = o.sing_a; sing_b = o.sing_b; mu = o.mu;
+}
+
+std::string Model::modelSignature() {
+  return std::to_string(nUsers) + "X" + std::to_string(nItems) + "_" + std::to_string(facDim) + "_" +
+         std::to_string(uReg) + "_" + std::to_string(iReg) + "_" + std::to_string(origLearnRate);
+}
+
+void Model::display() {
+  std::cout << "nUsers: " << nUsers << " nItems: " << nItems << std::endl;
+  std::cout << "facDim: " << facDim << std::endl;
+  std::cout << "uReg: " << uReg << " iReg: " << iReg << std::endl;
+  std::cout << "learnRate: " << learnRate << std::endl;
+  std::cout << "trainSeed: " << trainSeed;
+}
+
+void Model::syncHost() {
+  if (!hostStale || !dev) return;
+  if (uFac.rows != nUsers || uFac.cols != facDim) uFac = DenseF32(nUsers, facDim);
+  if (iFac.rows != nItems || iFac.cols != facDim) iFac = DenseF32(nItems, facDim);
+  dev->check(mfx_get_factors(dev->ctx, devSnap, uFac.data(), iFac.data(), MFX_ROWMAJOR), "mfx_get_factors");
+  hostStale = false;
+}
+
+void Model::pushToDevice() {
+  dev->check(mfx_set_factors(dev->ctx, uFac.data(), iFac.data(), MFX_ROWMAJOR), "mfx_set_factors");
+}
+
+void Model::saveFacs(std::string prefix) {
+  if (getenv("MFX_NO_SAVE")) return;
+  syncHost();
+  std::cout << "Saving model... " << prefix << std::endl;
+  const std::string sign = modelSignature();
+  const std::string uName = prefix + "_uFac_" + sign + ".mat";
+  writeMat(uFac, nUsers, facDim, uName.c_str());
+  std::cout << "uFac Norm: " << uFac.norm() << std::endl;
+  const std::string iName = prefix + "_iFac_" + sign + ".mat";
+  writeMat(iFac, nItems, facDim, iName.c_str());
+  std::cout << "iFac Norm: " << iFac.norm() << std::endl;
+}
+
+void Model::loadFacs(std::string prefix) {
+  const std::string sign = modelSignature();
+  const std::string uName = prefix + "_uFac_" + sign + ".mat";
+  std::cout << "Loading user factors: " << uName << std::endl;
+  if (isFileExist(uName.c_str())) {
+    readMat(uFac, nUsers, facDim, uName.c_str());
+    std::cout << "uFac Norm: " << uFac.norm() << std::endl;
+  } else {
+    std::cout << "File doesn't exist: " << uName << std::endl;
+  }
+  const std::string iName = prefix + "_iFac_" + sign + ".mat";
+  std::cout << "Loading item factors: " << iName << std::endl;
+  if (isFileExist(iName.c_str())) {
+    readMat(iFac, nItems, facDim, iName.c_str());
+    std::cout << "iFac Norm: " << iFac.norm() << std::endl;
+  } else {
+    std::cout << "File doesn't exist: " << iName << std::endl;
+  }
+  if (dev && devSnap == MFX_SNAP_CURRENT) pushToDevice();
+}
+
+double Model::estRating(int user, int item) {
+  syncHost();
+  float s = uFac(user, 0) * iFac(item, 0);
+  for (int k = 1; k < facDim; k++) s = s + uFac(user, k) * iFac(item, k);
+  return s;
+}
+
+void Model::attach(const Data& data) {
+  if (!dev || dev->mats[MFX_MAT_TRAIN] != data.trainMat) {
+    dev = MfxSession::open(data, nUsers, nItems, facDim);
+    devSnap = MFX_SNAP_CURRENT;
+    uint8_t dummy = 0;
+    (void)dummy;
+    dev->check(mfx_compute_invalid(dev->ctx, nullptr, nullptr), "mfx_compute_invalid");
+  }
+  pushToDevice();
+  hostStale = false;
+}
+
+void Model::deviceInvalid(const Data& data, IntSet& invalidUsers, IntSet& invalidItems) {
+  (void)data;
+  std::vector<uint8_t> iu(nUsers), ii(nItems);
+  dev->check(mfx_compute_invalid(dev->ctx, iu.data(), ii.data()), "mfx_compute_invalid");
+  for (int u = 0; u < nUsers; u++) if (iu[u]) invalidUsers.insert(u);
+  for (int i = 0; i < nItems; i++) if (ii[i]) invalidItems.insert(i);
+}
+
+void Model::evalDevice(const csr_t* mat, int withNorms, mfx_eval_out* out) {
+  const int w = dev ? dev->which(mat) : -1;
+  if (w < 0) {
+    std::cerr << "\nModel: matrix is not part of the device session" << std::endl;
+    exit(-2);
+  }
+  dev->check(mfx_eval(dev->ctx, w, devSnap, withNorms, out), "mfx_eval");
+}
+
+// model.cpp:214-251.  The masks on the device are the ones getInvalidUsersItems yields for the
+// session's train matrix, i.e. what every caller in the reference passes here.
+double Model::RMSE(csr_t* mat, IntSet& invalidUsers, IntSet& invalidItems) {
+  (void)invalidUsers; (void)invalidItems;
+  if (!mat) return NAN;
+  if (!dev || dev->which(mat) < 0) {
+    std::cerr << "\nModel::RMSE: no device session for this matrix (call a trainer first)" << std::endl;
+    exit(-2);
+  }
+  mfx_eval_out o;
+  evalDevice(mat, 0, &o);
+  return std::sqrt(o.sse / (double)o.n);
+}
+
+// model.cpp:191-211 (no masks).  On the train matrix the masked and unmasked sums coincide
+// (invalid users/items have no train rating), which is the only use on the training path
+// ("Obj b4 svd" print, modelMF.cpp:16-18).
+double Model::RMSE(csr_t* mat) {
+  IntSet a, b;
+  return RMSE(mat, a, b);
+}
+
+double Model::objective(const Data& data, IntSet& invalidUsers, IntSet& invalidItems) {
+  (void)invalidUsers; (void)invalidItems;
+  mfx_eval_out o;
+  evalDevice(data.trainMat, 1, &o);
+  // model.cpp:1793-1810: rmse + uRegErr*uReg + iRegErr*iReg with float uReg/iReg
+  return o.sse + o.unorm2 * uReg + o.inorm2 * iReg;
+}
+
+double Model::objective(const Data& data) {
+  IntSet a, b;
+  return objective(data, a, b);
+}
+
+// model.cpp:1471-1540
+bool Model::isTerminateModel(Model& bestModel, const Data& data, int iter, int& bestIter, double& bestObj,
+                             double& prevObj, double& bestValRMSE, double& prevValRMSE, IntSet& invalidUsers,
+                             IntSet& invalidItems) {
+  bool ret = false;
+  const double currObj = objective(data, invalidUsers, invalidItems);
+  double currValRMSE = -1;
+  if (data.valMat) {
+    currValRMSE = RMSE(data.valMat, invalidUsers, invalidItems);
+  } else {
+    std::cerr << "\nNo validation data" << std::endl;
+    exit(0);
+  }
+  if (currObj != currObj || currValRMSE != currValRMSE) {
+    std::cout << "Found nan " << std::endl;
+    if (learnRate > 1e-5) {
+      // *this = bestModel; learnRate = learnRate/2
+      dev->check(mfx_restore_best(dev->ctx), "mfx_restore_best");
+      copyScalarsFrom(bestModel);
+      hostStale = true;
+      learnRate = learnRate / 2;
+      return false;
+    }
+    return true;
+  }
+  if (currValRMSE < bestValRMSE) {
+    // bestModel = *this
+    dev->check(mfx_snapshot_best(dev->ctx), "mfx_snapshot_best");
+    bestModel.copyScalarsFrom(*this);
+    bestModel.hostStale = true;
+    bestValRMSE = currValRMSE;
+    bestIter = iter;
+  }
+  if (iter - bestIter >= 100) {
+    if (learnRate > 1e-5) learnRate = learnRate / 2;
+  }
+  if (iter - bestIter >= MF_CHANCE_ITER) {
+    printf("\nNOT CONVERGED: bestIter:%d bestObj: %.10e bestValRMSE: %.10e currIter:%d currObj: %.10e "
+           "currValRMSE: %.10e", bestIter, bestObj, bestValRMSE, iter, currObj, currValRMSE);
+    ret = true;
+  }
+  if (fabs(prevObj - currObj) < MF_EPS) {
+    printf("\nConverged in iteration: %d prevObj: %.10e currObj: %.10e bestValRMSE: %.10e", iter, prevObj,
+           currObj, bestValRMSE);
+    ret = true;
+  }
+  prevObj = currObj;
+  prevValRMSE = currValRMSE;
+  return ret;
+}
+
+// ---------------------------------------------------------------------------
+// ModelMF trainers
+// ---------------------------------------------------------------------------
+void ModelMF::train(const Data& d, Model& b, IntSet& iu, IntSet& ii) { run(K_SGD, "train", d, b, iu, ii); }
+void ModelMF::hogTrain(const Data& d, Model& b, IntSet& iu, IntSet& ii) { run(K_HOG, "hogTrain", d, b, iu, ii); }
+void ModelMF::trainSGDPar(const Data& d, Model& b, IntSet& iu, IntSet& ii) { run(K_SGDPAR, "trainSGDPar", d, b, iu, ii); }
+void ModelMF::trainUShuffle(const Data& d, Model& b, IntSet& iu, IntSet& ii) { run(K_SGDU, "trainUShuffle", d, b, iu, ii); }
+void ModelMF::trainALS(const Data& d, Model& b, IntSet& iu, IntSet& ii) { run(K_ALS, "trainALS", d, b, iu, ii); }
+void ModelMF::trainCCDPP(const Data& d, Model& b, IntSet& iu, IntSet& ii) { run(K_CCDPP, "trainCCDPP", d, b, iu, ii); }
+void ModelMF::trainCCDPPFreqAdap(const Data& d, Model& b, IntSet& iu, IntSet& ii) {
+  run(K_CCDPP_FA, "trainCCDPPFreqAdap", d, b, iu, ii);
+}
+void ModelMF::trainCCD(const Data&, Model&, IntSet&, IntSet&) {
+  // modelMF.cpp:1426-1653 (row-wise cyclic CD with a binary search per rating) is not on the
+  // MI355X path of this build; CCD++ (trainCCDPP / trainCCDPPFreqAdap) is.  See DESIGN.md.
+  std::cerr << "\nModelMF::trainCCD is not available in the MI355X build; use ccd++" << std::endl;
+}
+void ModelMF::trainSGDParSVD(const Data&, Model&, IntSet&, IntSet&) {
+  // needs SVDLIBC (svdLAS2A) for the initialisation (modelMF.cpp:368); not part of this build
+  std::cerr << "\nModelMF::trainSGDParSVD needs SVDLIBC and is not available in the MI355X build" << std::endl;
+}
+
+void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestModel, IntSet& invalidUsers,
+                  IntSet& invalidItems) {
+  std::cout << "\nModelMF::" << name << " trainSeed: " << trainSeed;
+  const bool exact = getenv("MFX_EXACT") != nullptr;   // replay the reference's sequential order bit by bit
+  const csr_t* trainMat = data.trainMat;
+
+  // bestModel starts as its own initialisation (main.cpp:1326-1327); it becomes the BEST snapshot
+  attach(data);
+  bestModel.dev = dev;
+  bestModel.devSnap = MFX_SNAP_BEST;
+  if (bestModel.uFac.rows == nUsers && bestModel.iFac.rows == nItems && bestModel.uFac.cols == facDim) {
+    dev->check(mfx_set_factors(dev->ctx, bestModel.uFac.data(), bestModel.iFac.data(), MFX_ROWMAJOR), "set best");
+    dev->check(mfx_snapshot_best(dev->ctx), "snapshot best");
+    pushToDevice();
+  } else {
+    dev->check(mfx_snapshot_best(dev->ctx), "snapshot best");
+  }
+  bestModel.hostStale = true;
+
+  std::cout << "\nObj b4 svd: " << objective(data) << " Train RMSE: " << RMSE(data.trainMat)
+            << " Train nnz: " << data.trainNNZ << std::endl;
+
+  int iter, bestIter = -1;
+  double bestObj, prevObj, bestValRMSE, prevValRMSE;
+  deviceInvalid(data, invalidUsers, invalidItems);   // getInvalidUsersItems + modelMF.cpp:40-45
+  prevObj = objective(data, invalidUsers, invalidItems);
+  bestObj = prevObj;
+  bestValRMSE = prevValRMSE = RMSE(data.valMat, invalidUsers, invalidItems);
+  std::cout << "\nObj aftr svd: " << prevObj << " Train RMSE: " << RMSE(data.trainMat, invalidUsers, invalidItems)
+            << " Val RMSE: " << bestValRMSE;
+  std::cout << "\nModelMF::" << name << " trainSeed: " << trainSeed << " invalidUsers: " << invalidUsers.size()
+            << " invalidItems: " << invalidItems.size() << std::endl;
+
+  std::mt19937 mt(trainSeed);
+  // every train rating belongs to a valid user and a valid item, so getUIRatings (util.cpp:722-747)
+  // is the CSR-order rating list; uiRatingInds indexes it (modelMF.cpp:65-68)
+  const int64_t nRatings = trainMat->nnz();
+  std::vector<size_t> uiRatingInds;
+  std::vector<uint64_t> userPerm;
+  std::vector<size_t> validUsers;
+  if ((kind == K_SGD || kind == K_HOG) && exact) {
+    uiRatingInds.resize((size_t)nRatings);
+    std::iota(uiRatingInds.begin(), uiRatingInds.end(), 0);
+  }
+  if (kind == K_SGDU) {
+    for (int u = 0; u < nUsers; u++)
+      if (!invalidUsers.count(u)) validUsers.push_back(u);
+    std::cout << "No. of valid users: " << validUsers.size() << std::endl;
+  }
+  std::cout << "\nTrain NNZ after removing invalid users and items: " << nRatings << std::endl;
+  std::vector<int> dims(facDim);
+  std::iota(dims.begin(), dims.end(), 0);
+  if (kind == K_CCDPP || kind == K_CCDPP_FA) dev->check(mfx_ccdpp_begin(dev->ctx), "mfx_ccdpp_begin");
+
+  mfx_sgd_opts o;
+  o.uReg = uReg; o.iReg = iReg; o.seed = (uint32_t)trainSeed; o.blocks = 0; o.reserved = 0; o.first = 0; o.count = 0;
+  o.arith = kind == K_HOG ? MFX_ARITH_F32 : kind == K_SGDPAR ? MFX_ARITH_REF64F : MFX_ARITH_REF64;
+
+  double subIterDuration = 0;
+  for (iter = 0; iter < maxIter; iter++) {
+    auto start = std::chrono::system_clock::now();
+    o.learnRate = learnRate;
+    o.epoch = iter;
+    switch (kind) {
+      case K_SGD:
+      case K_HOG:
+        if (exact) {
+          // modelMF.cpp:76-81: std::shuffle every epoch on one thread (parBlockShuffle with one
+          // OpenMP thread is a plain std::shuffle; the reference is only reproducible that way)
+          std::shuffle(uiRatingInds.begin(), uiRatingInds.end(), mt);
+          dev->check(mfx_sgd_set_order(dev->ctx, (const uint64_t*)uiRatingInds.data(), nRatings), "set_order");
+          o.mode = MFX_SGD_SERIAL; o.order = MFX_ORDER_HOST;
+        } else {
+          o.mode = MFX_SGD_TILED; o.order = MFX_ORDER_DEVICE;
+        }
+        dev->check(mfx_sgd_epoch(dev->ctx, &o), "mfx_sgd_epoch");
+        break;
+      case K_SGDPAR:   // stratified: user-block x item-block tiles, one L2 domain per tile
+        o.mode = MFX_SGD_TILED; o.order = MFX_ORDER_DEVICE;
+        dev->check(mfx_sgd_epoch(dev->ctx, &o), "mfx_sgd_epoch");
+        break;
+      case K_SGDU: {
+        std::shuffle(validUsers.begin(), validUsers.end(), mt);   // modelMF.cpp:635
+        if (exact) {
+          uiRatingInds.clear();
+          for (size_t u : validUsers)
+            for (int64_t e = trainMat->rowptr[u]; e < trainMat->rowptr[u + 1]; e++) uiRatingInds.push_back((size_t)e);
+          dev->check(mfx_sgd_set_order(dev->ctx, (const uint64_t*)uiRatingInds.data(), (int64_t)uiRatingInds.size()),
+                     "set_order");
+          o.mode = MFX_SGD_SERIAL; o.order = MFX_ORDER_HOST;
+        } else {
+          dev->check(mfx_sgd_set_order(dev->ctx, (const uint64_t*)validUsers.data(), (int64_t)validUsers.size()),
+                     "set_order");
+          o.mode = MFX_SGD_USERS; o.order = MFX_ORDER_HOST;
+        }
+        dev->check(mfx_sgd_epoch(dev->ctx, &o), "mfx_sgd_epoch");
+        break;
+      }
+      case K_ALS:      // modelMF.cpp:805-880
+        dev->check(mfx_als_half_sweep(dev->ctx, MFX_SIDE_USERS, uReg), "mfx_als_half_sweep");
+        dev->check(mfx_als_half_sweep(dev->ctx, MFX_SIDE_ITEMS, iReg), "mfx_als_half_sweep");
+        break;
+      case K_CCDPP:
+      case K_CCDPP_FA:
+        if (kind == K_CCDPP) std::shuffle(dims.begin(), dims.end(), mt);   // :1026 (not in FreqAdap, :1271)
+        for (int k : dims)
+          dev->check(mfx_ccdpp_rank1(dev->ctx, k, 5, uReg, iReg, iter > 0, kind == K_CCDPP_FA ? 75.0f : -1.0f),
+                     "mfx_ccdpp_rank1");
+        break;
+    }
+    hostStale = true;
+    dev->check(mfx_synchronize(dev->ctx), "mfx_synchronize");
+    subIterDuration = std::chrono::duration<double>(std::chrono::system_clock::now() - start).count();
+
+    if (iter % MF_OBJ_ITER == 0 || iter == maxIter - 1) {
+      if (isTerminateModel(bestModel, data, iter, bestIter, bestObj, prevObj, bestValRMSE, prevValRMSE,
+                           invalidUsers, invalidItems))
+        break;
+      if (iter % MF_DISP_ITER == 0) {
+        std::cout << "ModelMF::" << name << " trainSeed: " << trainSeed << " Iter: " << iter
+                  << " Objective: " << std::scientific << prevObj
+                  << " Train RMSE: " << RMSE(data.trainMat, invalidUsers, invalidItems)
+                  << " Val RMSE: " << prevValRMSE << " subIterDuration: " << subIterDuration << std::endl;
+      }
+      if ((iter % MF_SAVE_ITER == 0 || iter == maxIter - 1) && kind != K_SGDPAR)   // :335-338 commented out there
+        bestModel.saveFacs(std::string(data.prefix));
+    }
+  }
+  if (kind != K_SGDPAR) bestModel.saveFacs(std::string(data.prefix));
+  std::cout << "\nBest model validation RMSE: " << bestModel.RMSE(data.valMat, invalidUsers, invalidItems);
+  if (kind == K_CCDPP || kind == K_CCDPP_FA) dev->check(mfx_ccdpp_end(dev->ctx), "mfx_ccdpp_end");
+  syncHost();
+  bestModel.syncHost();
+}

@@ -1,0 +1,139 @@
+// mf_model.h -- Model and ModelMF with the reference's class surface (model.h:22-105,
+// modelMF.h:21-57).  The factor matrices live in HBM while a trainer runs; every inner loop
+// of the reference's trainers is one call into the C ABI of include/mfx.h.
+#ifndef MFHOST_MF_MODEL_H_
+#define MFHOST_MF_MODEL_H_
+#include <cmath>
+#include <memory>
+#include <string>
+#include <unordered_set>
+#include <vector>
+
+#include "mfx.h"
+#include "params_data.h"
+
+// constants of const.h:4-12 / modelMF.h:16-17
+#define MF_OBJ_ITER 1
+#define MF_DISP_ITER 50
+#define MF_SAVE_ITER 50
+#define MF_CHANCE_ITER 500
+#define MF_EPS 1e-5
+
+// Row-major dense float matrix (the reference uses column-major Eigen::MatrixXf; the
+// text factor files and every formula are layout independent).
+struct DenseF32 {
+  int rows = 0, cols = 0;
+  std::vector<float> a;
+  DenseF32() {}
+  DenseF32(int r, int c) : rows(r), cols(c), a((size_t)r * c, 0.0f) {}
+  float& operator()(int r, int c) { return a[(size_t)r * cols + c]; }
+  float operator()(int r, int c) const { return a[(size_t)r * cols + c]; }
+  float* data() { return a.data(); }
+  const float* data() const { return a.data(); }
+  void fill(float v) { std::fill(a.begin(), a.end(), v); }
+  double norm() const {
+    double s = 0;
+    for (float x : a) s += (double)x * x;
+    return std::sqrt(s);
+  }
+};
+
+// One mfx_ctx with the three rating matrices of a Data uploaded.  Shared by a trainer's
+// model (snapshot CURRENT) and its bestModel (snapshot BEST).
+class MfxSession {
+ public:
+  mfx_ctx* ctx = nullptr;
+  const csr_t* mats[3] = {nullptr, nullptr, nullptr};
+  int nUsers = 0, nItems = 0, K = 0;
+  ~MfxSession();
+  static std::shared_ptr<MfxSession> open(const Data& data, int nUsers, int nItems, int K);
+  int which(const csr_t* m) const;
+  void check(int rc, const char* what) const;   // prints mfx_last_error and exits on failure
+};
+
+class Model {
+ public:
+  int nUsers = 0, nItems = 0, facDim = 0, trainSeed = -1;
+  float origLearnRate = 0, learnRate = 0, rhoRMS = 0, alpha = 0;
+  int maxIter = 0;
+  float uReg = 0, iReg = 0, sing_a = 0, sing_b = 0;
+  DenseF32 uFac, iFac;
+  std::vector<float> uBias, iBias;
+  double mu = 0;
+
+  Model(const Params& params);                                   // model.cpp:2315-2366
+  Model(int nUsers, int nItems, int facDim);                     // model.cpp:2310-2311
+  Model(const Params& params, int seed);                         // model.cpp:2375-2377
+  Model(const Params& params, const char* uFacName, const char* iFacName, int seed);  // :2380-2386
+  virtual ~Model() {}
+
+  // the trainer entry points of model.h:56-105 (base class: not implemented, as in the reference)
+  typedef std::unordered_set<int> IntSet;
+  virtual void train(const Data&, Model&, IntSet&, IntSet&) { notInBase("train"); }
+  virtual void trainSGDPar(const Data&, Model&, IntSet&, IntSet&) { notInBase("trainSGDPar"); }
+  virtual void trainSGDParSVD(const Data&, Model&, IntSet&, IntSet&) { notInBase("trainSGDParSVD"); }
+  virtual void trainUShuffle(const Data&, Model&, IntSet&, IntSet&) { notInBase("trainUShuffle"); }
+  virtual void trainALS(const Data&, Model&, IntSet&, IntSet&) { notInBase("trainALS"); }
+  virtual void trainCCDPP(const Data&, Model&, IntSet&, IntSet&) { notInBase("trainCCDPP"); }
+  virtual void trainCCDPPFreqAdap(const Data&, Model&, IntSet&, IntSet&) { notInBase("trainCCDPPFreqAdap"); }
+  virtual void trainCCD(const Data&, Model&, IntSet&, IntSet&) { notInBase("trainCCD"); }
+  virtual void hogTrain(const Data&, Model&, IntSet&, IntSet&) { notInBase("hogTrain"); }
+
+  virtual double estRating(int user, int item);                                  // model.cpp:547-549
+  double RMSE(csr_t* mat);                                                         // model.cpp:191-211
+  double RMSE(csr_t* mat, IntSet& invalidUsers, IntSet& invalidItems);            // model.cpp:214-251
+  virtual double objective(const Data& data);                                     // model.cpp:1694-1722
+  virtual double objective(const Data& data, IntSet& invalidUsers, IntSet& invalidItems);  // :1770-1815
+  bool isTerminateModel(Model& bestModel, const Data& data, int iter, int& bestIter, double& bestObj,
+                        double& prevObj, double& bestValRMSE, double& prevValRMSE, IntSet& invalidUsers,
+                        IntSet& invalidItems);                                     // model.cpp:1471-1540
+  std::string modelSignature();                                                    // model.cpp:11-19
+  void display();
+  void saveFacs(std::string prefix);                                               // model.cpp:89-101
+  void loadFacs(std::string prefix);                                               // model.cpp:104-128
+
+  // ---- device mirror ------------------------------------------------------------
+  std::shared_ptr<MfxSession> dev;   // set while/after a trainer ran
+  int devSnap = MFX_SNAP_CURRENT;    // which device snapshot this object stands for
+  bool hostStale = false;            // device copy is newer than uFac/iFac
+  void syncHost();                   // download uFac/iFac if hostStale
+  void pushToDevice();               // upload uFac/iFac to the CURRENT snapshot
+  // scalar fields of `*this = other` without touching the factor storage
+  void copyScalarsFrom(const Model& o);
+
+ protected:
+  void notInBase(const char* what);
+  void attach(const Data& data);     // open a session for data (if none) and upload the factors
+  // getInvalidUsersItems + modelMF.cpp:40-45 on the device, returned as sets
+  void deviceInvalid(const Data& data, IntSet& invalidUsers, IntSet& invalidItems);
+  void evalDevice(const csr_t* mat, int withNorms, mfx_eval_out* out);
+};
+
+class ModelMF : public Model {
+ public:
+  ModelMF(int nUsers, int nItems, int facDim) : Model(nUsers, nItems, facDim) {}
+  ModelMF(const Params& params) : Model(params) {}
+  ModelMF(const Params& params, int seed) : Model(params, seed) {}
+  ModelMF(const Params& params, const char* uFacName, const char* iFacName, int seed)
+      : Model(params, uFacName, iFacName, seed) {}
+  void train(const Data& data, Model& bestModel, IntSet& invalidUsers, IntSet& invalidItems) override;
+  void trainSGDPar(const Data& data, Model& bestModel, IntSet& invalidUsers, IntSet& invalidItems) override;
+  void trainSGDParSVD(const Data& data, Model& bestModel, IntSet& invalidUsers, IntSet& invalidItems) override;
+  void trainUShuffle(const Data& data, Model& bestModel, IntSet& invalidUsers, IntSet& invalidItems) override;
+  void trainALS(const Data& data, Model& bestModel, IntSet& invalidUsers, IntSet& invalidItems) override;
+  void trainCCDPP(const Data& data, Model& bestModel, IntSet& invalidUsers, IntSet& invalidItems) override;
+  void trainCCDPPFreqAdap(const Data& data, Model& bestModel, IntSet& invalidUsers, IntSet& invalidItems) override;
+  void trainCCD(const Data& data, Model& bestModel, IntSet& invalidUsers, IntSet& invalidItems) override;
+  void hogTrain(const Data& data, Model& bestModel, IntSet& invalidUsers, IntSet& invalidItems) override;
+
+ private:
+  enum Kind { K_SGD, K_HOG, K_SGDPAR, K_SGDU, K_ALS, K_CCDPP, K_CCDPP_FA };
+  void run(Kind kind, const char* name, const Data& data, Model& bestModel, IntSet& invalidUsers,
+           IntSet& invalidItems);
+};
+
+// text factor files (io.cpp:83-154)
+void writeMat(const DenseF32& mat, int nrows, int ncols, const char* fileName);
+bool readMat(DenseF32& mat, int nrows, int ncols, const char* fileName);
+bool isFileExist(const char* fileName);
+#endif

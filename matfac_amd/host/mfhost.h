@@ -24,6 +24,18 @@ int32_t mfh_synth_nitems(const mfh_synth* s);
  * (its draws are still consumed so that V does not depend on whether U was asked for). */
 void mfh_init_factors(int32_t seed, int32_t nUsers, int32_t nItems, int32_t K, float* U, float* V);
 
+/* Run ModelMF::<method> (sgd | hogsgd | sgdpar | sgdu | als | ccdpp | ccd++) the way main() does
+ * (main.cpp:1325-1348, 1377-1382) on in-memory matrices.  All three matrices have `nrows` rows.
+ * Outputs (each may be NULL): last iterate, bestModel, stats = {train RMSE, test RMSE, val RMSE of
+ * bestModel, final learnRate of the model, of bestModel, nItems}, invalid user/item masks.
+ * prefix NULL: no factor files are written. */
+int mfh_train(const char* method, int32_t nrows, const int64_t* tr_ptr, const int32_t* tr_ind,
+              const float* tr_val, int32_t tr_ncols, const int64_t* va_ptr, const int32_t* va_ind,
+              const float* va_val, int32_t va_ncols, const int64_t* te_ptr, const int32_t* te_ind,
+              const float* te_val, int32_t te_ncols, int32_t K, int32_t maxIter, int32_t seed, float learnRate,
+              float uReg, float iReg, const char* prefix, float* Ulast, float* Vlast, float* Ubest, float* Vbest,
+              double* stats, uint8_t* invU, uint8_t* invI);
+
 #ifdef __cplusplus
 }
 #endif

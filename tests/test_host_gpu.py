@@ -1,0 +1,143 @@
+"""The host classes (matfac_amd/host: Params/Data/Model/ModelMF + the `mf` driver) run the reference's
+training loops end to end on the GPU; the oracle's orc_train is the CPU restatement of the same
+loops including Model::isTerminateModel.  MFX_EXACT=1 replays the sequential SGD orders bit by bit."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from matfac_amd import synth
+from oracle import binding as orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def host_train(method, d, K, maxIter, seed, lr, ureg, ireg, prefix=None, env=None):
+    lib = synth._host()
+    tr, va, te = d["train"], d["val"], d["test"]
+    nU, nI = d["nUsers"], d["nItems"]
+    Ul, Vl = np.empty((nU, K), np.float32), np.empty((nI, K), np.float32)
+    Ub, Vb = np.empty((nU, K), np.float32), np.empty((nI, K), np.float32)
+    stats = np.zeros(6)
+    invU, invI = np.empty(nU, np.uint8), np.empty(nI, np.uint8)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    old = {}
+    for k, v in (env or {}).items():
+        old[k] = os.environ.get(k)
+        os.environ[k] = v
+    try:
+        rc = lib.mfh_train(method.encode(), C.c_int32(tr.nrows), P(tr.rowptr), P(tr.rowind), P(tr.rowval),
+                           C.c_int32(tr.ncols), P(va.rowptr), P(va.rowind), P(va.rowval), C.c_int32(va.ncols),
+                           P(te.rowptr), P(te.rowind), P(te.rowval), C.c_int32(te.ncols), C.c_int32(K),
+                           C.c_int32(maxIter), C.c_int32(seed), C.c_float(lr), C.c_float(ureg), C.c_float(ireg),
+                           prefix.encode() if prefix else None, P(Ul), P(Vl), P(Ub), P(Vb), P(stats), P(invU), P(invI))
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert rc == 0
+    return dict(U=Ul, V=Vl, Ubest=Ub, Vbest=Vb, train=stats[0], test=stats[1], val=stats[2], lr=stats[3],
+                invU=invU, invI=invI, nItems=int(stats[5]))
+
+
+def oracle_train(method, d, K, maxIter, seed, lr, ureg, ireg, dot_mode=orc.DOT_SEQ):
+    tr, va, te = d["train"], d["val"], d["test"]
+    nU, nI = d["nUsers"], d["nItems"]
+    cp, ci, cv = orc.create_col_index(tr.nrows, tr.ncols, tr.rowptr, tr.rowind, tr.rowval)
+    U0, V0 = orc.init_factors(seed, nU, nI, K)
+    r = orc.train(method, U0, V0, (tr.nrows, tr.ncols, tr.rowptr, tr.rowind, tr.rowval, cp, ci, cv),
+                  (va.nrows, va.rowptr, va.rowind, va.rowval), nU, nI, K, maxIter, seed, lr, ureg, ireg,
+                  nthreads=1, dot_mode=dot_mode)
+    r["test"], _, _ = orc.rmse(r["Ubest"], r["Vbest"], nU, nI, te.nrows, te.rowptr, te.rowind, te.rowval,
+                               r["invU"], r["invI"], dot_mode)
+    r["valbest"], _, _ = orc.rmse(r["Ubest"], r["Vbest"], nU, nI, va.nrows, va.rowptr, va.rowind, va.rowval,
+                                  r["invU"], r["invI"], dot_mode)
+    return r
+
+
+def data(nU=600, nI=400, nnz=30000, seed=12):
+    return synth.make(dict(nU=nU, nI=nI, nnz=nnz, K=0), seed=seed)
+
+
+def test_train_exact_mode_is_bit_identical_to_sequential_reference_loop():
+    """ModelMF::train with MFX_EXACT=1: std::shuffle order + serial kernel + the host termination
+    rules == the oracle's full loop (device dot order): same best model, bit for bit."""
+    d, K = data(300, 200, 8000), 10
+    h = host_train("sgd", d, K, 25, 1, 0.01, 0.02, 0.03, env={"MFX_EXACT": "1"})
+    o = oracle_train(orc.M_SGD, d, K, 25, 1, 0.01, 0.02, 0.03, dot_mode=orc.DOT_TREE)
+    assert np.array_equal(h["invU"], o["invU"]) and np.array_equal(h["invI"], o["invI"])
+    assert np.array_equal(h["U"], o["U"]) and np.array_equal(h["V"], o["V"])
+    assert np.array_equal(h["Ubest"], o["Ubest"]) and np.array_equal(h["Vbest"], o["Vbest"])
+    assert abs(h["test"] - o["test"]) < 1e-12 and abs(h["val"] - o["valbest"]) < 1e-12
+    # and the reference's own dot order (sequential) lands on the same RMSE to round-off
+    o2 = oracle_train(orc.M_SGD, d, K, 25, 1, 0.01, 0.02, 0.03, dot_mode=orc.DOT_SEQ)
+    assert abs(h["test"] - o2["test"]) < 1e-4          # north_star: SGD test RMSE within 1e-4 under a fixed seed
+
+
+def test_ushuffle_exact_mode_is_bit_identical():
+    d, K = data(250, 180, 6000, seed=5), 64
+    h = host_train("sgdu", d, K, 12, 3, 0.01, 0.02, 0.02, env={"MFX_EXACT": "1"})
+    o = oracle_train(orc.M_SGDU, d, K, 12, 3, 0.01, 0.02, 0.02, dot_mode=orc.DOT_TREE)
+    assert np.array_equal(h["U"], o["U"]) and np.array_equal(h["V"], o["V"])
+    assert np.array_equal(h["Ubest"], o["Ubest"])
+
+
+def test_nan_guard_halves_learning_rate_like_the_reference():
+    d, K = data(200, 150, 5000, seed=7), 8
+    h = host_train("sgd", d, K, 6, 1, 50.0, 0.01, 0.01, env={"MFX_EXACT": "1"})
+    o = oracle_train(orc.M_SGD, d, K, 6, 1, 50.0, 0.01, 0.01, dot_mode=orc.DOT_TREE)
+    assert h["lr"] == pytest.approx(o["learnRate"]) and h["lr"] < 50.0
+    assert np.array_equal(h["Ubest"], o["Ubest"])
+
+
+@pytest.mark.parametrize("method,om,reg", [("als", orc.M_ALS, 3.0), ("ccdpp", orc.M_CCDPP, 0.5),
+                                            ("ccd++", orc.M_CCDPP_FA, 0.5)])
+def test_als_and_ccdpp_loops_match_oracle(method, om, reg):
+    d, K = data(), 16
+    h = host_train(method, d, K, 8, 1, 0.005, reg, reg)
+    o = oracle_train(om, d, K, 8, 1, 0.005, reg, reg)
+    # ALS/CCD++ within fp32 round-off (<= 1e-5 abs RMSE, <= 1e-4 rel factor error... the
+    # factor bound is scaled by the conditioning of the per-row systems for ALS)
+    assert abs(h["test"] - o["test"]) < 1e-5 and abs(h["val"] - o["valbest"]) < 1e-5
+    scale = np.abs(o["Ubest"]).max()
+    assert np.abs(h["Ubest"] - o["Ubest"]).max() < (1e-3 if method == "als" else 1e-4) * scale
+
+
+@pytest.mark.parametrize("method", ["sgd", "hogsgd", "sgdpar", "sgdu"])
+def test_fast_sgd_paths_reach_the_reference_rmse(method):
+    d, K = data(3000, 2000, 300000, seed=2), 16
+    h = host_train(method, d, K, 40, 1, 0.01, 0.02, 0.02)
+    o = oracle_train(orc.M_SGD, d, K, 40, 1, 0.01, 0.02, 0.02)
+    print(method, "test RMSE gpu %.5f cpu %.5f | val gpu %.5f cpu %.5f" % (h["test"], o["test"], h["val"], o["valbest"]))
+    assert abs(h["test"] - o["test"]) < 3e-2
+
+
+def test_mf_cli_end_to_end(tmp_path):
+    d, K = data(400, 300, 15000, seed=9), 12
+    files = {}
+    for name in ("train", "test", "val"):
+        m = d[name]
+        files[name] = str(tmp_path / (name + ".csr"))
+        orc.write_csr_text(files[name], m.nrows, m.rowptr, m.rowind, m.rowval)
+    prefix = str(tmp_path / "run")
+    cmd = [os.path.join(ROOT, "matfac_amd", "mf"), "--trainmat=" + files["train"], "--testmat", files["test"],
+           "--valmat=" + files["val"], "--prefix=" + prefix, "--facdim=%d" % K, "--maxiter=6", "--mf_method=als",
+           "--ureg=2.0", "--ireg=2.0", "--seed=1"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    test_rmse = float(re.search(r"Test RMSE: ([0-9.eE+-]+)", out.stdout).group(1))
+    o = oracle_train(orc.M_ALS, d, K, 6, 1, 0.005, 2.0, 2.0)
+    assert abs(test_rmse - o["test"]) < 2e-5
+    # factor files in the reference's format and naming (model.cpp:11-19, 89-101)
+    sig = "%dX%d_%d_%s_%s_%s" % (d["nUsers"], d["nItems"], K, "2.000000", "2.000000", "0.005000")
+    Ub = orc.read_mat(prefix + "_uFac_" + sig + ".mat", d["nUsers"], K)
+    assert np.allclose(Ub, o["Ubest"], rtol=1e-3, atol=1e-4)
+    # missing flags exit with -1 like the reference (main.cpp:53-64)
+    bad = subprocess.run([cmd[0], "--facdim=4"], capture_output=True, text=True)
+    assert bad.returncode != 0 and "Missing" in bad.stderr
