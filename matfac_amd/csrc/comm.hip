@@ -158,7 +158,7 @@ extern "C" int mfx_allreduce_item_factors(mfx_ctx* ctx, int op) {
   NEED(ctx->V, MFX_E_STATE, "mfx_allreduce_item_factors: no model");
   NEED(op == MFX_REDUCE_DELTA_SUM || op == MFX_REDUCE_AVERAGE, MFX_E_ARG, "mfx_allreduce_item_factors: op=%d", op);
   HIPCHK(hipSetDevice(ctx->device));
-  if (ctx->nranks == 1 || !ctx->comm) return MFX_OK;  // single rank: V is already the sum
+  if (!ctx->comm) return MFX_OK;  // no communicator: single device, V is already the sum
   int rc;
   if ((rc = ensure_sync_buffers(ctx))) return rc;
   const int64_t n = (int64_t)ctx->nI * ctx->ld, n4 = n / 4;
@@ -182,7 +182,7 @@ extern "C" int mfx_allreduce_item_factors(mfx_ctx* ctx, int op) {
 extern "C" int mfx_allreduce_f64(mfx_ctx* ctx, double* vals, int n) {
   if (!ctx) return MFX_E_ARG;
   NEED(vals && n > 0 && n <= 8, MFX_E_ARG, "mfx_allreduce_f64: n must be in [1,8]");
-  if (ctx->nranks == 1 || !ctx->comm) return MFX_OK;
+  if (!ctx->comm) return MFX_OK;
   HIPCHK(hipSetDevice(ctx->device));
   if (ctx->red_blocks < 1) {
     int rc;

@@ -128,20 +128,45 @@ __global__ __launch_bounds__(256) void eval_norm_kernel(const float* __restrict_
   if (threadIdx.x == 0) part_d[blockIdx.x] = bd;
 }
 
-__global__ void eval_finish_kernel(const double* __restrict__ p0, int n0, const int64_t* __restrict__ pi,
-                                   const double* __restrict__ p1, int n1, const double* __restrict__ p2, int n2,
-                                   double* __restrict__ out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double s = 0;
+// one 256-thread block; fixed association: thread t sums entries t, t+256, ... then a
+// fixed LDS tree -- reproducible for a given grid
+__device__ __forceinline__ double finish_sum(const double* __restrict__ p, int n, double* sh) {
+  double a = 0;
+  for (int k = threadIdx.x; k < n; k += 256) a += p[k];
+  sh[threadIdx.x] = a;
+  __syncthreads();
+  for (int w = 128; w >= 1; w >>= 1) {
+    if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  const double r = sh[0];
+  __syncthreads();
+  return r;
+}
+__global__ __launch_bounds__(256) void eval_finish_kernel(const double* __restrict__ p0, int n0,
+                                                          const int64_t* __restrict__ pi,
+                                                          const double* __restrict__ p1, int n1,
+                                                          const double* __restrict__ p2, int n2,
+                                                          double* __restrict__ out) {
+  __shared__ double sh[256];
+  __shared__ long long shi[256];
+  const double s = finish_sum(p0, n0, sh);
+  const double a = finish_sum(p1, n1, sh);
+  const double b = finish_sum(p2, n2, sh);
   long long c = 0;
-  for (int k = 0; k < n0; k++) { s += p0[k]; c += pi[k]; }
-  double a = 0, b = 0;
-  for (int k = 0; k < n1; k++) a += p1[k];
-  for (int k = 0; k < n2; k++) b += p2[k];
-  out[0] = s;
-  out[1] = (double)c;
-  out[2] = a;
-  out[3] = b;
+  for (int k = threadIdx.x; k < n0; k += 256) c += pi[k];
+  shi[threadIdx.x] = c;
+  __syncthreads();
+  for (int w = 128; w >= 1; w >>= 1) {
+    if ((int)threadIdx.x < w) shi[threadIdx.x] += shi[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = s;
+    out[1] = (double)shi[0];
+    out[2] = a;
+    out[3] = b;
+  }
 }
 
 template <int L, int C>
@@ -192,7 +217,7 @@ int mfx_launch_eval(mfx_ctx* ctx, const DevCSR& m, const float* U, const float* 
   }
   if (rc) return rc;
   double* dout = ctx->red_d + need;  // 4 doubles of the +8 tail
-  hipLaunchKernelGGL(eval_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->red_d, nb, ctx->red_i,
+  hipLaunchKernelGGL(eval_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->red_d, nb, ctx->red_i,
                      ctx->red_d + nb, with_norms ? nbu : 0, ctx->red_d + nb + nbu, with_norms ? nbi : 0, dout);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(ctx->red_out, dout, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

@@ -189,6 +189,10 @@ __global__ __launch_bounds__(256) void sgd_tiled_kernel(const int32_t* __restric
   const int t_last = SWEEP ? 63 : t_first;
   for (int tile = t_first; tile <= t_last; tile++) {
     const int64_t b = tile_start[tile], sz = tile_start[tile + 1] - b;
+    if (SWEEP) {  // nothing left in this tile (the normal case): do not queue on its counter
+      const unsigned long long seen = __hip_atomic_load(&tile_ctr[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((int64_t)seen >= sz) continue;
+    }
     for (;;) {
       unsigned long long got = 0;
       if (lane == 0) got = atomicAdd(&tile_ctr[tile], (unsigned long long)(64 * PULL));
