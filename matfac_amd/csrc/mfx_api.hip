@@ -105,7 +105,7 @@ void mfx_destroy(mfx_ctx* ctx) {
   for (auto& m : ctx->mat) free_csr(m);
   free_model(ctx);
   dev_free(ctx->eu); dev_free(ctx->ei); dev_free(ctx->er); dev_free(ctx->order);
-  dev_free(ctx->tu); dev_free(ctx->ti); dev_free(ctx->tr); dev_free(ctx->tile_start); dev_free(ctx->tile_ctr);
+  mfx_slots_free_internal(ctx);
   dev_free(ctx->ulist); dev_free(ctx->red_d); dev_free(ctx->red_i);
   if (ctx->red_out) (void)hipHostFree(ctx->red_out);
   for (auto& s : ctx->prof) {
@@ -158,7 +158,7 @@ extern "C" int mfx_set_csr(mfx_ctx* ctx, int which, int32_t nrows, int32_t ncols
   HIPCHK(hipSetDevice(ctx->device));
   DevCSR& m = ctx->mat[which];
   free_csr(m);
-  if (which == MFX_MAT_TRAIN) { mfx_ccd_free_internal(ctx); mfx_als_free_internal(ctx); mfx_segs_free_internal(ctx); }
+  if (which == MFX_MAT_TRAIN) { mfx_ccd_free_internal(ctx); mfx_als_free_internal(ctx); mfx_segs_free_internal(ctx); mfx_slots_free_internal(ctx); }
   int rc;
   if ((rc = dev_alloc(ctx, &m.rowptr, (size_t)nrows + 1))) return rc;
   if ((rc = dev_alloc(ctx, &m.rowind, (size_t)nnz))) return rc;
@@ -207,42 +207,6 @@ extern "C" int mfx_set_csr(mfx_ctx* ctx, int which, int32_t nrows, int32_t ncols
       HIPCHK(hipMemcpyAsync(m.colval, colval, sizeof(float) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream));
     }
     m.has_col = true;
-  }
-  std::vector<int32_t> tu_h, ti_h;
-  std::vector<float> tr_h;
-  if (which == MFX_MAT_TRAIN) {
-    // bucket the ratings by (user block, item block): stable counting sort over CSR order
-    dev_free(ctx->tu); dev_free(ctx->ti); dev_free(ctx->tr);
-    ctx->have_tiles = false;
-    int64_t cnt[65] = {0};
-    for (int32_t u = 0; u < nrows; u++) {
-      const int bu = mfx_user_block(u);
-      for (int64_t e = rowptr[u]; e < rowptr[u + 1]; e++) cnt[bu * 8 + mfx_item_block(rowind[e]) + 1]++;
-    }
-    for (int t = 0; t < 64; t++) cnt[t + 1] += cnt[t];
-    memcpy(ctx->tile_start_h, cnt, sizeof cnt);
-    tu_h.resize((size_t)nnz); ti_h.resize((size_t)nnz); tr_h.resize((size_t)nnz);
-    int64_t pos[64];
-    memcpy(pos, cnt, sizeof pos);
-    for (int32_t u = 0; u < nrows; u++) {
-      const int bu = mfx_user_block(u);
-      for (int64_t e = rowptr[u]; e < rowptr[u + 1]; e++) {
-        const int64_t d = pos[bu * 8 + mfx_item_block(rowind[e])]++;
-        tu_h[d] = u; ti_h[d] = rowind[e]; tr_h[d] = rowval[e];
-      }
-    }
-    if ((rc = dev_alloc(ctx, &ctx->tu, (size_t)nnz))) return rc;
-    if ((rc = dev_alloc(ctx, &ctx->ti, (size_t)nnz))) return rc;
-    if ((rc = dev_alloc(ctx, &ctx->tr, (size_t)nnz))) return rc;
-    if (!ctx->tile_start && (rc = dev_alloc(ctx, &ctx->tile_start, (size_t)65))) return rc;
-    if (!ctx->tile_ctr && (rc = dev_alloc(ctx, &ctx->tile_ctr, (size_t)64))) return rc;
-    if (nnz) {
-      HIPCHK(hipMemcpyAsync(ctx->tu, tu_h.data(), sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream));
-      HIPCHK(hipMemcpyAsync(ctx->ti, ti_h.data(), sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream));
-      HIPCHK(hipMemcpyAsync(ctx->tr, tr_h.data(), sizeof(float) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream));
-    }
-    HIPCHK(hipMemcpyAsync(ctx->tile_start, ctx->tile_start_h, sizeof(int64_t) * 65, hipMemcpyHostToDevice, ctx->stream));
-    ctx->have_tiles = true;
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));  // host buffers are borrowed for this call only
   m.present = true;
@@ -402,23 +366,6 @@ extern "C" int mfx_restore_best(mfx_ctx* ctx) {
 // Bijection on [0,n): alternating (unbalanced) Feistel network on ceil(log2 n) bits
 // keyed by (seed, epoch), cycle-walked into range.  Documented in DESIGN.md; the
 // python tests re-implement it to check the device list is that permutation.
-__host__ __device__ inline uint64_t mfx_feistel(uint64_t x, int abits, int bbits, uint32_t k0, uint32_t k1) {
-  const uint32_t maskA = (abits >= 32) ? 0xffffffffU : ((1U << abits) - 1U);
-  const uint32_t maskB = (bbits >= 32) ? 0xffffffffU : ((1U << bbits) - 1U);
-  uint32_t Lh = (uint32_t)(x >> bbits) & maskA, Rh = (uint32_t)x & maskB;
-#pragma unroll
-  for (int r = 0; r < 6; r++) {
-    if ((r & 1) == 0) Lh ^= mfx_mix32(Rh * 0x9e3779b1U + k0 + (uint32_t)r * 0x85ebca6bU) & maskA;
-    else Rh ^= mfx_mix32(Lh * 0xc2b2ae35U + k1 + (uint32_t)r * 0x27d4eb2fU) & maskB;
-  }
-  return ((uint64_t)Lh << bbits) | Rh;
-}
-__host__ __device__ inline int64_t mfx_perm_index(int64_t t, int64_t n, int abits, int bbits, uint32_t k0, uint32_t k1) {
-  uint64_t y = mfx_feistel((uint64_t)t, abits, bbits, k0, k1);
-  while (y >= (uint64_t)n) y = mfx_feistel(y, abits, bbits, k0, k1);
-  return (int64_t)y;
-}
-
 template <int MODE>  // 0: feistel, 1: order[] array
 __global__ void build_epoch_list_kernel(const int32_t* __restrict__ cu, const int32_t* __restrict__ ci,
                                         const float* __restrict__ cr, int64_t nsrc,
@@ -431,28 +378,6 @@ __global__ void build_epoch_list_kernel(const int32_t* __restrict__ cu, const in
     if (MODE == 0) s = mfx_perm_index(t, n, abits, bbits, k0, k1);
     else { s = (int64_t)order[t]; if (s < 0 || s >= nsrc) s = 0; }
     eu[t] = cu[s]; ei[t] = ci[s]; er[t] = cr[s];
-  }
-}
-
-// tiled epoch list: position t belongs to the tile whose range contains it; inside the
-// tile the visiting order is a fresh Feistel permutation keyed by (seed, epoch, tile)
-__global__ void build_tiled_epoch_list_kernel(const int32_t* __restrict__ tu, const int32_t* __restrict__ ti,
-                                              const float* __restrict__ tr, const int64_t* __restrict__ tile_start,
-                                              int64_t n, uint32_t k0, uint32_t k1, int32_t* __restrict__ eu,
-                                              int32_t* __restrict__ ei, float* __restrict__ er) {
-  __shared__ int64_t ts[65];
-  if (threadIdx.x < 65) ts[threadIdx.x] = tile_start[threadIdx.x];
-  __syncthreads();
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
-    int lo = 0, hi = 64;  // largest tile with ts[tile] <= t
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ts[mid] <= t) lo = mid; else hi = mid; }
-    const int64_t b = ts[lo], sz = ts[lo + 1] - b;
-    int bits = 2;
-    while (((int64_t)1 << bits) < sz) bits++;
-    const int abits = bits / 2, bbits = bits - abits;
-    const int64_t s = b + mfx_perm_index(t - b, sz, abits, bbits, k0 + (uint32_t)lo * 0x632be5abU, k1 ^ mfx_mix32((uint32_t)lo + 77U));
-    eu[t] = tu[s]; ei[t] = ti[s]; er[t] = tr[s];
   }
 }
 
@@ -521,27 +446,8 @@ extern "C" int mfx_sgd_epoch(mfx_ctx* ctx, const mfx_sgd_opts* o) {
 
   if (o->mode == MFX_SGD_TILED) {
     NEED(o->order == MFX_ORDER_DEVICE, MFX_E_ARG, "mfx_sgd_epoch: MFX_SGD_TILED needs MFX_ORDER_DEVICE");
-    NEED(ctx->have_tiles, MFX_E_STATE, "mfx_sgd_epoch: no tiles (train matrix not set)");
     NEED(o->count <= 0, MFX_E_ARG, "mfx_sgd_epoch: MFX_SGD_TILED visits the whole list");
-    const int64_t n = m.nnz;
-    if (n == 0) return MFX_OK;
-    int rc;
-    if ((rc = ensure_elist(ctx, n))) return rc;
-    {
-      ProfScope ps(ctx, MFX_K_PERMUTE);
-      const uint32_t k0 = mfx_mix32(o->seed ^ 0x3c6ef372U) + (uint32_t)o->epoch * 0x9e3779b9U;
-      const uint32_t k1 = mfx_mix32(o->seed * 0x85ebca6bU + 0xdaa66d2bU) ^ mfx_mix32((uint32_t)o->epoch + 0x1b873593U);
-      const int blocks = (int)std::min<int64_t>((n + 255) / 256, 8192);
-      if (tiled_variant() & 1) {  // experiment: keep the tile lists in their stored (user-major) order
-        HIPCHK(hipMemcpyAsync(ctx->eu, ctx->tu, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
-        HIPCHK(hipMemcpyAsync(ctx->ei, ctx->ti, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
-        HIPCHK(hipMemcpyAsync(ctx->er, ctx->tr, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
-      } else
-      hipLaunchKernelGGL(build_tiled_epoch_list_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ctx->tu, ctx->ti,
-                         ctx->tr, ctx->tile_start, n, k0, k1, ctx->eu, ctx->ei, ctx->er);
-      HIPCHK(hipGetLastError());
-    }
-    ctx->elist_n = n;
+    if (m.nnz == 0) return MFX_OK;
     return mfx_launch_sgd_tiled(ctx, o);
   }
 
@@ -586,6 +492,12 @@ extern "C" int mfx_sgd_epoch(mfx_ctx* ctx, const mfx_sgd_opts* o) {
 extern "C" int mfx_debug_epoch_list(mfx_ctx* ctx, int32_t* u, int32_t* i, float* r, int64_t cap, int64_t* n) {
   if (!ctx) return MFX_E_ARG;
   NEED(n, MFX_E_ARG, "mfx_debug_epoch_list: n NULL");
+  if (ctx->elist_n < 0) {   // last epoch was MFX_SGD_TILED: rebuild its visiting order
+    HIPCHK(hipSetDevice(ctx->device));
+    int rc = ensure_elist(ctx, ctx->mat[MFX_MAT_TRAIN].nnz);
+    if (rc) return rc;
+    if ((rc = mfx_slots_materialise_order(ctx))) return rc;
+  }
   *n = ctx->elist_n;
   if (!u && !i && !r) return MFX_OK;
   NEED(cap >= ctx->elist_n, MFX_E_ARG, "mfx_debug_epoch_list: cap too small");

@@ -68,13 +68,8 @@ struct mfx_ctx {
   int64_t order_n = 0, order_cap = 0;
   int32_t* ulist = nullptr;  // user list for MFX_SGD_USERS
   int64_t ulist_cap = 0;
-  // MFX_SGD_TILED: train ratings bucketed by (user block, item block), 64 tiles
-  int32_t *tu = nullptr, *ti = nullptr;
-  float* tr = nullptr;
-  int64_t* tile_start = nullptr;          // device [65]
-  unsigned long long* tile_ctr = nullptr; // device [64] work counters
-  int64_t tile_start_h[65] = {0};
-  bool have_tiles = false;
+  // MFX_SGD_TILED: slot lists (sgd_slots.hip owns the type)
+  void* slots = nullptr;
 
   // reduction scratch
   double* red_d = nullptr;   // [blocks][4]
@@ -151,6 +146,26 @@ __host__ __device__ static inline uint32_t mfx_mix32(uint32_t x) {
 __host__ __device__ static inline int mfx_user_block(int32_t u) { return (int)(mfx_mix32((uint32_t)u * 0x9e3779b1U + 0x1234567U) & 7U); }
 __host__ __device__ static inline int mfx_item_block(int32_t i) { return (int)(mfx_mix32((uint32_t)i * 0x85ebca6bU + 0x89abcdeU) & 7U); }
 
+// Bijection on [0,n): alternating (unbalanced) Feistel network on ceil(log2 n) bits, cycle-walked
+// into range (documented in DESIGN.md; tests re-check that the device lists are permutations).
+__host__ __device__ static inline uint64_t mfx_feistel(uint64_t x, int abits, int bbits, uint32_t k0, uint32_t k1) {
+  const uint32_t maskA = (abits >= 32) ? 0xffffffffU : ((1U << abits) - 1U);
+  const uint32_t maskB = (bbits >= 32) ? 0xffffffffU : ((1U << bbits) - 1U);
+  uint32_t Lh = (uint32_t)(x >> bbits) & maskA, Rh = (uint32_t)x & maskB;
+#pragma unroll
+  for (int r = 0; r < 6; r++) {
+    if ((r & 1) == 0) Lh ^= mfx_mix32(Rh * 0x9e3779b1U + k0 + (uint32_t)r * 0x85ebca6bU) & maskA;
+    else Rh ^= mfx_mix32(Lh * 0xc2b2ae35U + k1 + (uint32_t)r * 0x27d4eb2fU) & maskB;
+  }
+  return ((uint64_t)Lh << bbits) | Rh;
+}
+__host__ __device__ static inline int64_t mfx_perm_index(int64_t t, int64_t n, int abits, int bbits, uint32_t k0, uint32_t k1) {
+  uint64_t y = mfx_feistel((uint64_t)t, abits, bbits, k0, k1);
+  while (y >= (uint64_t)n) y = mfx_feistel(y, abits, bbits, k0, k1);
+  return (int64_t)y;
+}
+
+
 static inline void mfx_tree_shape(int K, int* L, int* C) {
   if (K <= 16) { *L = 4; *C = 1; }
   else if (K <= 32) { *L = 8; *C = 1; }
@@ -161,7 +176,8 @@ static inline void mfx_tree_shape(int K, int* L, int* C) {
 int mfx_launch_sgd(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_t count);
 int mfx_launch_sgd_users(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t nusers);
 int mfx_launch_sgd_tiled(mfx_ctx* ctx, const mfx_sgd_opts* o);
-int tiled_variant();  // experiment knob MFX_TILED_VARIANT
+int mfx_slots_materialise_order(mfx_ctx* ctx);
+void mfx_slots_free_internal(mfx_ctx* ctx);
 int mfx_launch_eval(mfx_ctx* ctx, const DevCSR& m, const float* U, const float* V,
                     int with_norms, mfx_eval_out* out);
 int mfx_comm_free_internal(mfx_ctx* ctx);

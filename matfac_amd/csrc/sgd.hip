@@ -14,115 +14,29 @@
 
 #include "mfx_internal.h"
 
-typedef float float4v __attribute__((ext_vector_type(4)));
-typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+#include "sgd_common.h"
 
-// Cache policy of the factor-row accesses (experiment knob MFX_SGD_POLICY):
-//   0 plain global loads/stores (L1 + write-back L2)
-//   1 sc1 loads and stores: agent scope -- loads bypass the CU's L1, stores write through
-//     the XCD's L2 (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & visibility")
-//   2 nt loads and stores   3 sc1 loads, plain stores   4 sc0 sc1 (system scope) both
-template <int POL>
-struct Rows {
-  float* base;
-  __amdgpu_buffer_rsrc_t rs;
-  __device__ __forceinline__ Rows(float* b, uint32_t bytes) : base(b) {
-    if (POL != 0) rs = __builtin_amdgcn_make_buffer_rsrc(b, 0, bytes, 0x00020000);
-  }
-  static constexpr int AUXL = POL == 1 ? 16 : POL == 2 ? 2 : POL == 3 ? 16 : 17;
-  static constexpr int AUXS = POL == 1 ? 16 : POL == 2 ? 2 : POL == 3 ? 0 : 17;
-  __device__ __forceinline__ float4v ld(int64_t elt) const {
-    if (POL == 0) return *(const float4v*)(base + elt);
-    uint4v v = __builtin_amdgcn_raw_buffer_load_b128(rs, (uint32_t)(elt * 4), 0, AUXL);
-    return __builtin_bit_cast(float4v, v);
-  }
-  __device__ __forceinline__ void st(int64_t elt, float4v v) const {
-    if (POL == 0) { *(float4v*)(base + elt) = v; return; }
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, v), rs, (uint32_t)(elt * 4), 0, AUXS);
-  }
-};
-
-template <int L>
-__device__ __forceinline__ float group_sum(float s) {
-#pragma unroll
-  for (int m = L / 2; m >= 1; m >>= 1) s = s + __shfl_xor(s, m, 64);
-  return s;
-}
-
-// p.q in device order (include/mfx.h)
-template <int L, int C>
-__device__ __forceinline__ float group_dot(const float4v (&p)[C], const float4v (&q)[C]) {
-  float a = 0.0f;
-#pragma unroll
-  for (int c = 0; c < C; c++) {
-    a = __builtin_fmaf(p[c].x, q[c].x, a);
-    a = __builtin_fmaf(p[c].y, q[c].y, a);
-    a = __builtin_fmaf(p[c].z, q[c].z, a);
-    a = __builtin_fmaf(p[c].w, q[c].w, a);
-  }
-  return group_sum<L>(a);
-}
-
-// x -= learnRate * (-2.0*diff*y + 2.0*reg*x)      modelMF.cpp:96 / :102
-__device__ __forceinline__ float upd_ref64(float x, float y, double m2diff, double reg2, double lr) {
-  return (float)((double)x - lr * (m2diff * (double)y + reg2 * (double)x));
-}
-// row -= learnRate*(-2.0*diff*other + 2.0*reg*row) with the scalars narrowed to
-// float by the Eigen row expression                modelMF.cpp:1759 / :1762
-__device__ __forceinline__ float upd_f32(float x, float y, float c1, float c2, float lr) {
-  return x - lr * (c1 * y + c2 * x);
-}
-
-template <int L, int C, int ARITH, int POL, bool QATOM = false>
+template <int L, int C, int ARITH, int POL>
 __device__ __forceinline__ void sgd_visit(const Rows<POL>& Um, const Rows<POL>& Vm, int64_t pe, int64_t qe,
                                           float r, float lr, float uReg, float iReg) {
-  float4v p[C], q[C], q0[C];
+  float4v p[C], q[C];
 #pragma unroll
   for (int c = 0; c < C; c++) {
     p[c] = Um.ld(pe + c * 4 * L);
     q[c] = Vm.ld(qe + c * 4 * L);
-    q0[c] = q[c];
   }
   const float est = group_dot<L, C>(p, q);
-  if (ARITH == MFX_ARITH_F32) {
-    const double diff = (double)r - (double)est;
-    const float c1 = (float)(-2.0 * diff);
-    const float cu = (float)(2.0 * (double)uReg), ci = (float)(2.0 * (double)iReg);
-#pragma unroll
-    for (int c = 0; c < C; c++) {
-#pragma unroll
-      for (int e = 0; e < 4; e++) p[c][e] = upd_f32(p[c][e], q[c][e], c1, cu, lr);
-#pragma unroll
-      for (int e = 0; e < 4; e++) q[c][e] = upd_f32(q[c][e], p[c][e], c1, ci, lr);
-    }
-  } else {
-    double diff;
-    if (ARITH == MFX_ARITH_REF64F) { const float d = r - est; diff = (double)d; }
-    else diff = (double)r - (double)est;
-    const double m2 = -2.0 * diff;
-    const double ru = 2.0 * (double)uReg, ri = 2.0 * (double)iReg, lrd = (double)lr;
-#pragma unroll
-    for (int c = 0; c < C; c++) {
-#pragma unroll
-      for (int e = 0; e < 4; e++) p[c][e] = upd_ref64(p[c][e], q[c][e], m2, ru, lrd);
-#pragma unroll
-      for (int e = 0; e < 4; e++) q[c][e] = upd_ref64(q[c][e], p[c][e], m2, ri, lrd);
-    }
-  }
+  sgd_axpys<C, ARITH>(p, q, r, est, lr, uReg, iReg);
 #pragma unroll
   for (int c = 0; c < C; c++) {
     Um.st(pe + c * 4 * L, p[c]);
-    if (!QATOM) Vm.st(qe + c * 4 * L, q[c]);
-    else {
-#pragma unroll
-      for (int e = 0; e < 4; e++) atomicAdd(Vm.base + qe + c * 4 * L + e, q[c][e] - q0[c][e]);
-    }
+    Vm.st(qe + c * 4 * L, q[c]);
   }
 }
 
 // One 64-rating chunk of the epoch list: coalesced SoA read by the whole wave, then the
 // chunk is walked G ratings at a time (group g takes entries g, G+g, 2G+g, ...).
-template <int L, int C, int ARITH, int POL, int VAR = 0>
+template <int L, int C, int ARITH, int POL>
 __device__ __forceinline__ void sgd_chunk(const Rows<POL>& Um, const Rows<POL>& Vm,
                                           const int32_t* __restrict__ eu, const int32_t* __restrict__ ei,
                                           const float* __restrict__ er, int64_t idx0, int nvalid, int lane,
@@ -136,13 +50,12 @@ __device__ __forceinline__ void sgd_chunk(const Rows<POL>& Um, const Rows<POL>& 
   const float mr = ok ? er[idx0 + lane] : 0.0f;
 #pragma unroll 1
   for (int s = 0; s < L; s++) {
-    const int e = (VAR & 4) ? g * L + s : s * G + g;
+    const int e = s * G + g;
     const int u = __shfl(mu, e, 64);
     const int it = __shfl(mi, e, 64);
     const float r = __shfl(mr, e, 64);
     if (e < nvalid)
-      sgd_visit<L, C, ARITH, POL, (VAR & 2) != 0>(Um, Vm, (int64_t)u * LD + 4 * j, (int64_t)it * LD + 4 * j, r, lr,
-                                                  uReg, iReg);
+      sgd_visit<L, C, ARITH, POL>(Um, Vm, (int64_t)u * LD + 4 * j, (int64_t)it * LD + 4 * j, r, lr, uReg, iReg);
   }
 }
 
@@ -160,52 +73,6 @@ __global__ __launch_bounds__(256) void sgd_hogwild_kernel(const int32_t* __restr
   for (int64_t base = wave * 64; base < count; base += nwaves * 64) {
     const int nvalid = (int)(count - base < 64 ? count - base : 64);
     sgd_chunk<L, C, ARITH, POL>(Um, Vm, eu, ei, er, first + base, nvalid, lane, lr, uReg, iReg);
-  }
-}
-
-// Tiled Hogwild (MFX_SGD_TILED).  The epoch list is stored tile by tile (tile =
-// user block x item block, 8 x 8).  In round r a workgroup that runs on XCD x works
-// only on tile (x, (x + r) & 7): during a round every user row and every item row is
-// touched from ONE XCD, i.e. through one coherent L2 (the per-XCD L2s are not coherent
-// with each other: MI355X_MICROARCH.md).  Loads bypass the CU's L1 (sc1) and are served
-// by that L2; stores are plain (write-back into the same L2); the kernel boundary
-// between rounds publishes them chip-wide.  Waves pull 64*PULL-rating pieces of their
-// tile from a per-tile counter, so the result does not depend on how many workgroups
-// the dispatcher put on each XCD; round = -1 sweeps whatever is left in ANY tile, which
-// makes "every rating exactly once per epoch" independent of placement altogether.
-template <int L, int C, int ARITH, bool SWEEP, int VAR = 0>
-__global__ __launch_bounds__(256) void sgd_tiled_kernel(const int32_t* __restrict__ eu,
-                                                        const int32_t* __restrict__ ei,
-                                                        const float* __restrict__ er,
-                                                        const int64_t* __restrict__ tile_start,
-                                                        unsigned long long* tile_ctr, int round, float* U,
-                                                        float* V, uint32_t ubytes, uint32_t vbytes, float lr,
-                                                        float uReg, float iReg) {
-  constexpr int PULL = 4;
-  const Rows<3> Um(U, ubytes), Vm(V, vbytes);
-  const int lane = threadIdx.x & 63;
-  const int xcc = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7);  // HW_REG_XCC_ID[3:0]
-  const int t_first = SWEEP ? 0 : xcc * 8 + ((xcc + round) & 7);
-  const int t_last = SWEEP ? 63 : t_first;
-  for (int tile = t_first; tile <= t_last; tile++) {
-    const int64_t b = tile_start[tile], sz = tile_start[tile + 1] - b;
-    if (SWEEP) {  // nothing left in this tile (the normal case): do not queue on its counter
-      const unsigned long long seen = __hip_atomic_load(&tile_ctr[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((int64_t)seen >= sz) continue;
-    }
-    for (;;) {
-      unsigned long long got = 0;
-      if (lane == 0) got = atomicAdd(&tile_ctr[tile], (unsigned long long)(64 * PULL));
-      const int64_t base = (int64_t)__shfl(got, 0, 64);
-      if (base >= sz) break;
-#pragma unroll 1
-      for (int c = 0; c < PULL; c++) {
-        const int64_t cb = base + (int64_t)c * 64;
-        if (cb >= sz) break;
-        const int nvalid = (int)(sz - cb < 64 ? sz - cb : 64);
-        sgd_chunk<L, C, ARITH, 3, VAR>(Um, Vm, eu, ei, er, b + cb, nvalid, lane, lr, uReg, iReg);
-      }
-    }
   }
 }
 
@@ -237,19 +104,20 @@ __global__ __launch_bounds__(256) void sgd_users_kernel(const int32_t* __restric
                                                         const int64_t* __restrict__ rowptr,
                                                         const int32_t* __restrict__ rowind,
                                                         const float* __restrict__ rowval, float* U, float* V,
-                                                        float lr, float uReg, float iReg) {
+                                                        uint32_t ubytes, uint32_t vbytes, float lr, float uReg,
+                                                        float iReg) {
   constexpr int G = 64 / L;
   constexpr int LD = 4 * L * C;
   const int lane = threadIdx.x & 63;
   const int g = lane / L, j = lane % L;
   const int64_t grp = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * G + g;
   const int64_t ngrp = (((int64_t)gridDim.x * blockDim.x) >> 6) * G;
-  const Rows<0> Um(U, 0), Vm(V, 0);
+  const Rows<1> Um(U, ubytes), Vm(V, vbytes);   // item rows are shared by all XCDs: agent-coherent accesses
   for (int64_t t = grp; t < nusers; t += ngrp) {
     const int u = ulist[t];
     const int64_t b = rowptr[u], e = rowptr[u + 1];
     for (int64_t ii = b; ii < e; ii++)
-      sgd_visit<L, C, ARITH, 0>(Um, Vm, (int64_t)u * LD + 4 * j, (int64_t)rowind[ii] * LD + 4 * j, rowval[ii], lr,
+      sgd_visit<L, C, ARITH, 1>(Um, Vm, (int64_t)u * LD + 4 * j, (int64_t)rowind[ii] * LD + 4 * j, rowval[ii], lr,
                                 uReg, iReg);
   }
 }
@@ -270,11 +138,6 @@ static int sgd_blocks(const mfx_ctx* ctx, const mfx_sgd_opts* o) {
   if (o->blocks > 0) return std::min(o->blocks, 8192);
   return std::max(8, std::min(2048, std::min(ctx->nU, ctx->nI) / 64));
 }
-int tiled_variant() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("MFX_TILED_VARIANT"); v = e ? atoi(e) : 0; }
-  return v;
-}
 static int sgd_policy() {
   static int pol = -1;
   if (pol < 0) {
@@ -289,36 +152,6 @@ static int sgd_policy() {
 }
 template <int L, int C, int ARITH>
 static int launch_lca(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_t count, int64_t nusers) {
-  if (o->mode == MFX_SGD_TILED) {
-    const uint64_t ub = (uint64_t)ctx->nU * ctx->ld * 4, vb = (uint64_t)ctx->nI * ctx->ld * 4;
-    if (ub >= (1ull << 32) || vb >= (1ull << 32))
-      return mfx_fail(ctx, MFX_E_ARG, "MFX_SGD_TILED: a factor matrix exceeds 4 GiB (buffer addressing)");
-    HIPCHK(hipMemsetAsync(ctx->tile_ctr, 0, 64 * sizeof(unsigned long long), ctx->stream));
-    const int blocks = sgd_blocks(ctx, o);
-    const int var = tiled_variant();
-    for (int round = 0; round < 8; round++) {   // 8 XCD-local rounds
-      ProfScope ps(ctx, MFX_K_SGD);
-#define MFX_LAUNCH_TILED(VV)                                                                                     \
-  hipLaunchKernelGGL((sgd_tiled_kernel<L, C, ARITH, false, VV>), dim3(blocks), dim3(256), 0, ctx->stream, ctx->eu, \
-                     ctx->ei, ctx->er, ctx->tile_start, ctx->tile_ctr, round, ctx->U, ctx->V, (uint32_t)ub,      \
-                     (uint32_t)vb, o->learnRate, o->uReg, o->iReg)
-      switch (var & 6) {
-        case 2: MFX_LAUNCH_TILED(2); break;
-        case 4: MFX_LAUNCH_TILED(4); break;
-        case 6: MFX_LAUNCH_TILED(6); break;
-        default: MFX_LAUNCH_TILED(0); break;
-      }
-#undef MFX_LAUNCH_TILED
-    }
-    {  // placement-independent sweep of whatever the rounds left
-      ProfScope ps(ctx, MFX_K_SGD_SWEEP);
-      hipLaunchKernelGGL((sgd_tiled_kernel<L, C, ARITH, true>), dim3(256), dim3(256), 0, ctx->stream, ctx->eu,
-                         ctx->ei, ctx->er, ctx->tile_start, ctx->tile_ctr, -1, ctx->U, ctx->V, (uint32_t)ub,
-                         (uint32_t)vb, o->learnRate, o->uReg, o->iReg);
-    }
-    HIPCHK(hipGetLastError());
-    return MFX_OK;
-  }
   ProfScope ps(ctx, MFX_K_SGD);
   if (o->mode == MFX_SGD_SERIAL) {
     hipLaunchKernelGGL((sgd_serial_kernel<L, C, ARITH>), dim3(1), dim3(64), 0, ctx->stream, ctx->eu, ctx->ei,
@@ -329,7 +162,8 @@ static int launch_lca(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_
     int blocks = (int)std::min<int64_t>((waves + 3) / 4, 2048);
     const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
     hipLaunchKernelGGL((sgd_users_kernel<L, C, ARITH>), dim3(blocks), dim3(256), 0, ctx->stream, ctx->ulist,
-                       nusers, m.rowptr, m.rowind, m.rowval, ctx->U, ctx->V, o->learnRate, o->uReg, o->iReg);
+                       nusers, m.rowptr, m.rowind, m.rowval, ctx->U, ctx->V, (uint32_t)((uint64_t)ctx->nU * ctx->ld * 4),
+                       (uint32_t)((uint64_t)ctx->nI * ctx->ld * 4), o->learnRate, o->uReg, o->iReg);
   } else {
     int64_t waves = (count + 63) / 64;
     int blocks = (int)std::min<int64_t>((waves + 3) / 4, sgd_blocks(ctx, o));
@@ -385,4 +219,3 @@ int mfx_launch_sgd(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_t c
 int mfx_launch_sgd_users(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t nusers) {
   return launch_any(ctx, o, 0, 0, nusers);
 }
-int mfx_launch_sgd_tiled(mfx_ctx* ctx, const mfx_sgd_opts* o) { return launch_any(ctx, o, 0, 0, 0); }

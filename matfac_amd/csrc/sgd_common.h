@@ -1,0 +1,98 @@
+// sgd_common.h -- device helpers shared by the SGD kernels (sgd.hip, sgd_slots.hip).
+#ifndef MFX_SGD_COMMON_H_
+#define MFX_SGD_COMMON_H_
+#include "mfx_internal.h"
+
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+
+// Cache policy of the factor-row accesses (experiment knob MFX_SGD_POLICY):
+//   0 plain global loads/stores (L1 + write-back L2)
+//   1 sc1 loads and stores: agent scope -- loads bypass the CU's L1, stores write through
+//     the XCD's L2 (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & visibility")
+//   2 nt loads and stores   3 sc1 loads, plain stores   4 sc0 sc1 (system scope) both
+template <int POL>
+struct Rows {
+  float* base;
+  __amdgpu_buffer_rsrc_t rs;
+  __device__ __forceinline__ Rows(float* b, uint32_t bytes) : base(b) {
+    if (POL != 0) rs = __builtin_amdgcn_make_buffer_rsrc(b, 0, bytes, 0x00020000);
+  }
+  static constexpr int AUXL = POL == 1 ? 16 : POL == 2 ? 2 : POL == 3 ? 16 : 17;
+  static constexpr int AUXS = POL == 1 ? 16 : POL == 2 ? 2 : POL == 3 ? 0 : 17;
+  __device__ __forceinline__ float4v ld(int64_t elt) const {
+    if (POL == 0) return *(const float4v*)(base + elt);
+    uint4v v = __builtin_amdgcn_raw_buffer_load_b128(rs, (uint32_t)(elt * 4), 0, AUXL);
+    return __builtin_bit_cast(float4v, v);
+  }
+  __device__ __forceinline__ void st(int64_t elt, float4v v) const {
+    if (POL == 0) { *(float4v*)(base + elt) = v; return; }
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, v), rs, (uint32_t)(elt * 4), 0, AUXS);
+  }
+};
+
+template <int L>
+__device__ __forceinline__ float group_sum(float s) {
+#pragma unroll
+  for (int m = L / 2; m >= 1; m >>= 1) s = s + __shfl_xor(s, m, 64);
+  return s;
+}
+
+// p.q in device order (include/mfx.h)
+template <int L, int C>
+__device__ __forceinline__ float group_dot(const float4v (&p)[C], const float4v (&q)[C]) {
+  float a = 0.0f;
+#pragma unroll
+  for (int c = 0; c < C; c++) {
+    a = __builtin_fmaf(p[c].x, q[c].x, a);
+    a = __builtin_fmaf(p[c].y, q[c].y, a);
+    a = __builtin_fmaf(p[c].z, q[c].z, a);
+    a = __builtin_fmaf(p[c].w, q[c].w, a);
+  }
+  return group_sum<L>(a);
+}
+
+// x -= learnRate * (-2.0*diff*y + 2.0*reg*x)      modelMF.cpp:96 / :102
+__device__ __forceinline__ float upd_ref64(float x, float y, double m2diff, double reg2, double lr) {
+  return (float)((double)x - lr * (m2diff * (double)y + reg2 * (double)x));
+}
+// row -= learnRate*(-2.0*diff*other + 2.0*reg*row) with the scalars narrowed to
+// float by the Eigen row expression                modelMF.cpp:1759 / :1762
+__device__ __forceinline__ float upd_f32(float x, float y, float c1, float c2, float lr) {
+  return x - lr * (c1 * y + c2 * x);
+}
+
+
+// The reference's update of one rating on the two rows held in registers:
+// user first, then the item with the ALREADY UPDATED user row (modelMF.cpp:94-103).
+template <int C, int ARITH>
+__device__ __forceinline__ void sgd_axpys(float4v (&p)[C], float4v (&q)[C], float r, float est, float lr,
+                                          float uReg, float iReg) {
+  if (ARITH == MFX_ARITH_F32) {
+    const double diff = (double)r - (double)est;
+    const float c1 = (float)(-2.0 * diff);
+    const float cu = (float)(2.0 * (double)uReg), ci = (float)(2.0 * (double)iReg);
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) p[c][e] = upd_f32(p[c][e], q[c][e], c1, cu, lr);
+#pragma unroll
+      for (int e = 0; e < 4; e++) q[c][e] = upd_f32(q[c][e], p[c][e], c1, ci, lr);
+    }
+  } else {
+    double diff;
+    if (ARITH == MFX_ARITH_REF64F) { const float d = r - est; diff = (double)d; }
+    else diff = (double)r - (double)est;
+    const double m2 = -2.0 * diff;
+    const double ru = 2.0 * (double)uReg, ri = 2.0 * (double)iReg, lrd = (double)lr;
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) p[c][e] = upd_ref64(p[c][e], q[c][e], m2, ru, lrd);
+#pragma unroll
+      for (int e = 0; e < 4; e++) q[c][e] = upd_ref64(q[c][e], p[c][e], m2, ri, lrd);
+    }
+  }
+}
+
+#endif

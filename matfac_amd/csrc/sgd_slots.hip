@@ -1,0 +1,380 @@
+// sgd_slots.hip -- MFX_SGD_TILED: XCD-tiled Hogwild with workgroup-owned item rows in LDS.
+//
+// Replaces the inner loops of ModelMF::train / hogTrain / trainSGDPar (modelMF.cpp:83-105,
+// 1747-1763, 273-304) for the parallel default path.
+//
+// Two facts of the chip shape the schedule (measurements in DESIGN.md section 3.1):
+//   (1) the 8 per-XCD L2 caches are not coherent with each other, so a row that is updated
+//       from several XCDs in one launch exists in several diverging copies;
+//   (2) lock-free updates of one row that are in flight together overwrite each other; with
+//       ~10^4 ratings in flight that is every update of a popular item but one.
+// Schedule: users and items are hashed into 8 blocks each (64 tiles).  In round r the
+// workgroups that find themselves on XCD x (HW_REG_XCC_ID) take only tile (x, (x+r) mod 8):
+// every user row is touched through one L2 per round (trainSGDPar's stratification with the
+// chip's own 8 strata).  Inside a tile the ratings are grouped item-major into SLOTS of
+// <= CAP_R ratings over <= ROWS items; a workgroup pulls a slot, stages the slot's item rows
+// in LDS, visits the slot's ratings in a fresh pseudo-random order (Feistel permutation keyed by
+// seed, epoch, slot) and applies the item-side update with ds_add_f32 on the LDS copy -- no item
+// update is lost and the 16 groups of the workgroup always read the freshest row.  The user
+// side stays a lock-free read-modify-write through the XCD's L2 (sc1 loads bypass the CU's L1).
+// An item with more ratings in a tile than CAP_R is cut into several single-item slots
+// ("shared"); those add their delta to the global row with float atomics at the end.
+// Slots are pulled from per-tile counters and a final sweep launch drains whatever is left, so
+// "every rating exactly once per epoch" holds for ANY workgroup->XCD placement.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "sgd_common.h"
+
+namespace {
+constexpr int CAP_R = 1024;   // ratings per slot
+
+struct SlotState {
+  int32_t* rec = nullptr;          // int4 per rating: user, local item index, rating bits, item
+  int64_t* slot_beg = nullptr;     // [nslots+1] rating range of a slot
+  int32_t* slot_ibeg = nullptr;    // [nslots+1] range into slot_items
+  int32_t* slot_items = nullptr;   // global item ids of every slot
+  uint8_t* slot_shared = nullptr;  // 1: the slot's single item also lives in other slots of the tile
+  int32_t* tile_slot = nullptr;    // [65] slot range of a tile
+  unsigned* ctr = nullptr;         // [64] slot counters
+  int64_t nslots = 0, nnz = 0;
+  int rows = 0;                    // item rows per slot the lists were built for
+  uint32_t last_k0 = 0, last_k1 = 0;
+  bool built = false;
+};
+}  // namespace
+
+static SlotState* state(mfx_ctx* ctx) { return (SlotState*)ctx->slots; }
+
+void mfx_slots_free_internal(mfx_ctx* ctx) {
+  SlotState* s = state(ctx);
+  if (!s) return;
+  dev_free(s->rec); dev_free(s->slot_beg); dev_free(s->slot_ibeg); dev_free(s->slot_items);
+  dev_free(s->slot_shared); dev_free(s->tile_slot); dev_free(s->ctr);
+  delete s;
+  ctx->slots = nullptr;
+}
+
+// ---------------------------------------------------------------------------
+// slot lists (host, once per train matrix and rank shape)
+// ---------------------------------------------------------------------------
+template <typename T>
+static int up(mfx_ctx* ctx, T** dst, const std::vector<T>& v) {
+  int rc = dev_alloc(ctx, dst, v.size());
+  if (rc) return rc;
+  if (!v.empty()) HIPCHK(hipMemcpyAsync(*dst, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice, ctx->stream));
+  return MFX_OK;
+}
+
+static int build_slots(mfx_ctx* ctx, SlotState* S, int rows) {
+  const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
+  const int64_t nnz = m.nnz;
+  std::vector<int32_t> ru((size_t)nnz), ri((size_t)nnz);
+  std::vector<float> rv((size_t)nnz);
+  if (nnz) {
+    HIPCHK(hipMemcpy(ru.data(), m.rowid, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ri.data(), m.rowind, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(rv.data(), m.rowval, sizeof(float) * (size_t)nnz, hipMemcpyDeviceToHost));
+  }
+  // ratings of each tile (stable in CSR order)
+  std::vector<int64_t> tstart(65, 0);
+  for (int64_t e = 0; e < nnz; e++) tstart[mfx_user_block(ru[e]) * 8 + mfx_item_block(ri[e]) + 1]++;
+  for (int t = 0; t < 64; t++) tstart[t + 1] += tstart[t];
+  std::vector<int64_t> byt((size_t)nnz);
+  {
+    std::vector<int64_t> pos(tstart.begin(), tstart.end() - 1);
+    for (int64_t e = 0; e < nnz; e++) byt[pos[mfx_user_block(ru[e]) * 8 + mfx_item_block(ri[e])]++] = e;
+  }
+  std::vector<int32_t> rec((size_t)nnz * 4), slot_ibeg(1, 0), slot_items, tile_slot(65, 0);
+  std::vector<int64_t> slot_beg(1, 0);
+  std::vector<uint8_t> slot_shared;
+  std::vector<int32_t> cnt((size_t)std::max(m.ncols, 1), 0);
+  std::vector<int32_t> items;
+  int64_t out = 0;
+  for (int t = 0; t < 64; t++) {
+    tile_slot[t] = (int32_t)slot_shared.size();
+    const int64_t b = tstart[t], e = tstart[t + 1];
+    items.clear();
+    for (int64_t x = b; x < e; x++) {
+      const int32_t it = ri[byt[x]];
+      if (cnt[it]++ == 0) items.push_back(it);
+    }
+    // items by descending number of ratings in this tile, ties by id
+    std::sort(items.begin(), items.end(), [&](int32_t a, int32_t c) { return cnt[a] != cnt[c] ? cnt[a] > cnt[c] : a < c; });
+    // ratings item-major: offsets per item, then a stable scatter
+    std::vector<int64_t> off(items.size() + 1, 0);
+    for (size_t k = 0; k < items.size(); k++) off[k + 1] = off[k] + cnt[items[k]];
+    std::vector<int64_t> sorted((size_t)(e - b));
+    {
+      std::vector<int64_t> where((size_t)items.size());
+      for (size_t k = 0; k < items.size(); k++) { where[k] = off[k]; cnt[items[k]] = (int32_t)k; }  // cnt := rank
+      for (int64_t x = b; x < e; x++) sorted[where[cnt[ri[byt[x]]]]++] = byt[x];
+    }
+    // cut into slots
+    int cur_r = 0, cur_i = 0;
+    auto close = [&](bool shared) {
+      if (cur_r == 0) return;
+      slot_beg.push_back(out);
+      slot_ibeg.push_back((int32_t)slot_items.size());
+      slot_shared.push_back(shared ? 1 : 0);
+      cur_r = cur_i = 0;
+    };
+    for (size_t k = 0; k < items.size(); k++) {
+      const int64_t n = off[k + 1] - off[k];
+      const int32_t it = items[k];
+      if (n > CAP_R / 2) {   // popular in this tile: slots of its own, shared when it needs several
+        close(false);
+        const bool shared = n > CAP_R;
+        for (int64_t p = 0; p < n; p += CAP_R) {
+          const int64_t q = std::min<int64_t>(n, p + CAP_R);
+          slot_items.push_back(it);
+          for (int64_t x = p; x < q; x++) {
+            const int64_t src = sorted[off[k] + x];
+            rec[4 * out] = ru[src]; rec[4 * out + 1] = 0; memcpy(&rec[4 * out + 2], &rv[src], 4); rec[4 * out + 3] = it;
+            out++;
+          }
+          cur_r = (int)(q - p); cur_i = 1;
+          close(shared);
+        }
+      } else {
+        if (cur_r + n > CAP_R || cur_i == rows) close(false);
+        slot_items.push_back(it);
+        for (int64_t x = 0; x < n; x++) {
+          const int64_t src = sorted[off[k] + x];
+          rec[4 * out] = ru[src]; rec[4 * out + 1] = cur_i; memcpy(&rec[4 * out + 2], &rv[src], 4); rec[4 * out + 3] = it;
+          out++;
+        }
+        cur_r += (int)n; cur_i++;
+      }
+    }
+    close(false);
+    for (int32_t it : items) cnt[it] = 0;
+  }
+  tile_slot[64] = (int32_t)slot_shared.size();
+  dev_free(S->rec); dev_free(S->slot_beg); dev_free(S->slot_ibeg); dev_free(S->slot_items);
+  dev_free(S->slot_shared); dev_free(S->tile_slot);
+  int rc;
+  if ((rc = up(ctx, &S->rec, rec))) return rc;
+  if ((rc = up(ctx, &S->slot_beg, slot_beg))) return rc;
+  if ((rc = up(ctx, &S->slot_ibeg, slot_ibeg))) return rc;
+  if ((rc = up(ctx, &S->slot_items, slot_items))) return rc;
+  if ((rc = up(ctx, &S->slot_shared, slot_shared))) return rc;
+  if ((rc = up(ctx, &S->tile_slot, tile_slot))) return rc;
+  if (!S->ctr && (rc = dev_alloc(ctx, &S->ctr, (size_t)64))) return rc;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  S->nslots = (int64_t)slot_shared.size();
+  S->nnz = nnz;
+  S->rows = rows;
+  S->built = true;
+  return MFX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// kernel
+// ---------------------------------------------------------------------------
+template <int C>
+struct SlotRows { static constexpr int value = 64 / C < 8 ? 8 : 64 / C; };
+
+__device__ __forceinline__ int64_t slot_perm(int64_t t, int64_t R, uint32_t k0, uint32_t k1) {
+  int bits = 2;
+  while (((int64_t)1 << bits) < R) bits++;
+  const int ab = bits / 2;
+  return mfx_perm_index(t, R, ab, bits - ab, k0, k1);
+}
+
+template <int L, int C, int ARITH, bool SWEEP>
+__global__ __launch_bounds__(256) void sgd_slots_kernel(const int4* __restrict__ rec,
+                                                        const int64_t* __restrict__ slot_beg,
+                                                        const int32_t* __restrict__ slot_ibeg,
+                                                        const int32_t* __restrict__ slot_items,
+                                                        const uint8_t* __restrict__ slot_shared,
+                                                        const int32_t* __restrict__ tile_slot, unsigned* ctr,
+                                                        int round, float* U, float* V, uint32_t ubytes, float lr,
+                                                        float uReg, float iReg, uint32_t k0, uint32_t k1) {
+  constexpr int G = 64 / L;
+  constexpr int LD = 4 * L * C;
+  constexpr int LD4 = LD / 4;
+  constexpr int ROWS = SlotRows<C>::value;
+  __shared__ __attribute__((aligned(16))) float q_lds[(ROWS + 1) * LD];   // last row: q_start of a shared slot
+  __shared__ int s_slot;
+  const Rows<3> Um(U, ubytes);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane / L, j = lane % L;
+  const int xcc = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7);  // HW_REG_XCC_ID[3:0]
+  const int t_first = SWEEP ? 0 : xcc * 8 + ((xcc + round) & 7);
+  const int t_last = SWEEP ? 63 : t_first;
+  float4v* q4 = (float4v*)q_lds;
+  for (int tile = t_first; tile <= t_last; tile++) {
+    const int s0 = tile_slot[tile], ns = tile_slot[tile + 1] - s0;
+    if (SWEEP) {  // nothing left in this tile (the normal case): do not queue on its counter
+      if (tid == 0) s_slot = (int)__hip_atomic_load(&ctr[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      const int seen = s_slot;
+      __syncthreads();
+      if (seen >= ns) continue;
+    }
+    for (;;) {
+      if (tid == 0) s_slot = (int)atomicAdd(&ctr[tile], 1u);
+      __syncthreads();
+      const int sl = s_slot;
+      __syncthreads();
+      if (sl >= ns) break;
+      const int slot = s0 + sl;
+      const int64_t rb = slot_beg[slot], R = slot_beg[slot + 1] - rb;
+      const int ib = slot_ibeg[slot], ni = slot_ibeg[slot + 1] - ib;
+      const bool shared = slot_shared[slot] != 0;
+      // stage the slot's item rows
+      for (int x = tid; x < ni * LD4; x += 256) {
+        const int row = x / LD4, c4 = x % LD4;
+        const float4v v = *(const float4v*)(V + (int64_t)slot_items[ib + row] * LD + 4 * c4);
+        q4[row * LD4 + c4] = v;
+        if (shared) q4[ROWS * LD4 + c4] = v;
+      }
+      __syncthreads();
+      const uint32_t ks0 = k0 + (uint32_t)slot * 0x632be5abU, ks1 = k1 ^ mfx_mix32((uint32_t)slot + 77U);
+      for (int64_t cb = (int64_t)wave * 64; cb < R; cb += 4 * 64) {
+        const int64_t t = cb + lane;
+        const bool ok = t < R;
+        int4 rc4 = make_int4(0, 0, 0, 0);
+        if (ok) rc4 = rec[rb + slot_perm(t, R, ks0, ks1)];
+        const int nvalid = (int)(R - cb < 64 ? R - cb : 64);
+#pragma unroll 1
+        for (int s = 0; s < L; s++) {
+          const int e = s * G + g;
+          const int u = __shfl(rc4.x, e, 64);
+          const int li = __shfl(rc4.y, e, 64);
+          const float r = __builtin_bit_cast(float, __shfl(rc4.z, e, 64));
+          if (e < nvalid) {
+            const int64_t pe = (int64_t)u * LD + 4 * j;
+            float* qrow = q_lds + li * LD + 4 * j;
+            float4v p[C], q[C], q0[C];
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+              p[c] = Um.ld(pe + c * 4 * L);
+              q[c] = *(const float4v*)(qrow + c * 4 * L);
+              q0[c] = q[c];
+            }
+            const float est = group_dot<L, C>(p, q);
+            sgd_axpys<C, ARITH>(p, q, r, est, lr, uReg, iReg);
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+              Um.st(pe + c * 4 * L, p[c]);
+#pragma unroll
+              for (int x = 0; x < 4; x++) atomicAdd(qrow + c * 4 * L + x, q[c][x] - q0[c][x]);   // ds_add_f32
+            }
+          }
+        }
+      }
+      __syncthreads();
+      // write the item rows back: owned rows are stored, a shared row adds its delta
+      if (!shared) {
+        for (int x = tid; x < ni * LD4; x += 256) {
+          const int row = x / LD4, c4 = x % LD4;
+          *(float4v*)(V + (int64_t)slot_items[ib + row] * LD + 4 * c4) = q4[row * LD4 + c4];
+        }
+      } else {
+        float* vrow = V + (int64_t)slot_items[ib] * LD;
+        for (int x = tid; x < LD; x += 256) atomicAdd(vrow + x, q_lds[x] - q_lds[ROWS * LD + x]);
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// test hook: materialise the visiting order of the last epoch (slot by slot)
+__global__ void slots_epoch_list_kernel(const int4* __restrict__ rec, const int64_t* __restrict__ slot_beg,
+                                        int64_t nslots, uint32_t k0, uint32_t k1, int32_t* __restrict__ eu,
+                                        int32_t* __restrict__ ei, float* __restrict__ er) {
+  for (int64_t slot = blockIdx.x; slot < nslots; slot += gridDim.x) {
+    const int64_t rb = slot_beg[slot], R = slot_beg[slot + 1] - rb;
+    const uint32_t ks0 = k0 + (uint32_t)slot * 0x632be5abU, ks1 = k1 ^ mfx_mix32((uint32_t)slot + 77U);
+    for (int64_t t = threadIdx.x; t < R; t += blockDim.x) {
+      const int4 r = rec[rb + slot_perm(t, R, ks0, ks1)];
+      eu[rb + t] = r.x; ei[rb + t] = r.w; er[rb + t] = __builtin_bit_cast(float, r.z);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// launch
+// ---------------------------------------------------------------------------
+static int env_blocks() {
+  static int b = -1;
+  if (b < 0) { const char* e = getenv("MFX_SGD_BLOCKS"); b = e ? atoi(e) : 0; if (b < 0) b = 0; }
+  return b;
+}
+
+template <int L, int C, int ARITH>
+static int launch_slots(mfx_ctx* ctx, SlotState* S, const mfx_sgd_opts* o, int blocks, uint32_t k0, uint32_t k1) {
+  const uint64_t ub = (uint64_t)ctx->nU * ctx->ld * 4;
+  HIPCHK(hipMemsetAsync(S->ctr, 0, 64 * sizeof(unsigned), ctx->stream));
+  for (int round = 0; round < 8; round++) {
+    ProfScope ps(ctx, MFX_K_SGD);
+    hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, false>), dim3(blocks), dim3(256), 0, ctx->stream,
+                       (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->slot_shared, S->tile_slot,
+                       S->ctr, round, ctx->U, ctx->V, (uint32_t)ub, o->learnRate, o->uReg, o->iReg, k0, k1);
+  }
+  {
+    ProfScope ps(ctx, MFX_K_SGD_SWEEP);
+    hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, true>), dim3(256), dim3(256), 0, ctx->stream,
+                       (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->slot_shared, S->tile_slot,
+                       S->ctr, -1, ctx->U, ctx->V, (uint32_t)ub, o->learnRate, o->uReg, o->iReg, k0, k1);
+  }
+  HIPCHK(hipGetLastError());
+  return MFX_OK;
+}
+
+template <int L, int C>
+static int launch_arith(mfx_ctx* ctx, SlotState* S, const mfx_sgd_opts* o, int blocks, uint32_t k0, uint32_t k1) {
+  switch (o->arith) {
+    case MFX_ARITH_REF64: return launch_slots<L, C, MFX_ARITH_REF64>(ctx, S, o, blocks, k0, k1);
+    case MFX_ARITH_REF64F: return launch_slots<L, C, MFX_ARITH_REF64F>(ctx, S, o, blocks, k0, k1);
+    default: return launch_slots<L, C, MFX_ARITH_F32>(ctx, S, o, blocks, k0, k1);
+  }
+}
+
+int mfx_launch_sgd_tiled(mfx_ctx* ctx, const mfx_sgd_opts* o) {
+  const uint64_t ub = (uint64_t)ctx->nU * ctx->ld * 4;
+  NEED(ub < (1ull << 32), MFX_E_ARG, "MFX_SGD_TILED: the user factor matrix exceeds 4 GiB (buffer addressing)");
+  SlotState* S = state(ctx);
+  if (!S) { S = new SlotState; ctx->slots = S; }
+  const int rows = ctx->C <= 8 ? (64 / ctx->C < 8 ? 8 : 64 / ctx->C) : 8;
+  if (!S->built || S->rows != rows || S->nnz != ctx->mat[MFX_MAT_TRAIN].nnz) {
+    int rc = build_slots(ctx, S, rows);
+    if (rc) return rc;
+  }
+  const uint32_t k0 = mfx_mix32(o->seed ^ 0x3c6ef372U) + (uint32_t)o->epoch * 0x9e3779b9U;
+  const uint32_t k1 = mfx_mix32(o->seed * 0x85ebca6bU + 0xdaa66d2bU) ^ mfx_mix32((uint32_t)o->epoch + 0x1b873593U);
+  S->last_k0 = k0; S->last_k1 = k1;
+  int blocks = env_blocks();
+  if (blocks <= 0) blocks = o->blocks > 0 ? std::min(o->blocks, 8192) : std::max(8, std::min(2048, ctx->nU / 64));
+  ctx->elist_n = -1;   // the visiting order is not materialised; mfx_debug_epoch_list rebuilds it on demand
+  const int L = ctx->L, C = ctx->C;
+  if (L == 4) return launch_arith<4, 1>(ctx, S, o, blocks, k0, k1);
+  if (L == 8) return launch_arith<8, 1>(ctx, S, o, blocks, k0, k1);
+  switch (C) {
+    case 1: return launch_arith<16, 1>(ctx, S, o, blocks, k0, k1);
+    case 2: return launch_arith<16, 2>(ctx, S, o, blocks, k0, k1);
+    case 3: return launch_arith<16, 3>(ctx, S, o, blocks, k0, k1);
+    case 4: return launch_arith<16, 4>(ctx, S, o, blocks, k0, k1);
+    case 5: return launch_arith<16, 5>(ctx, S, o, blocks, k0, k1);
+    case 6: return launch_arith<16, 6>(ctx, S, o, blocks, k0, k1);
+    case 7: return launch_arith<16, 7>(ctx, S, o, blocks, k0, k1);
+    case 8: return launch_arith<16, 8>(ctx, S, o, blocks, k0, k1);
+  }
+  return mfx_fail(ctx, MFX_E_ARG, "sgd tiled: unsupported rank shape L=%d C=%d", L, C);
+}
+
+// fills ctx->eu/ei/er with the order the last tiled epoch visited (test hook)
+int mfx_slots_materialise_order(mfx_ctx* ctx) {
+  SlotState* S = state(ctx);
+  NEED(S && S->built, MFX_E_STATE, "no tiled epoch has run");
+  const int blocks = (int)std::min<int64_t>(std::max<int64_t>(S->nslots, 1), 4096);
+  hipLaunchKernelGGL(slots_epoch_list_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const int4*)S->rec,
+                     S->slot_beg, S->nslots, S->last_k0, S->last_k1, ctx->eu, ctx->ei, ctx->er);
+  HIPCHK(hipGetLastError());
+  ctx->elist_n = S->nnz;
+  return MFX_OK;
+}
