@@ -17,8 +17,7 @@
 // seed, epoch, slot) and applies the item-side update with ds_add_f32 on the LDS copy -- no item
 // update is lost and the 16 groups of the workgroup always read the freshest row.  The user
 // side stays a lock-free read-modify-write through the XCD's L2 (sc1 loads bypass the CU's L1).
-// An item with more ratings in a tile than CAP_R is cut into several single-item slots
-// ("shared"); those add their delta to the global row with float atomics at the end.
+// An item with more than CAP_R/2 ratings in a tile gets ONE slot of its own, however long.
 // Slots are pulled from per-tile counters and a final sweep launch drains whatever is left, so
 // "every rating exactly once per epoch" holds for ANY workgroup->XCD placement.
 #include <algorithm>
@@ -124,20 +123,20 @@ static int build_slots(mfx_ctx* ctx, SlotState* S, int rows) {
     for (size_t k = 0; k < items.size(); k++) {
       const int64_t n = off[k + 1] - off[k];
       const int32_t it = items[k];
-      if (n > CAP_R / 2) {   // popular in this tile: slots of its own, shared when it needs several
+      if (n > CAP_R / 2) {
+        // popular in this tile: ONE slot of its own, however long.  (Cutting it into several
+        // concurrently processed slots and summing their deltas overshoots: measured NaN in the
+        // first epoch -- each replica makes the whole step.  One owner keeps it sequential; the
+        // slot list is longest-first so this pole starts first.)
         close(false);
-        const bool shared = n > CAP_R;
-        for (int64_t p = 0; p < n; p += CAP_R) {
-          const int64_t q = std::min<int64_t>(n, p + CAP_R);
-          slot_items.push_back(it);
-          for (int64_t x = p; x < q; x++) {
-            const int64_t src = sorted[off[k] + x];
-            rec[4 * out] = ru[src]; rec[4 * out + 1] = 0; memcpy(&rec[4 * out + 2], &rv[src], 4); rec[4 * out + 3] = it;
-            out++;
-          }
-          cur_r = (int)(q - p); cur_i = 1;
-          close(shared);
+        slot_items.push_back(it);
+        for (int64_t x = 0; x < n; x++) {
+          const int64_t src = sorted[off[k] + x];
+          rec[4 * out] = ru[src]; rec[4 * out + 1] = 0; memcpy(&rec[4 * out + 2], &rv[src], 4); rec[4 * out + 3] = it;
+          out++;
         }
+        cur_r = (int)std::min<int64_t>(n, 1 << 30); cur_i = 1;
+        close(false);
       } else {
         if (cur_r + n > CAP_R || cur_i == rows) close(false);
         slot_items.push_back(it);
@@ -164,6 +163,15 @@ static int build_slots(mfx_ctx* ctx, SlotState* S, int rows) {
   if ((rc = up(ctx, &S->tile_slot, tile_slot))) return rc;
   if (!S->ctr && (rc = dev_alloc(ctx, &S->ctr, (size_t)64))) return rc;
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (getenv("MFX_DEBUG")) {
+    int64_t mx = 0, small = 0;
+    for (size_t k = 0; k + 1 < slot_beg.size(); k++) {
+      mx = std::max(mx, slot_beg[k + 1] - slot_beg[k]);
+      small += (slot_beg[k + 1] - slot_beg[k]) < 256;
+    }
+    fprintf(stderr, "[mfx] slots: %zu for %lld ratings, longest %lld, <256 ratings: %lld, item refs %zu\n",
+            slot_shared.size(), (long long)nnz, (long long)mx, (long long)small, slot_items.size());
+  }
   S->nslots = (int64_t)slot_shared.size();
   S->nnz = nnz;
   S->rows = rows;
