@@ -29,6 +29,7 @@
 
 namespace {
 constexpr int CAP_R = 1024;   // ratings per slot
+constexpr int WG = 1024;      // threads per workgroup: 16 waves = 64 ratings in flight on one slot
 
 struct SlotState {
   int32_t* rec = nullptr;          // int4 per rating: user, local item index, rating bits, item
@@ -193,7 +194,7 @@ __device__ __forceinline__ int64_t slot_perm(int64_t t, int64_t R, uint32_t k0, 
 }
 
 template <int L, int C, int ARITH, bool SWEEP>
-__global__ __launch_bounds__(256) void sgd_slots_kernel(const int4* __restrict__ rec,
+__global__ __launch_bounds__(WG, 8) void sgd_slots_kernel(const int4* __restrict__ rec,
                                                         const int64_t* __restrict__ slot_beg,
                                                         const int32_t* __restrict__ slot_ibeg,
                                                         const int32_t* __restrict__ slot_items,
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(256) void sgd_slots_kernel(const int4* __restrict__
       const int ib = slot_ibeg[slot], ni = slot_ibeg[slot + 1] - ib;
       const bool shared = slot_shared[slot] != 0;
       // stage the slot's item rows
-      for (int x = tid; x < ni * LD4; x += 256) {
+      for (int x = tid; x < ni * LD4; x += WG) {
         const int row = x / LD4, c4 = x % LD4;
         const float4v v = *(const float4v*)(V + (int64_t)slot_items[ib + row] * LD + 4 * c4);
         q4[row * LD4 + c4] = v;
@@ -242,25 +243,40 @@ __global__ __launch_bounds__(256) void sgd_slots_kernel(const int4* __restrict__
       }
       __syncthreads();
       const uint32_t ks0 = k0 + (uint32_t)slot * 0x632be5abU, ks1 = k1 ^ mfx_mix32((uint32_t)slot + 77U);
-      for (int64_t cb = (int64_t)wave * 64; cb < R; cb += 4 * 64) {
+      for (int64_t cb = (int64_t)wave * 64; cb < R; cb += (WG / 64) * 64) {
         const int64_t t = cb + lane;
         const bool ok = t < R;
         int4 rc4 = make_int4(0, 0, 0, 0);
         if (ok) rc4 = rec[rb + slot_perm(t, R, ks0, ks1)];
         const int nvalid = (int)(R - cb < 64 ? R - cb : 64);
+        // software pipeline: the user row of step s+1 is requested before step s is computed
+        float4v pn[C];
+        int64_t pen = (int64_t)__shfl(rc4.x, g, 64) * LD + 4 * j;
+        if (g < nvalid) {
+#pragma unroll
+          for (int c = 0; c < C; c++) pn[c] = Um.ld(pen + c * 4 * L);
+        }
 #pragma unroll 1
         for (int s = 0; s < L; s++) {
           const int e = s * G + g;
-          const int u = __shfl(rc4.x, e, 64);
           const int li = __shfl(rc4.y, e, 64);
           const float r = __builtin_bit_cast(float, __shfl(rc4.z, e, 64));
+          float4v p[C];
+          const int64_t pe = pen;
+#pragma unroll
+          for (int c = 0; c < C; c++) p[c] = pn[c];
+          const int en = e + G;
+          const int un = __shfl(rc4.x, en & 63, 64);
+          if (s + 1 < L && en < nvalid) {
+            pen = (int64_t)un * LD + 4 * j;
+#pragma unroll
+            for (int c = 0; c < C; c++) pn[c] = Um.ld(pen + c * 4 * L);
+          }
           if (e < nvalid) {
-            const int64_t pe = (int64_t)u * LD + 4 * j;
             float* qrow = q_lds + li * LD + 4 * j;
-            float4v p[C], q[C], q0[C];
+            float4v q[C], q0[C];
 #pragma unroll
             for (int c = 0; c < C; c++) {
-              p[c] = Um.ld(pe + c * 4 * L);
               q[c] = *(const float4v*)(qrow + c * 4 * L);
               q0[c] = q[c];
             }
@@ -278,13 +294,13 @@ __global__ __launch_bounds__(256) void sgd_slots_kernel(const int4* __restrict__
       __syncthreads();
       // write the item rows back: owned rows are stored, a shared row adds its delta
       if (!shared) {
-        for (int x = tid; x < ni * LD4; x += 256) {
+        for (int x = tid; x < ni * LD4; x += WG) {
           const int row = x / LD4, c4 = x % LD4;
           *(float4v*)(V + (int64_t)slot_items[ib + row] * LD + 4 * c4) = q4[row * LD4 + c4];
         }
       } else {
         float* vrow = V + (int64_t)slot_items[ib] * LD;
-        for (int x = tid; x < LD; x += 256) atomicAdd(vrow + x, q_lds[x] - q_lds[ROWS * LD + x]);
+        for (int x = tid; x < LD; x += WG) atomicAdd(vrow + x, q_lds[x] - q_lds[ROWS * LD + x]);
       }
       __syncthreads();
     }
@@ -320,13 +336,13 @@ static int launch_slots(mfx_ctx* ctx, SlotState* S, const mfx_sgd_opts* o, int b
   HIPCHK(hipMemsetAsync(S->ctr, 0, 64 * sizeof(unsigned), ctx->stream));
   for (int round = 0; round < 8; round++) {
     ProfScope ps(ctx, MFX_K_SGD);
-    hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, false>), dim3(blocks), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, false>), dim3(blocks), dim3(WG), 0, ctx->stream,
                        (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->slot_shared, S->tile_slot,
                        S->ctr, round, ctx->U, ctx->V, (uint32_t)ub, o->learnRate, o->uReg, o->iReg, k0, k1);
   }
   {
     ProfScope ps(ctx, MFX_K_SGD_SWEEP);
-    hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, true>), dim3(256), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, true>), dim3(256), dim3(WG), 0, ctx->stream,
                        (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->slot_shared, S->tile_slot,
                        S->ctr, -1, ctx->U, ctx->V, (uint32_t)ub, o->learnRate, o->uReg, o->iReg, k0, k1);
   }
@@ -357,7 +373,9 @@ int mfx_launch_sgd_tiled(mfx_ctx* ctx, const mfx_sgd_opts* o) {
   const uint32_t k1 = mfx_mix32(o->seed * 0x85ebca6bU + 0xdaa66d2bU) ^ mfx_mix32((uint32_t)o->epoch + 0x1b873593U);
   S->last_k0 = k0; S->last_k1 = k1;
   int blocks = env_blocks();
+  // `blocks` counts 256-thread workgroups (include/mfx.h); this kernel runs WG-thread ones
   if (blocks <= 0) blocks = o->blocks > 0 ? std::min(o->blocks, 8192) : std::max(8, std::min(2048, ctx->nU / 64));
+  blocks = std::max(8, blocks * 256 / WG);
   ctx->elist_n = -1;   // the visiting order is not materialised; mfx_debug_epoch_list rebuilds it on demand
   const int L = ctx->L, C = ctx->C;
   if (L == 4) return launch_arith<4, 1>(ctx, S, o, blocks, k0, k1);
