@@ -14,8 +14,8 @@
 // chip's own 8 strata).  Inside a tile the ratings are grouped item-major into SLOTS of
 // <= CAP_R ratings over <= ROWS items; a workgroup pulls a slot, stages the slot's item rows
 // in LDS, visits the slot's ratings in a fresh pseudo-random order (Feistel permutation keyed by
-// seed, epoch, slot) and applies the item-side update with ds_add_f32 on the LDS copy -- no item
-// update is lost and the 16 groups of the workgroup always read the freshest row.  The user
+// seed, epoch, slot) and applies the item-side update with an LDS atomic add on a fixed-point copy of the
+// row -- no item update is lost and the 64 groups of the workgroup always read the freshest row.  The user
 // side stays a lock-free read-modify-write through the XCD's L2 (sc1 loads bypass the CU's L1).
 // An item with more than CAP_R/2 ratings in a tile gets ONE slot of its own, however long.
 // Slots are pulled from per-tile counters and a final sweep launch drains whatever is left, so
@@ -193,28 +193,36 @@ __device__ __forceinline__ int64_t slot_perm(int64_t t, int64_t R, uint32_t k0, 
   return mfx_perm_index(t, R, ab, bits - ab, k0, k1);
 }
 
+// Item rows of a slot live in LDS as Q = round(q * 2^24) (int32).  A visit reads q = float(Q) * 2^-24,
+// computes q_new with the reference's arithmetic and adds round((q_new - q) * 2^24) with ds_add_u32:
+// no item update is lost and every group reads the freshest row.  (ds_add_f32 was measured 7x slower
+// than the whole rest of the kernel; the integer add is free.)  Resolution 6e-8, range +-128; a slot
+// whose staged rows are not finite or exceed the range falls back to float rows with plain stores, and a
+// row that leaves the range while being updated is written back as NaN, so Model::isTerminateModel's NaN
+// guard (model.cpp:1486-1498) still sees a diverged model.
+constexpr float FIX_SCALE = 16777216.0f, FIX_INV = 1.0f / 16777216.0f, FIX_MAX = 127.0f;
+
 template <int L, int C, int ARITH, bool SWEEP>
 __global__ __launch_bounds__(WG, 8) void sgd_slots_kernel(const int4* __restrict__ rec,
-                                                        const int64_t* __restrict__ slot_beg,
-                                                        const int32_t* __restrict__ slot_ibeg,
-                                                        const int32_t* __restrict__ slot_items,
-                                                        const uint8_t* __restrict__ slot_shared,
-                                                        const int32_t* __restrict__ tile_slot, unsigned* ctr,
-                                                        int round, float* U, float* V, uint32_t ubytes, float lr,
-                                                        float uReg, float iReg, uint32_t k0, uint32_t k1) {
+                                                           const int64_t* __restrict__ slot_beg,
+                                                           const int32_t* __restrict__ slot_ibeg,
+                                                           const int32_t* __restrict__ slot_items,
+                                                           const int32_t* __restrict__ tile_slot, unsigned* ctr,
+                                                           int round, float* U, float* V, uint32_t ubytes, float lr,
+                                                           float uReg, float iReg, uint32_t k0, uint32_t k1) {
   constexpr int G = 64 / L;
   constexpr int LD = 4 * L * C;
   constexpr int LD4 = LD / 4;
   constexpr int ROWS = SlotRows<C>::value;
-  __shared__ __attribute__((aligned(16))) float q_lds[(ROWS + 1) * LD];   // last row: q_start of a shared slot
-  __shared__ int s_slot;
+  __shared__ __attribute__((aligned(16))) int q_lds[ROWS * LD];
+  __shared__ int s_slot, s_bad;
   const Rows<3> Um(U, ubytes);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane / L, j = lane % L;
   const int xcc = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7);  // HW_REG_XCC_ID[3:0]
   const int t_first = SWEEP ? 0 : xcc * 8 + ((xcc + round) & 7);
   const int t_last = SWEEP ? 63 : t_first;
-  float4v* q4 = (float4v*)q_lds;
+  int4* q4 = (int4*)q_lds;
   for (int tile = t_first; tile <= t_last; tile++) {
     const int s0 = tile_slot[tile], ns = tile_slot[tile + 1] - s0;
     if (SWEEP) {  // nothing left in this tile (the normal case): do not queue on its counter
@@ -225,7 +233,7 @@ __global__ __launch_bounds__(WG, 8) void sgd_slots_kernel(const int4* __restrict
       if (seen >= ns) continue;
     }
     for (;;) {
-      if (tid == 0) s_slot = (int)atomicAdd(&ctr[tile], 1u);
+      if (tid == 0) { s_slot = (int)atomicAdd(&ctr[tile], 1u); s_bad = 0; }
       __syncthreads();
       const int sl = s_slot;
       __syncthreads();
@@ -233,13 +241,24 @@ __global__ __launch_bounds__(WG, 8) void sgd_slots_kernel(const int4* __restrict
       const int slot = s0 + sl;
       const int64_t rb = slot_beg[slot], R = slot_beg[slot + 1] - rb;
       const int ib = slot_ibeg[slot], ni = slot_ibeg[slot + 1] - ib;
-      const bool shared = slot_shared[slot] != 0;
-      // stage the slot's item rows
+      // stage the slot's item rows (as floats first, to decide the representation)
+      bool mybad = false;
       for (int x = tid; x < ni * LD4; x += WG) {
         const int row = x / LD4, c4 = x % LD4;
         const float4v v = *(const float4v*)(V + (int64_t)slot_items[ib + row] * LD + 4 * c4);
-        q4[row * LD4 + c4] = v;
-        if (shared) q4[ROWS * LD4 + c4] = v;
+#pragma unroll
+        for (int e = 0; e < 4; e++) mybad |= !(__builtin_fabsf(v[e]) <= FIX_MAX);   // also true for NaN
+        q4[row * LD4 + c4] = __builtin_bit_cast(int4, v);
+      }
+      if (mybad) s_bad = 1;
+      __syncthreads();
+      const bool fix = s_bad == 0;
+      if (fix) {
+        for (int x = tid; x < ni * LD4; x += WG) {
+          const float4v v = __builtin_bit_cast(float4v, q4[x]);
+          q4[x] = make_int4(__float2int_rn(v.x * FIX_SCALE), __float2int_rn(v.y * FIX_SCALE),
+                            __float2int_rn(v.z * FIX_SCALE), __float2int_rn(v.w * FIX_SCALE));
+        }
       }
       __syncthreads();
       const uint32_t ks0 = k0 + (uint32_t)slot * 0x632be5abU, ks1 = k1 ^ mfx_mix32((uint32_t)slot + 77U);
@@ -273,11 +292,13 @@ __global__ __launch_bounds__(WG, 8) void sgd_slots_kernel(const int4* __restrict
             for (int c = 0; c < C; c++) pn[c] = Um.ld(pen + c * 4 * L);
           }
           if (e < nvalid) {
-            float* qrow = q_lds + li * LD + 4 * j;
+            int* qrow = q_lds + li * LD + 4 * j;
             float4v q[C], q0[C];
 #pragma unroll
             for (int c = 0; c < C; c++) {
-              q[c] = *(const float4v*)(qrow + c * 4 * L);
+              const int4 qi = *(const int4*)(qrow + c * 4 * L);
+              if (fix) q[c] = float4v{(float)qi.x * FIX_INV, (float)qi.y * FIX_INV, (float)qi.z * FIX_INV, (float)qi.w * FIX_INV};
+              else q[c] = __builtin_bit_cast(float4v, qi);
               q0[c] = q[c];
             }
             const float est = group_dot<L, C>(p, q);
@@ -285,22 +306,34 @@ __global__ __launch_bounds__(WG, 8) void sgd_slots_kernel(const int4* __restrict
 #pragma unroll
             for (int c = 0; c < C; c++) {
               Um.st(pe + c * 4 * L, p[c]);
+              if (fix) {
 #pragma unroll
-              for (int x = 0; x < 4; x++) atomicAdd(qrow + c * 4 * L + x, q[c][x] - q0[c][x]);   // ds_add_f32
+                for (int x = 0; x < 4; x++)
+                  atomicAdd(qrow + c * 4 * L + x, __float2int_rn((q[c][x] - q0[c][x]) * FIX_SCALE));   // ds_add_u32
+              } else {
+                *(int4*)(qrow + c * 4 * L) = __builtin_bit_cast(int4, q[c]);
+              }
             }
           }
         }
       }
       __syncthreads();
-      // write the item rows back: owned rows are stored, a shared row adds its delta
-      if (!shared) {
-        for (int x = tid; x < ni * LD4; x += WG) {
-          const int row = x / LD4, c4 = x % LD4;
-          *(float4v*)(V + (int64_t)slot_items[ib + row] * LD + 4 * c4) = q4[row * LD4 + c4];
+      // write the item rows back (this workgroup is their only owner during the round)
+      for (int x = tid; x < ni * LD4; x += WG) {
+        const int row = x / LD4, c4 = x % LD4;
+        const int4 qi = q4[x];
+        float4v v;
+        if (fix) {
+          const int lim = 0x7f000000;   // |q| beyond ~127: the row left the fixed-point range => diverged
+          const float nanv = __builtin_nanf("");
+          v = float4v{(qi.x > lim || qi.x < -lim) ? nanv : (float)qi.x * FIX_INV,
+                      (qi.y > lim || qi.y < -lim) ? nanv : (float)qi.y * FIX_INV,
+                      (qi.z > lim || qi.z < -lim) ? nanv : (float)qi.z * FIX_INV,
+                      (qi.w > lim || qi.w < -lim) ? nanv : (float)qi.w * FIX_INV};
+        } else {
+          v = __builtin_bit_cast(float4v, qi);
         }
-      } else {
-        float* vrow = V + (int64_t)slot_items[ib] * LD;
-        for (int x = tid; x < LD; x += WG) atomicAdd(vrow + x, q_lds[x] - q_lds[ROWS * LD + x]);
+        *(float4v*)(V + (int64_t)slot_items[ib + row] * LD + 4 * c4) = v;
       }
       __syncthreads();
     }
@@ -337,14 +370,14 @@ static int launch_slots(mfx_ctx* ctx, SlotState* S, const mfx_sgd_opts* o, int b
   for (int round = 0; round < 8; round++) {
     ProfScope ps(ctx, MFX_K_SGD);
     hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, false>), dim3(blocks), dim3(WG), 0, ctx->stream,
-                       (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->slot_shared, S->tile_slot,
-                       S->ctr, round, ctx->U, ctx->V, (uint32_t)ub, o->learnRate, o->uReg, o->iReg, k0, k1);
+                       (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->tile_slot, S->ctr, round,
+                       ctx->U, ctx->V, (uint32_t)ub, o->learnRate, o->uReg, o->iReg, k0, k1);
   }
   {
     ProfScope ps(ctx, MFX_K_SGD_SWEEP);
     hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, true>), dim3(256), dim3(WG), 0, ctx->stream,
-                       (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->slot_shared, S->tile_slot,
-                       S->ctr, -1, ctx->U, ctx->V, (uint32_t)ub, o->learnRate, o->uReg, o->iReg, k0, k1);
+                       (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->tile_slot, S->ctr, -1,
+                       ctx->U, ctx->V, (uint32_t)ub, o->learnRate, o->uReg, o->iReg, k0, k1);
   }
   HIPCHK(hipGetLastError());
   return MFX_OK;

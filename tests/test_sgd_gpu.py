@@ -60,10 +60,11 @@ def test_tiled_conflict_free_batch_bit_exact(K):
         u, i, r = ctx.debug_epoch_list()
     Uo, Vo = U0.copy(), V0.copy()
     orc.sgd_pass(Uo, Vo, tr.rowids(), tr.rowind, tr.rowval, None, 0.01, 0.05, 0.02, orc.ARITH_REF64, orc.DOT_TREE)
-    # every rating visited exactly once.  The user rows are bit-exact; the item rows are updated as
-    # q += (q_new - q) in LDS (ds_add_f32), which can round differently by one ulp of max(|q|,|q_new|).
-    assert np.array_equal(U, Uo)
-    assert np.abs(V - Vo).max() <= 2.0 ** -23 * np.abs(V0).max() and np.mean(V != Vo) < 0.02
+    # every rating visited exactly once.  The item rows are accumulated in LDS in 2^-24 fixed point
+    # (DESIGN.md 3.1): each differs from the oracle's fp32 row by at most ~2 * 2^-24; the user rows see the
+    # item row through that representation, hence the same bound scaled by lr * |diff|.
+    assert np.abs(V - Vo).max() <= 2.0e-7
+    assert np.abs(U - Uo).max() <= 2.0e-7
     assert np.array_equal(np.sort(u), np.arange(n))
 
 
