@@ -322,18 +322,24 @@ __global__ __launch_bounds__(WG, 8) void sgd_slots_kernel(const int4* __restrict
       for (int x = tid; x < ni * LD4; x += WG) {
         const int row = x / LD4, c4 = x % LD4;
         const int4 qi = q4[x];
+        float* vrow = V + (int64_t)slot_items[ib + row] * LD + 4 * c4;
         float4v v;
         if (fix) {
+          // new row = staged fp32 row + the accumulated fixed-point delta: an untouched row is
+          // written back bit for bit, a touched one carries only the rounding of its updates
+          const float4v v0 = *(const float4v*)vrow;
           const int lim = 0x7f000000;   // |q| beyond ~127: the row left the fixed-point range => diverged
           const float nanv = __builtin_nanf("");
-          v = float4v{(qi.x > lim || qi.x < -lim) ? nanv : (float)qi.x * FIX_INV,
-                      (qi.y > lim || qi.y < -lim) ? nanv : (float)qi.y * FIX_INV,
-                      (qi.z > lim || qi.z < -lim) ? nanv : (float)qi.z * FIX_INV,
-                      (qi.w > lim || qi.w < -lim) ? nanv : (float)qi.w * FIX_INV};
+          const int qa[4] = {qi.x, qi.y, qi.z, qi.w};
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const int q0i = __float2int_rn(v0[e] * FIX_SCALE);
+            v[e] = (qa[e] > lim || qa[e] < -lim) ? nanv : v0[e] + (float)(qa[e] - q0i) * FIX_INV;
+          }
         } else {
           v = __builtin_bit_cast(float4v, qi);
         }
-        *(float4v*)(V + (int64_t)slot_items[ib + row] * LD + 4 * c4) = v;
+        *(float4v*)vrow = v;
       }
       __syncthreads();
     }
