@@ -24,8 +24,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--rank-k", type=int, default=64, dest="K")
     ap.add_argument("--scale", type=float, default=1.0, help="scale nnz (debug only)")
@@ -149,8 +149,8 @@ def main():
                        "learnrate": lr, "ureg": ureg, "ireg": ireg, "arith": args.arith,
                        "parallelism": "user-block x%d" % N},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "sgd_tiled_kernel" if mode == mfx.SGD_TILED else "sgd_hogwild_kernel",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(mode),
+                         "kernel": "sgd_slots_kernel" if mode == mfx.SGD_TILED else "sgd_hogwild_kernel",
                          "avg_launch_ms": avg_ms, "launches": sgd_launches, "launches_per_step": launches_per_step,
                          "algorithmic_bytes_per_launch": alg_bytes},
             "permute_ms_per_step": perm_ms / max(1, args.steps),
@@ -166,6 +166,22 @@ def main():
     ctx.close()
     if rank == 0:
         print(json.dumps(out), flush=True)
+
+
+def pmc_traffic(mode):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
+    command (profiles/r01_pmc_summary.json: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, KB -> bytes).
+    rocprofv3 cannot run inside this process; None when no summary is committed for the kernel."""
+    from matfac_amd import mfx
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        d = json.load(open(path))
+        key = "sgd_slots_kernel" if mode == mfx.SGD_TILED else "sgd_hogwild_kernel"
+        return d[key]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
 
 
 def cpu_baseline(np, tr, nU, nI, K, lr, ureg, ireg, epochs):
