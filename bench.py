@@ -6,8 +6,8 @@
 One "step" = one SGD epoch (device-side reshuffle + Hogwild update kernel, modelMF.cpp:1739-1767)
 over the rank's train ratings.  N > 1: one process per GPU (torch.distributed.run), the rating
 matrix is sharded by user-row blocks (every rank owns a full ML-20M-shape block of users over the
-SAME item catalogue: weak scaling) and the item factors are all-reduced over RCCL after every
-local epoch.  Rank 0 prints ONE JSON line (see the driver contract in the task statement).
+SAME item catalogue: weak scaling) and the item-factor replicas are averaged with one RCCL all-reduce
+after every local epoch.  Rank 0 prints ONE JSON line (see the driver contract in the task statement).
 """
 import argparse
 import json
@@ -94,7 +94,7 @@ def main():
         ctx.sgd_epoch(lr, ureg, ireg, mode=mode, order=mfx.ORDER_DEVICE, arith=arith, seed=1, epoch=ep,
                       blocks=args.blocks)
         if N > 1:
-            ctx.allreduce_item_factors(mfx.REDUCE_DELTA_SUM)
+            ctx.allreduce_item_factors(mfx.REDUCE_AVERAGE)   # replicas of V averaged (summed deltas overshoot: DESIGN.md 3.1)
 
     def barrier():
         ctx.synchronize()
