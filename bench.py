@@ -48,7 +48,8 @@ def main():
     import numpy as np
 
     dist = None
-    if N > 1:
+    force_dist = os.environ.get("BENCH_FORCE_DIST") == "1"   # rehearse the N > 1 code path with one rank
+    if N > 1 or force_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -75,7 +76,7 @@ def main():
     _, V0 = synth.init_factors(1, 1, nI, K, want_u=False)            # V replica: identical everywhere
     ctx.set_factors(U0, V0)
     ctx.compute_invalid()
-    if N > 1:
+    if N > 1 or force_dist:
         import torch
         uid = [Ctx.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
@@ -93,12 +94,12 @@ def main():
     def step(ep):
         ctx.sgd_epoch(lr, ureg, ireg, mode=mode, order=mfx.ORDER_DEVICE, arith=arith, seed=1, epoch=ep,
                       blocks=args.blocks)
-        if N > 1:
+        if N > 1 or force_dist:
             ctx.allreduce_item_factors(mfx.REDUCE_AVERAGE)   # replicas of V averaged (summed deltas overshoot: DESIGN.md 3.1)
 
     def barrier():
         ctx.synchronize()
-        if N > 1:
+        if N > 1 or force_dist:
             import torch
             dist.barrier()
             torch.cuda.synchronize()
@@ -120,7 +121,7 @@ def main():
     tr_rmse = ctx.rmse(mfx.MAT_TRAIN)
 
     total_nnz = nnz
-    if N > 1:
+    if N > 1 or force_dist:
         import torch
         t = torch.tensor([elapsed, float(nnz)], dtype=torch.float64, device="cuda")
         tmax = t.clone()
@@ -159,7 +160,7 @@ def main():
         }
         if N == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(np, tr, nU, nI, K, lr, ureg, ireg, args.cpu_sample)
-    if N > 1:
+    if N > 1 or force_dist:
         ctx.comm_destroy()
         dist.barrier()
         dist.destroy_process_group()
