@@ -43,14 +43,28 @@ __global__ void store_col_kernel(float* __restrict__ X, int32_t n, int ld, int k
   if (t < n) X[t * ld + k] = xk[t];
 }
 
-// res[e] (+/-)= a[rowOf[e]] * b[colOf[e]]   -- float product, then float add/sub
+// res[e] (+/-)= a[rowOf[e]] * b[colOf[e]]   -- float product, then float add/sub.
+// Streaming: 16 bytes per lane per array (4 ratings per thread), the two factor vectors are L2 resident.
 template <int SIGN>
 __global__ __launch_bounds__(256) void resid_update_kernel(float* __restrict__ res, const int32_t* __restrict__ ia,
                                                            const int32_t* __restrict__ ib,
                                                            const float* __restrict__ a, const float* __restrict__ b,
                                                            int64_t n) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef int i4 __attribute__((ext_vector_type(4)));
+  const int64_t n4 = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride) {
+    const i4 x = ((const i4*)ia)[q], y = ((const i4*)ib)[q];
+    f4 r = ((const f4*)res)[q];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const float prod = a[x[e]] * b[y[e]];
+      r[e] = SIGN > 0 ? r[e] + prod : r[e] - prod;
+    }
+    ((f4*)res)[q] = r;
+  }
+  for (int64_t e = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
     const float prod = a[ia[e]] * b[ib[e]];
     res[e] = SIGN > 0 ? res[e] + prod : res[e] - prod;
   }
@@ -79,12 +93,21 @@ __global__ __launch_bounds__(256) void ccd_pass_kernel(const int32_t* __restrict
   for (int64_t s = grp; s < nseg; s += ngrp) {
     const int64_t b = seg_beg[s], e = seg_end[s];
     double num = 0.0, den = 0.0;
-    for (int64_t t = b + j; t < e; t += 16) {
+    int64_t t = b + j;
+    // 4 independent 16-rating strides per trip: the loads of one trip are all in flight together
+    for (; t + 48 < e; t += 64) {
+      const int i0 = ind[t], i1 = ind[t + 16], i2 = ind[t + 32], i3 = ind[t + 48];
+      const float r0 = res[t], r1 = res[t + 16], r2 = res[t + 32], r3 = res[t + 48];
+      const float o0 = other[i0], o1 = other[i1], o2 = other[i2], o3 = other[i3];
+      num += (double)(r0 * o0); den += (double)(o0 * o0);   // float products (modelMF.cpp:1069-1070)
+      num += (double)(r1 * o1); den += (double)(o1 * o1);
+      num += (double)(r2 * o2); den += (double)(o2 * o2);
+      num += (double)(r3 * o3); den += (double)(o3 * o3);
+    }
+    for (; t < e; t += 16) {
       const float o = other[ind[t]];
-      const float p = res[t] * o;   // float product (modelMF.cpp:1069)
-      const float q = o * o;        // (modelMF.cpp:1070)
-      num += (double)p;
-      den += (double)q;
+      num += (double)(res[t] * o);
+      den += (double)(o * o);
     }
     num = group16_sum(num);
     den = group16_sum(den);
@@ -199,7 +222,7 @@ static int run_resid(mfx_ctx* ctx) {
   const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
   if (m.nnz == 0) return MFX_OK;
   ProfScope ps(ctx, MFX_K_CCD_RESID);
-  const int blocks = (int)std::min<int64_t>((m.nnz + 255) / 256, 256 * 16);
+  const int blocks = (int)std::min<int64_t>((m.nnz / 4 + 255) / 256 + 1, 256 * 16);
   // row view: res_row[e] +-= u_k[rowid[e]] * v_k[rowind[e]]; column view likewise
   hipLaunchKernelGGL(resid_update_kernel<SIGN>, dim3(blocks), dim3(256), 0, ctx->stream, ctx->res_row, m.rowid,
                      m.rowind, ctx->uk, ctx->vk, m.nnz);
