@@ -124,7 +124,9 @@ typedef struct {
                           4*64/L ratings in flight); 0 = auto: min(nUsers,nItems)/64
                           clamped to [8,2048] -- lock-free SGD loses updates when the
                           ratings in flight are not << min(nUsers,nItems)            */
-  int32_t reserved;
+  int32_t own;         /* MFX_SGD_TILED: which rows a workgroup owns in LDS for a slot (lossless
+                          updates on that side): 0 = alternate, item rows on even epochs and user
+                          rows on odd ones; 1 = item rows; 2 = user rows                          */
   int64_t first, count; /* sub-range of the epoch list; count <= 0: everything  */
 } mfx_sgd_opts;
 /* Permutation of the train ratings (indices into the CSR-order rating list with

@@ -31,8 +31,8 @@ namespace {
 constexpr int CAP_R = 1024;   // ratings per slot
 constexpr int WG = 1024;      // threads per workgroup: 16 waves = 64 ratings in flight on one slot
 
-struct SlotState {
-  int32_t* rec = nullptr;          // int4 per rating: user, local item index, rating bits, item
+struct SlotList {
+  int32_t* rec = nullptr;          // int4 per rating: other-side index, local owned index, rating bits, owned index
   int64_t* slot_beg = nullptr;     // [nslots+1] rating range of a slot
   int32_t* slot_ibeg = nullptr;    // [nslots+1] range into slot_items
   int32_t* slot_items = nullptr;   // global item ids of every slot
@@ -40,20 +40,27 @@ struct SlotState {
   int32_t* tile_slot = nullptr;    // [65] slot range of a tile
   unsigned* ctr = nullptr;         // [64] slot counters
   int64_t nslots = 0, nnz = 0;
-  int rows = 0;                    // item rows per slot the lists were built for
-  uint32_t last_k0 = 0, last_k1 = 0;
+  int rows = 0;                    // owned rows per slot the lists were built for
   bool built = false;
+};
+// side 0: item rows owned (slots item-major), side 1: user rows owned (slots user-major)
+struct SlotState {
+  SlotList side[2];
+  uint32_t last_k0 = 0, last_k1 = 0;
+  int last_side = 0;
 };
 }  // namespace
 
 static SlotState* state(mfx_ctx* ctx) { return (SlotState*)ctx->slots; }
 
 void mfx_slots_free_internal(mfx_ctx* ctx) {
-  SlotState* s = state(ctx);
-  if (!s) return;
-  dev_free(s->rec); dev_free(s->slot_beg); dev_free(s->slot_ibeg); dev_free(s->slot_items);
-  dev_free(s->slot_shared); dev_free(s->tile_slot); dev_free(s->ctr);
-  delete s;
+  SlotState* st = state(ctx);
+  if (!st) return;
+  for (SlotList& s : st->side) {
+    dev_free(s.rec); dev_free(s.slot_beg); dev_free(s.slot_ibeg); dev_free(s.slot_items);
+    dev_free(s.slot_shared); dev_free(s.tile_slot); dev_free(s.ctr);
+  }
+  delete st;
   ctx->slots = nullptr;
 }
 
@@ -68,7 +75,7 @@ static int up(mfx_ctx* ctx, T** dst, const std::vector<T>& v) {
   return MFX_OK;
 }
 
-static int build_slots(mfx_ctx* ctx, SlotState* S, int rows) {
+static int build_slots(mfx_ctx* ctx, SlotList* S, int rows, int side) {
   const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
   const int64_t nnz = m.nnz;
   std::vector<int32_t> ru((size_t)nnz), ri((size_t)nnz);
@@ -78,6 +85,10 @@ static int build_slots(mfx_ctx* ctx, SlotState* S, int rows) {
     HIPCHK(hipMemcpy(ri.data(), m.rowind, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(rv.data(), m.rowval, sizeof(float) * (size_t)nnz, hipMemcpyDeviceToHost));
   }
+  // own[] = index on the owned side (grouping key), oth[] = index on the lock-free side
+  const std::vector<int32_t>& own = side == 0 ? ri : ru;
+  const std::vector<int32_t>& oth = side == 0 ? ru : ri;
+  const int32_t nown = side == 0 ? m.ncols : m.nrows;
   // ratings of each tile (stable in CSR order)
   std::vector<int64_t> tstart(65, 0);
   for (int64_t e = 0; e < nnz; e++) tstart[mfx_user_block(ru[e]) * 8 + mfx_item_block(ri[e]) + 1]++;
@@ -90,7 +101,7 @@ static int build_slots(mfx_ctx* ctx, SlotState* S, int rows) {
   std::vector<int32_t> rec((size_t)nnz * 4), slot_ibeg(1, 0), slot_items, tile_slot(65, 0);
   std::vector<int64_t> slot_beg(1, 0);
   std::vector<uint8_t> slot_shared;
-  std::vector<int32_t> cnt((size_t)std::max(m.ncols, 1), 0);
+  std::vector<int32_t> cnt((size_t)std::max(nown, 1), 0);
   std::vector<int32_t> items;
   int64_t out = 0;
   for (int t = 0; t < 64; t++) {
@@ -98,7 +109,7 @@ static int build_slots(mfx_ctx* ctx, SlotState* S, int rows) {
     const int64_t b = tstart[t], e = tstart[t + 1];
     items.clear();
     for (int64_t x = b; x < e; x++) {
-      const int32_t it = ri[byt[x]];
+      const int32_t it = own[byt[x]];
       if (cnt[it]++ == 0) items.push_back(it);
     }
     // items by descending number of ratings in this tile, ties by id
@@ -110,7 +121,7 @@ static int build_slots(mfx_ctx* ctx, SlotState* S, int rows) {
     {
       std::vector<int64_t> where((size_t)items.size());
       for (size_t k = 0; k < items.size(); k++) { where[k] = off[k]; cnt[items[k]] = (int32_t)k; }  // cnt := rank
-      for (int64_t x = b; x < e; x++) sorted[where[cnt[ri[byt[x]]]]++] = byt[x];
+      for (int64_t x = b; x < e; x++) sorted[where[cnt[own[byt[x]]]]++] = byt[x];
     }
     // cut into slots
     int cur_r = 0, cur_i = 0;
@@ -133,7 +144,7 @@ static int build_slots(mfx_ctx* ctx, SlotState* S, int rows) {
         slot_items.push_back(it);
         for (int64_t x = 0; x < n; x++) {
           const int64_t src = sorted[off[k] + x];
-          rec[4 * out] = ru[src]; rec[4 * out + 1] = 0; memcpy(&rec[4 * out + 2], &rv[src], 4); rec[4 * out + 3] = it;
+          rec[4 * out] = oth[src]; rec[4 * out + 1] = 0; memcpy(&rec[4 * out + 2], &rv[src], 4); rec[4 * out + 3] = it;
           out++;
         }
         cur_r = (int)std::min<int64_t>(n, 1 << 30); cur_i = 1;
@@ -143,7 +154,7 @@ static int build_slots(mfx_ctx* ctx, SlotState* S, int rows) {
         slot_items.push_back(it);
         for (int64_t x = 0; x < n; x++) {
           const int64_t src = sorted[off[k] + x];
-          rec[4 * out] = ru[src]; rec[4 * out + 1] = cur_i; memcpy(&rec[4 * out + 2], &rv[src], 4); rec[4 * out + 3] = it;
+          rec[4 * out] = oth[src]; rec[4 * out + 1] = cur_i; memcpy(&rec[4 * out + 2], &rv[src], 4); rec[4 * out + 3] = it;
           out++;
         }
         cur_r += (int)n; cur_i++;
@@ -170,8 +181,8 @@ static int build_slots(mfx_ctx* ctx, SlotState* S, int rows) {
       mx = std::max(mx, slot_beg[k + 1] - slot_beg[k]);
       small += (slot_beg[k + 1] - slot_beg[k]) < 256;
     }
-    fprintf(stderr, "[mfx] slots: %zu for %lld ratings, longest %lld, <256 ratings: %lld, item refs %zu\n",
-            slot_shared.size(), (long long)nnz, (long long)mx, (long long)small, slot_items.size());
+    fprintf(stderr, "[mfx] slots (%s rows owned): %zu for %lld ratings, longest %lld, <256 ratings: %lld, row refs %zu\n",
+            side == 0 ? "item" : "user", slot_shared.size(), (long long)nnz, (long long)mx, (long long)small, slot_items.size());
   }
   S->nslots = (int64_t)slot_shared.size();
   S->nnz = nnz;
@@ -202,21 +213,23 @@ __device__ __forceinline__ int64_t slot_perm(int64_t t, int64_t R, uint32_t k0, 
 // guard (model.cpp:1486-1498) still sees a diverged model.
 constexpr float FIX_SCALE = 16777216.0f, FIX_INV = 1.0f / 16777216.0f, FIX_MAX = 127.0f;
 
-template <int L, int C, int ARITH, bool SWEEP>
+template <int L, int C, int ARITH, bool SWEEP, bool OWN_U>
 __global__ __launch_bounds__(WG, 8) void sgd_slots_kernel(const int4* __restrict__ rec,
                                                            const int64_t* __restrict__ slot_beg,
                                                            const int32_t* __restrict__ slot_ibeg,
                                                            const int32_t* __restrict__ slot_items,
                                                            const int32_t* __restrict__ tile_slot, unsigned* ctr,
-                                                           int round, float* U, float* V, uint32_t ubytes, float lr,
-                                                           float uReg, float iReg, uint32_t k0, uint32_t k1) {
+                                                           int round, float* Oth, float* Own, uint32_t obytes,
+                                                           float lr, float uReg, float iReg, uint32_t k0,
+                                                           uint32_t k1) {
   constexpr int G = 64 / L;
   constexpr int LD = 4 * L * C;
   constexpr int LD4 = LD / 4;
   constexpr int ROWS = SlotRows<C>::value;
   __shared__ __attribute__((aligned(16))) int q_lds[ROWS * LD];
   __shared__ int s_slot, s_bad;
-  const Rows<3> Um(U, ubytes);
+  // Oth: the lock-free side (user rows when item rows are owned, and vice versa); Own: staged in LDS
+  const Rows<3> Um(Oth, obytes);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane / L, j = lane % L;
   const int xcc = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7);  // HW_REG_XCC_ID[3:0]
@@ -245,7 +258,7 @@ __global__ __launch_bounds__(WG, 8) void sgd_slots_kernel(const int4* __restrict
       bool mybad = false;
       for (int x = tid; x < ni * LD4; x += WG) {
         const int row = x / LD4, c4 = x % LD4;
-        const float4v v = *(const float4v*)(V + (int64_t)slot_items[ib + row] * LD + 4 * c4);
+        const float4v v = *(const float4v*)(Own + (int64_t)slot_items[ib + row] * LD + 4 * c4);
 #pragma unroll
         for (int e = 0; e < 4; e++) mybad |= !(__builtin_fabsf(v[e]) <= FIX_MAX);   // also true for NaN
         q4[row * LD4 + c4] = __builtin_bit_cast(int4, v);
@@ -301,8 +314,11 @@ __global__ __launch_bounds__(WG, 8) void sgd_slots_kernel(const int4* __restrict
               else q[c] = __builtin_bit_cast(float4v, qi);
               q0[c] = q[c];
             }
+            // p = the row from global memory, q = the owned row; the reference updates the USER row first
+            // and the item row with the updated user row (modelMF.cpp:94-103) whichever side is owned
             const float est = group_dot<L, C>(p, q);
-            sgd_axpys<C, ARITH>(p, q, r, est, lr, uReg, iReg);
+            if (OWN_U) sgd_axpys<C, ARITH>(q, p, r, est, lr, uReg, iReg);
+            else sgd_axpys<C, ARITH>(p, q, r, est, lr, uReg, iReg);
 #pragma unroll
             for (int c = 0; c < C; c++) {
               Um.st(pe + c * 4 * L, p[c]);
@@ -322,7 +338,7 @@ __global__ __launch_bounds__(WG, 8) void sgd_slots_kernel(const int4* __restrict
       for (int x = tid; x < ni * LD4; x += WG) {
         const int row = x / LD4, c4 = x % LD4;
         const int4 qi = q4[x];
-        float* vrow = V + (int64_t)slot_items[ib + row] * LD + 4 * c4;
+        float* vrow = Own + (int64_t)slot_items[ib + row] * LD + 4 * c4;
         float4v v;
         if (fix) {
           // new row = staged fp32 row + the accumulated fixed-point delta: an untouched row is
@@ -348,14 +364,14 @@ __global__ __launch_bounds__(WG, 8) void sgd_slots_kernel(const int4* __restrict
 
 // test hook: materialise the visiting order of the last epoch (slot by slot)
 __global__ void slots_epoch_list_kernel(const int4* __restrict__ rec, const int64_t* __restrict__ slot_beg,
-                                        int64_t nslots, uint32_t k0, uint32_t k1, int32_t* __restrict__ eu,
+                                        int64_t nslots, int own_u, uint32_t k0, uint32_t k1, int32_t* __restrict__ eu,
                                         int32_t* __restrict__ ei, float* __restrict__ er) {
   for (int64_t slot = blockIdx.x; slot < nslots; slot += gridDim.x) {
     const int64_t rb = slot_beg[slot], R = slot_beg[slot + 1] - rb;
     const uint32_t ks0 = k0 + (uint32_t)slot * 0x632be5abU, ks1 = k1 ^ mfx_mix32((uint32_t)slot + 77U);
     for (int64_t t = threadIdx.x; t < R; t += blockDim.x) {
       const int4 r = rec[rb + slot_perm(t, R, ks0, ks1)];
-      eu[rb + t] = r.x; ei[rb + t] = r.w; er[rb + t] = __builtin_bit_cast(float, r.z);
+      eu[rb + t] = own_u ? r.w : r.x; ei[rb + t] = own_u ? r.x : r.w; er[rb + t] = __builtin_bit_cast(float, r.z);
     }
   }
 }
@@ -369,76 +385,86 @@ static int env_blocks() {
   return b;
 }
 
-template <int L, int C, int ARITH>
-static int launch_slots(mfx_ctx* ctx, SlotState* S, const mfx_sgd_opts* o, int blocks, uint32_t k0, uint32_t k1) {
-  const uint64_t ub = (uint64_t)ctx->nU * ctx->ld * 4;
+template <int L, int C, int ARITH, bool OWN_U>
+static int launch_slots(mfx_ctx* ctx, SlotList* S, const mfx_sgd_opts* o, int blocks, uint32_t k0, uint32_t k1) {
+  float* oth = OWN_U ? ctx->V : ctx->U;
+  float* own = OWN_U ? ctx->U : ctx->V;
+  const uint64_t ob = (uint64_t)(OWN_U ? ctx->nI : ctx->nU) * ctx->ld * 4;
   HIPCHK(hipMemsetAsync(S->ctr, 0, 64 * sizeof(unsigned), ctx->stream));
   for (int round = 0; round < 8; round++) {
     ProfScope ps(ctx, MFX_K_SGD);
-    hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, false>), dim3(blocks), dim3(WG), 0, ctx->stream,
+    hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, false, OWN_U>), dim3(blocks), dim3(WG), 0, ctx->stream,
                        (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->tile_slot, S->ctr, round,
-                       ctx->U, ctx->V, (uint32_t)ub, o->learnRate, o->uReg, o->iReg, k0, k1);
+                       oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1);
   }
   {
     ProfScope ps(ctx, MFX_K_SGD_SWEEP);
-    hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, true>), dim3(256), dim3(WG), 0, ctx->stream,
+    hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, true, OWN_U>), dim3(256), dim3(WG), 0, ctx->stream,
                        (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->tile_slot, S->ctr, -1,
-                       ctx->U, ctx->V, (uint32_t)ub, o->learnRate, o->uReg, o->iReg, k0, k1);
+                       oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1);
   }
   HIPCHK(hipGetLastError());
   return MFX_OK;
 }
 
 template <int L, int C>
-static int launch_arith(mfx_ctx* ctx, SlotState* S, const mfx_sgd_opts* o, int blocks, uint32_t k0, uint32_t k1) {
+static int launch_arith(mfx_ctx* ctx, SlotList* S, int side, const mfx_sgd_opts* o, int blocks, uint32_t k0,
+                        uint32_t k1) {
+#define MFX_SIDE(A) \
+  (side ? launch_slots<L, C, A, true>(ctx, S, o, blocks, k0, k1) : launch_slots<L, C, A, false>(ctx, S, o, blocks, k0, k1))
   switch (o->arith) {
-    case MFX_ARITH_REF64: return launch_slots<L, C, MFX_ARITH_REF64>(ctx, S, o, blocks, k0, k1);
-    case MFX_ARITH_REF64F: return launch_slots<L, C, MFX_ARITH_REF64F>(ctx, S, o, blocks, k0, k1);
-    default: return launch_slots<L, C, MFX_ARITH_F32>(ctx, S, o, blocks, k0, k1);
+    case MFX_ARITH_REF64: return MFX_SIDE(MFX_ARITH_REF64);
+    case MFX_ARITH_REF64F: return MFX_SIDE(MFX_ARITH_REF64F);
+    default: return MFX_SIDE(MFX_ARITH_F32);
   }
+#undef MFX_SIDE
 }
 
 int mfx_launch_sgd_tiled(mfx_ctx* ctx, const mfx_sgd_opts* o) {
-  const uint64_t ub = (uint64_t)ctx->nU * ctx->ld * 4;
-  NEED(ub < (1ull << 32), MFX_E_ARG, "MFX_SGD_TILED: the user factor matrix exceeds 4 GiB (buffer addressing)");
-  SlotState* S = state(ctx);
-  if (!S) { S = new SlotState; ctx->slots = S; }
+  // which side is owned this epoch: o->own = 1 items, 2 users, 0 = alternate (items on even epochs)
+  const int side = o->own == 1 ? 0 : o->own == 2 ? 1 : (o->epoch & 1);
+  const uint64_t ob = (uint64_t)(side ? ctx->nI : ctx->nU) * ctx->ld * 4;
+  NEED(ob < (1ull << 32), MFX_E_ARG, "MFX_SGD_TILED: a factor matrix exceeds 4 GiB (buffer addressing)");
+  SlotState* st = state(ctx);
+  if (!st) { st = new SlotState; ctx->slots = st; }
+  SlotList* S = &st->side[side];
   const int rows = ctx->C <= 8 ? (64 / ctx->C < 8 ? 8 : 64 / ctx->C) : 8;
   if (!S->built || S->rows != rows || S->nnz != ctx->mat[MFX_MAT_TRAIN].nnz) {
-    int rc = build_slots(ctx, S, rows);
+    int rc = build_slots(ctx, S, rows, side);
     if (rc) return rc;
   }
   const uint32_t k0 = mfx_mix32(o->seed ^ 0x3c6ef372U) + (uint32_t)o->epoch * 0x9e3779b9U;
   const uint32_t k1 = mfx_mix32(o->seed * 0x85ebca6bU + 0xdaa66d2bU) ^ mfx_mix32((uint32_t)o->epoch + 0x1b873593U);
-  S->last_k0 = k0; S->last_k1 = k1;
+  st->last_k0 = k0; st->last_k1 = k1; st->last_side = side;
   int blocks = env_blocks();
   // `blocks` counts 256-thread workgroups (include/mfx.h); this kernel runs WG-thread ones
   if (blocks <= 0) blocks = o->blocks > 0 ? std::min(o->blocks, 8192) : std::max(8, std::min(2048, ctx->nU / 64));
   blocks = std::max(8, blocks * 256 / WG);
   ctx->elist_n = -1;   // the visiting order is not materialised; mfx_debug_epoch_list rebuilds it on demand
   const int L = ctx->L, C = ctx->C;
-  if (L == 4) return launch_arith<4, 1>(ctx, S, o, blocks, k0, k1);
-  if (L == 8) return launch_arith<8, 1>(ctx, S, o, blocks, k0, k1);
+  if (L == 4) return launch_arith<4, 1>(ctx, S, side, o, blocks, k0, k1);
+  if (L == 8) return launch_arith<8, 1>(ctx, S, side, o, blocks, k0, k1);
   switch (C) {
-    case 1: return launch_arith<16, 1>(ctx, S, o, blocks, k0, k1);
-    case 2: return launch_arith<16, 2>(ctx, S, o, blocks, k0, k1);
-    case 3: return launch_arith<16, 3>(ctx, S, o, blocks, k0, k1);
-    case 4: return launch_arith<16, 4>(ctx, S, o, blocks, k0, k1);
-    case 5: return launch_arith<16, 5>(ctx, S, o, blocks, k0, k1);
-    case 6: return launch_arith<16, 6>(ctx, S, o, blocks, k0, k1);
-    case 7: return launch_arith<16, 7>(ctx, S, o, blocks, k0, k1);
-    case 8: return launch_arith<16, 8>(ctx, S, o, blocks, k0, k1);
+    case 1: return launch_arith<16, 1>(ctx, S, side, o, blocks, k0, k1);
+    case 2: return launch_arith<16, 2>(ctx, S, side, o, blocks, k0, k1);
+    case 3: return launch_arith<16, 3>(ctx, S, side, o, blocks, k0, k1);
+    case 4: return launch_arith<16, 4>(ctx, S, side, o, blocks, k0, k1);
+    case 5: return launch_arith<16, 5>(ctx, S, side, o, blocks, k0, k1);
+    case 6: return launch_arith<16, 6>(ctx, S, side, o, blocks, k0, k1);
+    case 7: return launch_arith<16, 7>(ctx, S, side, o, blocks, k0, k1);
+    case 8: return launch_arith<16, 8>(ctx, S, side, o, blocks, k0, k1);
   }
   return mfx_fail(ctx, MFX_E_ARG, "sgd tiled: unsupported rank shape L=%d C=%d", L, C);
 }
 
 // fills ctx->eu/ei/er with the order the last tiled epoch visited (test hook)
 int mfx_slots_materialise_order(mfx_ctx* ctx) {
-  SlotState* S = state(ctx);
-  NEED(S && S->built, MFX_E_STATE, "no tiled epoch has run");
+  SlotState* st = state(ctx);
+  NEED(st && st->side[st->last_side].built, MFX_E_STATE, "no tiled epoch has run");
+  SlotList* S = &st->side[st->last_side];
   const int blocks = (int)std::min<int64_t>(std::max<int64_t>(S->nslots, 1), 4096);
   hipLaunchKernelGGL(slots_epoch_list_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const int4*)S->rec,
-                     S->slot_beg, S->nslots, S->last_k0, S->last_k1, ctx->eu, ctx->ei, ctx->er);
+                     S->slot_beg, S->nslots, st->last_side, st->last_k0, st->last_k1, ctx->eu, ctx->ei, ctx->er);
   HIPCHK(hipGetLastError());
   ctx->elist_n = S->nnz;
   return MFX_OK;

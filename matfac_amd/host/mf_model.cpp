@@ -415,7 +415,7 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
   if (kind == K_CCDPP || kind == K_CCDPP_FA) dev->check(mfx_ccdpp_begin(dev->ctx), "mfx_ccdpp_begin");
 
   mfx_sgd_opts o;
-  o.uReg = uReg; o.iReg = iReg; o.seed = (uint32_t)trainSeed; o.blocks = 0; o.reserved = 0; o.first = 0; o.count = 0;
+  o.uReg = uReg; o.iReg = iReg; o.seed = (uint32_t)trainSeed; o.blocks = 0; o.own = 0; o.first = 0; o.count = 0;
   o.arith = kind == K_HOG ? MFX_ARITH_F32 : kind == K_SGDPAR ? MFX_ARITH_REF64F : MFX_ARITH_REF64;
 
   double subIterDuration = 0;

@@ -27,7 +27,7 @@ class MfxError(RuntimeError):
 class SgdOpts(C.Structure):
     _fields_ = [("mode", C.c_int32), ("order", C.c_int32), ("arith", C.c_int32),
                 ("learnRate", C.c_float), ("uReg", C.c_float), ("iReg", C.c_float),
-                ("seed", C.c_uint32), ("epoch", C.c_int32), ("blocks", C.c_int32), ("reserved", C.c_int32),
+                ("seed", C.c_uint32), ("epoch", C.c_int32), ("blocks", C.c_int32), ("own", C.c_int32),
                 ("first", C.c_int64), ("count", C.c_int64)]
 
 
@@ -135,8 +135,8 @@ class Ctx:
         self._chk(self.lib.mfx_sgd_set_order(self.h, k[1], C.c_int64(k[0].size)))
 
     def sgd_epoch(self, lr, uReg, iReg, mode=SGD_HOGWILD, order=ORDER_DEVICE, arith=ARITH_F32, seed=1,
-                  epoch=0, first=0, count=0, blocks=0):
-        o = SgdOpts(mode, order, arith, lr, uReg, iReg, seed, epoch, blocks, 0, first, count)
+                  epoch=0, first=0, count=0, blocks=0, own=0):
+        o = SgdOpts(mode, order, arith, lr, uReg, iReg, seed, epoch, blocks, own, first, count)
         self._chk(self.lib.mfx_sgd_epoch(self.h, C.byref(o)))
 
     def debug_epoch_list(self):

@@ -19,10 +19,10 @@ for blocks in [int(b) for b in os.environ.get("BLOCKS", "2048,1024,512").split("
         traj = []
         t0 = time.perf_counter()
         for ep in range(int(os.environ.get("EPOCHS", 8))):
-            ctx.sgd_epoch(lr, 0.01, 0.01, mode=mfx.SGD_TILED, seed=1, epoch=ep, blocks=blocks)
+            ctx.sgd_epoch(lr, 0.01, 0.01, mode=mfx.SGD_TILED, seed=1, epoch=ep, blocks=blocks, own=int(os.environ.get('OWN', 0)))
             traj.append(round(ctx.rmse(mfx.MAT_TRAIN), 4))
         wall = time.perf_counter() - t0
         ms, n = ctx.prof_get(mfx.K_SGD); sw, ns = ctx.prof_get(mfx.K_SGD_SWEEP)
-        print(json.dumps(dict(blocks=blocks, lr=lr, round_ms=ms / max(n, 1), sweep_ms=sw / max(ns, 1),
+        print(json.dumps(dict(own=os.environ.get('OWN','0'), blocks=blocks, lr=lr, round_ms=ms / max(n, 1), sweep_ms=sw / max(ns, 1),
                               kernel_gups=tr.nnz * (n / 8) / (ms + sw) / 1e6, traj=traj)), flush=True)
         ctx.close()
