@@ -125,8 +125,9 @@ typedef struct {
                           clamped to [8,2048] -- lock-free SGD loses updates when the
                           ratings in flight are not << min(nUsers,nItems)            */
   int32_t own;         /* MFX_SGD_TILED: which rows a workgroup owns in LDS for a slot (lossless
-                          updates on that side): 0 = alternate, item rows on even epochs and user
-                          rows on odd ones; 1 = item rows; 2 = user rows                          */
+                          updates on that side): 0 = item rows (default; popular items are where
+                          lock-free updates collide), 1 = user rows, 2 = alternate by epoch --
+                          1 and 2 are experiments: measured worse / unstable       */
   int64_t first, count; /* sub-range of the epoch list; count <= 0: everything  */
 } mfx_sgd_opts;
 /* Permutation of the train ratings (indices into the CSR-order rating list with

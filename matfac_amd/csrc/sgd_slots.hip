@@ -421,8 +421,8 @@ static int launch_arith(mfx_ctx* ctx, SlotList* S, int side, const mfx_sgd_opts*
 }
 
 int mfx_launch_sgd_tiled(mfx_ctx* ctx, const mfx_sgd_opts* o) {
-  // which side is owned this epoch: o->own = 1 items, 2 users, 0 = alternate (items on even epochs)
-  const int side = o->own == 1 ? 0 : o->own == 2 ? 1 : (o->epoch & 1);
+  // which side is owned this epoch: o->own = 0 item rows (default), 1 user rows, 2 alternate
+  const int side = o->own == 1 ? 1 : o->own == 2 ? (o->epoch & 1) : 0;
   const uint64_t ob = (uint64_t)(side ? ctx->nI : ctx->nU) * ctx->ld * 4;
   NEED(ob < (1ull << 32), MFX_E_ARG, "MFX_SGD_TILED: a factor matrix exceeds 4 GiB (buffer addressing)");
   SlotState* st = state(ctx);
