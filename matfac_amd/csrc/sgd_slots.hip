@@ -36,7 +36,6 @@ struct SlotList {
   int64_t* slot_beg = nullptr;     // [nslots+1] rating range of a slot
   int32_t* slot_ibeg = nullptr;    // [nslots+1] range into slot_items
   int32_t* slot_items = nullptr;   // global item ids of every slot
-  uint8_t* slot_shared = nullptr;  // 1: the slot's single item also lives in other slots of the tile
   int32_t* tile_slot = nullptr;    // [65] slot range of a tile
   unsigned* ctr = nullptr;         // [64] slot counters
   int64_t nslots = 0, nnz = 0;
@@ -58,7 +57,7 @@ void mfx_slots_free_internal(mfx_ctx* ctx) {
   if (!st) return;
   for (SlotList& s : st->side) {
     dev_free(s.rec); dev_free(s.slot_beg); dev_free(s.slot_ibeg); dev_free(s.slot_items);
-    dev_free(s.slot_shared); dev_free(s.tile_slot); dev_free(s.ctr);
+    dev_free(s.tile_slot); dev_free(s.ctr);
   }
   delete st;
   ctx->slots = nullptr;
@@ -100,12 +99,12 @@ static int build_slots(mfx_ctx* ctx, SlotList* S, int rows, int side) {
   }
   std::vector<int32_t> rec((size_t)nnz * 4), slot_ibeg(1, 0), slot_items, tile_slot(65, 0);
   std::vector<int64_t> slot_beg(1, 0);
-  std::vector<uint8_t> slot_shared;
+  int32_t nslots = 0;
   std::vector<int32_t> cnt((size_t)std::max(nown, 1), 0);
   std::vector<int32_t> items;
   int64_t out = 0;
   for (int t = 0; t < 64; t++) {
-    tile_slot[t] = (int32_t)slot_shared.size();
+    tile_slot[t] = nslots;
     const int64_t b = tstart[t], e = tstart[t + 1];
     items.clear();
     for (int64_t x = b; x < e; x++) {
@@ -125,11 +124,11 @@ static int build_slots(mfx_ctx* ctx, SlotList* S, int rows, int side) {
     }
     // cut into slots
     int cur_r = 0, cur_i = 0;
-    auto close = [&](bool shared) {
+    auto close = [&]() {
       if (cur_r == 0) return;
       slot_beg.push_back(out);
       slot_ibeg.push_back((int32_t)slot_items.size());
-      slot_shared.push_back(shared ? 1 : 0);
+      nslots++;
       cur_r = cur_i = 0;
     };
     for (size_t k = 0; k < items.size(); k++) {
@@ -140,7 +139,7 @@ static int build_slots(mfx_ctx* ctx, SlotList* S, int rows, int side) {
         // concurrently processed slots and summing their deltas overshoots: measured NaN in the
         // first epoch -- each replica makes the whole step.  One owner keeps it sequential; the
         // slot list is longest-first so this pole starts first.)
-        close(false);
+        close();
         slot_items.push_back(it);
         for (int64_t x = 0; x < n; x++) {
           const int64_t src = sorted[off[k] + x];
@@ -148,9 +147,9 @@ static int build_slots(mfx_ctx* ctx, SlotList* S, int rows, int side) {
           out++;
         }
         cur_r = (int)std::min<int64_t>(n, 1 << 30); cur_i = 1;
-        close(false);
+        close();
       } else {
-        if (cur_r + n > CAP_R || cur_i == rows) close(false);
+        if (cur_r + n > CAP_R || cur_i == rows) close();
         slot_items.push_back(it);
         for (int64_t x = 0; x < n; x++) {
           const int64_t src = sorted[off[k] + x];
@@ -160,18 +159,17 @@ static int build_slots(mfx_ctx* ctx, SlotList* S, int rows, int side) {
         cur_r += (int)n; cur_i++;
       }
     }
-    close(false);
+    close();
     for (int32_t it : items) cnt[it] = 0;
   }
-  tile_slot[64] = (int32_t)slot_shared.size();
+  tile_slot[64] = nslots;
   dev_free(S->rec); dev_free(S->slot_beg); dev_free(S->slot_ibeg); dev_free(S->slot_items);
-  dev_free(S->slot_shared); dev_free(S->tile_slot);
+  dev_free(S->tile_slot);
   int rc;
   if ((rc = up(ctx, &S->rec, rec))) return rc;
   if ((rc = up(ctx, &S->slot_beg, slot_beg))) return rc;
   if ((rc = up(ctx, &S->slot_ibeg, slot_ibeg))) return rc;
   if ((rc = up(ctx, &S->slot_items, slot_items))) return rc;
-  if ((rc = up(ctx, &S->slot_shared, slot_shared))) return rc;
   if ((rc = up(ctx, &S->tile_slot, tile_slot))) return rc;
   if (!S->ctr && (rc = dev_alloc(ctx, &S->ctr, (size_t)64))) return rc;
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -182,9 +180,9 @@ static int build_slots(mfx_ctx* ctx, SlotList* S, int rows, int side) {
       small += (slot_beg[k + 1] - slot_beg[k]) < 256;
     }
     fprintf(stderr, "[mfx] slots (%s rows owned): %zu for %lld ratings, longest %lld, <256 ratings: %lld, row refs %zu\n",
-            side == 0 ? "item" : "user", slot_shared.size(), (long long)nnz, (long long)mx, (long long)small, slot_items.size());
+            side == 0 ? "item" : "user", (size_t)nslots, (long long)nnz, (long long)mx, (long long)small, slot_items.size());
   }
-  S->nslots = (int64_t)slot_shared.size();
+  S->nslots = nslots;
   S->nnz = nnz;
   S->rows = rows;
   S->built = true;
@@ -213,8 +211,9 @@ __device__ __forceinline__ int64_t slot_perm(int64_t t, int64_t R, uint32_t k0, 
 // guard (model.cpp:1486-1498) still sees a diverged model.
 constexpr float FIX_SCALE = 16777216.0f, FIX_INV = 1.0f / 16777216.0f, FIX_MAX = 127.0f;
 
+// C = 1 (K <= 64): 2 workgroups per CU (<= 64 VGPRs); wider ranks keep 1 workgroup per CU and get 128 VGPRs
 template <int L, int C, int ARITH, bool SWEEP, bool OWN_U>
-__global__ __launch_bounds__(WG, 8) void sgd_slots_kernel(const int4* __restrict__ rec,
+__global__ __launch_bounds__(WG, (C == 1 ? 8 : 4)) void sgd_slots_kernel(const int4* __restrict__ rec,
                                                            const int64_t* __restrict__ slot_beg,
                                                            const int32_t* __restrict__ slot_ibeg,
                                                            const int32_t* __restrict__ slot_items,
