@@ -36,6 +36,11 @@ def main():
     ap.add_argument("--cpu-sample", type=float, default=1.0, help="epochs of the CPU baseline sample")
     args = ap.parse_args()
 
+    # everything but the final JSON line goes to stderr (RCCL prints its version banner on stdout)
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -165,6 +170,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
     if rank == 0:
         print(json.dumps(out), flush=True)
 
