@@ -15,6 +15,7 @@
 // v_readlane broadcasts of the pivot row: no LDS, no pivoting (A + reg*I is SPD; Eigen's
 // LDLT pivots on the diagonal, which changes round-off only -- see DESIGN.md).
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "mfx_internal.h"
@@ -135,6 +136,7 @@ __device__ __forceinline__ float gram_solve(const GramAcc& g, int K, float reg, 
   return x;
 }
 
+template <bool SOLVE>
 __global__ __launch_bounds__(64) void als_segment_kernel(const int32_t* __restrict__ seg_row,
                                                          const int64_t* __restrict__ seg_beg,
                                                          const int64_t* __restrict__ seg_end,
@@ -150,8 +152,12 @@ __global__ __launch_bounds__(64) void als_segment_kernel(const int32_t* __restri
     gram_accumulate(g, Y, ind, val, seg_beg[s], seg_end[s], lane, ld);
     const int slab = seg_slab[s];
     if (slab < 0) {
-      const float x = gram_solve(g, K, reg, lane);
-      if (lane < K) X[(int64_t)seg_row[s] * ld + lane] = x;
+      if (SOLVE) {
+        const float x = gram_solve(g, K, reg, lane);
+        if (lane < K) X[(int64_t)seg_row[s] * ld + lane] = x;
+      } else if (lane < K) {   // timing probe (MFX_ALS_NOSOLVE): keep the accumulators alive, skip the solve
+        X[(int64_t)seg_row[s] * ld + lane] = g.t[0][0][0] + g.t[0][1][1] + g.t[1][0][2] + g.t[1][1][3] + g.b0 + g.b1;
+      }
     } else {
       float* o = slabs + (int64_t)slab * SLAB + lane;
 #pragma unroll
@@ -300,8 +306,13 @@ extern "C" int mfx_als_half_sweep(mfx_ctx* ctx, int side, float reg) {
   if (sd.nseg > 0) {
     ProfScope ps(ctx, MFX_K_ALS_GRAM);
     const int blocks = (int)std::min<int64_t>(sd.nseg, 256 * 16);
-    hipLaunchKernelGGL(als_segment_kernel, dim3(blocks), dim3(64), 0, ctx->stream, sd.seg_row, sd.seg_beg,
-                       sd.seg_end, sd.seg_slab, sd.nseg, ind, val, Y, X, ctx->als_slabs, ctx->K, ctx->ld, reg);
+    static const bool nosolve = getenv("MFX_ALS_NOSOLVE") != nullptr;   // timing probe only
+    if (nosolve)
+      hipLaunchKernelGGL(als_segment_kernel<false>, dim3(blocks), dim3(64), 0, ctx->stream, sd.seg_row, sd.seg_beg,
+                         sd.seg_end, sd.seg_slab, sd.nseg, ind, val, Y, X, ctx->als_slabs, ctx->K, ctx->ld, reg);
+    else
+      hipLaunchKernelGGL(als_segment_kernel<true>, dim3(blocks), dim3(64), 0, ctx->stream, sd.seg_row, sd.seg_beg,
+                         sd.seg_end, sd.seg_slab, sd.nseg, ind, val, Y, X, ctx->als_slabs, ctx->K, ctx->ld, reg);
     HIPCHK(hipGetLastError());
   }
   if (sd.nmrow > 0) {

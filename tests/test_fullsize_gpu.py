@@ -1,0 +1,101 @@
+"""Size-independent properties at the full BASELINE.json sizes (C2: ML-20M shape, 20 M train ratings,
+rank 64), where the oracle is too slow to replay whole epochs: every rating visited exactly once, ALS
+rows solve their normal equations, the two CCD++ residual views stay in lock-step, objective decreases."""
+import numpy as np
+import pytest
+
+from matfac_amd import Ctx, mfx, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def c2():
+    shape = dict(synth.SHAPES["C2"])
+    shape["nnz"] = int(shape["nnz"] / 0.8)
+    d = synth.make(shape, seed=1)
+    d["nItems"] = shape["nI"]
+    return d
+
+
+def _ctx(d, K):
+    tr, va = d["train"], d["val"]
+    ctx = Ctx(0)
+    ctx.set_csr(mfx.MAT_TRAIN, tr.nrows, d["nItems"], tr.rowptr, tr.rowind, tr.rowval)
+    ctx.set_csr(mfx.MAT_VAL, va.nrows, d["nItems"], va.rowptr, va.rowind, va.rowval)
+    ctx.set_model(d["nUsers"], d["nItems"], K)
+    U0, V0 = synth.init_factors(1, d["nUsers"], d["nItems"], K)
+    ctx.set_factors(U0, V0)
+    ctx.compute_invalid()
+    return ctx, U0, V0
+
+
+def test_tiled_sgd_visits_every_rating_once_and_learns(c2):
+    tr = c2["train"]
+    ctx, U0, V0 = _ctx(c2, 64)
+    key = tr.rowids().astype(np.int64) * c2["nItems"] + tr.rowind
+    r0 = ctx.rmse(mfx.MAT_TRAIN)
+    for ep in range(3):
+        ctx.sgd_epoch(0.0025, 0.01, 0.01, mode=mfx.SGD_TILED, seed=1, epoch=ep)
+    u, i, r = ctx.debug_epoch_list()
+    k = u.astype(np.int64) * c2["nItems"] + i
+    assert k.size == tr.nnz
+    ks = np.sort(k)
+    assert np.array_equal(ks, key)                       # CSR keys are already sorted: a permutation, no dup, no miss
+    assert np.array_equal(r[np.argsort(k, kind="stable")], tr.rowval)
+    r3 = ctx.rmse(mfx.MAT_TRAIN)
+    assert np.isfinite(r3) and r3 < 0.5 * r0
+    U, V = ctx.get_factors()
+    assert np.isfinite(U).all() and np.isfinite(V).all()
+    ctx.close()
+
+
+def test_als_rows_solve_their_normal_equations_at_full_size(c2):
+    tr = c2["train"]
+    K, reg = 64, 5.0
+    ctx, U0, V0 = _ctx(c2, K)
+    rng = np.random.default_rng(0)
+    V0 = rng.normal(0, 0.3, V0.shape).astype(np.float32)
+    ctx.set_factors(U0, V0)
+    ctx.als_half_sweep(mfx.SIDE_USERS, reg)
+    U1, _ = ctx.get_factors()
+    deg = np.diff(tr.rowptr)
+    rows = list(np.argsort(deg)[-3:]) + list(np.argsort(deg)[:3]) + list(rng.integers(0, tr.nrows, 40))
+    for u in rows:
+        sl = slice(tr.rowptr[u], tr.rowptr[u + 1])
+        Q = V0[tr.rowind[sl]].astype(np.float64)
+        A = Q.T @ Q + reg * np.eye(K)
+        b = Q.T @ tr.rowval[sl].astype(np.float64)
+        assert np.linalg.norm(A @ U1[u].astype(np.float64) - b) / np.linalg.norm(b) < 1e-4, u
+    # a full iteration lowers the objective and the item side handles the 40k-rating columns (split rows)
+    o0 = ctx.objective(reg, reg)
+    ctx.als_half_sweep(mfx.SIDE_ITEMS, reg)
+    o1 = ctx.objective(reg, reg)
+    ctx.als_half_sweep(mfx.SIDE_USERS, reg)
+    ctx.als_half_sweep(mfx.SIDE_ITEMS, reg)
+    o2 = ctx.objective(reg, reg)
+    assert o1 < o0 and o2 < o1
+    ctx.close()
+
+
+def test_ccdpp_views_in_lockstep_and_monotone_at_full_size(c2):
+    tr = c2["train"]
+    K, reg = 64, 2.0
+    ctx, U0, V0 = _ctx(c2, K)
+    ctx.ccdpp_begin()
+    objs = []
+    for k in range(4):
+        ctx.ccdpp_rank1(k, reg, reg, add_back=False)
+        objs.append(ctx.objective(reg, reg))
+    rr, rc = ctx.debug_residuals(tr.nnz)
+    order = np.argsort(tr.rowind, kind="stable")
+    assert np.array_equal(rr[order], rc)
+    assert all(b <= a * (1 + 1e-6) for a, b in zip(objs, objs[1:]))
+    # the residual is r - p.q for the factors learnt so far
+    U, V = ctx.get_factors()
+    sel = np.random.default_rng(1).integers(0, tr.nnz, 200000)
+    ru = tr.rowids()[sel]
+    est = np.einsum("ij,ij->i", U[ru].astype(np.float64), V[tr.rowind[sel]].astype(np.float64))
+    assert np.abs(rr[sel] - (tr.rowval[sel] - est)).max() < 1e-3
+    ctx.ccdpp_end()
+    ctx.close()
