@@ -61,23 +61,36 @@ __device__ __forceinline__ void gram_accumulate(GramAcc& g, const float* __restr
     const int mj = ok ? ind[base + lane] : 0;
     const float mr = ok ? val[base + lane] : 0.0f;
     const int n = (int)(end - base < 64 ? end - base : 64);
-#pragma unroll 2
-    for (int s = 0; s < n; s += 2) {
-      const int e = s + half;
-      const int j = __shfl(mj, e, 64);
-      const float r = __shfl(mr, e, 64);
-      // ratings <= 0 are skipped (modelMF.cpp:819,857); a missing odd partner contributes 0
-      const float w = (e < n && r > 0.0f) ? 1.0f : 0.0f;
-      const float* y = Y + (int64_t)j * ld;
-      const float y0 = idx < ld ? y[idx] : 0.0f, y1 = 32 + idx < ld ? y[32 + idx] : 0.0f;
-      const float a0 = w * y0, a1 = w * y1;
-      g.t[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, y0, g.t[0][0], 0, 0, 0);
-      g.t[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, y1, g.t[0][1], 0, 0, 0);
-      g.t[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, y0, g.t[1][0], 0, 0, 0);
-      g.t[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, y1, g.t[1][1], 0, 0, 0);
-      const float wr = w * r;
-      g.b0 = __builtin_fmaf(wr, y0, g.b0);
-      g.b1 = __builtin_fmaf(wr, y1, g.b1);
+    // batches of B steps (2 ratings each): all 2B row loads of a batch are issued before its 4B MFMAs,
+    // so ~16 gathered rows per wave are in flight instead of 2 (the loop was latency-bound)
+    constexpr int B = 8;
+    for (int s0 = 0; s0 < n; s0 += 2 * B) {
+      float y0[B], y1[B], wr[B], w[B];
+#pragma unroll
+      for (int t = 0; t < B; t++) {
+        const int e = s0 + 2 * t + half;
+        const int j = __shfl(mj, e & 63, 64);
+        const float r = __shfl(mr, e & 63, 64);
+        // ratings <= 0 are skipped (modelMF.cpp:819,857); a missing partner contributes 0
+        const bool use = e < n && r > 0.0f;
+        w[t] = use ? 1.0f : 0.0f;
+        wr[t] = use ? r : 0.0f;
+        const float* y = Y + (int64_t)(e < n ? j : 0) * ld;
+        y0[t] = idx < ld ? y[idx] : 0.0f;
+        y1[t] = 32 + idx < ld ? y[32 + idx] : 0.0f;
+      }
+#pragma unroll
+      for (int t = 0; t < B; t++) {
+        if (s0 + 2 * t < n) {   // wave-uniform
+          const float a0 = w[t] * y0[t], a1 = w[t] * y1[t];
+          g.t[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, y0[t], g.t[0][0], 0, 0, 0);
+          g.t[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, y1[t], g.t[0][1], 0, 0, 0);
+          g.t[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, y0[t], g.t[1][0], 0, 0, 0);
+          g.t[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, y1[t], g.t[1][1], 0, 0, 0);
+          g.b0 = __builtin_fmaf(wr[t], y0[t], g.b0);
+          g.b1 = __builtin_fmaf(wr[t], y1[t], g.b1);
+        }
+      }
     }
   }
 }
