@@ -45,13 +45,27 @@ __global__ void store_col_kernel(float* __restrict__ X, int32_t n, int ld, int k
 
 // res[e] (+/-)= a[rowOf[e]] * b[colOf[e]]   -- float product, then float add/sub.
 // Streaming: 16 bytes per lane per array (4 ratings per thread), the two factor vectors are L2 resident.
-template <int SIGN>
-__global__ __launch_bounds__(256) void resid_update_kernel(float* __restrict__ res, const int32_t* __restrict__ ia,
-                                                           const int32_t* __restrict__ ib,
-                                                           const float* __restrict__ a, const float* __restrict__ b,
-                                                           int64_t n) {
+// LDSB: the vector b (v_k in the row view) is first staged in LDS -- a 4-byte gather from L2 moves a whole
+// 128-byte line, which made these kernels L2-bandwidth-bound; from LDS the gather is free.
+extern __shared__ __attribute__((aligned(16))) float ccd_lds[];
+
+__device__ __forceinline__ void stage_vector(const float* __restrict__ v, int n) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int n4 = n >> 2;
+  for (int q = threadIdx.x; q < n4; q += blockDim.x) ((f4*)ccd_lds)[q] = ((const f4*)v)[q];
+  for (int q = (n4 << 2) + threadIdx.x; q < n; q += blockDim.x) ccd_lds[q] = v[q];
+  __syncthreads();
+}
+
+template <int SIGN, bool LDSB>
+__global__ __launch_bounds__(1024) void resid_update_kernel(float* __restrict__ res, const int32_t* __restrict__ ia,
+                                                            const int32_t* __restrict__ ib,
+                                                            const float* __restrict__ a, const float* __restrict__ bg,
+                                                            int nb, int64_t n) {
   typedef float f4 __attribute__((ext_vector_type(4)));
   typedef int i4 __attribute__((ext_vector_type(4)));
+  if (LDSB) stage_vector(bg, nb);
+  const float* b = LDSB ? ccd_lds : bg;
   const int64_t n4 = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride) {
@@ -77,15 +91,18 @@ __device__ __forceinline__ double group16_sum(double v) {
 }
 
 // One 16-lane group per row segment.
-__global__ __launch_bounds__(256) void ccd_pass_kernel(const int32_t* __restrict__ seg_row,
+template <bool LDSO>
+__global__ __launch_bounds__(1024) void ccd_pass_kernel(const int32_t* __restrict__ seg_row,
                                                        const int64_t* __restrict__ seg_beg,
                                                        const int64_t* __restrict__ seg_end,
                                                        const int32_t* __restrict__ seg_slab, int64_t nseg,
                                                        const float* __restrict__ res,
                                                        const int32_t* __restrict__ ind,
-                                                       const float* __restrict__ other, float reg,
+                                                       const float* __restrict__ otherg, int nother, float reg,
                                                        float* __restrict__ mine, double* __restrict__ part,
                                                        const int64_t* __restrict__ ptr, float freq_thresh, int k) {
+  if (LDSO) stage_vector(otherg, nother);
+  const float* other = LDSO ? ccd_lds : otherg;
   const int lane = threadIdx.x & 63;
   const int j = lane & 15;
   const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
@@ -190,6 +207,12 @@ extern "C" int mfx_ccdpp_begin(mfx_ctx* ctx) {
   return MFX_OK;
 }
 
+constexpr size_t LDS_BUDGET = 160 * 1024;
+static bool lds_fits(size_t bytes) { return bytes > 0 && bytes <= 150 * 1024; }
+static hipError_t set_lds(mfx_ctx*, const void* fn, size_t bytes) {
+  return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
 static int run_pass(mfx_ctx* ctx, int side, float reg, float freq_thresh, int k) {
   const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
   RowSegs* sg;
@@ -200,12 +223,23 @@ static int run_pass(mfx_ctx* ctx, int side, float reg, float freq_thresh, int k)
   const float* other = side == 0 ? ctx->vk : ctx->uk;
   float* mine = side == 0 ? ctx->uk : ctx->vk;
   const int64_t* ptr = side == 0 ? m.rowptr : m.colptr;
+  const int nother = side == 0 ? ctx->nI : ctx->nU;
   if (sg->nseg > 0) {
     ProfScope ps(ctx, side == 0 ? MFX_K_CCD_ROW : MFX_K_CCD_COL);
-    const int blocks = (int)std::min<int64_t>((sg->nseg + 15) / 16, 256 * 8);
-    hipLaunchKernelGGL(ccd_pass_kernel, dim3(blocks), dim3(256), 0, ctx->stream, sg->seg_row, sg->seg_beg,
-                       sg->seg_end, sg->seg_slab, sg->nseg, res, ind, other, reg, mine, ctx->ccd_part, ptr,
-                       freq_thresh, k);
+    const size_t lds = (size_t)nother * sizeof(float);
+    if (lds_fits(lds)) {   // the gathered vector fits in LDS (items: C2 107 KB, C4 71 KB)
+      const int per_cu = (int)std::min<size_t>(2, LDS_BUDGET / lds);
+      const int blocks = (int)std::min<int64_t>((sg->nseg + 63) / 64, 256 * per_cu);
+      HIPCHK(set_lds(ctx, (const void*)ccd_pass_kernel<true>, lds));
+      hipLaunchKernelGGL(ccd_pass_kernel<true>, dim3(blocks), dim3(1024), lds, ctx->stream, sg->seg_row, sg->seg_beg,
+                         sg->seg_end, sg->seg_slab, sg->nseg, res, ind, other, nother, reg, mine, ctx->ccd_part, ptr,
+                         freq_thresh, k);
+    } else {
+      const int blocks = (int)std::min<int64_t>((sg->nseg + 63) / 64, 256 * 2);
+      hipLaunchKernelGGL(ccd_pass_kernel<false>, dim3(blocks), dim3(1024), 0, ctx->stream, sg->seg_row, sg->seg_beg,
+                         sg->seg_end, sg->seg_slab, sg->nseg, res, ind, other, nother, reg, mine, ctx->ccd_part, ptr,
+                         freq_thresh, k);
+    }
     HIPCHK(hipGetLastError());
   }
   if (sg->nmrow > 0) {
@@ -222,12 +256,21 @@ static int run_resid(mfx_ctx* ctx) {
   const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
   if (m.nnz == 0) return MFX_OK;
   ProfScope ps(ctx, MFX_K_CCD_RESID);
-  const int blocks = (int)std::min<int64_t>((m.nnz / 4 + 255) / 256 + 1, 256 * 16);
-  // row view: res_row[e] +-= u_k[rowid[e]] * v_k[rowind[e]]; column view likewise
-  hipLaunchKernelGGL(resid_update_kernel<SIGN>, dim3(blocks), dim3(256), 0, ctx->stream, ctx->res_row, m.rowid,
-                     m.rowind, ctx->uk, ctx->vk, m.nnz);
-  hipLaunchKernelGGL(resid_update_kernel<SIGN>, dim3(blocks), dim3(256), 0, ctx->stream, ctx->res_col, m.colind,
-                     ctx->colid, ctx->uk, ctx->vk, m.nnz);
+  const int blocks = (int)std::min<int64_t>((m.nnz / 4 + 1023) / 1024 + 1, 256 * 2);
+  // row view: res_row[e] +-= u_k[rowid[e]] * v_k[rowind[e]] (v_k gathered: staged in LDS when it fits);
+  // column view: res_col[e] +-= u_k[colind[e]] * v_k[colid[e]] (u_k gathered from L2)
+  const size_t lds = (size_t)ctx->nI * sizeof(float);
+  if (lds_fits(lds)) {
+    const int per_cu = (int)std::min<size_t>(2, LDS_BUDGET / lds);
+    HIPCHK(set_lds(ctx, (const void*)resid_update_kernel<SIGN, true>, lds));
+    hipLaunchKernelGGL((resid_update_kernel<SIGN, true>), dim3(std::min(blocks, 256 * per_cu)), dim3(1024), lds,
+                       ctx->stream, ctx->res_row, m.rowid, m.rowind, ctx->uk, ctx->vk, ctx->nI, m.nnz);
+  } else {
+    hipLaunchKernelGGL((resid_update_kernel<SIGN, false>), dim3(blocks), dim3(1024), 0, ctx->stream, ctx->res_row,
+                       m.rowid, m.rowind, ctx->uk, ctx->vk, ctx->nI, m.nnz);
+  }
+  hipLaunchKernelGGL((resid_update_kernel<SIGN, false>), dim3(blocks), dim3(1024), 0, ctx->stream, ctx->res_col,
+                     m.colind, ctx->colid, ctx->uk, ctx->vk, ctx->nI, m.nnz);
   HIPCHK(hipGetLastError());
   return MFX_OK;
 }
