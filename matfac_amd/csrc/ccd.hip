@@ -17,6 +17,8 @@
 
 void mfx_ccd_free_internal(mfx_ctx* ctx) {
   dev_free(ctx->res_row); dev_free(ctx->res_col); dev_free(ctx->uk); dev_free(ctx->vk);
+  dev_free(ctx->uk_pend); dev_free(ctx->vk_pend);
+  ctx->ccd_pending = false;
   dev_free(ctx->ccd_part); dev_free(ctx->colid);
   ctx->ccd_part_cap = 0;
   ctx->ccd_active = false;
@@ -82,6 +84,47 @@ __global__ __launch_bounds__(1024) void resid_update_kernel(float* __restrict__ 
     const float prod = a[ia[e]] * b[ib[e]];
     res[e] = SIGN > 0 ? res[e] + prod : res[e] - prod;
   }
+}
+
+// res = (res - a0*b0) + a1*b1 in one sweep: the subtract of factor k (modelMF.cpp:1095-1116) and the add-back
+// of the next factor (:1032-1056) touch the same residual entries back to back; the two roundings are kept.
+template <bool LDSB>
+__global__ __launch_bounds__(1024) void resid_fused_kernel(float* __restrict__ res, const int32_t* __restrict__ ia,
+                                                           const int32_t* __restrict__ ib,
+                                                           const float* __restrict__ a0, const float* __restrict__ b0g,
+                                                           const float* __restrict__ a1, const float* __restrict__ b1g,
+                                                           int nb, int64_t n) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef int i4 __attribute__((ext_vector_type(4)));
+  if (LDSB) {
+    const int n4 = nb >> 2;
+    for (int q = threadIdx.x; q < n4; q += blockDim.x) {
+      ((f4*)ccd_lds)[q] = ((const f4*)b0g)[q];
+      ((f4*)(ccd_lds + ((nb + 3) & ~3)))[q] = ((const f4*)b1g)[q];
+    }
+    for (int q = (n4 << 2) + threadIdx.x; q < nb; q += blockDim.x) {
+      ccd_lds[q] = b0g[q];
+      ccd_lds[((nb + 3) & ~3) + q] = b1g[q];
+    }
+    __syncthreads();
+  }
+  const float* b0 = LDSB ? ccd_lds : b0g;
+  const float* b1 = LDSB ? ccd_lds + ((nb + 3) & ~3) : b1g;
+  const int64_t n4 = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride) {
+    const i4 x = ((const i4*)ia)[q], y = ((const i4*)ib)[q];
+    f4 r = ((const f4*)res)[q];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const float p0 = a0[x[e]] * b0[y[e]];
+      const float p1 = a1[x[e]] * b1[y[e]];
+      r[e] = (r[e] - p0) + p1;
+    }
+    ((f4*)res)[q] = r;
+  }
+  for (int64_t e = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride)
+    res[e] = (res[e] - a0[ia[e]] * b0[ib[e]]) + a1[ia[e]] * b1[ib[e]];
 }
 
 __device__ __forceinline__ double group16_sum(double v) {
@@ -182,6 +225,8 @@ extern "C" int mfx_ccdpp_begin(mfx_ctx* ctx) {
   if ((rc = dev_alloc(ctx, &ctx->colid, nnz))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->uk, (size_t)ctx->nU))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->vk, (size_t)ctx->nI))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->uk_pend, (size_t)ctx->nU))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->vk_pend, (size_t)ctx->nI))) return rc;
   // res = gk_csr_Dup(trainMat) (modelMF.cpp:1013): both value arrays
   if (nnz) {
     HIPCHK(hipMemcpyAsync(ctx->res_row, m.rowval, sizeof(float) * nnz, hipMemcpyDeviceToDevice, ctx->stream));
@@ -252,7 +297,7 @@ static int run_pass(mfx_ctx* ctx, int side, float reg, float freq_thresh, int k)
 }
 
 template <int SIGN>
-static int run_resid(mfx_ctx* ctx) {
+static int run_resid(mfx_ctx* ctx, const float* uk, const float* vk) {
   const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
   if (m.nnz == 0) return MFX_OK;
   ProfScope ps(ctx, MFX_K_CCD_RESID);
@@ -264,15 +309,45 @@ static int run_resid(mfx_ctx* ctx) {
     const int per_cu = (int)std::min<size_t>(2, LDS_BUDGET / lds);
     HIPCHK(set_lds(ctx, (const void*)resid_update_kernel<SIGN, true>, lds));
     hipLaunchKernelGGL((resid_update_kernel<SIGN, true>), dim3(std::min(blocks, 256 * per_cu)), dim3(1024), lds,
-                       ctx->stream, ctx->res_row, m.rowid, m.rowind, ctx->uk, ctx->vk, ctx->nI, m.nnz);
+                       ctx->stream, ctx->res_row, m.rowid, m.rowind, uk, vk, ctx->nI, m.nnz);
   } else {
     hipLaunchKernelGGL((resid_update_kernel<SIGN, false>), dim3(blocks), dim3(1024), 0, ctx->stream, ctx->res_row,
-                       m.rowid, m.rowind, ctx->uk, ctx->vk, ctx->nI, m.nnz);
+                       m.rowid, m.rowind, uk, vk, ctx->nI, m.nnz);
   }
   hipLaunchKernelGGL((resid_update_kernel<SIGN, false>), dim3(blocks), dim3(1024), 0, ctx->stream, ctx->res_col,
-                     m.colind, ctx->colid, ctx->uk, ctx->vk, ctx->nI, m.nnz);
+                     m.colind, ctx->colid, uk, vk, ctx->nI, m.nnz);
   HIPCHK(hipGetLastError());
   return MFX_OK;
+}
+
+// subtract of the pending factor fused with the add-back of the new one
+static int run_resid_fused(mfx_ctx* ctx, const float* uk0, const float* vk0, const float* uk1, const float* vk1) {
+  const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
+  if (m.nnz == 0) return MFX_OK;
+  ProfScope ps(ctx, MFX_K_CCD_RESID);
+  const int blocks = (int)std::min<int64_t>((m.nnz / 4 + 1023) / 1024 + 1, 256 * 2);
+  const size_t lds = 2 * (((size_t)ctx->nI + 3) & ~(size_t)3) * sizeof(float);
+  if (lds_fits(lds)) {
+    HIPCHK(set_lds(ctx, (const void*)resid_fused_kernel<true>, lds));
+    hipLaunchKernelGGL(resid_fused_kernel<true>, dim3(std::min(blocks, 256)), dim3(1024), lds, ctx->stream,
+                       ctx->res_row, m.rowid, m.rowind, uk0, vk0, uk1, vk1, ctx->nI, m.nnz);
+  } else {
+    hipLaunchKernelGGL(resid_fused_kernel<false>, dim3(blocks), dim3(1024), 0, ctx->stream, ctx->res_row, m.rowid,
+                       m.rowind, uk0, vk0, uk1, vk1, ctx->nI, m.nnz);
+  }
+  // column view: the gathered vector is u_k (too long for LDS); here a = v_k indexed by column id
+  hipLaunchKernelGGL(resid_fused_kernel<false>, dim3(blocks), dim3(1024), 0, ctx->stream, ctx->res_col, ctx->colid,
+                     m.colind, vk0, uk0, vk1, uk1, ctx->nU, m.nnz);
+  HIPCHK(hipGetLastError());
+  return MFX_OK;
+}
+
+// The subtract of a finished factor is deferred so that it can share a sweep with the next add-back;
+// anything that looks at the residuals (or ends the session) flushes it first.
+static int ccd_flush(mfx_ctx* ctx) {
+  if (!ctx->ccd_pending) return MFX_OK;
+  ctx->ccd_pending = false;
+  return run_resid<-1>(ctx, ctx->uk_pend, ctx->vk_pend);
 }
 
 extern "C" int mfx_ccdpp_rank1(mfx_ctx* ctx, int32_t k, int32_t inner, float uReg, float iReg, int32_t add_back,
@@ -288,22 +363,32 @@ extern "C" int mfx_ccdpp_rank1(mfx_ctx* ctx, int32_t k, int32_t inner, float uRe
   hipLaunchKernelGGL(extract_col_kernel, dim3(bi), dim3(256), 0, ctx->stream, ctx->V, ctx->nI, ctx->ld, k, ctx->vk);
   HIPCHK(hipGetLastError());
   int rc;
-  if (add_back && (rc = run_resid<+1>(ctx))) return rc;     // :1032-1056
+  if (ctx->ccd_pending && add_back) {                       // previous factor's :1095-1116 + this one's :1032-1056
+    ctx->ccd_pending = false;
+    if ((rc = run_resid_fused(ctx, ctx->uk_pend, ctx->vk_pend, ctx->uk, ctx->vk))) return rc;
+  } else {
+    if ((rc = ccd_flush(ctx))) return rc;
+    if (add_back && (rc = run_resid<+1>(ctx, ctx->uk, ctx->vk))) return rc;   // :1032-1056
+  }
   for (int it = 0; it < inner; it++) {                      // :1058-1092
     if ((rc = run_pass(ctx, 0, uReg, -1.0f, k))) return rc;
     if ((rc = run_pass(ctx, 1, iReg, freq_thresh, k))) return rc;
   }
-  if ((rc = run_resid<-1>(ctx))) return rc;                 // :1095-1116
   // uFac.col(k) = u_k; iFac.col(k) = v_k  (:1119-1120)
   hipLaunchKernelGGL(store_col_kernel, dim3(bu), dim3(256), 0, ctx->stream, ctx->U, ctx->nU, ctx->ld, k, ctx->uk);
   hipLaunchKernelGGL(store_col_kernel, dim3(bi), dim3(256), 0, ctx->stream, ctx->V, ctx->nI, ctx->ld, k, ctx->vk);
   HIPCHK(hipGetLastError());
+  // res -= u_k v_k^T (:1095-1116) is deferred: keep (u_k, v_k) aside
+  std::swap(ctx->uk, ctx->uk_pend);
+  std::swap(ctx->vk, ctx->vk_pend);
+  ctx->ccd_pending = true;
   return MFX_OK;
 }
 
 extern "C" int mfx_ccdpp_end(mfx_ctx* ctx) {
   if (!ctx) return MFX_E_ARG;
   HIPCHK(hipSetDevice(ctx->device));
+  if (ctx->ccd_active) { int rc = ccd_flush(ctx); if (rc) return rc; }
   HIPCHK(hipStreamSynchronize(ctx->stream));
   mfx_ccd_free_internal(ctx);
   return MFX_OK;
@@ -313,6 +398,7 @@ extern "C" int mfx_debug_residuals(mfx_ctx* ctx, float* res_row, float* res_col)
   if (!ctx) return MFX_E_ARG;
   NEED(ctx->ccd_active, MFX_E_STATE, "mfx_debug_residuals: CCD++ not active");
   HIPCHK(hipSetDevice(ctx->device));
+  { int rc = ccd_flush(ctx); if (rc) return rc; }
   HIPCHK(hipStreamSynchronize(ctx->stream));
   const size_t nnz = (size_t)ctx->mat[MFX_MAT_TRAIN].nnz;
   if (nnz == 0) return MFX_OK;

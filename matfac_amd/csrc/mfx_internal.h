@@ -79,7 +79,8 @@ struct mfx_ctx {
 
   // CCD++ state
   float *res_row = nullptr, *res_col = nullptr, *uk = nullptr, *vk = nullptr;
-  bool ccd_active = false;
+  float *uk_pend = nullptr, *vk_pend = nullptr;   // factor whose residual subtract is deferred
+  bool ccd_active = false, ccd_pending = false;
 
   RowSegs segs[2];
   // ALS partial-Gramian slabs
