@@ -25,8 +25,8 @@
  * one rating and each lane owns 4 consecutive floats per chunk:
  *      K <= 16: L=4,C=1   K <= 32: L=8,C=1   else L=16, C=ceil(K/64).
  * The fp32 dot product is evaluated as: per-lane fma chain over the lane's
- * elements (chunk-major) starting from 0, then an xor butterfly (L/2,...,1)
- * over the L lanes.  (Eigen's order for row.dot(row) is unspecified; the CPU
+ * elements (chunk-major) starting from 0, then an xor butterfly (levels 1, 2,
+ * ..., L/2) over the L lanes.  (Eigen's order for row.dot(row) is unspecified; the CPU
  * oracle can evaluate either order.)
  */
 #ifndef MFX_H_

@@ -8,16 +8,7 @@
 // run to run (the reference's OpenMP reduction order is thread-dependent).
 #include <algorithm>
 
-#include "mfx_internal.h"
-
-typedef float float4v __attribute__((ext_vector_type(4)));
-
-template <int L>
-__device__ __forceinline__ float group_sum_f(float s) {
-#pragma unroll
-  for (int m = L / 2; m >= 1; m >>= 1) s = s + __shfl_xor(s, m, 64);
-  return s;
-}
+#include "sgd_common.h"
 
 template <int L, int C>
 __device__ __forceinline__ float row_dot(const float* __restrict__ a, const float* __restrict__ b) {
@@ -31,7 +22,7 @@ __device__ __forceinline__ float row_dot(const float* __restrict__ a, const floa
     s = __builtin_fmaf(x.z, y.z, s);
     s = __builtin_fmaf(x.w, y.w, s);
   }
-  return group_sum_f<L>(s);
+  return group_sum<L>(s);
 }
 
 __device__ __forceinline__ double wave_sum_d(double v) {

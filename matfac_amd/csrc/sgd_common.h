@@ -31,10 +31,21 @@ struct Rows {
   }
 };
 
+// All-reduce sum over the L lanes of a group with DPP (no LDS traffic), levels xor 1, 2, 4, 8.  For the
+// levels 1 and 2 every lane adds its xor partner (quad_perm); from then on the four lanes of a quad (the
+// eight of a half) hold the same bits, so any lane of the partner quad / half serves as the xor partner
+// (row_half_mirror, row_mirror): bit for bit the ascending xor butterfly documented in include/mfx.h.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false));
+}
 template <int L>
 __device__ __forceinline__ float group_sum(float s) {
-#pragma unroll
-  for (int m = L / 2; m >= 1; m >>= 1) s = s + __shfl_xor(s, m, 64);
+  static_assert(L == 4 || L == 8 || L == 16, "group size");
+  s = s + dpp_f<0xB1>(s);                 // quad_perm [1,0,3,2]                 (xor 1)
+  s = s + dpp_f<0x4E>(s);                 // quad_perm [2,3,0,1]                 (xor 2)
+  if (L >= 8) s = s + dpp_f<0x141>(s);    // row_half_mirror: lane i <-> 7-i    (partner quad; xor 4 level)
+  if (L >= 16) s = s + dpp_f<0x140>(s);   // row_mirror:      lane i <-> 15-i   (partner half; xor 8 level)
   return s;
 }
 

@@ -211,6 +211,67 @@ __device__ __forceinline__ int64_t slot_perm(int64_t t, int64_t R, uint32_t k0, 
 // guard (model.cpp:1486-1498) still sees a diverged model.
 constexpr float FIX_SCALE = 16777216.0f, FIX_INV = 1.0f / 16777216.0f, FIX_MAX = 127.0f;
 
+// entry S*G+g of the chunk: row_share broadcast of the transposed chunk (L == 16) or a cross-lane read
+template <int L, int S>
+__device__ __forceinline__ int slot_take(int v, int g) {
+  if constexpr (L == 16) return __builtin_amdgcn_update_dpp(0, v, 0x150 + S, 0xF, 0xF, false);   // row_share:S
+  else return __shfl(v, S * (64 / L) + g, 64);
+}
+
+// The L steps of one 64-rating chunk, unrolled by template recursion (the DPP controls are immediates).
+template <int L, int C, int ARITH, bool OWN_U, int S>
+struct SlotSteps {
+  static __device__ __forceinline__ void run(const Rows<3>& Um, int* q_lds, int tx, int ty, int tz, int g, int j,
+                                             int nvalid, bool fix, float lr, float uReg, float iReg,
+                                             float4v (&pn)[C], int64_t& pen) {
+    constexpr int G = 64 / L;
+    constexpr int LD = 4 * L * C;
+    const int e = S * G + g;
+    const int li = slot_take<L, S>(ty, g);
+    const float r = __builtin_bit_cast(float, slot_take<L, S>(tz, g));
+    float4v p[C];
+    const int64_t pe = pen;
+#pragma unroll
+    for (int c = 0; c < C; c++) p[c] = pn[c];
+    if constexpr (S + 1 < L) {
+      const int un = slot_take<L, S + 1>(tx, g);
+      if (e + G < nvalid) {
+        pen = (int64_t)un * LD + 4 * j;
+#pragma unroll
+        for (int c = 0; c < C; c++) pn[c] = Um.ld(pen + c * 4 * L);
+      }
+    }
+    if (e < nvalid) {
+      int* qrow = q_lds + li * LD + 4 * j;
+      float4v q[C], q0[C];
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        const int4 qi = *(const int4*)(qrow + c * 4 * L);
+        if (fix) q[c] = float4v{(float)qi.x * FIX_INV, (float)qi.y * FIX_INV, (float)qi.z * FIX_INV, (float)qi.w * FIX_INV};
+        else q[c] = __builtin_bit_cast(float4v, qi);
+        q0[c] = q[c];
+      }
+      // p = the row from global memory, q = the owned row; the reference updates the USER row first
+      // and the item row with the updated user row (modelMF.cpp:94-103) whichever side is owned
+      const float est = group_dot<L, C>(p, q);
+      if (OWN_U) sgd_axpys<C, ARITH>(q, p, r, est, lr, uReg, iReg);
+      else sgd_axpys<C, ARITH>(p, q, r, est, lr, uReg, iReg);
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        Um.st(pe + c * 4 * L, p[c]);
+        if (fix) {
+#pragma unroll
+          for (int x = 0; x < 4; x++)
+            atomicAdd(qrow + c * 4 * L + x, __float2int_rn((q[c][x] - q0[c][x]) * FIX_SCALE));   // ds_add_u32
+        } else {
+          *(int4*)(qrow + c * 4 * L) = __builtin_bit_cast(int4, q[c]);
+        }
+      }
+    }
+    if constexpr (S + 1 < L) SlotSteps<L, C, ARITH, OWN_U, S + 1>::run(Um, q_lds, tx, ty, tz, g, j, nvalid, fix, lr, uReg, iReg, pn, pen);
+  }
+};
+
 // C = 1 (K <= 64): 2 workgroups per CU (<= 64 VGPRs); wider ranks keep 1 workgroup per CU and get 128 VGPRs
 template <int L, int C, int ARITH, bool SWEEP, bool OWN_U>
 __global__ __launch_bounds__(WG, (C == 1 ? 8 : 4)) void sgd_slots_kernel(const int4* __restrict__ rec,
@@ -280,57 +341,21 @@ __global__ __launch_bounds__(WG, (C == 1 ? 8 : 4)) void sgd_slots_kernel(const i
         int4 rc4 = make_int4(0, 0, 0, 0);
         if (ok) rc4 = rec[rb + slot_perm(t, R, ks0, ks1)];
         const int nvalid = (int)(R - cb < 64 ? R - cb : 64);
+        // L == 16: a group is one DPP row.  Transpose the chunk once (3 ds_bpermute) so that lane s of row g
+        // holds entry s*G+g; every step then takes its entry with a row_share broadcast (no LDS traffic).
+        int tx = rc4.x, ty = rc4.y, tz = rc4.z;
+        if (L == 16) {
+          const int src = (lane & 15) * G + (lane >> 4);
+          tx = __shfl(rc4.x, src, 64); ty = __shfl(rc4.y, src, 64); tz = __shfl(rc4.z, src, 64);
+        }
         // software pipeline: the user row of step s+1 is requested before step s is computed
         float4v pn[C];
-        int64_t pen = (int64_t)__shfl(rc4.x, g, 64) * LD + 4 * j;
+        int64_t pen = (int64_t)slot_take<L, 0>(tx, g) * LD + 4 * j;
         if (g < nvalid) {
 #pragma unroll
           for (int c = 0; c < C; c++) pn[c] = Um.ld(pen + c * 4 * L);
         }
-#pragma unroll 1
-        for (int s = 0; s < L; s++) {
-          const int e = s * G + g;
-          const int li = __shfl(rc4.y, e, 64);
-          const float r = __builtin_bit_cast(float, __shfl(rc4.z, e, 64));
-          float4v p[C];
-          const int64_t pe = pen;
-#pragma unroll
-          for (int c = 0; c < C; c++) p[c] = pn[c];
-          const int en = e + G;
-          const int un = __shfl(rc4.x, en & 63, 64);
-          if (s + 1 < L && en < nvalid) {
-            pen = (int64_t)un * LD + 4 * j;
-#pragma unroll
-            for (int c = 0; c < C; c++) pn[c] = Um.ld(pen + c * 4 * L);
-          }
-          if (e < nvalid) {
-            int* qrow = q_lds + li * LD + 4 * j;
-            float4v q[C], q0[C];
-#pragma unroll
-            for (int c = 0; c < C; c++) {
-              const int4 qi = *(const int4*)(qrow + c * 4 * L);
-              if (fix) q[c] = float4v{(float)qi.x * FIX_INV, (float)qi.y * FIX_INV, (float)qi.z * FIX_INV, (float)qi.w * FIX_INV};
-              else q[c] = __builtin_bit_cast(float4v, qi);
-              q0[c] = q[c];
-            }
-            // p = the row from global memory, q = the owned row; the reference updates the USER row first
-            // and the item row with the updated user row (modelMF.cpp:94-103) whichever side is owned
-            const float est = group_dot<L, C>(p, q);
-            if (OWN_U) sgd_axpys<C, ARITH>(q, p, r, est, lr, uReg, iReg);
-            else sgd_axpys<C, ARITH>(p, q, r, est, lr, uReg, iReg);
-#pragma unroll
-            for (int c = 0; c < C; c++) {
-              Um.st(pe + c * 4 * L, p[c]);
-              if (fix) {
-#pragma unroll
-                for (int x = 0; x < 4; x++)
-                  atomicAdd(qrow + c * 4 * L + x, __float2int_rn((q[c][x] - q0[c][x]) * FIX_SCALE));   // ds_add_u32
-              } else {
-                *(int4*)(qrow + c * 4 * L) = __builtin_bit_cast(int4, q[c]);
-              }
-            }
-          }
-        }
+        SlotSteps<L, C, ARITH, OWN_U, 0>::run(Um, q_lds, tx, ty, tz, g, j, nvalid, fix, lr, uReg, iReg, pn, pen);
       }
       __syncthreads();
       // write the item rows back (this workgroup is their only owner during the round)

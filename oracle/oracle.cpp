@@ -44,7 +44,7 @@ static inline float dot_seq(const float* p, const float* q, int K) {
 }
 
 // The order the HIP kernels use: lane j accumulates its elements with an fma
-// chain starting from 0, then an xor butterfly over the L lanes.
+// chain starting from 0, then an xor butterfly over the L lanes (levels 1, 2, ..., L/2).
 static inline float dot_tree(const float* p, const float* q, int K) {
   int L, C;
   orc_tree_shape(K, &L, &C);
@@ -58,7 +58,7 @@ static inline float dot_tree(const float* p, const float* q, int K) {
       }
     s[j] = a;
   }
-  for (int m = L / 2; m >= 1; m >>= 1) {
+  for (int m = 1; m < L; m <<= 1) {
     for (int j = 0; j < L; j++) t[j] = s[j] + s[j ^ m];
     for (int j = 0; j < L; j++) s[j] = t[j];
   }

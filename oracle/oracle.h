@@ -37,7 +37,7 @@ extern "C" {
 /* ORC_DOT_SEQ : k = 0..K-1, separate fp32 multiply and add (what Eigen's
  *               non-vectorisable strided row.dot(row) does; model.cpp:547-549).
  * ORC_DOT_TREE: the order the HIP kernels use (per-lane fma chain + xor
- *               butterfly over L lanes, C chunks); see orc_tree_shape().      */
+ *               butterfly, levels 1..L/2, over L lanes, C chunks); see orc_tree_shape().      */
 enum { ORC_DOT_SEQ = 0, ORC_DOT_TREE = 1 };
 
 /* ---- SGD arithmetic ---------------------------------------------------- */
