@@ -29,6 +29,14 @@
 
 namespace {
 constexpr int CAP_R = 1024;   // ratings per slot
+// User blocks per XCD (MFX_NUB): 8*SUB user blocks x 8 item blocks = 64*SUB tiles, 8*SUB rounds per epoch.
+#ifndef MFX_SUB
+#define MFX_SUB 1
+#endif
+constexpr int SUB = MFX_SUB, NUB = 8 * SUB, NTILE = NUB * 8;
+__host__ __device__ static inline int slot_user_block(int32_t u) {
+  return (int)(mfx_mix32((uint32_t)u * 0x9e3779b1U + 0x1234567U) & (uint32_t)(NUB - 1));
+}
 constexpr int WG = 1024;      // threads per workgroup: 16 waves = 64 ratings in flight on one slot
 
 struct SlotList {
@@ -36,8 +44,8 @@ struct SlotList {
   int64_t* slot_beg = nullptr;     // [nslots+1] rating range of a slot
   int32_t* slot_ibeg = nullptr;    // [nslots+1] range into slot_items
   int32_t* slot_items = nullptr;   // global item ids of every slot
-  int32_t* tile_slot = nullptr;    // [65] slot range of a tile
-  unsigned* ctr = nullptr;         // [64] slot counters
+  int32_t* tile_slot = nullptr;    // [NTILE+1] slot range of a tile
+  unsigned* ctr = nullptr;         // [NTILE] slot counters
   int64_t nslots = 0, nnz = 0;
   int rows = 0;                    // owned rows per slot the lists were built for
   bool built = false;
@@ -89,21 +97,21 @@ static int build_slots(mfx_ctx* ctx, SlotList* S, int rows, int side) {
   const std::vector<int32_t>& oth = side == 0 ? ru : ri;
   const int32_t nown = side == 0 ? m.ncols : m.nrows;
   // ratings of each tile (stable in CSR order)
-  std::vector<int64_t> tstart(65, 0);
-  for (int64_t e = 0; e < nnz; e++) tstart[mfx_user_block(ru[e]) * 8 + mfx_item_block(ri[e]) + 1]++;
-  for (int t = 0; t < 64; t++) tstart[t + 1] += tstart[t];
+  std::vector<int64_t> tstart(NTILE + 1, 0);
+  for (int64_t e = 0; e < nnz; e++) tstart[slot_user_block(ru[e]) * 8 + mfx_item_block(ri[e]) + 1]++;
+  for (int t = 0; t < NTILE; t++) tstart[t + 1] += tstart[t];
   std::vector<int64_t> byt((size_t)nnz);
   {
     std::vector<int64_t> pos(tstart.begin(), tstart.end() - 1);
-    for (int64_t e = 0; e < nnz; e++) byt[pos[mfx_user_block(ru[e]) * 8 + mfx_item_block(ri[e])]++] = e;
+    for (int64_t e = 0; e < nnz; e++) byt[pos[slot_user_block(ru[e]) * 8 + mfx_item_block(ri[e])]++] = e;
   }
-  std::vector<int32_t> rec((size_t)nnz * 4), slot_ibeg(1, 0), slot_items, tile_slot(65, 0);
+  std::vector<int32_t> rec((size_t)nnz * 4), slot_ibeg(1, 0), slot_items, tile_slot(NTILE + 1, 0);
   std::vector<int64_t> slot_beg(1, 0);
   int32_t nslots = 0;
   std::vector<int32_t> cnt((size_t)std::max(nown, 1), 0);
   std::vector<int32_t> items;
   int64_t out = 0;
-  for (int t = 0; t < 64; t++) {
+  for (int t = 0; t < NTILE; t++) {
     tile_slot[t] = nslots;
     const int64_t b = tstart[t], e = tstart[t + 1];
     items.clear();
@@ -162,7 +170,7 @@ static int build_slots(mfx_ctx* ctx, SlotList* S, int rows, int side) {
     close();
     for (int32_t it : items) cnt[it] = 0;
   }
-  tile_slot[64] = nslots;
+  tile_slot[NTILE] = nslots;
   dev_free(S->rec); dev_free(S->slot_beg); dev_free(S->slot_ibeg); dev_free(S->slot_items);
   dev_free(S->tile_slot);
   int rc;
@@ -171,7 +179,7 @@ static int build_slots(mfx_ctx* ctx, SlotList* S, int rows, int side) {
   if ((rc = up(ctx, &S->slot_ibeg, slot_ibeg))) return rc;
   if ((rc = up(ctx, &S->slot_items, slot_items))) return rc;
   if ((rc = up(ctx, &S->tile_slot, tile_slot))) return rc;
-  if (!S->ctr && (rc = dev_alloc(ctx, &S->ctr, (size_t)64))) return rc;
+  if (!S->ctr && (rc = dev_alloc(ctx, &S->ctr, (size_t)NTILE))) return rc;
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (getenv("MFX_DEBUG")) {
     int64_t mx = 0, small = 0;
@@ -223,22 +231,24 @@ template <int L, int C, int ARITH, bool OWN_U, int S>
 struct SlotSteps {
   static __device__ __forceinline__ void run(const Rows<3>& Um, int* q_lds, int tx, int ty, int tz, int g, int j,
                                              int nvalid, bool fix, float lr, float uReg, float iReg,
-                                             float4v (&pn)[C], int64_t& pen) {
+                                             float4v (&pn)[C], int64_t& pen, float4v (&pnn)[C], int64_t& penn) {
     constexpr int G = 64 / L;
     constexpr int LD = 4 * L * C;
     const int e = S * G + g;
     const int li = slot_take<L, S>(ty, g);
     const float r = __builtin_bit_cast(float, slot_take<L, S>(tz, g));
+    // rows of steps S+1 and S+2 are already requested; take S, shift, request S+2
     float4v p[C];
     const int64_t pe = pen;
 #pragma unroll
-    for (int c = 0; c < C; c++) p[c] = pn[c];
-    if constexpr (S + 1 < L) {
-      const int un = slot_take<L, S + 1>(tx, g);
-      if (e + G < nvalid) {
-        pen = (int64_t)un * LD + 4 * j;
+    for (int c = 0; c < C; c++) { p[c] = pn[c]; pn[c] = pnn[c]; }
+    pen = penn;
+    if constexpr (S + 2 < L) {
+      const int un = slot_take<L, S + 2>(tx, g);
+      if (e + 2 * G < nvalid) {
+        penn = (int64_t)un * LD + 4 * j;
 #pragma unroll
-        for (int c = 0; c < C; c++) pn[c] = Um.ld(pen + c * 4 * L);
+        for (int c = 0; c < C; c++) pnn[c] = Um.ld(penn + c * 4 * L);
       }
     }
     if (e < nvalid) {
@@ -268,7 +278,8 @@ struct SlotSteps {
         }
       }
     }
-    if constexpr (S + 1 < L) SlotSteps<L, C, ARITH, OWN_U, S + 1>::run(Um, q_lds, tx, ty, tz, g, j, nvalid, fix, lr, uReg, iReg, pn, pen);
+    if constexpr (S + 1 < L)
+      SlotSteps<L, C, ARITH, OWN_U, S + 1>::run(Um, q_lds, tx, ty, tz, g, j, nvalid, fix, lr, uReg, iReg, pn, pen, pnn, penn);
   }
 };
 
@@ -293,8 +304,9 @@ __global__ __launch_bounds__(WG, (C == 1 ? 8 : 4)) void sgd_slots_kernel(const i
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane / L, j = lane % L;
   const int xcc = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7);  // HW_REG_XCC_ID[3:0]
-  const int t_first = SWEEP ? 0 : xcc * 8 + ((xcc + round) & 7);
-  const int t_last = SWEEP ? 63 : t_first;
+  // round r: XCD x takes user block x*SUB + r%SUB and item block (x + r/SUB) mod 8
+  const int t_first = SWEEP ? 0 : (xcc * SUB + round % SUB) * 8 + ((xcc + round / SUB) & 7);
+  const int t_last = SWEEP ? NTILE - 1 : t_first;
   int4* q4 = (int4*)q_lds;
   for (int tile = t_first; tile <= t_last; tile++) {
     const int s0 = tile_slot[tile], ns = tile_slot[tile + 1] - s0;
@@ -348,14 +360,20 @@ __global__ __launch_bounds__(WG, (C == 1 ? 8 : 4)) void sgd_slots_kernel(const i
           const int src = (lane & 15) * G + (lane >> 4);
           tx = __shfl(rc4.x, src, 64); ty = __shfl(rc4.y, src, 64); tz = __shfl(rc4.z, src, 64);
         }
-        // software pipeline: the user row of step s+1 is requested before step s is computed
-        float4v pn[C];
+        // software pipeline: the lock-free rows of steps s+1 and s+2 are requested before step s is computed
+        float4v pn[C], pnn[C];
         int64_t pen = (int64_t)slot_take<L, 0>(tx, g) * LD + 4 * j;
+        int64_t penn = (int64_t)slot_take<L, 1>(tx, g) * LD + 4 * j;
         if (g < nvalid) {
 #pragma unroll
           for (int c = 0; c < C; c++) pn[c] = Um.ld(pen + c * 4 * L);
         }
-        SlotSteps<L, C, ARITH, OWN_U, 0>::run(Um, q_lds, tx, ty, tz, g, j, nvalid, fix, lr, uReg, iReg, pn, pen);
+        if (G + g < nvalid) {
+#pragma unroll
+          for (int c = 0; c < C; c++) pnn[c] = Um.ld(penn + c * 4 * L);
+        }
+        SlotSteps<L, C, ARITH, OWN_U, 0>::run(Um, q_lds, tx, ty, tz, g, j, nvalid, fix, lr, uReg, iReg, pn, pen, pnn,
+                                              penn);
       }
       __syncthreads();
       // write the item rows back (this workgroup is their only owner during the round)
@@ -414,8 +432,8 @@ static int launch_slots(mfx_ctx* ctx, SlotList* S, const mfx_sgd_opts* o, int bl
   float* oth = OWN_U ? ctx->V : ctx->U;
   float* own = OWN_U ? ctx->U : ctx->V;
   const uint64_t ob = (uint64_t)(OWN_U ? ctx->nI : ctx->nU) * ctx->ld * 4;
-  HIPCHK(hipMemsetAsync(S->ctr, 0, 64 * sizeof(unsigned), ctx->stream));
-  for (int round = 0; round < 8; round++) {
+  HIPCHK(hipMemsetAsync(S->ctr, 0, NTILE * sizeof(unsigned), ctx->stream));
+  for (int round = 0; round < NUB; round++) {
     ProfScope ps(ctx, MFX_K_SGD);
     hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, false, OWN_U>), dim3(blocks), dim3(WG), 0, ctx->stream,
                        (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->tile_slot, S->ctr, round,
