@@ -45,6 +45,8 @@ extern "C" int mfh_train(const char* method, int32_t nrows, const int64_t* tr_pt
     stats[3] = model.learnRate;
     stats[4] = best.learnRate;
     stats[5] = data.nItems;
+    stats[6] = model.lastLoopSeconds;
+    stats[7] = model.lastIters;
   }
   if (invU) for (int u = 0; u < data.nUsers; u++) invU[u] = iu.count(u) ? 1 : 0;
   if (invI) for (int i = 0; i < data.nItems; i++) invI[i] = ii.count(i) ? 1 : 0;

@@ -419,6 +419,7 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
   o.arith = kind == K_HOG ? MFX_ARITH_F32 : kind == K_SGDPAR ? MFX_ARITH_REF64F : MFX_ARITH_REF64;
 
   double subIterDuration = 0;
+  const auto loopStart = std::chrono::steady_clock::now();
   for (iter = 0; iter < maxIter; iter++) {
     auto start = std::chrono::system_clock::now();
     o.learnRate = learnRate;
@@ -488,6 +489,8 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
         bestModel.saveFacs(std::string(data.prefix));
     }
   }
+  lastLoopSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - loopStart).count();
+  lastIters = std::min(iter + 1, maxIter);
   if (kind != K_SGDPAR) bestModel.saveFacs(std::string(data.prefix));
   std::cout << "\nBest model validation RMSE: " << bestModel.RMSE(data.valMat, invalidUsers, invalidItems);
   if (kind == K_CCDPP || kind == K_CCDPP_FA) dev->check(mfx_ccdpp_end(dev->ctx), "mfx_ccdpp_end");

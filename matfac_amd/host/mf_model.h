@@ -96,6 +96,8 @@ class Model {
   std::shared_ptr<MfxSession> dev;   // set while/after a trainer ran
   int devSnap = MFX_SNAP_CURRENT;    // which device snapshot this object stands for
   bool hostStale = false;            // device copy is newer than uFac/iFac
+  double lastLoopSeconds = 0;        // wall time of the last trainer's iteration loop (updates + termination checks)
+  int lastIters = 0;
   void syncHost();                   // download uFac/iFac if hostStale
   void pushToDevice();               // upload uFac/iFac to the CURRENT snapshot
   // scalar fields of `*this = other` without touching the factor storage

@@ -27,7 +27,8 @@ void mfh_init_factors(int32_t seed, int32_t nUsers, int32_t nItems, int32_t K, f
 /* Run ModelMF::<method> (sgd | hogsgd | sgdpar | sgdu | als | ccdpp | ccd++) the way main() does
  * (main.cpp:1325-1348, 1377-1382) on in-memory matrices.  All three matrices have `nrows` rows.
  * Outputs (each may be NULL): last iterate, bestModel, stats = {train RMSE, test RMSE, val RMSE of
- * bestModel, final learnRate of the model, of bestModel, nItems}, invalid user/item masks.
+ * bestModel, final learnRate of the model, of bestModel, nItems, seconds in the iteration loop,
+ * iterations run} (8 doubles), invalid user/item masks.
  * prefix NULL: no factor files are written. */
 int mfh_train(const char* method, int32_t nrows, const int64_t* tr_ptr, const int32_t* tr_ind,
               const float* tr_val, int32_t tr_ncols, const int64_t* va_ptr, const int32_t* va_ind,

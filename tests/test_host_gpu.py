@@ -22,7 +22,7 @@ def host_train(method, d, K, maxIter, seed, lr, ureg, ireg, prefix=None, env=Non
     nU, nI = d["nUsers"], d["nItems"]
     Ul, Vl = np.empty((nU, K), np.float32), np.empty((nI, K), np.float32)
     Ub, Vb = np.empty((nU, K), np.float32), np.empty((nI, K), np.float32)
-    stats = np.zeros(6)
+    stats = np.zeros(8)
     invU, invI = np.empty(nU, np.uint8), np.empty(nI, np.uint8)
     P = lambda a: a.ctypes.data_as(C.c_void_p)
     old = {}
@@ -43,7 +43,7 @@ def host_train(method, d, K, maxIter, seed, lr, ureg, ireg, prefix=None, env=Non
                 os.environ[k] = v
     assert rc == 0
     return dict(U=Ul, V=Vl, Ubest=Ub, Vbest=Vb, train=stats[0], test=stats[1], val=stats[2], lr=stats[3],
-                invU=invU, invI=invI, nItems=int(stats[5]))
+                invU=invU, invI=invI, nItems=int(stats[5]), loop_s=stats[6], iters=int(stats[7]))
 
 
 def oracle_train(method, d, K, maxIter, seed, lr, ureg, ireg, dot_mode=orc.DOT_SEQ):
