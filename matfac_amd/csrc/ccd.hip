@@ -1,4 +1,4 @@
-// ccd.hip -- CCD++ rank-one sweeps for gfx950.
+// ccd.hip -- CCD++ rank-one sweeps for gfx950 (row view + driver; the column view is ccd_cols.hip).
 //
 // Replaces ModelMF::trainCCDPP (modelMF.cpp:1013-1121) and trainCCDPPFreqAdap
 // (:1258-1360).  State: the residual R - U V^T on BOTH views (CSR values res_row,
@@ -20,6 +20,7 @@ void mfx_ccd_free_internal(mfx_ctx* ctx) {
   dev_free(ctx->uk_pend); dev_free(ctx->vk_pend);
   ctx->ccd_pending = false;
   dev_free(ctx->ccd_part); dev_free(ctx->colid);
+  mfx_ccd_cols_free(ctx);
   ctx->ccd_part_cap = 0;
   ctx->ccd_active = false;
 }
@@ -221,8 +222,6 @@ extern "C" int mfx_ccdpp_begin(mfx_ctx* ctx) {
   int rc;
   const size_t nnz = (size_t)m.nnz;
   if ((rc = dev_alloc(ctx, &ctx->res_row, nnz))) return rc;
-  if ((rc = dev_alloc(ctx, &ctx->res_col, nnz))) return rc;
-  if ((rc = dev_alloc(ctx, &ctx->colid, nnz))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->uk, (size_t)ctx->nU))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->vk, (size_t)ctx->nI))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->uk_pend, (size_t)ctx->nU))) return rc;
@@ -230,23 +229,17 @@ extern "C" int mfx_ccdpp_begin(mfx_ctx* ctx) {
   // res = gk_csr_Dup(trainMat) (modelMF.cpp:1013): both value arrays
   if (nnz) {
     HIPCHK(hipMemcpyAsync(ctx->res_row, m.rowval, sizeof(float) * nnz, hipMemcpyDeviceToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->res_col, m.colval, sizeof(float) * nnz, hipMemcpyDeviceToDevice, ctx->stream));
   }
-  if (m.ncols > 0) {
-    const int blocks = (int)std::min<int64_t>(((int64_t)m.ncols + 3) / 4, 4096);
-    hipLaunchKernelGGL(expand_colid_kernel, dim3(blocks), dim3(256), 0, ctx->stream, m.colptr, m.ncols, ctx->colid);
-    HIPCHK(hipGetLastError());
-  }
+  // the column view (res->colval) lives in user-strip-major order: ccd_cols.hip
+  if ((rc = mfx_ccd_cols_build(ctx))) return rc;
   // uFac.fill(0) (modelMF.cpp:1020)
   HIPCHK(hipMemsetAsync(ctx->U, 0, sizeof(float) * (size_t)ctx->nU * ctx->ld, ctx->stream));
   RowSegs* sg;
-  for (int side = 0; side < 2; side++) {
-    if ((rc = mfx_get_segments(ctx, side, &sg))) return rc;
-    if (sg->nslab > ctx->ccd_part_cap) {
-      dev_free(ctx->ccd_part);
-      if ((rc = dev_alloc(ctx, &ctx->ccd_part, (size_t)sg->nslab * 2))) return rc;
-      ctx->ccd_part_cap = sg->nslab;
-    }
+  if ((rc = mfx_get_segments(ctx, 0, &sg))) return rc;
+  if (sg->nslab > ctx->ccd_part_cap) {
+    dev_free(ctx->ccd_part);
+    if ((rc = dev_alloc(ctx, &ctx->ccd_part, (size_t)sg->nslab * 2))) return rc;
+    ctx->ccd_part_cap = sg->nslab;
   }
   ctx->ccd_active = true;
   return MFX_OK;
@@ -259,6 +252,7 @@ static hipError_t set_lds(mfx_ctx*, const void* fn, size_t bytes) {
 }
 
 static int run_pass(mfx_ctx* ctx, int side, float reg, float freq_thresh, int k) {
+  if (side == 1) return mfx_ccd_cols_pass(ctx, ctx->uk, ctx->vk, reg, freq_thresh, k);
   const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
   RowSegs* sg;
   int rc = mfx_get_segments(ctx, side, &sg);
@@ -314,10 +308,8 @@ static int run_resid(mfx_ctx* ctx, const float* uk, const float* vk) {
     hipLaunchKernelGGL((resid_update_kernel<SIGN, false>), dim3(blocks), dim3(1024), 0, ctx->stream, ctx->res_row,
                        m.rowid, m.rowind, uk, vk, ctx->nI, m.nnz);
   }
-  hipLaunchKernelGGL((resid_update_kernel<SIGN, false>), dim3(blocks), dim3(1024), 0, ctx->stream, ctx->res_col,
-                     m.colind, ctx->colid, uk, vk, ctx->nI, m.nnz);
   HIPCHK(hipGetLastError());
-  return MFX_OK;
+  return mfx_ccd_cols_resid(ctx, SIGN, uk, vk, nullptr, nullptr);
 }
 
 // subtract of the pending factor fused with the add-back of the new one
@@ -335,11 +327,8 @@ static int run_resid_fused(mfx_ctx* ctx, const float* uk0, const float* vk0, con
     hipLaunchKernelGGL(resid_fused_kernel<false>, dim3(blocks), dim3(1024), 0, ctx->stream, ctx->res_row, m.rowid,
                        m.rowind, uk0, vk0, uk1, vk1, ctx->nI, m.nnz);
   }
-  // column view: the gathered vector is u_k (too long for LDS); here a = v_k indexed by column id
-  hipLaunchKernelGGL(resid_fused_kernel<false>, dim3(blocks), dim3(1024), 0, ctx->stream, ctx->res_col, ctx->colid,
-                     m.colind, vk0, uk0, vk1, uk1, ctx->nU, m.nnz);
   HIPCHK(hipGetLastError());
-  return MFX_OK;
+  return mfx_ccd_cols_resid(ctx, 2, uk0, vk0, uk1, vk1);
 }
 
 // The subtract of a finished factor is deferred so that it can share a sweep with the next add-back;
@@ -403,6 +392,6 @@ extern "C" int mfx_debug_residuals(mfx_ctx* ctx, float* res_row, float* res_col)
   const size_t nnz = (size_t)ctx->mat[MFX_MAT_TRAIN].nnz;
   if (nnz == 0) return MFX_OK;
   if (res_row) HIPCHK(hipMemcpy(res_row, ctx->res_row, sizeof(float) * nnz, hipMemcpyDeviceToHost));
-  if (res_col) HIPCHK(hipMemcpy(res_col, ctx->res_col, sizeof(float) * nnz, hipMemcpyDeviceToHost));
+  if (res_col) return mfx_ccd_cols_export(ctx, res_col);
   return MFX_OK;
 }

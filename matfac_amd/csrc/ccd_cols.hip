@@ -1,0 +1,349 @@
+// ccd_cols.hip -- the column view of CCD++ with the user vector staged in LDS.
+//
+// The column sweep v_k[i] = sum_u res_ui u_k[u] / (iReg + sum_u u_k[u]^2) (modelMF.cpp:1078-1090) and the
+// column-view residual updates (:1045-1055, :1106-1116) gather u_k[u] for the users of a column.  From L2
+// every 4-byte gather moves a 128-byte line, which made these kernels L2-bandwidth-bound (measured: the
+// same residual kernel runs 2.7x faster on the row view, where the gathered v_k sits in LDS).  u_k does not fit in
+// LDS (C4: 1.9 MB), so the column view is stored in USER-BLOCK-major order: block b holds, column by
+// column, the entries whose user lies in [b*UB, (b+1)*UB), users ascending -- i.e. the reference's
+// colind/colval (gk_csr_CreateIndex order) cut into UB-user strips.  A workgroup stages u_k[b*UB ...] (32 KB)
+// in LDS and works on entries of that strip only.  Column sums are formed per (strip, column) segment of <= 1024
+// entries and finished per column in a fixed order (strip-major), so every sum has a fixed association.
+#include <algorithm>
+#include <vector>
+
+#include "mfx_internal.h"
+
+namespace {
+constexpr int UB = 8192;          // users per strip: 32 KB of u_k (two vectors fit for the fused update)
+constexpr int CSEG = 1024;        // entries per segment
+constexpr int SEGS_PER_WG = 256;  // segments a 1024-thread workgroup (64 groups) works through
+constexpr int64_t ENT_PER_WG = 128 * 1024;
+
+struct ColState {
+  int nb = 0;                       // strips
+  int64_t nnz = 0;
+  int32_t* off = nullptr;           // [nI][nb+1] CSC position where strip b starts inside column i (relative to colptr[i])
+  int64_t* dst = nullptr;           // [nb][nI] blocked position of segment (b,i)
+  int32_t* buser = nullptr;         // blocked: user - b*UB
+  int32_t* bcol = nullptr;          // blocked: column id
+  float* res = nullptr;             // blocked residual (the reference's res->colval in strip-major order)
+  // pass segments
+  int64_t* seg_beg = nullptr; int64_t* seg_end = nullptr; int32_t* seg_col = nullptr;
+  int64_t nseg = 0;
+  double* part = nullptr;           // [nseg][2]
+  int32_t* col_ptr = nullptr;       // [nI+1] column -> its segments (strip-major order)
+  int32_t* col_seg = nullptr;
+  // workgroup tables
+  int32_t* pw_blk = nullptr; int32_t* pw_s0 = nullptr; int32_t* pw_s1 = nullptr; int npw = 0;       // pass
+  int32_t* rw_blk = nullptr; int64_t* rw_e0 = nullptr; int64_t* rw_e1 = nullptr; int nrw = 0;       // residual
+};
+ColState* st(mfx_ctx* ctx) { return (ColState*)ctx->ccd_cols; }
+
+template <typename T>
+int up(mfx_ctx* ctx, T** dst, const std::vector<T>& v) {
+  int rc = dev_alloc(ctx, dst, v.size());
+  if (rc) return rc;
+  if (!v.empty()) HIPCHK(hipMemcpyAsync(*dst, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice, ctx->stream));
+  return MFX_OK;
+}
+}  // namespace
+
+void mfx_ccd_cols_free(mfx_ctx* ctx) {
+  ColState* s = st(ctx);
+  if (!s) return;
+  dev_free(s->off); dev_free(s->dst); dev_free(s->buser); dev_free(s->bcol); dev_free(s->res);
+  dev_free(s->seg_beg); dev_free(s->seg_end); dev_free(s->seg_col); dev_free(s->part);
+  dev_free(s->col_ptr); dev_free(s->col_seg);
+  dev_free(s->pw_blk); dev_free(s->pw_s0); dev_free(s->pw_s1);
+  dev_free(s->rw_blk); dev_free(s->rw_e0); dev_free(s->rw_e1);
+  delete s;
+  ctx->ccd_cols = nullptr;
+}
+
+// off[i][b] = first entry of column i whose user is >= b*UB (users ascend inside a column)
+__global__ void strip_offsets_kernel(const int64_t* __restrict__ colptr, const int32_t* __restrict__ colind,
+                                     int32_t ncols, int nb, int32_t* __restrict__ off) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)ncols * (nb + 1)) return;
+  const int i = (int)(t / (nb + 1)), b = (int)(t % (nb + 1));
+  const int64_t beg = colptr[i], end = colptr[i + 1];
+  int64_t lo = beg, hi = end;
+  const int64_t key = (int64_t)b * UB;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (colind[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  off[t] = (int32_t)(lo - beg);
+}
+
+// copy the (strip, column) pieces into strip-major order
+__global__ __launch_bounds__(256) void strip_scatter_kernel(const int64_t* __restrict__ colptr,
+                                                            const int32_t* __restrict__ colind,
+                                                            const float* __restrict__ colval,
+                                                            const int32_t* __restrict__ off,
+                                                            const int64_t* __restrict__ dst, int32_t ncols, int nb,
+                                                            int32_t* __restrict__ buser, int32_t* __restrict__ bcol,
+                                                            float* __restrict__ res) {
+  const int j = threadIdx.x & 15;
+  const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
+  for (int64_t p = grp; p < (int64_t)ncols * nb; p += ngrp) {
+    const int b = (int)(p / ncols), i = (int)(p % ncols);
+    const int64_t src = colptr[i] + off[(int64_t)i * (nb + 1) + b];
+    const int64_t n = off[(int64_t)i * (nb + 1) + b + 1] - off[(int64_t)i * (nb + 1) + b];
+    const int64_t d = dst[(int64_t)b * ncols + i];
+    for (int64_t t = j; t < n; t += 16) {
+      buser[d + t] = colind[src + t] - b * UB;
+      bcol[d + t] = i;
+      res[d + t] = colval[src + t];
+    }
+  }
+}
+
+// inverse of the scatter for the test hook: strip-major residual -> CSC order
+__global__ __launch_bounds__(256) void strip_gather_kernel(const int64_t* __restrict__ colptr,
+                                                           const int32_t* __restrict__ off,
+                                                           const int64_t* __restrict__ dst, int32_t ncols, int nb,
+                                                           const float* __restrict__ res, float* __restrict__ out) {
+  const int j = threadIdx.x & 15;
+  const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
+  for (int64_t p = grp; p < (int64_t)ncols * nb; p += ngrp) {
+    const int b = (int)(p / ncols), i = (int)(p % ncols);
+    const int64_t src = colptr[i] + off[(int64_t)i * (nb + 1) + b];
+    const int64_t n = off[(int64_t)i * (nb + 1) + b + 1] - off[(int64_t)i * (nb + 1) + b];
+    const int64_t d = dst[(int64_t)b * ncols + i];
+    for (int64_t t = j; t < n; t += 16) out[src + t] = res[d + t];
+  }
+}
+
+int mfx_ccd_cols_build(mfx_ctx* ctx) {
+  const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
+  mfx_ccd_cols_free(ctx);
+  ColState* s = new ColState;
+  ctx->ccd_cols = s;
+  const int32_t nI = m.ncols;
+  const int nb = std::max(1, (m.nrows + UB - 1) / UB);
+  s->nb = nb;
+  s->nnz = m.nnz;
+  int rc;
+  if ((rc = dev_alloc(ctx, &s->off, (size_t)nI * (nb + 1)))) return rc;
+  {
+    const int64_t n = (int64_t)nI * (nb + 1);
+    hipLaunchKernelGGL(strip_offsets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, m.colptr,
+                       m.colind, nI, nb, s->off);
+    HIPCHK(hipGetLastError());
+  }
+  std::vector<int32_t> off((size_t)nI * (nb + 1));
+  HIPCHK(hipMemcpyAsync(off.data(), s->off, sizeof(int32_t) * off.size(), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  // strip-major positions, segments, per-column segment lists, workgroup tables
+  std::vector<int64_t> dst((size_t)nb * nI), seg_beg, seg_end, rw_e0, rw_e1;
+  std::vector<int32_t> seg_col, pw_blk, pw_s0, pw_s1, rw_blk;
+  std::vector<int32_t> col_cnt((size_t)nI, 0);
+  int64_t pos = 0;
+  for (int b = 0; b < nb; b++) {
+    const int64_t ent0 = pos;
+    const int32_t sg0 = (int32_t)seg_col.size();
+    for (int32_t i = 0; i < nI; i++) {
+      const int64_t n = off[(size_t)i * (nb + 1) + b + 1] - off[(size_t)i * (nb + 1) + b];
+      dst[(size_t)b * nI + i] = pos;
+      for (int64_t c = 0; c < n; c += CSEG) {
+        seg_beg.push_back(pos + c);
+        seg_end.push_back(pos + std::min<int64_t>(n, c + CSEG));
+        seg_col.push_back(i);
+        col_cnt[i]++;
+      }
+      pos += n;
+    }
+    const int32_t sg1 = (int32_t)seg_col.size();
+    for (int32_t a = sg0; a < sg1; a += SEGS_PER_WG) { pw_blk.push_back(b); pw_s0.push_back(a); pw_s1.push_back(std::min(sg1, a + SEGS_PER_WG)); }
+    for (int64_t a = ent0; a < pos; a += ENT_PER_WG) { rw_blk.push_back(b); rw_e0.push_back(a); rw_e1.push_back(std::min(pos, a + ENT_PER_WG)); }
+  }
+  std::vector<int32_t> col_ptr((size_t)nI + 1, 0), col_seg(seg_col.size());
+  for (int32_t i = 0; i < nI; i++) col_ptr[i + 1] = col_ptr[i] + col_cnt[i];
+  {
+    std::vector<int32_t> w(col_ptr.begin(), col_ptr.end() - 1);
+    for (size_t k = 0; k < seg_col.size(); k++) col_seg[w[seg_col[k]]++] = (int32_t)k;   // strip-major inside a column
+  }
+  if ((rc = up(ctx, &s->dst, dst))) return rc;
+  if ((rc = up(ctx, &s->seg_beg, seg_beg))) return rc;
+  if ((rc = up(ctx, &s->seg_end, seg_end))) return rc;
+  if ((rc = up(ctx, &s->seg_col, seg_col))) return rc;
+  if ((rc = up(ctx, &s->col_ptr, col_ptr))) return rc;
+  if ((rc = up(ctx, &s->col_seg, col_seg))) return rc;
+  if ((rc = up(ctx, &s->pw_blk, pw_blk))) return rc;
+  if ((rc = up(ctx, &s->pw_s0, pw_s0))) return rc;
+  if ((rc = up(ctx, &s->pw_s1, pw_s1))) return rc;
+  if ((rc = up(ctx, &s->rw_blk, rw_blk))) return rc;
+  if ((rc = up(ctx, &s->rw_e0, rw_e0))) return rc;
+  if ((rc = up(ctx, &s->rw_e1, rw_e1))) return rc;
+  s->nseg = (int64_t)seg_col.size();
+  s->npw = (int)pw_blk.size();
+  s->nrw = (int)rw_blk.size();
+  if ((rc = dev_alloc(ctx, &s->part, (size_t)s->nseg * 2))) return rc;
+  if ((rc = dev_alloc(ctx, &s->buser, (size_t)m.nnz))) return rc;
+  if ((rc = dev_alloc(ctx, &s->bcol, (size_t)m.nnz))) return rc;
+  if ((rc = dev_alloc(ctx, &s->res, (size_t)m.nnz))) return rc;
+  if (m.nnz > 0) {
+    hipLaunchKernelGGL(strip_scatter_kernel, dim3(2048), dim3(256), 0, ctx->stream, m.colptr, m.colind, m.colval,
+                       s->off, s->dst, nI, nb, s->buser, s->bcol, s->res);
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return MFX_OK;
+}
+
+__device__ __forceinline__ void stage_strip(float* lds, const float* __restrict__ v, int first, int n) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  // first is a multiple of UB, so the source is 16-byte aligned
+  const int n4 = n >> 2;
+  for (int q = threadIdx.x; q < n4; q += blockDim.x) ((f4*)lds)[q] = ((const f4*)(v + first))[q];
+  for (int q = (n4 << 2) + threadIdx.x; q < n; q += blockDim.x) lds[q] = v[first + q];
+}
+
+__device__ __forceinline__ double g16_sum(double v) {
+#pragma unroll
+  for (int m = 8; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+// column pass: one 16-lane group per (strip, column) segment, u_k strip in LDS
+__global__ __launch_bounds__(1024) void colpass_kernel(const int32_t* __restrict__ pw_blk,
+                                                       const int32_t* __restrict__ pw_s0,
+                                                       const int32_t* __restrict__ pw_s1,
+                                                       const int64_t* __restrict__ seg_beg,
+                                                       const int64_t* __restrict__ seg_end,
+                                                       const float* __restrict__ res,
+                                                       const int32_t* __restrict__ buser,
+                                                       const float* __restrict__ uk, int nU,
+                                                       double* __restrict__ part) {
+  __shared__ __attribute__((aligned(16))) float su[UB];
+  const int b = pw_blk[blockIdx.x];
+  stage_strip(su, uk, b * UB, min(UB, nU - b * UB));
+  __syncthreads();
+  const int j = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  for (int s = pw_s0[blockIdx.x] + grp; s < pw_s1[blockIdx.x]; s += 64) {
+    const int64_t beg = seg_beg[s], end = seg_end[s];
+    double num = 0.0, den = 0.0;
+    int64_t t = beg + j;
+    for (; t + 48 < end; t += 64) {
+      const float o0 = su[buser[t]], o1 = su[buser[t + 16]], o2 = su[buser[t + 32]], o3 = su[buser[t + 48]];
+      const float r0 = res[t], r1 = res[t + 16], r2 = res[t + 32], r3 = res[t + 48];
+      num += (double)(r0 * o0); den += (double)(o0 * o0);   // float products (modelMF.cpp:1085-1086)
+      num += (double)(r1 * o1); den += (double)(o1 * o1);
+      num += (double)(r2 * o2); den += (double)(o2 * o2);
+      num += (double)(r3 * o3); den += (double)(o3 * o3);
+    }
+    for (; t < end; t += 16) {
+      const float o = su[buser[t]];
+      num += (double)(res[t] * o);
+      den += (double)(o * o);
+    }
+    num = g16_sum(num);
+    den = g16_sum(den);
+    if (j == 0) { part[2 * (int64_t)s] = num; part[2 * (int64_t)s + 1] = den; }
+  }
+}
+
+// v_k[i] from the column's segment partials in strip-major order; one 16-lane group per column
+__global__ __launch_bounds__(256) void colfinish_kernel(const int32_t* __restrict__ col_ptr,
+                                                        const int32_t* __restrict__ col_seg,
+                                                        const double* __restrict__ part, int32_t ncols, float reg,
+                                                        float* __restrict__ vk, const int64_t* __restrict__ colptr,
+                                                        float freq_thresh, int k) {
+  const int j = threadIdx.x & 15;
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  if (i >= ncols) return;
+  const int a = col_ptr[i], e = col_ptr[i + 1];
+  if (a == e) return;   // an item without train ratings is invalid: v_k keeps iFac(i,k) (modelMF.cpp:1079-1081)
+  double num = 0.0, den = 0.0;
+  for (int t = a + j; t < e; t += 16) {   // lane-strided in list order, then a fixed butterfly
+    num += part[2 * (int64_t)col_seg[t]];
+    den += part[2 * (int64_t)col_seg[t] + 1];
+  }
+  num = g16_sum(num);
+  den = g16_sum(den);
+  if (j == 0) {
+    float v = (float)(num / ((double)reg + den));
+    if (freq_thresh >= 0.0f) {  // modelMF.cpp:1336-1342
+      const double freq = (double)(colptr[i + 1] - colptr[i]);
+      if (freq < (double)freq_thresh && k > 0) v = 0.0f;
+    }
+    vk[i] = v;
+  }
+}
+
+// residual update on the strip-major column view.  MODE +1: res += u0*v0, -1: res -= u0*v0,
+// 2: res = (res - u0*v0) + u1*v1 (deferred subtract fused with the next add-back)
+template <int MODE>
+__global__ __launch_bounds__(1024) void colresid_kernel(const int32_t* __restrict__ rw_blk,
+                                                        const int64_t* __restrict__ rw_e0,
+                                                        const int64_t* __restrict__ rw_e1, float* __restrict__ res,
+                                                        const int32_t* __restrict__ buser,
+                                                        const int32_t* __restrict__ bcol,
+                                                        const float* __restrict__ uk0, const float* __restrict__ vk0,
+                                                        const float* __restrict__ uk1, const float* __restrict__ vk1,
+                                                        int nU) {
+  __shared__ __attribute__((aligned(16))) float su[(MODE == 2 ? 2 : 1) * UB];
+  const int b = rw_blk[blockIdx.x];
+  const int n = min(UB, nU - b * UB);
+  stage_strip(su, uk0, b * UB, n);
+  if (MODE == 2) stage_strip(su + UB, uk1, b * UB, n);
+  __syncthreads();
+  for (int64_t t = rw_e0[blockIdx.x] + threadIdx.x; t < rw_e1[blockIdx.x]; t += blockDim.x) {
+    const int lu = buser[t], c = bcol[t];
+    const float p0 = su[lu] * vk0[c];   // u_k(u)*v_k(item): float product (modelMF.cpp:1053, :1114)
+    float r = res[t];
+    if (MODE == 1) r = r + p0;
+    else r = r - p0;
+    if (MODE == 2) r = r + su[UB + lu] * vk1[c];
+    res[t] = r;
+  }
+}
+
+int mfx_ccd_cols_pass(mfx_ctx* ctx, const float* uk, float* vk, float reg, float freq_thresh, int k) {
+  ColState* s = st(ctx);
+  const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
+  if (s->npw > 0) {
+    ProfScope ps(ctx, MFX_K_CCD_COL);
+    hipLaunchKernelGGL(colpass_kernel, dim3(s->npw), dim3(1024), 0, ctx->stream, s->pw_blk, s->pw_s0, s->pw_s1,
+                       s->seg_beg, s->seg_end, s->res, s->buser, uk, m.nrows, s->part);
+    hipLaunchKernelGGL(colfinish_kernel, dim3((unsigned)(((int64_t)m.ncols * 16 + 255) / 256)), dim3(256), 0,
+                       ctx->stream, s->col_ptr, s->col_seg, s->part, m.ncols, reg, vk, m.colptr, freq_thresh, k);
+    HIPCHK(hipGetLastError());
+  }
+  return MFX_OK;
+}
+
+int mfx_ccd_cols_resid(mfx_ctx* ctx, int mode, const float* uk0, const float* vk0, const float* uk1,
+                       const float* vk1) {
+  ColState* s = st(ctx);
+  const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
+  if (s->nrw == 0) return MFX_OK;
+#define MFX_CR(MD)                                                                                             \
+  hipLaunchKernelGGL(colresid_kernel<MD>, dim3(s->nrw), dim3(1024), 0, ctx->stream, s->rw_blk, s->rw_e0, s->rw_e1, \
+                     s->res, s->buser, s->bcol, uk0, vk0, uk1, vk1, m.nrows)
+  if (mode == 1) MFX_CR(1); else if (mode == 2) MFX_CR(2); else MFX_CR(-1);
+#undef MFX_CR
+  HIPCHK(hipGetLastError());
+  return MFX_OK;
+}
+
+// test hook: the residual in the reference's CSC order
+int mfx_ccd_cols_export(mfx_ctx* ctx, float* host_out) {
+  ColState* s = st(ctx);
+  const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
+  if (m.nnz == 0) return MFX_OK;
+  float* tmp = nullptr;
+  int rc = dev_alloc(ctx, &tmp, (size_t)m.nnz);
+  if (rc) return rc;
+  hipLaunchKernelGGL(strip_gather_kernel, dim3(2048), dim3(256), 0, ctx->stream, m.colptr, s->off, s->dst, m.ncols,
+                     s->nb, s->res, tmp);
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) e = hipMemcpy(host_out, tmp, sizeof(float) * (size_t)m.nnz, hipMemcpyDeviceToHost);
+  dev_free(tmp);
+  if (e != hipSuccess) return mfx_fail(ctx, MFX_E_HIP, "mfx_ccd_cols_export: %s", hipGetErrorString(e));
+  return MFX_OK;
+}

@@ -90,6 +90,7 @@ struct mfx_ctx {
   double* ccd_part = nullptr;
   int64_t ccd_part_cap = 0;
   int32_t* colid = nullptr;
+  void* ccd_cols = nullptr;   // strip-major column view (ccd_cols.hip owns the type)
 
   // comm
   void* comm = nullptr;      // ncclComm_t
@@ -185,6 +186,12 @@ int mfx_comm_free_internal(mfx_ctx* ctx);
 void mfx_ccd_free_internal(mfx_ctx* ctx);
 void mfx_als_free_internal(mfx_ctx* ctx);
 void mfx_segs_free_internal(mfx_ctx* ctx);
+// CCD++ column view (ccd_cols.hip)
+int mfx_ccd_cols_build(mfx_ctx* ctx);
+void mfx_ccd_cols_free(mfx_ctx* ctx);
+int mfx_ccd_cols_pass(mfx_ctx* ctx, const float* uk, float* vk, float reg, float freq_thresh, int k);
+int mfx_ccd_cols_resid(mfx_ctx* ctx, int mode, const float* uk0, const float* vk0, const float* uk1, const float* vk1);
+int mfx_ccd_cols_export(mfx_ctx* ctx, float* host_out);
 int mfx_get_segments(mfx_ctx* ctx, int side, RowSegs** out);
 
 #endif
