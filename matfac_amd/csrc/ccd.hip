@@ -190,18 +190,26 @@ __global__ __launch_bounds__(1024) void ccd_pass_kernel(const int32_t* __restric
   }
 }
 
-__global__ void ccd_finish_kernel(const int32_t* __restrict__ mrow, const int32_t* __restrict__ mrow_first,
-                                  const int32_t* __restrict__ mrow_n, int64_t nmrow,
-                                  const double* __restrict__ part, float reg, float* __restrict__ mine,
-                                  const int64_t* __restrict__ ptr, float freq_thresh, int k) {
-  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// rows with several segments: partials summed by a 16-lane group, lane-strided in segment order then a fixed
+// butterfly (a single thread walking ~100 partials made this 57 us launch 13 % of a factor)
+__global__ __launch_bounds__(256) void ccd_finish_kernel(const int32_t* __restrict__ mrow,
+                                                         const int32_t* __restrict__ mrow_first,
+                                                         const int32_t* __restrict__ mrow_n, int64_t nmrow,
+                                                         const double* __restrict__ part, float reg,
+                                                         float* __restrict__ mine, const int64_t* __restrict__ ptr,
+                                                         float freq_thresh, int k) {
+  const int j = threadIdx.x & 15;
+  const int64_t m = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
   if (m >= nmrow) return;
   double num = 0.0, den = 0.0;
   const int first = mrow_first[m], n = mrow_n[m];
-  for (int s = 0; s < n; s++) {
+  for (int s = j; s < n; s += 16) {
     num += part[2 * (int64_t)(first + s)];
     den += part[2 * (int64_t)(first + s) + 1];
   }
+  num = group16_sum(num);
+  den = group16_sum(den);
+  if (j != 0) return;
   const int row = mrow[m];
   float v = (float)(num / ((double)reg + den));
   if (freq_thresh >= 0.0f) {
@@ -282,7 +290,7 @@ static int run_pass(mfx_ctx* ctx, int side, float reg, float freq_thresh, int k)
     HIPCHK(hipGetLastError());
   }
   if (sg->nmrow > 0) {
-    hipLaunchKernelGGL(ccd_finish_kernel, dim3((unsigned)((sg->nmrow + 255) / 256)), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(ccd_finish_kernel, dim3((unsigned)((sg->nmrow * 16 + 255) / 256)), dim3(256), 0, ctx->stream,
                        sg->mrow, sg->mrow_first, sg->mrow_n, sg->nmrow, ctx->ccd_part, reg, mine, ptr,
                        freq_thresh, k);
     HIPCHK(hipGetLastError());
