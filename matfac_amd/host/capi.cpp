@@ -53,3 +53,39 @@ extern "C" int mfh_train(const char* method, int32_t nrows, const int64_t* tr_pt
   if (!prefix) unsetenv("MFX_NO_SAVE");
   return 0;
 }
+
+// Text-CSR loader / writer of the host library (csr.cpp) for the CPU-side tests: two-call protocol like
+// the oracle's reader (arrays may be NULL to query the sizes).  Returns 0, or -1 with the message in err.
+extern "C" int mfh_csr_read_text(const char* path, int32_t* nrows, int32_t* ncols, int64_t* nnz, int64_t* rowptr,
+                                 int32_t* rowind, float* rowval, int64_t* colptr, int32_t* colind, float* colval,
+                                 char* err, int errcap) {
+  std::string e;
+  csr_t* m = csr_read_text(path, &e);
+  if (!m) {
+    if (err && errcap > 0) { strncpy(err, e.c_str(), errcap - 1); err[errcap - 1] = 0; }
+    return -1;
+  }
+  *nrows = m->nrows; *ncols = m->ncols; *nnz = m->nnz();
+  if (rowptr) {
+    memcpy(rowptr, m->rowptr, sizeof(int64_t) * ((size_t)m->nrows + 1));
+    memcpy(rowind, m->rowind, sizeof(int32_t) * (size_t)m->nnz());
+    memcpy(rowval, m->rowval, sizeof(float) * (size_t)m->nnz());
+  }
+  if (colptr) {
+    csr_create_col_index(m);
+    memcpy(colptr, m->colptr, sizeof(int64_t) * ((size_t)m->ncols + 1));
+    memcpy(colind, m->colind, sizeof(int32_t) * (size_t)m->nnz());
+    memcpy(colval, m->colval, sizeof(float) * (size_t)m->nnz());
+  }
+  csr_free(&m);
+  return 0;
+}
+
+extern "C" int mfh_data_shape(const char* train, const char* test, const char* val, int32_t* nUsers, int32_t* nItems,
+                              int32_t* trainNNZ) {
+  std::string e, tr = train, te = test, va = val, pfx = "x";
+  Params params(1, 1, 1, 1, 0.f, 0.f, 0.f, 0.f, 0.f, tr, te, va, e, e, e, e, e, pfx);
+  Data data(params);
+  *nUsers = data.nUsers; *nItems = data.nItems; *trainNNZ = data.trainNNZ;
+  return 0;
+}

@@ -37,6 +37,13 @@ int mfh_train(const char* method, int32_t nrows, const int64_t* tr_ptr, const in
               float uReg, float iReg, const char* prefix, float* Ulast, float* Vlast, float* Ubest, float* Vbest,
               double* stats, uint8_t* invU, uint8_t* invI);
 
+/* csr_read_text / csr_create_col_index (csr.cpp) and Data::Data(const Params&) (params_data.cpp) for tests */
+int mfh_csr_read_text(const char* path, int32_t* nrows, int32_t* ncols, int64_t* nnz, int64_t* rowptr,
+                      int32_t* rowind, float* rowval, int64_t* colptr, int32_t* colind, float* colval, char* err,
+                      int errcap);
+int mfh_data_shape(const char* train, const char* test, const char* val, int32_t* nUsers, int32_t* nItems,
+                   int32_t* trainNNZ);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,91 @@
+"""CPU-side tests of the host library (matfac_amd/host): the text-CSR loader that replaces gk_csr_Read /
+gk_csr_CreateIndex, Data's nUsers/nItems rule (datastruct.cpp:23,91), the factor initialisation stream and
+the synthetic generator.  The oracle's independent reader/writer is the checker."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from matfac_amd import synth
+from oracle import binding as orc
+
+
+def host_read(path, want_cols=True):
+    lib = synth._host()
+    nr, nc, nz = C.c_int32(), C.c_int32(), C.c_int64()
+    err = C.create_string_buffer(256)
+    rc = lib.mfh_csr_read_text(path.encode(), C.byref(nr), C.byref(nc), C.byref(nz), None, None, None, None, None,
+                               None, err, 256)
+    if rc:
+        raise IOError(err.value.decode())
+    rp = np.empty(nr.value + 1, np.int64); ri = np.empty(nz.value, np.int32); rv = np.empty(nz.value, np.float32)
+    cp = np.empty(nc.value + 1, np.int64); ci = np.empty(nz.value, np.int32); cv = np.empty(nz.value, np.float32)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = lib.mfh_csr_read_text(path.encode(), C.byref(nr), C.byref(nc), C.byref(nz), P(rp), P(ri), P(rv),
+                               P(cp) if want_cols else None, P(ci), P(cv), err, 256)
+    assert rc == 0
+    return nr.value, nc.value, rp, ri, rv, cp, ci, cv
+
+
+def test_text_csr_loader_matches_oracle_reader(tmp_path):
+    d = synth.make(dict(nU=150, nI=90, nnz=3000, K=0), seed=8)
+    tr = d["train"]
+    p = str(tmp_path / "t.csr")
+    orc.write_csr_text(p, tr.nrows, tr.rowptr, tr.rowind, tr.rowval)
+    nr, nc, rp, ri, rv, cp, ci, cv = host_read(p)
+    onr, onc, orp, ori, orv = orc.read_csr_text(p)
+    assert (nr, nc) == (onr, onc) == (tr.nrows, tr.ncols)
+    assert np.array_equal(rp, orp) and np.array_equal(ri, ori) and np.array_equal(rv, orv)
+    ocp, oci, ocv = orc.create_col_index(nr, nc, rp, ri, rv)
+    assert np.array_equal(cp, ocp) and np.array_equal(ci, oci) and np.array_equal(cv, ocv)
+
+
+def test_loader_edge_cases(tmp_path):
+    p = str(tmp_path / "e.csr")
+    open(p, "w").write("% header comment\n3 4.5 0 1\n\n\n7 2\n")      # unsorted row, two empty users, comment
+    nr, nc, rp, ri, rv, cp, ci, cv = host_read(p)
+    assert (nr, nc) == (4, 8)
+    assert rp.tolist() == [0, 2, 2, 2, 3] and ri.tolist() == [3, 0, 7] and rv.tolist() == [4.5, 1.0, 2.0]
+    assert cp.tolist() == [0, 1, 1, 1, 2, 2, 2, 2, 3] and ci.tolist() == [0, 0, 3]
+    open(p, "w").write("0 1.0 2\n")                                       # odd token count
+    with pytest.raises(IOError):
+        host_read(p)
+    with pytest.raises(IOError):
+        host_read(str(tmp_path / "missing.csr"))
+    open(p, "w").write("")                                                 # empty file: 0 x 0
+    nr, nc, rp, *_ = host_read(p)
+    assert (nr, nc) == (0, 0) and rp.tolist() == [0]
+
+
+def test_data_shape_rule(tmp_path):
+    """nUsers = train rows; nItems = 1 + max item over train, test AND val (datastruct.cpp:91)."""
+    tr, te, va = (str(tmp_path / n) for n in ("tr", "te", "va"))
+    open(tr, "w").write("0 5 1 3\n2 4\n")
+    open(te, "w").write("6 1\n\n")
+    open(va, "w").write("\n4 2\n")
+    lib = synth._host()
+    nU, nI, nz = C.c_int32(), C.c_int32(), C.c_int32()
+    assert lib.mfh_data_shape(tr.encode(), te.encode(), va.encode(), C.byref(nU), C.byref(nI), C.byref(nz)) == 0
+    assert (nU.value, nI.value, nz.value) == (2, 7, 3)
+
+
+def test_init_factors_stream_and_generator_invariants():
+    U, V = synth.init_factors(1, 6, 5, 8)
+    Uo, Vo = orc.init_factors(1, 6, 5, 8)
+    assert np.array_equal(U, Uo) and np.array_equal(V, Vo)
+    _, V2 = synth.init_factors(1, 6, 5, 8, want_u=False)                   # V does not depend on U being requested
+    assert np.array_equal(V2, Vo)
+    a = synth.make("C1", seed=1)
+    b = synth.make("C1", seed=1)
+    c = synth.make("C1", seed=1, shard=1)
+    f = a["full"]
+    assert f.nnz == 100_000 and a["train"].nnz + a["val"].nnz + a["test"].nnz == f.nnz
+    assert np.array_equal(f.rowind, b["full"].rowind) and np.array_equal(f.rowval, b["full"].rowval)   # deterministic
+    assert not np.array_equal(f.rowind[:1000], c["full"].rowind[:1000])                                  # another user block
+    assert np.diff(a["train"].rowptr).min() >= 1                            # every user keeps a train rating
+    key = f.rowids().astype(np.int64) * f.ncols + f.rowind
+    assert np.all(np.diff(key) > 0)                                         # sorted, no duplicate (user, item)
+    assert set(np.unique(f.rowval)) <= set(np.arange(0.5, 5.01, 0.5).astype(np.float32))
+    # same item catalogue across shards: the popular items coincide
+    top = lambda m: set(np.argsort(np.bincount(m.rowind, minlength=1682))[-20:])
+    assert len(top(f) & top(c["full"])) >= 12
