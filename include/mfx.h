@@ -139,6 +139,11 @@ int mfx_sgd_epoch(mfx_ctx* ctx, const mfx_sgd_opts* opts);
 /* test hook: the (u,i,r) list the last epoch visited, in visiting order */
 int mfx_debug_epoch_list(mfx_ctx* ctx, int32_t* u, int32_t* i, float* r, int64_t cap,
                          int64_t* n);
+/* test hook: digest of the slot lists the last MFX_SGD_TILED epoch ran on.  counts = {slots, ratings, row
+ * references, rows per slot}; sums = FNV-1a of {rating records, slot_beg, slot_ibeg, slot rows, tile_slot} */
+int mfx_debug_slots_digest(mfx_ctx* ctx, int64_t counts[4], uint64_t sums[5]);
+/* test hook: the column view of the train matrix as the device holds it (given or built by mfx_set_csr) */
+int mfx_debug_col_view(mfx_ctx* ctx, int64_t* colptr, int32_t* colind, float* colval);
 
 /* ---- evaluation: replaces Model::objective (model.cpp:1770-1815) and
  *      Model::RMSE (model.cpp:214-251)                                          */

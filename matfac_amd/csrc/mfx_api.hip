@@ -175,24 +175,9 @@ extern "C" int mfx_set_csr(mfx_ctx* ctx, int which, int32_t nrows, int32_t ncols
     hipLaunchKernelGGL(expand_rowid_kernel, dim3(blocks), dim3(256), 0, ctx->stream, m.rowptr, nrows, m.rowid);
     HIPCHK(hipGetLastError());
   }
-  // column view: given, or built here (stable counting sort == gk_csr_CreateIndex(COL))
-  std::vector<int64_t> cp;
-  std::vector<int32_t> ci;
-  std::vector<float> cv;
+  // column view: given, or built on the device (stable sort by column == gk_csr_CreateIndex(COL))
   if (!colptr && which == MFX_MAT_TRAIN) {
-    cp.assign((size_t)ncols + 1, 0);
-    ci.resize((size_t)nnz);
-    cv.resize((size_t)nnz);
-    for (int64_t e = 0; e < nnz; e++) cp[rowind[e] + 1]++;
-    for (int32_t j = 0; j < ncols; j++) cp[j + 1] += cp[j];
-    std::vector<int64_t> pos(cp.begin(), cp.end() - 1);
-    for (int32_t u = 0; u < nrows; u++)
-      for (int64_t e = rowptr[u]; e < rowptr[u + 1]; e++) {
-        int64_t d = pos[rowind[e]]++;
-        ci[d] = u;
-        cv[d] = rowval[e];
-      }
-    colptr = cp.data(); colind = ci.data(); colval = cv.data();
+    if ((rc = mfx_build_col_index_device(ctx, m))) return rc;
   }
   if (colptr) {
     NEED(colptr[0] == 0 && colptr[ncols] == nnz, MFX_E_ARG, "mfx_set_csr: colptr inconsistent with nnz");
@@ -211,6 +196,21 @@ extern "C" int mfx_set_csr(mfx_ctx* ctx, int which, int32_t nrows, int32_t ncols
   HIPCHK(hipStreamSynchronize(ctx->stream));  // host buffers are borrowed for this call only
   m.present = true;
   if (which == MFX_MAT_TRAIN) ctx->have_invalid = false;
+  return MFX_OK;
+}
+
+extern "C" int mfx_debug_col_view(mfx_ctx* ctx, int64_t* colptr, int32_t* colind, float* colval) {
+  if (!ctx) return MFX_E_ARG;
+  const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
+  NEED(m.present && m.has_col, MFX_E_STATE, "mfx_debug_col_view: no train matrix with a column view");
+  NEED(colptr && colind && colval, MFX_E_ARG, "mfx_debug_col_view: NULL output");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpy(colptr, m.colptr, sizeof(int64_t) * ((size_t)m.ncols + 1), hipMemcpyDeviceToHost));
+  if (m.nnz) {
+    HIPCHK(hipMemcpy(colind, m.colind, sizeof(int32_t) * (size_t)m.nnz, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(colval, m.colval, sizeof(float) * (size_t)m.nnz, hipMemcpyDeviceToHost));
+  }
   return MFX_OK;
 }
 

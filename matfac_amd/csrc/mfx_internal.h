@@ -192,6 +192,8 @@ void mfx_ccd_cols_free(mfx_ctx* ctx);
 int mfx_ccd_cols_pass(mfx_ctx* ctx, const float* uk, float* vk, float reg, float freq_thresh, int k);
 int mfx_ccd_cols_resid(mfx_ctx* ctx, int mode, const float* uk0, const float* vk0, const float* uk1, const float* vk1);
 int mfx_ccd_cols_export(mfx_ctx* ctx, float* host_out);
+// column view of a matrix built on the device (setup.hip)
+int mfx_build_col_index_device(mfx_ctx* ctx, DevCSR& m);
 int mfx_get_segments(mfx_ctx* ctx, int side, RowSegs** out);
 
 #endif

@@ -1,0 +1,322 @@
+// setup.hip -- one-time preprocessing of the train matrix on the device: the column view
+// (gk_csr_CreateIndex(GK_CSR_COL), called from Data::Data, datastruct.cpp:60-62) and the slot lists of
+// MFX_SGD_TILED.  Integer work: radix sorts / scans from rocPRIM plus a few hand-written passes; both
+// results are bit-identical to the host builders they replace (tests/test_setup_gpu.py).
+#include <cstring>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_reduce.hpp>
+#include <rocprim/device/device_run_length_encode.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "sgd_slots.h"
+
+namespace {
+// device temporaries of one build, released together
+struct Scratch {
+  std::vector<void*> ptrs;
+  ~Scratch() { for (void* p : ptrs) (void)hipFree(p); }
+  template <typename T>
+  int get(mfx_ctx* ctx, T** p, size_t n) {
+    *p = nullptr;
+    HIPCHK(hipMalloc((void**)p, (n ? n : 1) * sizeof(T)));
+    ptrs.push_back(*p);
+    return MFX_OK;
+  }
+};
+static int bits_for(uint64_t n) {   // bits needed for values in [0, n)
+  int b = 1;
+  while (b < 63 && ((uint64_t)1 << b) < n) b++;
+  return b;
+}
+constexpr int TB = 256;
+static inline int grid_for(int64_t n) { return (int)std::min<int64_t>(std::max<int64_t>((n + TB - 1) / TB, 1), 1 << 16); }
+}  // namespace
+
+template <typename K, typename V>
+static int sort_pairs(mfx_ctx* ctx, Scratch& sc, const K* kin, K* kout, const V* vin, V* vout, size_t n, int bits) {
+  size_t bytes = 0;
+  HIPCHK(rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, 0, bits, ctx->stream));
+  char* tmp;
+  int rc = sc.get(ctx, &tmp, bytes);
+  if (rc) return rc;
+  HIPCHK(rocprim::radix_sort_pairs(tmp, bytes, kin, kout, vin, vout, n, 0, bits, ctx->stream));
+  return MFX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// column view
+// ---------------------------------------------------------------------------
+__global__ void col_keys_kernel(const int32_t* __restrict__ rowind, int64_t nnz, uint32_t* __restrict__ key, uint32_t* __restrict__ val) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x) {
+    key[e] = (uint32_t)rowind[e];
+    val[e] = (uint32_t)e;
+  }
+}
+__global__ void col_gather_kernel(const uint32_t* __restrict__ src, const int32_t* __restrict__ rowid,
+                                  const float* __restrict__ rowval, int64_t nnz, int32_t* __restrict__ colind,
+                                  float* __restrict__ colval) {
+  for (int64_t d = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; d < nnz; d += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t e = src[d];
+    colind[d] = rowid[e];
+    colval[d] = rowval[e];
+  }
+}
+// ptr[j] = number of sorted keys < j
+__global__ void lower_bounds_kernel(const uint32_t* __restrict__ keys, int64_t n, int64_t nptr, int64_t* __restrict__ ptr) {
+  for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < nptr; j += (int64_t)gridDim.x * blockDim.x) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if ((int64_t)keys[mid] < j) lo = mid + 1; else hi = mid;
+    }
+    ptr[j] = lo;
+  }
+}
+
+// Stable sort of the ratings by column = the reference's counting sort: inside a column the users ascend.
+int mfx_build_col_index_device(mfx_ctx* ctx, DevCSR& m) {
+  const int64_t nnz = m.nnz;
+  NEED(nnz < ((int64_t)1 << 31), MFX_E_ARG, "column view on the device: nnz must be < 2^31");
+  int rc;
+  if ((rc = dev_alloc(ctx, &m.colptr, (size_t)m.ncols + 1))) return rc;
+  if ((rc = dev_alloc(ctx, &m.colind, (size_t)nnz))) return rc;
+  if ((rc = dev_alloc(ctx, &m.colval, (size_t)nnz))) return rc;
+  Scratch sc;
+  uint32_t *k0, *k1, *v0, *v1;
+  if ((rc = sc.get(ctx, &k0, (size_t)nnz)) || (rc = sc.get(ctx, &k1, (size_t)nnz)) || (rc = sc.get(ctx, &v0, (size_t)nnz)) ||
+      (rc = sc.get(ctx, &v1, (size_t)nnz)))
+    return rc;
+  if (nnz) {
+    hipLaunchKernelGGL(col_keys_kernel, dim3(grid_for(nnz)), dim3(TB), 0, ctx->stream, m.rowind, nnz, k0, v0);
+    if ((rc = sort_pairs(ctx, sc, k0, k1, v0, v1, (size_t)nnz, bits_for((uint64_t)std::max(m.ncols, 1))))) return rc;
+    hipLaunchKernelGGL(col_gather_kernel, dim3(grid_for(nnz)), dim3(TB), 0, ctx->stream, v1, m.rowid, m.rowval, nnz, m.colind, m.colval);
+  }
+  hipLaunchKernelGGL(lower_bounds_kernel, dim3(grid_for(m.ncols + 1)), dim3(TB), 0, ctx->stream, k1, nnz, (int64_t)m.ncols + 1, m.colptr);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  m.has_col = true;
+  return MFX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// slot lists
+// ---------------------------------------------------------------------------
+// key = tile << ownbits | owned index; value = CSR position
+__global__ void slot_keys_kernel(const int32_t* __restrict__ rowid, const int32_t* __restrict__ rowind, int64_t nnz, int side,
+                                 int ownbits, uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t u = rowid[e], i = rowind[e];
+    const uint64_t tile = (uint64_t)(slot_user_block(u) * 8 + mfx_item_block(i));
+    key[e] = (tile << ownbits) | (uint64_t)(uint32_t)(side == 0 ? i : u);
+    val[e] = (uint32_t)e;
+  }
+}
+// runs (tile, owned row) ordered inside a tile by descending length; the stable sort keeps ascending ids on ties
+__global__ void run_keys_kernel(const uint64_t* __restrict__ uniq, const uint32_t* __restrict__ cnt, int64_t R, int ownbits,
+                                int cbits, uint32_t cmax, uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < R; r += (int64_t)gridDim.x * blockDim.x) {
+    key[r] = ((uint64_t)(uniq[r] >> ownbits) << cbits) | (uint64_t)(cmax - cnt[r]);
+    val[r] = (uint32_t)r;
+  }
+}
+__global__ void run_gather_kernel(const uint32_t* __restrict__ ord, const uint64_t* __restrict__ uniq,
+                                  const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ src, int64_t R, int ownbits,
+                                  uint32_t* __restrict__ tile2, uint32_t* __restrict__ cnt2, uint32_t* __restrict__ src2,
+                                  int32_t* __restrict__ own2) {
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < R; r += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t o = ord[r];
+    const uint64_t k = uniq[o];
+    tile2[r] = (uint32_t)(k >> ownbits);
+    own2[r] = (int32_t)(k & (((uint64_t)1 << ownbits) - 1));
+    cnt2[r] = cnt[o];
+    src2[r] = src[o];
+  }
+}
+// The greedy cut of a tile's runs into slots (the loop of the host builder), one wavefront per tile:
+// 64 run lengths are loaded at a time and walked with a uniform state.
+__global__ __launch_bounds__(64) void slot_cut_kernel(const int64_t* __restrict__ trun, const uint32_t* __restrict__ cnt2, int rows,
+                                                      int32_t* __restrict__ li, uint32_t* __restrict__ head) {
+  const int t = blockIdx.x, lane = threadIdx.x;
+  const int64_t b = trun[t], e = trun[t + 1];
+  int cur_r = 0, cur_i = 0;
+  for (int64_t base = b; base < e; base += 64) {
+    const int64_t r = base + lane;
+    const int n_l = r < e ? (int)min(cnt2[r], (uint32_t)0x7fffffff) : 0;
+    const int m = (int)min((int64_t)64, e - base);
+    int my_li = 0, my_head = 0;
+    for (int j = 0; j < m; j++) {
+      const int n = __shfl(n_l, j, 64);
+      int h, l;
+      if (n > CAP_R / 2) { h = 1; l = 0; cur_r = 0; cur_i = 0; }    // a slot of its own
+      else {
+        if (cur_r + n > CAP_R || cur_i == rows) { cur_r = 0; cur_i = 0; }
+        h = cur_r == 0; l = cur_i;
+        cur_r += n; cur_i++;
+      }
+      if (j == lane) { my_li = l; my_head = h; }
+    }
+    if (r < e) { li[r] = my_li; head[r] = (uint32_t)my_head; }
+  }
+}
+__global__ void slot_heads_kernel(const uint32_t* __restrict__ head, const uint32_t* __restrict__ hs, const int64_t* __restrict__ dst,
+                                  int64_t R, int64_t nslots, int64_t nnz, const int64_t* __restrict__ trun, int ntile,
+                                  int64_t* __restrict__ slot_beg, int32_t* __restrict__ slot_ibeg, int32_t* __restrict__ tile_slot) {
+  const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  for (int64_t r = gid; r < R; r += (int64_t)gridDim.x * blockDim.x)
+    if (head[r]) { slot_beg[hs[r] - 1] = dst[r]; slot_ibeg[hs[r] - 1] = (int32_t)r; }
+  if (gid == 0) { slot_beg[nslots] = nnz; slot_ibeg[nslots] = (int32_t)R; }
+  if (gid <= ntile) tile_slot[gid] = trun[gid] < R ? (int32_t)(hs[trun[gid]] - 1) : (int32_t)nslots;
+}
+// rating o of the slot-ordered list: its run by binary search over the runs' first positions
+__global__ void slot_scatter_kernel(const int64_t* __restrict__ dst, int64_t R, int64_t nnz, const uint32_t* __restrict__ src2,
+                                    const uint32_t* __restrict__ sorted_e, const int32_t* __restrict__ li,
+                                    const int32_t* __restrict__ own2, const int32_t* __restrict__ rowid,
+                                    const int32_t* __restrict__ rowind, const float* __restrict__ rowval, int side,
+                                    int4* __restrict__ rec) {
+  for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < nnz; o += (int64_t)gridDim.x * blockDim.x) {
+    int64_t lo = 0, hi = R;              // last run with dst[run] <= o
+    while (hi - lo > 1) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (dst[mid] <= o) lo = mid; else hi = mid;
+    }
+    const uint32_t e = sorted_e[(int64_t)src2[lo] + (o - dst[lo])];
+    rec[o] = make_int4(side == 0 ? rowid[e] : rowind[e], li[lo], __float_as_int(rowval[e]), own2[lo]);
+  }
+}
+__global__ void tile_bounds_kernel(const uint32_t* __restrict__ tile2, int64_t R, int ntile, int64_t* __restrict__ trun) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t > ntile) return;
+  int64_t lo = 0, hi = R;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if ((int)tile2[mid] < t) lo = mid + 1; else hi = mid;
+  }
+  trun[t] = lo;
+}
+
+int mfx_slots_build_device(mfx_ctx* ctx, SlotList* S, int rows, int side) {
+  const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
+  const int64_t nnz = m.nnz;
+  NEED(nnz > 0 && nnz < ((int64_t)1 << 31), MFX_E_ARG, "slot lists on the device: need 0 < nnz < 2^31");
+  const int32_t nown = side == 0 ? m.ncols : m.nrows;
+  const int ownbits = bits_for((uint64_t)std::max(nown, 1)), tilebits = bits_for(NTILE);
+  Scratch sc;
+  int rc;
+  hipStream_t st = ctx->stream;
+
+  // 1. ratings grouped by (tile, owned row), CSR order inside a group
+  uint64_t *k0, *k1;
+  uint32_t *v0, *v1;
+  if ((rc = sc.get(ctx, &k0, (size_t)nnz)) || (rc = sc.get(ctx, &k1, (size_t)nnz)) || (rc = sc.get(ctx, &v0, (size_t)nnz)) ||
+      (rc = sc.get(ctx, &v1, (size_t)nnz)))
+    return rc;
+  hipLaunchKernelGGL(slot_keys_kernel, dim3(grid_for(nnz)), dim3(TB), 0, st, m.rowid, m.rowind, nnz, side, ownbits, k0, v0);
+  if ((rc = sort_pairs(ctx, sc, k0, k1, v0, v1, (size_t)nnz, ownbits + tilebits))) return rc;
+
+  // 2. runs: (tile, owned row) -> number of ratings; k0 / v0 are free again and hold the unique keys / counts
+  uint64_t* uniq = k0;
+  uint32_t* cnt = v0;
+  uint64_t* d_R;      // [0] number of runs, [1] longest run
+  if ((rc = sc.get(ctx, &d_R, 2))) return rc;
+  {
+    size_t bytes = 0;
+    HIPCHK(rocprim::run_length_encode(nullptr, bytes, k1, (unsigned)nnz, uniq, cnt, d_R, st));
+    char* tmp;
+    if ((rc = sc.get(ctx, &tmp, bytes))) return rc;
+    HIPCHK(rocprim::run_length_encode(tmp, bytes, k1, (unsigned)nnz, uniq, cnt, d_R, st));
+  }
+  uint64_t hR = 0;
+  HIPCHK(hipMemcpyAsync(&hR, d_R, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  const int64_t R = (int64_t)hR;
+  uint32_t* d_max = (uint32_t*)(d_R + 1);
+  {
+    size_t bytes = 0;
+    HIPCHK(rocprim::reduce(nullptr, bytes, cnt, d_max, 0u, (size_t)R, rocprim::maximum<uint32_t>(), st));
+    char* tmp;
+    if ((rc = sc.get(ctx, &tmp, bytes))) return rc;
+    HIPCHK(rocprim::reduce(tmp, bytes, cnt, d_max, 0u, (size_t)R, rocprim::maximum<uint32_t>(), st));
+  }
+  uint32_t cmax = 0;
+  HIPCHK(hipMemcpyAsync(&cmax, d_max, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  // first position of each run in the sorted order
+  uint32_t* src;
+  if ((rc = sc.get(ctx, &src, (size_t)R))) return rc;
+  {
+    size_t bytes = 0;
+    HIPCHK(rocprim::exclusive_scan(nullptr, bytes, cnt, src, 0u, (size_t)R, rocprim::plus<uint32_t>(), st));
+    char* tmp;
+    if ((rc = sc.get(ctx, &tmp, bytes))) return rc;
+    HIPCHK(rocprim::exclusive_scan(tmp, bytes, cnt, src, 0u, (size_t)R, rocprim::plus<uint32_t>(), st));
+  }
+  HIPCHK(hipStreamSynchronize(st));
+
+  // 3. runs of a tile by descending length
+  const int cbits = bits_for((uint64_t)cmax + 1);
+  uint64_t *rk0, *rk1;
+  uint32_t *rv0, *ord;
+  if ((rc = sc.get(ctx, &rk0, (size_t)R)) || (rc = sc.get(ctx, &rk1, (size_t)R)) || (rc = sc.get(ctx, &rv0, (size_t)R)) ||
+      (rc = sc.get(ctx, &ord, (size_t)R)))
+    return rc;
+  hipLaunchKernelGGL(run_keys_kernel, dim3(grid_for(R)), dim3(TB), 0, st, uniq, cnt, R, ownbits, cbits, cmax, rk0, rv0);
+  if ((rc = sort_pairs(ctx, sc, rk0, rk1, rv0, ord, (size_t)R, cbits + tilebits))) return rc;
+  uint32_t *tile2, *cnt2, *src2, *head, *hs;
+  int32_t *own2, *li;
+  int64_t *dst, *trun;
+  if ((rc = sc.get(ctx, &tile2, (size_t)R)) || (rc = sc.get(ctx, &cnt2, (size_t)R)) || (rc = sc.get(ctx, &src2, (size_t)R)) ||
+      (rc = sc.get(ctx, &head, (size_t)R)) || (rc = sc.get(ctx, &hs, (size_t)R)) || (rc = sc.get(ctx, &li, (size_t)R)) ||
+      (rc = sc.get(ctx, &dst, (size_t)R + 1)) || (rc = sc.get(ctx, &trun, (size_t)NTILE + 1)))
+    return rc;
+  if ((rc = dev_alloc(ctx, &own2, (size_t)R))) return rc;     // becomes S->slot_items
+  hipLaunchKernelGGL(run_gather_kernel, dim3(grid_for(R)), dim3(TB), 0, st, ord, uniq, cnt, src, R, ownbits, tile2, cnt2, src2, own2);
+  {
+    size_t bytes = 0;
+    HIPCHK(rocprim::exclusive_scan(nullptr, bytes, cnt2, dst, (int64_t)0, (size_t)R, rocprim::plus<int64_t>(), st));
+    char* tmp;
+    if ((rc = sc.get(ctx, &tmp, bytes))) { dev_free(own2); return rc; }
+    HIPCHK(rocprim::exclusive_scan(tmp, bytes, cnt2, dst, (int64_t)0, (size_t)R, rocprim::plus<int64_t>(), st));
+  }
+  hipLaunchKernelGGL(tile_bounds_kernel, dim3(1), dim3(TB), 0, st, tile2, R, NTILE, trun);
+
+  // 4. cut into slots
+  hipLaunchKernelGGL(slot_cut_kernel, dim3(NTILE), dim3(64), 0, st, trun, cnt2, rows, li, head);
+  {
+    size_t bytes = 0;
+    HIPCHK(rocprim::inclusive_scan(nullptr, bytes, head, hs, (size_t)R, rocprim::plus<uint32_t>(), st));
+    char* tmp;
+    if ((rc = sc.get(ctx, &tmp, bytes))) { dev_free(own2); return rc; }
+    HIPCHK(rocprim::inclusive_scan(tmp, bytes, head, hs, (size_t)R, rocprim::plus<uint32_t>(), st));
+  }
+  uint32_t hns = 0;
+  if (hipMemcpyAsync(&hns, hs + (R - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess) {
+    dev_free(own2);
+    return mfx_fail(ctx, MFX_E_HIP, "slot lists on the device: %s", hipGetErrorString(hipGetLastError()));
+  }
+  const int64_t nslots = (int64_t)hns;
+
+  dev_free(S->rec); dev_free(S->slot_beg); dev_free(S->slot_ibeg); dev_free(S->slot_items); dev_free(S->tile_slot);
+  S->slot_items = own2;
+  if ((rc = dev_alloc(ctx, &S->rec, (size_t)nnz * 4)) || (rc = dev_alloc(ctx, &S->slot_beg, (size_t)nslots + 1)) ||
+      (rc = dev_alloc(ctx, &S->slot_ibeg, (size_t)nslots + 1)) || (rc = dev_alloc(ctx, &S->tile_slot, (size_t)NTILE + 1)))
+    return rc;
+  if (!S->ctr && (rc = dev_alloc(ctx, &S->ctr, (size_t)NTILE))) return rc;
+  static_assert(NTILE + 1 <= TB, "tile_slot is written by the first workgroup");
+  hipLaunchKernelGGL(slot_heads_kernel, dim3(grid_for(R)), dim3(TB), 0, st, head, hs, dst, R, nslots, nnz, trun, NTILE,
+                     S->slot_beg, S->slot_ibeg, S->tile_slot);
+  // 5. the ratings in slot order
+  hipLaunchKernelGGL(slot_scatter_kernel, dim3(grid_for(nnz)), dim3(TB), 0, st, dst, R, nnz, src2, v1, li, own2, m.rowid, m.rowind,
+                     m.rowval, side, (int4*)S->rec);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(st));
+  if (getenv("MFX_DEBUG"))
+    fprintf(stderr, "[mfx] slots (%s rows owned, device build): %lld for %lld ratings, %lld row refs, longest run %u\n",
+            side == 0 ? "item" : "user", (long long)nslots, (long long)nnz, (long long)R, cmax);
+  S->nslots = nslots;
+  S->nnz = nnz;
+  S->rows = rows;
+  S->built = true;
+  return MFX_OK;
+}

@@ -1,0 +1,40 @@
+// sgd_slots.h -- slot lists of MFX_SGD_TILED, shared by the kernel (sgd_slots.hip) and the device-side
+// builder (setup.hip).
+#ifndef MFX_SGD_SLOTS_H_
+#define MFX_SGD_SLOTS_H_
+
+#include "mfx_internal.h"
+
+constexpr int CAP_R = 1024;   // ratings per slot
+// User blocks per XCD (MFX_NUB): 8*SUB user blocks x 8 item blocks = 64*SUB tiles, 8*SUB rounds per epoch.
+#ifndef MFX_SUB
+#define MFX_SUB 1
+#endif
+constexpr int SUB = MFX_SUB, NUB = 8 * SUB, NTILE = NUB * 8;
+__host__ __device__ static inline int slot_user_block(int32_t u) {
+  return (int)(mfx_mix32((uint32_t)u * 0x9e3779b1U + 0x1234567U) & (uint32_t)(NUB - 1));
+}
+constexpr int WG = 1024;      // threads per workgroup: 16 waves = 64 ratings in flight on one slot
+
+struct SlotList {
+  int32_t* rec = nullptr;          // int4 per rating: other-side index, local owned index, rating bits, owned index
+  int64_t* slot_beg = nullptr;     // [nslots+1] rating range of a slot
+  int32_t* slot_ibeg = nullptr;    // [nslots+1] range into slot_items
+  int32_t* slot_items = nullptr;   // global item ids of every slot
+  int32_t* tile_slot = nullptr;    // [NTILE+1] slot range of a tile
+  unsigned* ctr = nullptr;         // [NTILE] slot counters
+  int64_t nslots = 0, nnz = 0;
+  int rows = 0;                    // owned rows per slot the lists were built for
+  bool built = false;
+};
+// side 0: item rows owned (slots item-major), side 1: user rows owned (slots user-major)
+struct SlotState {
+  SlotList side[2];
+  uint32_t last_k0 = 0, last_k1 = 0;
+  int last_side = 0;
+};
+
+// builds S on the device from the train matrix (setup.hip); same lists as the host builder in sgd_slots.hip
+int mfx_slots_build_device(mfx_ctx* ctx, SlotList* S, int rows, int side);
+
+#endif

@@ -26,37 +26,8 @@
 #include <vector>
 
 #include "sgd_common.h"
+#include "sgd_slots.h"
 
-namespace {
-constexpr int CAP_R = 1024;   // ratings per slot
-// User blocks per XCD (MFX_NUB): 8*SUB user blocks x 8 item blocks = 64*SUB tiles, 8*SUB rounds per epoch.
-#ifndef MFX_SUB
-#define MFX_SUB 1
-#endif
-constexpr int SUB = MFX_SUB, NUB = 8 * SUB, NTILE = NUB * 8;
-__host__ __device__ static inline int slot_user_block(int32_t u) {
-  return (int)(mfx_mix32((uint32_t)u * 0x9e3779b1U + 0x1234567U) & (uint32_t)(NUB - 1));
-}
-constexpr int WG = 1024;      // threads per workgroup: 16 waves = 64 ratings in flight on one slot
-
-struct SlotList {
-  int32_t* rec = nullptr;          // int4 per rating: other-side index, local owned index, rating bits, owned index
-  int64_t* slot_beg = nullptr;     // [nslots+1] rating range of a slot
-  int32_t* slot_ibeg = nullptr;    // [nslots+1] range into slot_items
-  int32_t* slot_items = nullptr;   // global item ids of every slot
-  int32_t* tile_slot = nullptr;    // [NTILE+1] slot range of a tile
-  unsigned* ctr = nullptr;         // [NTILE] slot counters
-  int64_t nslots = 0, nnz = 0;
-  int rows = 0;                    // owned rows per slot the lists were built for
-  bool built = false;
-};
-// side 0: item rows owned (slots item-major), side 1: user rows owned (slots user-major)
-struct SlotState {
-  SlotList side[2];
-  uint32_t last_k0 = 0, last_k1 = 0;
-  int last_side = 0;
-};
-}  // namespace
 
 static SlotState* state(mfx_ctx* ctx) { return (SlotState*)ctx->slots; }
 
@@ -72,7 +43,7 @@ void mfx_slots_free_internal(mfx_ctx* ctx) {
 }
 
 // ---------------------------------------------------------------------------
-// slot lists (host, once per train matrix and rank shape)
+// slot lists (once per train matrix and rank shape)
 // ---------------------------------------------------------------------------
 template <typename T>
 static int up(mfx_ctx* ctx, T** dst, const std::vector<T>& v) {
@@ -85,6 +56,9 @@ static int up(mfx_ctx* ctx, T** dst, const std::vector<T>& v) {
 static int build_slots(mfx_ctx* ctx, SlotList* S, int rows, int side) {
   const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
   const int64_t nnz = m.nnz;
+  // the device builder (setup.hip) makes the same lists; this host version is the readable statement of
+  // them, the cross-check of tests/test_setup_gpu.py (MFX_SLOTS_HOST=1) and the path for nnz >= 2^31
+  if (nnz > 0 && nnz < ((int64_t)1 << 31) && !getenv("MFX_SLOTS_HOST")) return mfx_slots_build_device(ctx, S, rows, side);
   std::vector<int32_t> ru((size_t)nnz), ri((size_t)nnz);
   std::vector<float> rv((size_t)nnz);
   if (nnz) {
@@ -509,5 +483,37 @@ int mfx_slots_materialise_order(mfx_ctx* ctx) {
                      S->slot_beg, S->nslots, st->last_side, st->last_k0, st->last_k1, ctx->eu, ctx->ei, ctx->er);
   HIPCHK(hipGetLastError());
   ctx->elist_n = S->nnz;
+  return MFX_OK;
+}
+
+static uint64_t fnv1a(const void* p, size_t n, uint64_t h = 1469598103934665603ULL) {
+  const uint8_t* b = (const uint8_t*)p;
+  for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ULL; }
+  return h;
+}
+template <typename T>
+static int digest_dev(mfx_ctx* ctx, const T* dev, size_t n, uint64_t* out) {
+  std::vector<T> h(n);
+  if (n) HIPCHK(hipMemcpy(h.data(), dev, sizeof(T) * n, hipMemcpyDeviceToHost));
+  *out = fnv1a(h.data(), sizeof(T) * n);
+  return MFX_OK;
+}
+extern "C" int mfx_debug_slots_digest(mfx_ctx* ctx, int64_t counts[4], uint64_t sums[5]) {
+  if (!ctx) return MFX_E_ARG;
+  SlotState* st = state(ctx);
+  NEED(st && st->side[st->last_side].built && counts && sums, MFX_E_STATE, "mfx_debug_slots_digest: no tiled epoch has run");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const SlotList& S = st->side[st->last_side];
+  std::vector<int32_t> ib((size_t)S.nslots + 1);
+  HIPCHK(hipMemcpy(ib.data(), S.slot_ibeg, sizeof(int32_t) * ib.size(), hipMemcpyDeviceToHost));
+  const int64_t refs = ib[(size_t)S.nslots];
+  counts[0] = S.nslots; counts[1] = S.nnz; counts[2] = refs; counts[3] = S.rows;
+  int rc;
+  if ((rc = digest_dev(ctx, S.rec, (size_t)S.nnz * 4, &sums[0]))) return rc;
+  if ((rc = digest_dev(ctx, S.slot_beg, (size_t)S.nslots + 1, &sums[1]))) return rc;
+  if ((rc = digest_dev(ctx, S.slot_ibeg, (size_t)S.nslots + 1, &sums[2]))) return rc;
+  if ((rc = digest_dev(ctx, S.slot_items, (size_t)refs, &sums[3]))) return rc;
+  if ((rc = digest_dev(ctx, S.tile_slot, (size_t)NTILE + 1, &sums[4]))) return rc;
   return MFX_OK;
 }

@@ -149,6 +149,20 @@ class Ctx:
                                                 r.ctypes.data_as(C.c_void_p), C.c_int64(n.value), C.byref(n)))
         return u, i, r
 
+    def debug_slots_digest(self):
+        counts = (C.c_int64 * 4)()
+        sums = (C.c_uint64 * 5)()
+        self._chk(self.lib.mfx_debug_slots_digest(self.h, counts, sums))
+        return list(counts), list(sums)
+
+    def debug_col_view(self, ncols, nnz):
+        cp = np.empty(ncols + 1, np.int64)
+        ci = np.empty(nnz, np.int32)
+        cv = np.empty(nnz, np.float32)
+        self._chk(self.lib.mfx_debug_col_view(self.h, cp.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p),
+                                              cv.ctypes.data_as(C.c_void_p)))
+        return cp, ci, cv
+
     # ---- evaluation -----------------------------------------------------------
     def eval(self, which, snapshot=SNAP_CURRENT, with_norms=False):
         out = EvalOut()
