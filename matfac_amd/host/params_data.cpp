@@ -53,8 +53,9 @@ void Data::finish() {
   maxItemInd = max_item(testMat, maxItemInd);
   maxItemInd = max_item(valMat, maxItemInd);
   nItems = maxItemInd + 1;
-  for (csr_t* m : {trainMat, testMat, valMat})
-    if (m && !m->colptr) csr_create_col_index(m);
+  // The reference builds the column views here (gk_csr_CreateIndex, datastruct.cpp:60-62).  The MF path reads
+  // only the train matrix' column view, and only on the device: mfx_set_csr builds it there (setup.hip) when
+  // none is passed.  csr_create_col_index(m) is there for a caller that wants one on the host.
 }
 
 Data::Data(csr_t* p_trainMat, csr_t* p_testMat) : trainMat(p_trainMat), testMat(p_testMat) {

@@ -89,3 +89,38 @@ def test_init_factors_stream_and_generator_invariants():
     # same item catalogue across shards: the popular items coincide
     top = lambda m: set(np.argsort(np.bincount(m.rowind, minlength=1682))[-20:])
     assert len(top(f) & top(c["full"])) >= 12
+
+
+def test_parallel_reader_number_formats_and_piece_cuts(tmp_path):
+    """The mapped, multi-piece reader against the oracle's getline/strtol/strtof reader: every float spelling
+    bit for bit, comment/empty lines and a missing final newline, on a file big enough for several pieces."""
+    rng = np.random.default_rng(5)
+    vals = rng.normal(3, 2, 400000).astype(np.float32)
+    spell = ["%.9g", "%g", "%.3f", "%.17g", "%e", "%.1f", "%.12f"]
+    special = ["inf", "-inf", "+3", ".5", "5.", "1e+5", "1E-3", "0x1.8p1", "1e-40", "3.4028235e38", "1e39", "0",
+               "-0.0", "0.1", "16777217", "8388608.5", "8388609.5", "0.000000000000000000001", "123456789012345678",
+               "1.00000005960464477539", "1.0000000596046447753906250", "1.00000017881393432617187500"]
+    lines, k = [], 0
+    for u in range(30000):
+        if u % 997 == 0:
+            lines.append("% a comment line that is not a user")
+        n = int(rng.integers(0, 25))
+        toks = []
+        for _ in range(n):
+            v = special[k % len(special)] if k % 53 == 0 else spell[k % len(spell)] % vals[k % len(vals)]
+            toks.append("%d %s" % (int(rng.integers(0, 50000)), v))
+            k += 1
+        sep = "  " if u % 5 == 0 else " "
+        lines.append(("\t" if u % 7 == 0 else "") + sep.join(toks) + (" \r" if u % 11 == 0 else ""))
+    p = str(tmp_path / "big.csr")
+    open(p, "w").write("\n".join(lines))                                   # no newline at the end
+    assert len("\n".join(lines)) > 3 << 20
+    nr, nc, rp, ri, rv, *_ = host_read(p, want_cols=False)
+    onr, onc, orp, ori, orv = orc.read_csr_text(p)
+    assert (nr, nc) == (onr, onc) and nr == 30000
+    assert np.array_equal(rp, orp) and np.array_equal(ri, ori)
+    assert np.array_equal(rv.view(np.uint32), orv.view(np.uint32))        # bit patterns: -0.0, inf, roundings
+    open(p, "a").write("\n7 x\n")
+    with pytest.raises(IOError) as e:
+        host_read(p)
+    assert "line %d" % (len(lines) + 1) in str(e.value)
