@@ -173,6 +173,22 @@ int mfx_ccdpp_end(mfx_ctx* ctx);
 /* test hook: the two residual views */
 int mfx_debug_residuals(mfx_ctx* ctx, float* res_row, float* res_col);
 
+/* ---- cyclic coordinate descent: replaces the loops of ModelMF::trainCCD
+ *      (modelMF.cpp:1528-1565 users, :1567-1605 items) -------------------------- */
+/* res = gk_csr_Dup(trainMat) on both views (:1509) and uFac = 0 (:1516-1522).
+ * Needs the stable column view (the one gk_csr_CreateIndex / mfx_set_csr build).  */
+int mfx_ccd_begin(mfx_ctx* ctx);
+/* One sweep over the users (MFX_SIDE_USERS, reg = uReg) or the items.  Every row
+ * visits the K factors in its own order: order[row * K + step] (host, one row per
+ * user resp. item of the train matrix; the reference's std::shuffle(udims, mt),
+ * :1539-1540) or, with order == NULL, a permutation derived on the device from
+ * (seed, iter, side, row).                                                        */
+int mfx_ccd_sweep(mfx_ctx* ctx, int32_t side, float reg, const uint16_t* order, uint32_t seed,
+                  int32_t iter);
+int mfx_ccd_end(mfx_ctx* ctx);
+/* test hook: the residuals on both views (either pointer may be NULL) */
+int mfx_debug_ccd_residuals(mfx_ctx* ctx, float* res_row, float* res_col);
+
 /* ---- multi-GPU: user-row-block sharding, item-factor exchange over RCCL ------ */
 /* The reference is single-process; this is new.  Each rank owns a
  * user block (its CSR rows + U shard) and a replica of V.  After local work,
@@ -196,7 +212,8 @@ enum {
   MFX_K_SGD = 0, MFX_K_PERMUTE = 1, MFX_K_EVAL = 2, MFX_K_ALS_GRAM = 3,
   MFX_K_ALS_SOLVE = 4, MFX_K_CCD_ROW = 5, MFX_K_CCD_COL = 6, MFX_K_CCD_RESID = 7,
   MFX_K_SGD_SWEEP = 8, /* MFX_SGD_TILED: the placement-independent leftover sweep */
-  MFX_K_COUNT = 9
+  MFX_K_CD = 9,        /* one mfx_ccd_sweep (transpose + row kernels + view copy) */
+  MFX_K_COUNT = 10
 };
 int mfx_prof_enable(mfx_ctx* ctx, int on);
 int mfx_prof_reset(mfx_ctx* ctx);

@@ -100,6 +100,7 @@ void mfx_destroy(mfx_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   mfx_comm_free_internal(ctx);
   mfx_ccd_free_internal(ctx);
+  mfx_cd_free_internal(ctx);
   mfx_als_free_internal(ctx);
   mfx_segs_free_internal(ctx);
   for (auto& m : ctx->mat) free_csr(m);
@@ -158,7 +159,7 @@ extern "C" int mfx_set_csr(mfx_ctx* ctx, int which, int32_t nrows, int32_t ncols
   HIPCHK(hipSetDevice(ctx->device));
   DevCSR& m = ctx->mat[which];
   free_csr(m);
-  if (which == MFX_MAT_TRAIN) { mfx_ccd_free_internal(ctx); mfx_als_free_internal(ctx); mfx_segs_free_internal(ctx); mfx_slots_free_internal(ctx); }
+  if (which == MFX_MAT_TRAIN) { mfx_ccd_free_internal(ctx); mfx_cd_free_internal(ctx); mfx_als_free_internal(ctx); mfx_segs_free_internal(ctx); mfx_slots_free_internal(ctx); }
   int rc;
   if ((rc = dev_alloc(ctx, &m.rowptr, (size_t)nrows + 1))) return rc;
   if ((rc = dev_alloc(ctx, &m.rowind, (size_t)nnz))) return rc;
@@ -224,6 +225,7 @@ extern "C" int mfx_set_model(mfx_ctx* ctx, int32_t nUsers, int32_t nItems, int32
   HIPCHK(hipSetDevice(ctx->device));
   free_model(ctx);
   mfx_ccd_free_internal(ctx);
+  mfx_cd_free_internal(ctx);
   ctx->nU = nUsers; ctx->nI = nItems; ctx->K = K;
   mfx_tree_shape(K, &ctx->L, &ctx->C);
   ctx->ld = 4 * ctx->L * ctx->C;

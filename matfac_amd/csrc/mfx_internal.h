@@ -91,6 +91,7 @@ struct mfx_ctx {
   int64_t ccd_part_cap = 0;
   int32_t* colid = nullptr;
   void* ccd_cols = nullptr;   // strip-major column view (ccd_cols.hip owns the type)
+  void* cd = nullptr;         // trainCCD state (cd.hip owns the type)
 
   // comm
   void* comm = nullptr;      // ncclComm_t
@@ -194,6 +195,9 @@ int mfx_ccd_cols_resid(mfx_ctx* ctx, int mode, const float* uk0, const float* vk
 int mfx_ccd_cols_export(mfx_ctx* ctx, float* host_out);
 // column view of a matrix built on the device (setup.hip)
 int mfx_build_col_index_device(mfx_ctx* ctx, DevCSR& m);
+// map[d] = CSR position of the d-th entry of the (stable) column view (setup.hip); caller frees
+int mfx_build_c2r_map_device(mfx_ctx* ctx, const DevCSR& m, uint32_t** map);
+void mfx_cd_free_internal(mfx_ctx* ctx);
 int mfx_get_segments(mfx_ctx* ctx, int side, RowSegs** out);
 
 #endif

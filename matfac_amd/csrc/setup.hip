@@ -100,6 +100,21 @@ int mfx_build_col_index_device(mfx_ctx* ctx, DevCSR& m) {
   return MFX_OK;
 }
 
+int mfx_build_c2r_map_device(mfx_ctx* ctx, const DevCSR& m, uint32_t** map) {
+  const int64_t nnz = m.nnz;
+  NEED(nnz < ((int64_t)1 << 31), MFX_E_ARG, "position map on the device: nnz must be < 2^31");
+  int rc;
+  if ((rc = dev_alloc(ctx, map, (size_t)nnz))) return rc;
+  if (!nnz) return MFX_OK;
+  Scratch sc;
+  uint32_t *k0, *k1, *v0;
+  if ((rc = sc.get(ctx, &k0, (size_t)nnz)) || (rc = sc.get(ctx, &k1, (size_t)nnz)) || (rc = sc.get(ctx, &v0, (size_t)nnz))) return rc;
+  hipLaunchKernelGGL(col_keys_kernel, dim3(grid_for(nnz)), dim3(TB), 0, ctx->stream, m.rowind, nnz, k0, v0);
+  if ((rc = sort_pairs(ctx, sc, k0, k1, v0, *map, (size_t)nnz, bits_for((uint64_t)std::max(m.ncols, 1))))) return rc;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return MFX_OK;
+}
+
 // ---------------------------------------------------------------------------
 // slot lists
 // ---------------------------------------------------------------------------

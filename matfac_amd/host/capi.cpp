@@ -27,6 +27,7 @@ extern "C" int mfh_train(const char* method, int32_t nrows, const int64_t* tr_pt
   const std::string m = method;
   if (m == "ccd++") model.trainCCDPPFreqAdap(data, best, iu, ii);
   else if (m == "ccdpp") model.trainCCDPP(data, best, iu, ii);
+  else if (m == "ccd") model.trainCCD(data, best, iu, ii);
   else if (m == "als") model.trainALS(data, best, iu, ii);
   else if (m == "hogsgd") model.hogTrain(data, best, iu, ii);
   else if (m == "sgdu") model.trainUShuffle(data, best, iu, ii);

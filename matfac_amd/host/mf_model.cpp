@@ -350,11 +350,7 @@ void ModelMF::trainCCDPP(const Data& d, Model& b, IntSet& iu, IntSet& ii) { run(
 void ModelMF::trainCCDPPFreqAdap(const Data& d, Model& b, IntSet& iu, IntSet& ii) {
   run(K_CCDPP_FA, "trainCCDPPFreqAdap", d, b, iu, ii);
 }
-void ModelMF::trainCCD(const Data&, Model&, IntSet&, IntSet&) {
-  // modelMF.cpp:1426-1653 (row-wise cyclic CD with a binary search per rating) is not on the
-  // MI355X path of this build; CCD++ (trainCCDPP / trainCCDPPFreqAdap) is.  See DESIGN.md.
-  std::cerr << "\nModelMF::trainCCD is not available in the MI355X build; use ccd++" << std::endl;
-}
+void ModelMF::trainCCD(const Data& d, Model& b, IntSet& iu, IntSet& ii) { run(K_CCD, "trainCCD", d, b, iu, ii); }
 void ModelMF::trainSGDParSVD(const Data&, Model&, IntSet&, IntSet&) {
   // needs SVDLIBC (svdLAS2A) for the initialisation (modelMF.cpp:368); not part of this build
   std::cerr << "\nModelMF::trainSGDParSVD needs SVDLIBC and is not available in the MI355X build" << std::endl;
@@ -413,6 +409,9 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
   std::vector<int> dims(facDim);
   std::iota(dims.begin(), dims.end(), 0);
   if (kind == K_CCDPP || kind == K_CCDPP_FA) dev->check(mfx_ccdpp_begin(dev->ctx), "mfx_ccdpp_begin");
+  // trainCCD: res = gk_csr_Dup(trainMat), uFac = 0 (modelMF.cpp:1509-1522)
+  std::vector<uint16_t> uOrder, iOrder;
+  if (kind == K_CCD) dev->check(mfx_ccd_begin(dev->ctx), "mfx_ccd_begin");
 
   mfx_sgd_opts o;
   o.uReg = uReg; o.iReg = iReg; o.seed = (uint32_t)trainSeed; o.blocks = 0; o.own = 0; o.first = 0; o.count = 0;
@@ -470,6 +469,28 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
           dev->check(mfx_ccdpp_rank1(dev->ctx, k, 5, uReg, iReg, iter > 0, kind == K_CCDPP_FA ? 75.0f : -1.0f),
                      "mfx_ccdpp_rank1");
         break;
+      case K_CCD: {
+        const uint16_t *uo = nullptr, *io = nullptr;
+        if (exact) {
+          // the reference draws every row's factor order from the shared mt (modelMF.cpp:1539-1540,
+          // :1577-1578); on one thread that is users in order, then items in order
+          uOrder.assign((size_t)trainMat->nrows * facDim, 0);
+          iOrder.assign((size_t)trainMat->ncols * facDim, 0);
+          auto draw = [&](std::vector<uint16_t>& out, int row) {
+            std::vector<int> udims(dims);
+            std::shuffle(udims.begin(), udims.end(), mt);
+            for (int s = 0; s < facDim; s++) out[(size_t)row * facDim + s] = (uint16_t)udims[s];
+          };
+          for (int u = 0; u < nUsers; u++)
+            if (!invalidUsers.count(u)) draw(uOrder, u);
+          for (int item = 0; item < nItems; item++)
+            if (!invalidItems.count(item) && item < trainMat->ncols) draw(iOrder, item);
+          uo = uOrder.data(); io = iOrder.data();
+        }
+        dev->check(mfx_ccd_sweep(dev->ctx, MFX_SIDE_USERS, uReg, uo, (uint32_t)trainSeed, iter), "mfx_ccd_sweep");
+        dev->check(mfx_ccd_sweep(dev->ctx, MFX_SIDE_ITEMS, iReg, io, (uint32_t)trainSeed, iter), "mfx_ccd_sweep");
+        break;
+      }
     }
     hostStale = true;
     dev->check(mfx_synchronize(dev->ctx), "mfx_synchronize");
@@ -494,6 +515,7 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
   if (kind != K_SGDPAR) bestModel.saveFacs(std::string(data.prefix));
   std::cout << "\nBest model validation RMSE: " << bestModel.RMSE(data.valMat, invalidUsers, invalidItems);
   if (kind == K_CCDPP || kind == K_CCDPP_FA) dev->check(mfx_ccdpp_end(dev->ctx), "mfx_ccdpp_end");
+  if (kind == K_CCD) dev->check(mfx_ccd_end(dev->ctx), "mfx_ccd_end");
   syncHost();
   bestModel.syncHost();
 }

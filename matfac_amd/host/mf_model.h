@@ -129,7 +129,7 @@ class ModelMF : public Model {
   void hogTrain(const Data& data, Model& bestModel, IntSet& invalidUsers, IntSet& invalidItems) override;
 
  private:
-  enum Kind { K_SGD, K_HOG, K_SGDPAR, K_SGDU, K_ALS, K_CCDPP, K_CCDPP_FA };
+  enum Kind { K_SGD, K_HOG, K_SGDPAR, K_SGDU, K_ALS, K_CCDPP, K_CCDPP_FA, K_CCD };
   void run(Kind kind, const char* name, const Data& data, Model& bestModel, IntSet& invalidUsers,
            IntSet& invalidItems);
 };

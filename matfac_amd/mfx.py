@@ -14,7 +14,7 @@ SGD_HOGWILD, SGD_SERIAL, SGD_USERS, SGD_TILED = 0, 1, 2, 3
 ORDER_DEVICE, ORDER_HOST, ORDER_NATURAL = 0, 1, 2
 ARITH_REF64, ARITH_REF64F, ARITH_F32 = 0, 1, 2
 REDUCE_DELTA_SUM, REDUCE_AVERAGE = 0, 1
-K_SGD, K_PERMUTE, K_EVAL, K_ALS_GRAM, K_ALS_SOLVE, K_CCD_ROW, K_CCD_COL, K_CCD_RESID, K_SGD_SWEEP = range(9)
+K_SGD, K_PERMUTE, K_EVAL, K_ALS_GRAM, K_ALS_SOLVE, K_CCD_ROW, K_CCD_COL, K_CCD_RESID, K_SGD_SWEEP, K_CD = range(10)
 E_NODEVICE = -6
 
 
@@ -196,6 +196,24 @@ class Ctx:
         a = np.empty(nnz, np.float32)
         b = np.empty(nnz, np.float32)
         self._chk(self.lib.mfx_debug_residuals(self.h, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)))
+        return a, b
+
+    # ---- cyclic coordinate descent (trainCCD) ---------------------------------------
+    def ccd_begin(self):
+        self._chk(self.lib.mfx_ccd_begin(self.h))
+
+    def ccd_sweep(self, side, reg, order=None, seed=1, it=0):
+        keep = _p(order, np.uint16)
+        self._chk(self.lib.mfx_ccd_sweep(self.h, C.c_int32(side), C.c_float(reg), keep[1] if keep else None,
+                                         C.c_uint32(seed), C.c_int32(it)))
+
+    def ccd_end(self):
+        self._chk(self.lib.mfx_ccd_end(self.h))
+
+    def debug_ccd_residuals(self, nnz):
+        a = np.empty(nnz, np.float32)
+        b = np.empty(nnz, np.float32)
+        self._chk(self.lib.mfx_debug_ccd_residuals(self.h, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)))
         return a, b
 
     # ---- multi-GPU ------------------------------------------------------------

@@ -238,10 +238,15 @@ def ccdpp_rank1(k, U, V, nUsers, nItems, ncols, rowptr, rowind, res_row, colptr,
 
 
 def ccd_iter(U, V, nUsers, nItems, ncols, rowptr, rowind, res_row, colptr, colind, res_col, invU, invI,
-             uReg, iReg, mt):
+             uReg, iReg, mt=None, uorder=None, iorder=None, orders_given=False):
+    """One trainCCD iteration.  uorder/iorder: uint16 [n][K] factor orders per row -- used when
+    orders_given, else filled with what std::shuffle(udims, mt) produced."""
+    for o in (uorder, iorder):
+        assert o is None or (o.dtype == np.uint16 and o.flags.c_contiguous)
+    P = lambda o: o.ctypes.data_as(C.c_void_p) if o is not None else None
     lib.orc_ccd_iter(U.shape[1], F(U), F(V), nUsers, nItems, ncols, I64(rowptr), I32(rowind), F(res_row),
                      I64(colptr), I32(colind), F(res_col), U8(invU), U8(invI), C.c_float(uReg),
-                     C.c_float(iReg), mt.h)
+                     C.c_float(iReg), mt.h if mt is not None else None, P(uorder), P(iorder), int(orders_given))
 
 
 def train(method, U0, V0, train_csr, val_csr, nUsers, nItems, K, maxIter, seed, lr, uReg, iReg,

@@ -632,16 +632,28 @@ void orc_ccd_iter(int K, float* U, float* V, int32_t nUsers, int32_t nItems, int
                   const int64_t* rowptr, const int32_t* rowind, float* res_row,
                   const int64_t* colptr, const int32_t* colind, float* res_col,
                   const uint8_t* invU, const uint8_t* invI, float uReg, float iReg,
-                  void* mth) {
-  std::mt19937& mt = *(std::mt19937*)mth;
+                  void* mth, uint16_t* uorder, uint16_t* iorder, int orders_given) {
+  // uorder [nUsers][K] / iorder [nItems][K]: the factor order of every row.  orders_given: take them
+  // from the caller; otherwise they come from std::shuffle(udims, mt) as in the reference and are
+  // written out (when non-NULL) so that a test can replay them elsewhere.
+  std::mt19937 dummy;
+  std::mt19937& mt = mth ? *(std::mt19937*)mth : dummy;
   std::vector<int> dims(K);
   std::iota(dims.begin(), dims.end(), 0);
+  auto row_order = [&](uint16_t* store, int row) {
+    std::vector<int> udims(dims);
+    if (orders_given) { for (int s = 0; s < K; s++) udims[s] = store[(int64_t)row * K + s]; }
+    else {
+      std::shuffle(udims.begin(), udims.end(), mt);
+      if (store) for (int s = 0; s < K; s++) store[(int64_t)row * K + s] = (uint16_t)udims[s];
+    }
+    return udims;
+  };
 #define UF(u, k) U[(int64_t)(u) * K + (k)]
 #define IF(i, k) V[(int64_t)(i) * K + (k)]
   for (int u = 0; u < nUsers; u++) {
     if (invU[u]) continue;
-    std::vector<int> udims(dims);
-    std::shuffle(udims.begin(), udims.end(), mt);
+    std::vector<int> udims = row_order(uorder, u);
     for (const auto& k : udims) {
       double num = 0, denom = uReg, newV;
       for (int64_t ii = rowptr[u]; ii < rowptr[u + 1]; ii++) {
@@ -662,8 +674,7 @@ void orc_ccd_iter(int K, float* U, float* V, int32_t nUsers, int32_t nItems, int
   }
   for (int item = 0; item < nItems; item++) {
     if (invI[item] || item >= ncols) continue;
-    std::vector<int> udims(dims);
-    std::shuffle(udims.begin(), udims.end(), mt);
+    std::vector<int> udims = row_order(iorder, item);
     for (const auto& k : udims) {
       double num = 0, denom = iReg, newV;
       for (int64_t uu = colptr[item]; uu < colptr[item + 1]; uu++) {
@@ -804,7 +815,7 @@ int orc_train(const orc_train_cfg* c, float* U, float* V, float* Ubest, float* V
       case ORC_M_CCD:
         orc_ccd_iter(K, cur.U.data(), cur.V.data(), nU, nI, c->tr_ncols, c->tr_rowptr,
                      c->tr_rowind, res_row.data(), c->tr_colptr, c->tr_colind, res_col.data(),
-                     invU, invI, uReg, iReg, &mt);
+                     invU, invI, uReg, iReg, &mt, nullptr, nullptr, 0);
         break;
     }
 

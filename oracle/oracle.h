@@ -146,7 +146,7 @@ void orc_ccd_iter(int K, float* U, float* V, int32_t nUsers, int32_t nItems,
                   int32_t ncols, const int64_t* rowptr, const int32_t* rowind,
                   float* res_row, const int64_t* colptr, const int32_t* colind,
                   float* res_col, const uint8_t* invU, const uint8_t* invI, float uReg,
-                  float iReg, void* mt);
+                  float iReg, void* mt, uint16_t* uorder, uint16_t* iorder, int orders_given);
 
 /* ---- full training loops with isTerminateModel (model.cpp:1471-1540) ---- */
 enum {

@@ -58,3 +58,26 @@ if "ccd" in what:
                           row_pass_GBs=8 * tr.nnz / (r_ms / max(r_n, 1) * 1e-3) / 1e9,
                           resid_GBs=2 * 12 * tr.nnz / (x_ms / max(x_n, 1) * 1e-3) / 1e9)), flush=True)
     ctx.ccdpp_end(); ctx.close()
+if "cd" in what:      # trainCCD (a12) on the C2 matrix
+    K = int(os.environ.get("CD_K", 64))
+    shape = dict(synth.SHAPES["C2"]); shape["nnz"] = int(shape["nnz"] / 0.8)
+    d = synth.make(shape, seed=1); tr, va = d["train"], d["val"]; nU, nI = d["nUsers"], shape["nI"]
+    U0, V0 = synth.init_factors(1, nU, nI, K)
+    ctx = Ctx(0)
+    ctx.set_csr(mfx.MAT_TRAIN, tr.nrows, nI, tr.rowptr, tr.rowind, tr.rowval)
+    ctx.set_csr(mfx.MAT_VAL, va.nrows, nI, va.rowptr, va.rowind, va.rowval)
+    ctx.set_model(nU, nI, K); ctx.set_factors(U0, V0); ctx.compute_invalid()
+    t0 = time.perf_counter(); ctx.ccd_begin(); ctx.synchronize(); begin = time.perf_counter() - t0
+    reg = 5.0
+    ctx.prof_enable(True)
+    traj = []; su = si = 0.0
+    iters = 4
+    for it in range(iters):
+        ctx.prof_reset(); ctx.ccd_sweep(mfx.SIDE_USERS, reg, None, 1, it); ctx.synchronize(); su += ctx.prof_get(mfx.K_CD)[0]
+        ctx.prof_reset(); ctx.ccd_sweep(mfx.SIDE_ITEMS, reg, None, 1, it); ctx.synchronize(); si += ctx.prof_get(mfx.K_CD)[0]
+        traj.append(round(ctx.rmse(mfx.MAT_VAL), 5))
+    # per (rating, k): residual 4 B read + 4 B write, index 4 B, gathered element 4 B
+    print(json.dumps(dict(path="CCD (trainCCD) C2", nnz=tr.nnz, K=K, begin_s=begin, user_sweep_ms=su / iters, item_sweep_ms=si / iters,
+                          ms_per_iter=(su + si) / iters, rating_factor_updates_per_s=2 * tr.nnz * K / ((su + si) / iters * 1e-3),
+                          val_rmse=traj)), flush=True)
+    ctx.ccd_end(); ctx.close()

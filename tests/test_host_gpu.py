@@ -109,6 +109,22 @@ def test_als_and_ccdpp_loops_match_oracle(method, om, reg):
     assert np.abs(h["Ubest"] - o["Ubest"]).max() < (1e-3 if method == "als" else 1e-4) * scale
 
 
+def test_ccd_loop_matches_oracle_with_replayed_factor_orders_and_converges_with_device_orders():
+    """trainCCD: with MFX_EXACT the host draws every row's factor order from mt19937 as the one-thread reference
+    does (modelMF.cpp:1539-1540); otherwise the orders come from the device and only the quality is comparable."""
+    d, K = data(), 16
+    o = oracle_train(orc.M_CCD, d, K, 6, 1, 0.005, 0.5, 0.5)
+    h = host_train("ccd", d, K, 6, 1, 0.005, 0.5, 0.5, env={"MFX_EXACT": "1"})
+    assert abs(h["test"] - o["test"]) < 1e-5 and abs(h["val"] - o["valbest"]) < 1e-5
+    scale = np.abs(o["Ubest"]).max()
+    assert np.abs(h["Ubest"] - o["Ubest"]).max() < 1e-4 * scale and np.abs(h["Vbest"] - o["Vbest"]).max() < 1e-4 * scale
+    # different (device-drawn) factor orders take a different path to the same quality
+    o2 = oracle_train(orc.M_CCD, d, K, 20, 1, 0.005, 0.5, 0.5)
+    f = host_train("ccd", d, K, 20, 1, 0.005, 0.5, 0.5)
+    print("ccd 20 iterations: val gpu %.5f cpu %.5f | test gpu %.5f cpu %.5f" % (f["val"], o2["valbest"], f["test"], o2["test"]))
+    assert abs(f["val"] - o2["valbest"]) < 3e-2 and abs(f["test"] - o2["test"]) < 3e-2
+
+
 @pytest.mark.parametrize("method", ["sgd", "hogsgd", "sgdpar", "sgdu"])
 def test_fast_sgd_paths_reach_the_reference_rmse(method):
     d, K = data(3000, 2000, 300000, seed=2), 16
