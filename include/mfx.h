@@ -198,6 +198,11 @@ enum { MFX_REDUCE_DELTA_SUM = 0, MFX_REDUCE_AVERAGE = 1 };
 #define MFX_UNIQUE_ID_BYTES 128
 int mfx_comm_unique_id(void* id128);
 int mfx_comm_init(mfx_ctx* ctx, int nranks, int rank, const void* id128);
+/* Bring-your-own all-reduce (MPI, gloo, ...): fn must sum `count` elements of `host_buf` (dtype 0 = float,
+ * 1 = double) over all ranks in place and return 0.  The library stages device buffers through pinned host
+ * memory around the call.  Everything that works over RCCL works over this, slower.                          */
+typedef int (*mfx_reduce_fn)(void* user, void* host_buf, int64_t count, int dtype);
+int mfx_comm_init_external(mfx_ctx* ctx, int nranks, int rank, mfx_reduce_fn fn, void* user);
 int mfx_comm_destroy(mfx_ctx* ctx);
 /* declare the current V identical on all ranks (call after mfx_set_factors, before
  * the first local epoch): V_sync <- V                                             */

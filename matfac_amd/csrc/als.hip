@@ -149,7 +149,31 @@ __device__ __forceinline__ float gram_solve(const GramAcc& g, int K, float reg, 
   return x;
 }
 
-template <bool SOLVE>
+// store / load the accumulators of one row (SLAB floats, lane-interleaved)
+__device__ __forceinline__ void gram_store(const GramAcc& g, float* o) {
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) o[((i * 2 + j) * 16 + r) * 64] = g.t[i][j][r];
+  o[64 * 64] = g.b0;
+  o[65 * 64] = g.b1;
+}
+__device__ __forceinline__ void gram_add(GramAcc& g, const float* o) {
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) g.t[i][j][r] += o[((i * 2 + j) * 16 + r) * 64];
+  g.b0 += o[64 * 64];
+  g.b1 += o[65 * 64];
+}
+
+// SOLVE 1: solve single-segment rows in place; 0: timing probe; 2 (sharded item sweep): emit every row's
+// accumulators to grow[row] for the all-reduce over the ranks
+template <int SOLVE>
 __global__ __launch_bounds__(64) void als_segment_kernel(const int32_t* __restrict__ seg_row,
                                                          const int64_t* __restrict__ seg_beg,
                                                          const int64_t* __restrict__ seg_end,
@@ -157,7 +181,8 @@ __global__ __launch_bounds__(64) void als_segment_kernel(const int32_t* __restri
                                                          const int32_t* __restrict__ ind,
                                                          const float* __restrict__ val,
                                                          const float* __restrict__ Y, float* __restrict__ X,
-                                                         float* __restrict__ slabs, int K, int ld, float reg) {
+                                                         float* __restrict__ slabs, int K, int ld, float reg,
+                                                         float* __restrict__ grow) {
   const int lane = threadIdx.x;
   for (int64_t s = blockIdx.x; s < nseg; s += gridDim.x) {
     GramAcc g;
@@ -165,49 +190,49 @@ __global__ __launch_bounds__(64) void als_segment_kernel(const int32_t* __restri
     gram_accumulate(g, Y, ind, val, seg_beg[s], seg_end[s], lane, ld);
     const int slab = seg_slab[s];
     if (slab < 0) {
-      if (SOLVE) {
+      if (SOLVE == 2) {
+        gram_store(g, grow + (int64_t)seg_row[s] * SLAB + lane);
+      } else if (SOLVE == 1) {
         const float x = gram_solve(g, K, reg, lane);
         if (lane < K) X[(int64_t)seg_row[s] * ld + lane] = x;
       } else if (lane < K) {   // timing probe (MFX_ALS_NOSOLVE): keep the accumulators alive, skip the solve
         X[(int64_t)seg_row[s] * ld + lane] = g.t[0][0][0] + g.t[0][1][1] + g.t[1][0][2] + g.t[1][1][3] + g.b0 + g.b1;
       }
     } else {
-      float* o = slabs + (int64_t)slab * SLAB + lane;
-#pragma unroll
-      for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-          for (int r = 0; r < 16; r++) o[((i * 2 + j) * 16 + r) * 64] = g.t[i][j][r];
-      o[64 * 64] = g.b0;
-      o[65 * 64] = g.b1;
+      gram_store(g, slabs + (int64_t)slab * SLAB + lane);
     }
   }
 }
 
+template <bool EMIT>
 __global__ __launch_bounds__(64) void als_reduce_kernel(const int32_t* __restrict__ mrow,
                                                         const int32_t* __restrict__ mrow_first,
                                                         const int32_t* __restrict__ mrow_n, int64_t nmrow,
                                                         const float* __restrict__ slabs, float* __restrict__ X,
-                                                        int K, int ld, float reg) {
+                                                        int K, int ld, float reg, float* __restrict__ grow) {
   const int lane = threadIdx.x;
   for (int64_t m = blockIdx.x; m < nmrow; m += gridDim.x) {
     GramAcc g;
     gram_zero(g);
     const int first = mrow_first[m], n = mrow_n[m];
-    for (int s = 0; s < n; s++) {  // fixed segment order: reproducible
-      const float* o = slabs + (int64_t)(first + s) * SLAB + lane;
-#pragma unroll
-      for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-          for (int r = 0; r < 16; r++) g.t[i][j][r] += o[((i * 2 + j) * 16 + r) * 64];
-      g.b0 += o[64 * 64];
-      g.b1 += o[65 * 64];
-    }
+    for (int s = 0; s < n; s++)   // fixed segment order: reproducible
+      gram_add(g, slabs + (int64_t)(first + s) * SLAB + lane);
+    if (EMIT) { gram_store(g, grow + (int64_t)mrow[m] * SLAB + lane); continue; }
     const float x = gram_solve(g, K, reg, lane);
     if (lane < K) X[(int64_t)mrow[m] * ld + lane] = x;
+  }
+}
+// sharded item sweep: solve every item some rank has ratings for, from the accumulators summed over the ranks
+__global__ __launch_bounds__(64) void als_global_solve_kernel(const float* __restrict__ grow, const double* __restrict__ gcol,
+                                                              int32_t nrows, float* __restrict__ X, int K, int ld, float reg) {
+  const int lane = threadIdx.x;
+  for (int64_t r = blockIdx.x; r < nrows; r += gridDim.x) {
+    if (gcol[r] == 0.0) continue;
+    GramAcc g;
+    gram_zero(g);
+    gram_add(g, grow + r * SLAB + lane);
+    const float x = gram_solve(g, K, reg, lane);
+    if (lane < K) X[r * ld + lane] = x;
   }
 }
 
@@ -316,23 +341,53 @@ extern "C" int mfx_als_half_sweep(mfx_ctx* ctx, int side, float reg) {
   const float* val = side == MFX_SIDE_USERS ? m.rowval : m.colval;
   const float* Y = side == MFX_SIDE_USERS ? ctx->V : ctx->U;
   float* X = side == MFX_SIDE_USERS ? ctx->U : ctx->V;
+  if (side == MFX_SIDE_ITEMS && mfx_sharded(ctx)) {
+    // An item's users live on several ranks (user-block sharding): every rank accumulates (A, b) over ITS users,
+    // the accumulators are summed over the ranks, and every rank solves every item (V stays replicated).
+    const double* gcol;
+    int rc = mfx_comm_global_col_counts(ctx, &gcol);
+    if (rc) return rc;
+    const size_t gn = (size_t)m.ncols * SLAB;
+    if (!ctx->als_global && (rc = dev_alloc(ctx, &ctx->als_global, gn))) return rc;
+    HIPCHK(hipMemsetAsync(ctx->als_global, 0, gn * sizeof(float), ctx->stream));
+    if (sd.nseg > 0) {
+      ProfScope ps(ctx, MFX_K_ALS_GRAM);
+      hipLaunchKernelGGL(als_segment_kernel<2>, dim3((int)std::min<int64_t>(sd.nseg, 256 * 16)), dim3(64), 0, ctx->stream,
+                         sd.seg_row, sd.seg_beg, sd.seg_end, sd.seg_slab, sd.nseg, ind, val, Y, X, ctx->als_slabs, ctx->K,
+                         ctx->ld, reg, ctx->als_global);
+      HIPCHK(hipGetLastError());
+    }
+    if (sd.nmrow > 0) {
+      hipLaunchKernelGGL(als_reduce_kernel<true>, dim3((int)std::min<int64_t>(sd.nmrow, 256 * 16)), dim3(64), 0, ctx->stream,
+                         sd.mrow, sd.mrow_first, sd.mrow_n, sd.nmrow, ctx->als_slabs, X, ctx->K, ctx->ld, reg, ctx->als_global);
+      HIPCHK(hipGetLastError());
+    }
+    if ((rc = mfx_comm_allreduce(ctx, ctx->als_global, gn, 0))) return rc;
+    if (m.ncols > 0) {
+      ProfScope ps(ctx, MFX_K_ALS_SOLVE);
+      hipLaunchKernelGGL(als_global_solve_kernel, dim3(std::min(m.ncols, 256 * 16)), dim3(64), 0, ctx->stream, ctx->als_global, gcol,
+                         m.ncols, X, ctx->K, ctx->ld, reg);
+      HIPCHK(hipGetLastError());
+    }
+    return MFX_OK;
+  }
   if (sd.nseg > 0) {
     ProfScope ps(ctx, MFX_K_ALS_GRAM);
     const int blocks = (int)std::min<int64_t>(sd.nseg, 256 * 16);
     static const bool nosolve = getenv("MFX_ALS_NOSOLVE") != nullptr;   // timing probe only
     if (nosolve)
-      hipLaunchKernelGGL(als_segment_kernel<false>, dim3(blocks), dim3(64), 0, ctx->stream, sd.seg_row, sd.seg_beg,
-                         sd.seg_end, sd.seg_slab, sd.nseg, ind, val, Y, X, ctx->als_slabs, ctx->K, ctx->ld, reg);
+      hipLaunchKernelGGL(als_segment_kernel<0>, dim3(blocks), dim3(64), 0, ctx->stream, sd.seg_row, sd.seg_beg,
+                         sd.seg_end, sd.seg_slab, sd.nseg, ind, val, Y, X, ctx->als_slabs, ctx->K, ctx->ld, reg, (float*)nullptr);
     else
-      hipLaunchKernelGGL(als_segment_kernel<true>, dim3(blocks), dim3(64), 0, ctx->stream, sd.seg_row, sd.seg_beg,
-                         sd.seg_end, sd.seg_slab, sd.nseg, ind, val, Y, X, ctx->als_slabs, ctx->K, ctx->ld, reg);
+      hipLaunchKernelGGL(als_segment_kernel<1>, dim3(blocks), dim3(64), 0, ctx->stream, sd.seg_row, sd.seg_beg,
+                         sd.seg_end, sd.seg_slab, sd.nseg, ind, val, Y, X, ctx->als_slabs, ctx->K, ctx->ld, reg, (float*)nullptr);
     HIPCHK(hipGetLastError());
   }
   if (sd.nmrow > 0) {
     ProfScope ps(ctx, MFX_K_ALS_SOLVE);
     const int blocks = (int)std::min<int64_t>(sd.nmrow, 256 * 16);
-    hipLaunchKernelGGL(als_reduce_kernel, dim3(blocks), dim3(64), 0, ctx->stream, sd.mrow, sd.mrow_first,
-                       sd.mrow_n, sd.nmrow, ctx->als_slabs, X, ctx->K, ctx->ld, reg);
+    hipLaunchKernelGGL(als_reduce_kernel<false>, dim3(blocks), dim3(64), 0, ctx->stream, sd.mrow, sd.mrow_first,
+                       sd.mrow_n, sd.nmrow, ctx->als_slabs, X, ctx->K, ctx->ld, reg, (float*)nullptr);
     HIPCHK(hipGetLastError());
   }
   return MFX_OK;

@@ -32,6 +32,7 @@ struct ColState {
   int64_t* seg_beg = nullptr; int64_t* seg_end = nullptr; int32_t* seg_col = nullptr;
   int64_t nseg = 0;
   double* part = nullptr;           // [nseg][2]
+  double* sums = nullptr;           // sharded runs: [ncols][2] (num, den) for the all-reduce
   int32_t* col_ptr = nullptr;       // [nI+1] column -> its segments (strip-major order)
   int32_t* col_seg = nullptr;
   // workgroup tables
@@ -53,7 +54,7 @@ void mfx_ccd_cols_free(mfx_ctx* ctx) {
   ColState* s = st(ctx);
   if (!s) return;
   dev_free(s->off); dev_free(s->dst); dev_free(s->buser); dev_free(s->bcol); dev_free(s->res);
-  dev_free(s->seg_beg); dev_free(s->seg_end); dev_free(s->seg_col); dev_free(s->part);
+  dev_free(s->seg_beg); dev_free(s->seg_end); dev_free(s->seg_col); dev_free(s->part); dev_free(s->sums);
   dev_free(s->col_ptr); dev_free(s->col_seg);
   dev_free(s->pw_blk); dev_free(s->pw_s0); dev_free(s->pw_s1);
   dev_free(s->rw_blk); dev_free(s->rw_e0); dev_free(s->rw_e1);
@@ -247,17 +248,22 @@ __global__ __launch_bounds__(1024) void colpass_kernel(const int32_t* __restrict
   }
 }
 
-// v_k[i] from the column's segment partials in strip-major order; one 16-lane group per column
+// v_k[i] from the column's segment partials in strip-major order; one 16-lane group per column.
+// SUMS (sharded runs): only emit (num, den) of this rank's users; coldivide_kernel finishes after the all-reduce.
+template <bool SUMS>
 __global__ __launch_bounds__(256) void colfinish_kernel(const int32_t* __restrict__ col_ptr,
                                                         const int32_t* __restrict__ col_seg,
                                                         const double* __restrict__ part, int32_t ncols, float reg,
                                                         float* __restrict__ vk, const int64_t* __restrict__ colptr,
-                                                        float freq_thresh, int k) {
+                                                        float freq_thresh, int k, double* __restrict__ sums) {
   const int j = threadIdx.x & 15;
   const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
   if (i >= ncols) return;
   const int a = col_ptr[i], e = col_ptr[i + 1];
-  if (a == e) return;   // an item without train ratings is invalid: v_k keeps iFac(i,k) (modelMF.cpp:1079-1081)
+  if (a == e) {         // an item without train ratings is invalid: v_k keeps iFac(i,k) (modelMF.cpp:1079-1081)
+    if (SUMS && j == 0) { sums[2 * i] = 0.0; sums[2 * i + 1] = 0.0; }
+    return;
+  }
   double num = 0.0, den = 0.0;
   for (int t = a + j; t < e; t += 16) {   // lane-strided in list order, then a fixed butterfly
     num += part[2 * (int64_t)col_seg[t]];
@@ -266,6 +272,7 @@ __global__ __launch_bounds__(256) void colfinish_kernel(const int32_t* __restric
   num = g16_sum(num);
   den = g16_sum(den);
   if (j == 0) {
+    if (SUMS) { sums[2 * i] = num; sums[2 * i + 1] = den; return; }
     float v = (float)(num / ((double)reg + den));
     if (freq_thresh >= 0.0f) {  // modelMF.cpp:1336-1342
       const double freq = (double)(colptr[i + 1] - colptr[i]);
@@ -273,6 +280,15 @@ __global__ __launch_bounds__(256) void colfinish_kernel(const int32_t* __restric
     }
     vk[i] = v;
   }
+}
+// sharded runs: v_k[i] from the sums over all ranks; gcol = ratings per item over all ranks
+__global__ void coldivide_kernel(const double* __restrict__ sums, const double* __restrict__ gcol, int32_t ncols, float reg,
+                                 float* __restrict__ vk, float freq_thresh, int k) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ncols || gcol[i] == 0.0) return;
+  float v = (float)(sums[2 * i] / ((double)reg + sums[2 * i + 1]));
+  if (freq_thresh >= 0.0f && gcol[i] < (double)freq_thresh && k > 0) v = 0.0f;
+  vk[i] = v;
 }
 
 // residual update on the strip-major column view.  MODE +1: res += u0*v0, -1: res -= u0*v0,
@@ -310,8 +326,30 @@ int mfx_ccd_cols_pass(mfx_ctx* ctx, const float* uk, float* vk, float reg, float
     ProfScope ps(ctx, MFX_K_CCD_COL);
     hipLaunchKernelGGL(colpass_kernel, dim3(s->npw), dim3(1024), 0, ctx->stream, s->pw_blk, s->pw_s0, s->pw_s1,
                        s->seg_beg, s->seg_end, s->res, s->buser, uk, m.nrows, s->part);
-    hipLaunchKernelGGL(colfinish_kernel, dim3((unsigned)(((int64_t)m.ncols * 16 + 255) / 256)), dim3(256), 0,
-                       ctx->stream, s->col_ptr, s->col_seg, s->part, m.ncols, reg, vk, m.colptr, freq_thresh, k);
+    const unsigned fb = (unsigned)(((int64_t)m.ncols * 16 + 255) / 256);
+    if (!mfx_sharded(ctx)) {
+      hipLaunchKernelGGL(colfinish_kernel<false>, dim3(fb), dim3(256), 0, ctx->stream, s->col_ptr, s->col_seg, s->part,
+                         m.ncols, reg, vk, m.colptr, freq_thresh, k, (double*)nullptr);
+      HIPCHK(hipGetLastError());
+      return MFX_OK;
+    }
+  }
+  if (mfx_sharded(ctx) && m.ncols > 0) {
+    // the users of one item live on several ranks: sum (num, den) over the ranks, then divide everywhere
+    int rc;
+    if (!s->sums && (rc = dev_alloc(ctx, &s->sums, (size_t)m.ncols * 2))) return rc;
+    const double* gcol;
+    if ((rc = mfx_comm_global_col_counts(ctx, &gcol))) return rc;
+    if (s->npw > 0) {
+      hipLaunchKernelGGL(colfinish_kernel<true>, dim3((unsigned)(((int64_t)m.ncols * 16 + 255) / 256)), dim3(256), 0, ctx->stream,
+                         s->col_ptr, s->col_seg, s->part, m.ncols, reg, vk, m.colptr, freq_thresh, k, s->sums);
+      HIPCHK(hipGetLastError());
+    } else {
+      HIPCHK(hipMemsetAsync(s->sums, 0, sizeof(double) * 2 * (size_t)m.ncols, ctx->stream));
+    }
+    if ((rc = mfx_comm_allreduce(ctx, s->sums, (size_t)m.ncols * 2, 1))) return rc;
+    hipLaunchKernelGGL(coldivide_kernel, dim3((m.ncols + 255) / 256), dim3(256), 0, ctx->stream, s->sums, gcol, m.ncols, reg, vk,
+                       freq_thresh, k);
     HIPCHK(hipGetLastError());
   }
   return MFX_OK;

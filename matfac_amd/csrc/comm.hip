@@ -89,9 +89,44 @@ __global__ void scale_copy_kernel(float* __restrict__ v, float* __restrict__ vsy
 int mfx_comm_free_internal(mfx_ctx* ctx) {
   if (ctx->comm && g_rccl.destroy) g_rccl.destroy(ctx->comm);
   ctx->comm = nullptr;
+  ctx->ext_reduce = nullptr;
+  ctx->ext_user = nullptr;
+  mfx_comm_drop_col_counts(ctx);
   ctx->nranks = 1;
   ctx->rank = 0;
   dev_free(ctx->comm_tmp);
+  if (ctx->ext_stage) (void)hipHostFree(ctx->ext_stage);
+  ctx->ext_stage = nullptr;
+  ctx->ext_stage_bytes = 0;
+  return MFX_OK;
+}
+
+// Sum `count` elements (dtype 0 = float, 1 = double) of a device buffer over all ranks, in place, ordered
+// on ctx->stream.  RCCL when mfx_comm_init made a communicator; the caller's own all-reduce on a host copy
+// when mfx_comm_init_external registered one (MPI / gloo callers, and the two-process tests).
+int mfx_comm_allreduce(mfx_ctx* ctx, void* dev, size_t count, int dtype) {
+  if (ctx->nranks <= 1 && !ctx->comm && !ctx->ext_reduce) return MFX_OK;
+  if (count == 0) return MFX_OK;
+  if (ctx->comm) {
+    int r = g_rccl.allreduce(dev, dev, count, dtype ? kNcclDouble : kNcclFloat, kNcclSum, ctx->comm, ctx->stream);
+    NEED(r == 0, MFX_E_COMM, "ncclAllReduce: %s", rccl_err(r));
+    return MFX_OK;
+  }
+  NEED(ctx->ext_reduce, MFX_E_STATE, "all-reduce requested without a communicator");
+  const size_t bytes = count * (dtype ? 8 : 4);
+  if (bytes > ctx->ext_stage_bytes) {
+    if (ctx->ext_stage) (void)hipHostFree(ctx->ext_stage);
+    ctx->ext_stage = nullptr;
+    ctx->ext_stage_bytes = 0;
+    HIPCHK(hipHostMalloc(&ctx->ext_stage, bytes, hipHostMallocDefault));
+    ctx->ext_stage_bytes = bytes;
+  }
+  HIPCHK(hipMemcpyAsync(ctx->ext_stage, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const int r = ctx->ext_reduce(ctx->ext_user, ctx->ext_stage, (int64_t)count, dtype);
+  NEED(r == 0, MFX_E_COMM, "external all-reduce returned %d", r);
+  HIPCHK(hipMemcpyAsync(dev, ctx->ext_stage, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   return MFX_OK;
 }
 
@@ -118,6 +153,39 @@ extern "C" int mfx_comm_init(mfx_ctx* ctx, int nranks, int rank, const void* id1
   int rc = g_rccl.init_rank(&comm, nranks, id, rank);
   NEED(rc == 0, MFX_E_COMM, "ncclCommInitRank: %s", rccl_err(rc));
   ctx->comm = comm;
+  ctx->nranks = nranks;
+  ctx->rank = rank;
+  return MFX_OK;
+}
+
+__global__ void col_count_kernel(const int64_t* __restrict__ colptr, int32_t ncols, double* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < ncols) out[t] = (double)(colptr[t + 1] - colptr[t]);
+}
+void mfx_comm_drop_col_counts(mfx_ctx* ctx) { dev_free(ctx->gcol); dev_free(ctx->als_global); }
+int mfx_comm_global_col_counts(mfx_ctx* ctx, const double** out) {
+  const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
+  NEED(m.present && m.has_col, MFX_E_STATE, "global item counts: train matrix with column view needed");
+  if (!ctx->gcol) {
+    int rc = dev_alloc(ctx, &ctx->gcol, (size_t)m.ncols);
+    if (rc) return rc;
+    if (m.ncols > 0) {
+      hipLaunchKernelGGL(col_count_kernel, dim3((m.ncols + 255) / 256), dim3(256), 0, ctx->stream, m.colptr, m.ncols, ctx->gcol);
+      HIPCHK(hipGetLastError());
+      if ((rc = mfx_comm_allreduce(ctx, ctx->gcol, (size_t)m.ncols, 1))) { dev_free(ctx->gcol); return rc; }
+    }
+  }
+  *out = ctx->gcol;
+  return MFX_OK;
+}
+
+extern "C" int mfx_comm_init_external(mfx_ctx* ctx, int nranks, int rank, mfx_reduce_fn fn, void* user) {
+  if (!ctx) return MFX_E_ARG;
+  NEED(nranks >= 1 && rank >= 0 && rank < nranks && fn, MFX_E_ARG, "mfx_comm_init_external: nranks=%d rank=%d", nranks, rank);
+  HIPCHK(hipSetDevice(ctx->device));
+  mfx_comm_free_internal(ctx);
+  ctx->ext_reduce = fn;
+  ctx->ext_user = user;
   ctx->nranks = nranks;
   ctx->rank = rank;
   return MFX_OK;
@@ -158,7 +226,7 @@ extern "C" int mfx_allreduce_item_factors(mfx_ctx* ctx, int op) {
   NEED(ctx->V, MFX_E_STATE, "mfx_allreduce_item_factors: no model");
   NEED(op == MFX_REDUCE_DELTA_SUM || op == MFX_REDUCE_AVERAGE, MFX_E_ARG, "mfx_allreduce_item_factors: op=%d", op);
   HIPCHK(hipSetDevice(ctx->device));
-  if (!ctx->comm) return MFX_OK;  // no communicator: single device, V is already the sum
+  if (!ctx->comm && !ctx->ext_reduce) return MFX_OK;  // no communicator: single device, V is already the sum
   int rc;
   if ((rc = ensure_sync_buffers(ctx))) return rc;
   const int64_t n = (int64_t)ctx->nI * ctx->ld, n4 = n / 4;
@@ -166,12 +234,10 @@ extern "C" int mfx_allreduce_item_factors(mfx_ctx* ctx, int op) {
   if (op == MFX_REDUCE_DELTA_SUM) {
     hipLaunchKernelGGL(delta_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ctx->V, ctx->Vsync, ctx->comm_tmp, n4);
     HIPCHK(hipGetLastError());
-    int r = g_rccl.allreduce(ctx->comm_tmp, ctx->comm_tmp, (size_t)n, kNcclFloat, kNcclSum, ctx->comm, ctx->stream);
-    NEED(r == 0, MFX_E_COMM, "ncclAllReduce: %s", rccl_err(r));
+    if ((rc = mfx_comm_allreduce(ctx, ctx->comm_tmp, (size_t)n, 0))) return rc;
     hipLaunchKernelGGL(apply_delta_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ctx->V, ctx->Vsync, ctx->comm_tmp, n4);
   } else {
-    int r = g_rccl.allreduce(ctx->V, ctx->V, (size_t)n, kNcclFloat, kNcclSum, ctx->comm, ctx->stream);
-    NEED(r == 0, MFX_E_COMM, "ncclAllReduce: %s", rccl_err(r));
+    if ((rc = mfx_comm_allreduce(ctx, ctx->V, (size_t)n, 0))) return rc;
     hipLaunchKernelGGL(scale_copy_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ctx->V, ctx->Vsync,
                        1.0f / (float)ctx->nranks, n4);
   }
@@ -182,7 +248,7 @@ extern "C" int mfx_allreduce_item_factors(mfx_ctx* ctx, int op) {
 extern "C" int mfx_allreduce_f64(mfx_ctx* ctx, double* vals, int n) {
   if (!ctx) return MFX_E_ARG;
   NEED(vals && n > 0 && n <= 8, MFX_E_ARG, "mfx_allreduce_f64: n must be in [1,8]");
-  if (!ctx->comm) return MFX_OK;
+  if (!ctx->comm && !ctx->ext_reduce) return MFX_OK;
   HIPCHK(hipSetDevice(ctx->device));
   if (ctx->red_blocks < 1) {
     int rc;
@@ -192,8 +258,8 @@ extern "C" int mfx_allreduce_f64(mfx_ctx* ctx, double* vals, int n) {
     ctx->red_blocks = 8;
   }
   HIPCHK(hipMemcpyAsync(ctx->red_d, vals, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
-  int r = g_rccl.allreduce(ctx->red_d, ctx->red_d, (size_t)n, kNcclDouble, kNcclSum, ctx->comm, ctx->stream);
-  NEED(r == 0, MFX_E_COMM, "ncclAllReduce(f64): %s", rccl_err(r));
+  int rc = mfx_comm_allreduce(ctx, ctx->red_d, (size_t)n, 1);
+  if (rc) return rc;
   HIPCHK(hipMemcpyAsync(ctx->red_out, ctx->red_d, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   for (int k = 0; k < n; k++) vals[k] = ctx->red_out[k];

@@ -159,7 +159,7 @@ extern "C" int mfx_set_csr(mfx_ctx* ctx, int which, int32_t nrows, int32_t ncols
   HIPCHK(hipSetDevice(ctx->device));
   DevCSR& m = ctx->mat[which];
   free_csr(m);
-  if (which == MFX_MAT_TRAIN) { mfx_ccd_free_internal(ctx); mfx_cd_free_internal(ctx); mfx_als_free_internal(ctx); mfx_segs_free_internal(ctx); mfx_slots_free_internal(ctx); }
+  if (which == MFX_MAT_TRAIN) { mfx_comm_drop_col_counts(ctx); mfx_ccd_free_internal(ctx); mfx_cd_free_internal(ctx); mfx_als_free_internal(ctx); mfx_segs_free_internal(ctx); mfx_slots_free_internal(ctx); }
   int rc;
   if ((rc = dev_alloc(ctx, &m.rowptr, (size_t)nrows + 1))) return rc;
   if ((rc = dev_alloc(ctx, &m.rowind, (size_t)nnz))) return rc;
@@ -327,6 +327,11 @@ __global__ void invalid_kernel(const int64_t* __restrict__ ptr, int32_t nmat, in
   if (t < n) inv[t] = (t >= nmat) || (ptr[t + 1] == ptr[t]);
 }
 
+__global__ void invalid_items_global_kernel(const double* __restrict__ gcol, int32_t ncols, int32_t n, uint8_t* __restrict__ inv) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) inv[t] = (t >= ncols) || (gcol[t] == 0.0);
+}
+
 extern "C" int mfx_compute_invalid(mfx_ctx* ctx, uint8_t* invalidUsers, uint8_t* invalidItems) {
   if (!ctx) return MFX_E_ARG;
   const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
@@ -335,8 +340,16 @@ extern "C" int mfx_compute_invalid(mfx_ctx* ctx, uint8_t* invalidUsers, uint8_t*
   HIPCHK(hipSetDevice(ctx->device));
   hipLaunchKernelGGL(invalid_kernel, dim3((ctx->nU + 255) / 256), dim3(256), 0, ctx->stream,
                      m.rowptr, m.nrows, ctx->nU, ctx->invU);
-  hipLaunchKernelGGL(invalid_kernel, dim3((ctx->nI + 255) / 256), dim3(256), 0, ctx->stream,
-                     m.colptr, m.ncols, ctx->nI, ctx->invI);
+  if (mfx_sharded(ctx)) {   // an item is invalid when NO rank has a rating for it
+    const double* gcol;
+    int rc = mfx_comm_global_col_counts(ctx, &gcol);
+    if (rc) return rc;
+    hipLaunchKernelGGL(invalid_items_global_kernel, dim3((ctx->nI + 255) / 256), dim3(256), 0, ctx->stream, gcol, m.ncols,
+                       ctx->nI, ctx->invI);
+  } else {
+    hipLaunchKernelGGL(invalid_kernel, dim3((ctx->nI + 255) / 256), dim3(256), 0, ctx->stream,
+                       m.colptr, m.ncols, ctx->nI, ctx->invI);
+  }
   HIPCHK(hipGetLastError());
   if (invalidUsers) HIPCHK(hipMemcpyAsync(invalidUsers, ctx->invU, (size_t)ctx->nU, hipMemcpyDeviceToHost, ctx->stream));
   if (invalidItems) HIPCHK(hipMemcpyAsync(invalidItems, ctx->invI, (size_t)ctx->nI, hipMemcpyDeviceToHost, ctx->stream));

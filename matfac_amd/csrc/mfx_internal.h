@@ -97,6 +97,12 @@ struct mfx_ctx {
   void* comm = nullptr;      // ncclComm_t
   int nranks = 1, rank = 0;
   float* comm_tmp = nullptr;
+  mfx_reduce_fn ext_reduce = nullptr;   // caller-supplied all-reduce on a host copy (mfx_comm_init_external)
+  void* ext_user = nullptr;
+  void* ext_stage = nullptr;            // pinned staging buffer for it
+  size_t ext_stage_bytes = 0;
+  double* gcol = nullptr;               // sharded runs: ratings per item over ALL ranks [train ncols]
+  float* als_global = nullptr;          // sharded ALS: per-item (A, b) summed over ranks
 
   bool prof_on = false;
   ProfSlot prof[MFX_K_COUNT];
@@ -184,6 +190,11 @@ void mfx_slots_free_internal(mfx_ctx* ctx);
 int mfx_launch_eval(mfx_ctx* ctx, const DevCSR& m, const float* U, const float* V,
                     int with_norms, mfx_eval_out* out);
 int mfx_comm_free_internal(mfx_ctx* ctx);
+int mfx_comm_allreduce(mfx_ctx* ctx, void* dev, size_t count, int dtype);   // sum over ranks, dtype 0 f32 / 1 f64
+static inline bool mfx_sharded(const mfx_ctx* ctx);
+// ratings per item summed over the ranks (device, cached until the train matrix changes)
+int mfx_comm_global_col_counts(mfx_ctx* ctx, const double** out);
+void mfx_comm_drop_col_counts(mfx_ctx* ctx);
 void mfx_ccd_free_internal(mfx_ctx* ctx);
 void mfx_als_free_internal(mfx_ctx* ctx);
 void mfx_segs_free_internal(mfx_ctx* ctx);
@@ -199,5 +210,7 @@ int mfx_build_col_index_device(mfx_ctx* ctx, DevCSR& m);
 int mfx_build_c2r_map_device(mfx_ctx* ctx, const DevCSR& m, uint32_t** map);
 void mfx_cd_free_internal(mfx_ctx* ctx);
 int mfx_get_segments(mfx_ctx* ctx, int side, RowSegs** out);
+
+static inline bool mfx_sharded(const mfx_ctx* ctx) { return ctx->comm != nullptr || ctx->ext_reduce != nullptr; }
 
 #endif

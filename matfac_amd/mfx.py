@@ -18,6 +18,9 @@ K_SGD, K_PERMUTE, K_EVAL, K_ALS_GRAM, K_ALS_SOLVE, K_CCD_ROW, K_CCD_COL, K_CCD_R
 E_NODEVICE = -6
 
 
+REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int)
+
+
 class MfxError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("mfx error %d: %s" % (code, msg))
@@ -229,6 +232,21 @@ class Ctx:
 
     def comm_init(self, nranks, rank, uid):
         self._chk(self.lib.mfx_comm_init(self.h, nranks, rank, C.c_char_p(uid)))
+
+    def comm_init_external(self, nranks, rank, reduce):
+        """reduce(array) must sum the numpy array (float32 or float64, a view of the library's host buffer) over
+        all ranks IN PLACE -- e.g. torch.distributed.all_reduce(torch.from_numpy(a)) over gloo, or MPI."""
+        def thunk(user, ptr, count, dtype):
+            try:
+                ct = C.c_double if dtype else C.c_float
+                reduce(np.ctypeslib.as_array((ct * count).from_address(ptr)))
+                return 0
+            except Exception:                       # must not unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._reduce_cb = REDUCE_FN(thunk)          # keep the callback alive as long as the ctx
+        self._chk(self.lib.mfx_comm_init_external(self.h, nranks, rank, self._reduce_cb, None))
 
     def comm_mark_synced(self):
         self._chk(self.lib.mfx_comm_mark_synced(self.h))

@@ -1,0 +1,119 @@
+"""The N > 1 path on the device: two processes, each with its own context and its block of user rows, the
+exchanges carried by gloo through mfx_comm_init_external (the same library code runs over RCCL when
+mfx_comm_init made the communicator).  Sharded CCD++ / ALS / SGD against the one-context run of the same work."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from matfac_amd import Ctx, mfx, synth
+from matfac_amd import dist as mdist
+from oracle import binding as orc
+
+pytestmark = pytest.mark.gpu
+K = 16
+
+
+def _problem():
+    d = synth.make(dict(nU=3000, nI=400, nnz=150000, K=K), seed=12)
+    tr = d["train"]
+    nI = max(d["nItems"], tr.ncols)
+    U0, V0 = synth.init_factors(3, tr.nrows, nI, K)
+    return tr, nI, (U0 * 30).astype(np.float32), (V0 * 30).astype(np.float32)
+
+
+def _run(ctx, nI, tr, U0, V0, exchange):
+    """The work both layouts do; `exchange` is called where the sharded run needs the item factors agreed."""
+    out = {}
+    ctx.set_csr(mfx.MAT_TRAIN, tr.nrows, nI, tr.rowptr, tr.rowind, tr.rowval)
+    ctx.set_model(tr.nrows, nI, K)
+    invU, invI = ctx.compute_invalid()
+    out["invI"] = invI.copy()
+    # CCD++ with FreqAdap (modelMF.cpp:1272-1360): 2 outer iterations
+    ctx.set_factors(U0, V0)
+    ctx.ccdpp_begin()
+    for it in range(2):
+        for k in range(K):
+            ctx.ccdpp_rank1(k, 0.4, 0.6, add_back=it > 0, freq_thresh=75.0)
+    ctx.ccdpp_end()
+    out["ccd_U"], out["ccd_V"] = ctx.get_factors()
+    e = ctx.eval(mfx.MAT_TRAIN)
+    out["ccd_sse"] = np.array([e.sse, float(e.n)])
+    # ALS: 2 iterations
+    ctx.set_factors(U0, V0)
+    for it in range(2):
+        ctx.als_half_sweep(mfx.SIDE_USERS, 2.0)
+        ctx.als_half_sweep(mfx.SIDE_ITEMS, 3.0)
+    out["als_U"], out["als_V"] = ctx.get_factors()
+    # SGD: CSR order on one group (deterministic), one exchange per epoch
+    ctx.set_factors(U0, V0)
+    exchange("mark")
+    for ep in range(2):
+        ctx.sgd_epoch(0.002, 0.05, 0.05, mode=mfx.SGD_SERIAL, order=mfx.ORDER_NATURAL, arith=mfx.ARITH_REF64)
+        exchange("sum")
+    out["sgd_U"], out["sgd_V"] = ctx.get_factors()
+    return out
+
+
+def _worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tr, nI, U0, V0 = _problem()
+    b = mdist.user_blocks(tr.rowptr, world)
+    lo, hi = int(b[rank]), int(b[rank + 1])
+    sh = mdist.take_rows(tr, lo, hi)
+    with Ctx(0) as ctx:
+        ctx.comm_init_external(world, rank, lambda a: dist.all_reduce(torch.from_numpy(a), op=dist.ReduceOp.SUM))
+
+        def exchange(what):
+            if what == "mark":
+                ctx.comm_mark_synced()
+            else:
+                ctx.allreduce_item_factors(mfx.REDUCE_DELTA_SUM)
+        out = _run(ctx, nI, sh, U0[lo:hi], V0, exchange)
+        out["ccd_sse_all"] = ctx.allreduce_f64(out["ccd_sse"])
+    np.savez(os.path.join(out_dir, "r%d.npz" % rank), lo=lo, hi=hi, **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_shards_equal_one_context(tmp_path):
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r = [np.load(str(tmp_path / ("r%d.npz" % g))) for g in range(2)]
+    tr, nI, U0, V0 = _problem()
+    with Ctx(0) as ctx:
+        one = _run(ctx, nI, tr, U0, V0, lambda what: None)
+    assert r[0]["hi"] == r[1]["lo"] and r[0]["lo"] == 0 and r[1]["hi"] == tr.nrows
+    # an item rated only by the other rank's users is valid on both
+    assert np.array_equal(r[0]["invI"], one["invI"]) and np.array_equal(r[1]["invI"], one["invI"])
+    cat = lambda key: np.concatenate([r[0][key], r[1][key]])
+    for algo, tol in (("ccd", 2e-5), ("als", 5e-4)):
+        scale = float(np.abs(one[algo + "_V"]).max())
+        assert np.array_equal(r[0][algo + "_V"], r[1][algo + "_V"]), algo           # replicas agree bit for bit
+        assert np.abs(r[0][algo + "_V"] - one[algo + "_V"]).max() < tol * scale, algo
+        assert np.abs(cat(algo + "_U") - one[algo + "_U"]).max() < tol * max(scale, float(np.abs(one[algo + "_U"]).max())), algo
+    assert np.allclose(r[0]["ccd_sse_all"], r[1]["ccd_sse_all"])
+    assert r[0]["ccd_sse_all"][1] == tr.nnz and abs(r[0]["ccd_sse_all"][0] - one["ccd_sse"][0]) < 1e-4 * one["ccd_sse"][0]
+    # SGD: each rank sweeps its rows in CSR order against its own copy of V, then V <- V_sync + sum of deltas
+    U, V = U0.copy(), V0.copy()
+    for ep in range(2):
+        parts = []
+        for g in range(2):
+            lo, hi = int(r[g]["lo"]), int(r[g]["hi"])
+            sh = mdist.take_rows(tr, lo, hi)
+            Ul, Vl = U[lo:hi].copy(), V.copy()
+            orc.sgd_pass(Ul, Vl, sh.rowids(), sh.rowind, sh.rowval, None, 0.002, 0.05, 0.05, orc.ARITH_REF64, orc.DOT_TREE)
+            U[lo:hi] = Ul
+            parts.append(Vl)
+        V = mdist.delta_sum(V, parts)
+    assert np.array_equal(r[0]["sgd_V"], r[1]["sgd_V"])
+    assert np.array_equal(cat("sgd_U"), U) and np.array_equal(r[0]["sgd_V"], V)
