@@ -156,6 +156,11 @@ typedef struct {
 /* objective = sse + uReg*unorm2 + iReg*inorm2 ; RMSE = sqrt(sse/n).
  * with_norms != 0 also fills unorm2/inorm2.                                     */
 int mfx_eval(mfx_ctx* ctx, int which, int snapshot, int with_norms, mfx_eval_out* out);
+/* Model::RMSE(mat, filtItems, ...) (model.cpp:348-394) and Model::RMSEU(mat, filtUsers, ...) (:446-486): the
+ * evaluation restricted to the users / items whose keep flag is non-zero (either array may be NULL = keep
+ * all; keepUsers has nUsers entries, keepItems nItems).  out->sse and out->n as mfx_eval, no norms.          */
+int mfx_eval_filtered(mfx_ctx* ctx, int which, int snapshot, const uint8_t* keepUsers,
+                      const uint8_t* keepItems, mfx_eval_out* out);
 
 /* ---- ALS: replaces modelMF.cpp:805-841 (users) / :844-880 (items) ----------- */
 int mfx_als_half_sweep(mfx_ctx* ctx, int side, float reg);

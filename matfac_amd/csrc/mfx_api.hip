@@ -539,6 +539,49 @@ extern "C" int mfx_eval(mfx_ctx* ctx, int which, int snapshot, int with_norms, m
                          with_norms, out);
 }
 
+__global__ void mask_combine_kernel(const uint8_t* __restrict__ inv, const uint8_t* __restrict__ keep, int32_t n, uint8_t* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) out[t] = inv[t] | (keep[t] ? 0 : 1);
+}
+
+extern "C" int mfx_eval_filtered(mfx_ctx* ctx, int which, int snapshot, const uint8_t* keepUsers, const uint8_t* keepItems,
+                                 mfx_eval_out* out) {
+  if (!ctx) return MFX_E_ARG;
+  NEED(out, MFX_E_ARG, "mfx_eval_filtered: out NULL");
+  NEED(which >= 0 && which < 3, MFX_E_ARG, "mfx_eval_filtered: which=%d", which);
+  NEED(ctx->mat[which].present, MFX_E_STATE, "mfx_eval_filtered: matrix %d not set", which);
+  NEED(ctx->U, MFX_E_STATE, "mfx_eval_filtered: no model");
+  NEED(ctx->have_invalid, MFX_E_STATE, "mfx_eval_filtered: call mfx_compute_invalid first");
+  NEED(snapshot == MFX_SNAP_CURRENT || snapshot == MFX_SNAP_BEST, MFX_E_ARG, "mfx_eval_filtered: snapshot");
+  HIPCHK(hipSetDevice(ctx->device));
+  // the evaluation kernels mask with invU / invI: run them with (invalid OR not kept) in their place
+  uint8_t *mu = nullptr, *mi = nullptr, *stage = nullptr;
+  uint8_t *saveU = ctx->invU, *saveI = ctx->invI;
+  int rc = MFX_OK;
+  auto combine = [&](const uint8_t* keep, const uint8_t* inv, int32_t n, uint8_t** out_mask) -> int {
+    int r;
+    if ((r = dev_alloc(ctx, out_mask, (size_t)n))) return r;
+    if ((r = dev_alloc(ctx, &stage, (size_t)n))) return r;
+    HIPCHK(hipMemcpyAsync(stage, keep, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(mask_combine_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, inv, stage, n, *out_mask);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    dev_free(stage);
+    return MFX_OK;
+  };
+  if (keepUsers) rc = combine(keepUsers, ctx->invU, ctx->nU, &mu);
+  if (!rc && keepItems) rc = combine(keepItems, ctx->invI, ctx->nI, &mi);
+  if (!rc) {
+    if (mu) ctx->invU = mu;
+    if (mi) ctx->invI = mi;
+    rc = mfx_launch_eval(ctx, ctx->mat[which], snapshot ? ctx->Ubest : ctx->U, snapshot ? ctx->Vbest : ctx->V, 0, out);
+    ctx->invU = saveU;
+    ctx->invI = saveI;
+  }
+  dev_free(stage); dev_free(mu); dev_free(mi);
+  return rc;
+}
+
 // ---------------------------------------------------------------------------
 // measurement
 // ---------------------------------------------------------------------------

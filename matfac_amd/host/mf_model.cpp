@@ -266,6 +266,29 @@ double Model::RMSE(csr_t* mat, IntSet& invalidUsers, IntSet& invalidItems) {
   return std::sqrt(o.sse / (double)o.n);
 }
 
+// model.cpp:348-394 / :446-486: RMSE over the ratings of the given items / users only; (count, rmse)
+static std::pair<int, double> filteredRMSE(Model& md, csr_t* mat, const Model::IntSet* users, const Model::IntSet* items) {
+  if (!mat || !md.dev || md.dev->which(mat) < 0) {
+    std::cerr << "\nModel::RMSE(filtered): no device session for this matrix (call a trainer first)" << std::endl;
+    exit(-2);
+  }
+  std::vector<uint8_t> ku, ki;
+  if (users) { ku.assign((size_t)md.nUsers, 0); for (int u : *users) if (u >= 0 && u < md.nUsers) ku[u] = 1; }
+  if (items) { ki.assign((size_t)md.nItems, 0); for (int i : *items) if (i >= 0 && i < md.nItems) ki[i] = 1; }
+  mfx_eval_out o;
+  md.dev->check(mfx_eval_filtered(md.dev->ctx, md.dev->which(mat), md.devSnap, users ? ku.data() : nullptr,
+                                  items ? ki.data() : nullptr, &o), "mfx_eval_filtered");
+  return std::make_pair((int)o.n, std::sqrt(o.sse / (double)o.n));
+}
+std::pair<int, double> Model::RMSE(csr_t* mat, IntSet& filtItems, IntSet& invalidUsers, IntSet& invalidItems) {
+  (void)invalidUsers; (void)invalidItems;
+  return filteredRMSE(*this, mat, nullptr, &filtItems);
+}
+std::pair<int, double> Model::RMSEU(csr_t* mat, IntSet& filtUsers, IntSet& invalidUsers, IntSet& invalidItems) {
+  (void)invalidUsers; (void)invalidItems;
+  return filteredRMSE(*this, mat, &filtUsers, nullptr);
+}
+
 // model.cpp:191-211 (no masks).  On the train matrix the masked and unmasked sums coincide
 // (invalid users/items have no train rating), which is the only use on the training path
 // ("Obj b4 svd" print, modelMF.cpp:16-18).

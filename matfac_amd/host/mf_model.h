@@ -82,6 +82,8 @@ class Model {
   virtual double estRating(int user, int item);                                  // model.cpp:547-549
   double RMSE(csr_t* mat);                                                         // model.cpp:191-211
   double RMSE(csr_t* mat, IntSet& invalidUsers, IntSet& invalidItems);            // model.cpp:214-251
+  std::pair<int, double> RMSE(csr_t* mat, IntSet& filtItems, IntSet& invalidUsers, IntSet& invalidItems);   // :348-394
+  std::pair<int, double> RMSEU(csr_t* mat, IntSet& filtUsers, IntSet& invalidUsers, IntSet& invalidItems);  // :446-486
   virtual double objective(const Data& data);                                     // model.cpp:1694-1722
   virtual double objective(const Data& data, IntSet& invalidUsers, IntSet& invalidItems);  // :1770-1815
   bool isTerminateModel(Model& bestModel, const Data& data, int iter, int& bestIter, double& bestObj,

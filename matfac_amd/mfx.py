@@ -172,6 +172,12 @@ class Ctx:
         self._chk(self.lib.mfx_eval(self.h, which, snapshot, int(with_norms), C.byref(out)))
         return out
 
+    def eval_filtered(self, which, keep_users=None, keep_items=None, snapshot=SNAP_CURRENT):
+        out = EvalOut()
+        ku, ki = _p(keep_users, np.uint8), _p(keep_items, np.uint8)
+        self._chk(self.lib.mfx_eval_filtered(self.h, which, snapshot, ku[1] if ku else None, ki[1] if ki else None, C.byref(out)))
+        return out
+
     def objective(self, uReg, iReg, snapshot=SNAP_CURRENT):
         """Model::objective (model.cpp:1770-1815) from the device sums."""
         o = self.eval(MAT_TRAIN, snapshot, True)

@@ -104,6 +104,34 @@ def test_all_trainers_leave_invalid_rows_alone_and_match_oracle(K):
         assert np.all(U[[1, 4]] == 0) and np.array_equal(V[4:], V0[4:])      # uFac.fill(0); invalid items keep iFac
 
 
+def test_filtered_evaluation_matches_oracle_masks():
+    """Model::RMSE(mat, filtItems, ...) / RMSEU (model.cpp:348-394, 446-486) = the masked evaluation with (invalid OR not kept)."""
+    d = synth.make(dict(nU=500, nI=200, nnz=20000, K=8), seed=3)
+    tr, te = d["train"], d["test"]
+    nU, nI = d["nUsers"], max(d["nItems"], tr.ncols)
+    rng = np.random.default_rng(1)
+    U = rng.normal(0, 0.6, (nU, 8)).astype(np.float32)
+    V = rng.normal(0, 0.6, (nI, 8)).astype(np.float32)
+    ku = (rng.random(nU) < 0.3).astype(np.uint8)
+    ki = (rng.random(nI) < 0.6).astype(np.uint8)
+    oU, oI = orc.invalid(tr.nrows, tr.ncols, tr.rowptr, tr.rowind, nU, nI)
+    with Ctx(0) as ctx:
+        ctx.set_csr(mfx.MAT_TRAIN, tr.nrows, tr.ncols, tr.rowptr, tr.rowind, tr.rowval)
+        ctx.set_csr(mfx.MAT_TEST, te.nrows, nI, te.rowptr, te.rowind, te.rowval)
+        ctx.set_model(nU, nI, 8)
+        ctx.set_factors(U, V)
+        ctx.compute_invalid()
+        full = ctx.eval(mfx.MAT_TEST)
+        for keep_u, keep_i in ((ku, None), (None, ki), (ku, ki)):
+            e = ctx.eval_filtered(mfx.MAT_TEST, keep_u, keep_i)
+            mu = oU | (1 - keep_u) if keep_u is not None else oU
+            mi = oI | (1 - keep_i) if keep_i is not None else oI
+            _, sse, n = orc.rmse(U, V, nU, nI, te.nrows, te.rowptr, te.rowind, te.rowval, mu.astype(np.uint8), mi.astype(np.uint8), orc.DOT_TREE)
+            assert e.n == n and 0 < n < full.n and abs(e.sse - sse) <= 1e-12 * sse
+        again = ctx.eval(mfx.MAT_TEST)                      # the filter does not stick
+        assert (again.n, again.sse) == (full.n, full.sse)
+
+
 def test_single_rating_and_argument_errors():
     tr = synth.CSR(1, 1, np.array([0, 1]), np.array([0], np.int32), np.array([3.0], np.float32))
     with Ctx(0) as ctx:
