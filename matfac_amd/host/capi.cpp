@@ -90,3 +90,17 @@ extern "C" int mfh_data_shape(const char* train, const char* test, const char* v
   *nUsers = data.nUsers; *nItems = data.nItems; *trainNNZ = data.trainNNZ;
   return 0;
 }
+
+// factor-file round trip for the tests: bin != 0 -> writeMatBin/readMatBin, else writeMat/readMat
+extern "C" int mfh_mat_write(const char* path, const float* data, int32_t n, int32_t k, int32_t bin) {
+  DenseF32 m(n, k);
+  memcpy(m.data(), data, sizeof(float) * (size_t)n * k);
+  if (bin) writeMatBin(m, n, k, path); else writeMat(m, n, k, path);
+  return 0;
+}
+extern "C" int mfh_mat_read(const char* path, float* data, int32_t n, int32_t k) {
+  DenseF32 m;
+  if (!readMat(m, n, k, path)) return -1;
+  memcpy(data, m.data(), sizeof(float) * (size_t)n * k);
+  return 0;
+}

@@ -73,7 +73,40 @@ void writeMat(const DenseF32& mat, int nrows, int ncols, const char* fileName) {
   }
 }
 
+// io.cpp:172-184: every value as one double, row by row -- lossless for float factors
+void writeMatBin(const DenseF32& mat, int nrows, int ncols, const char* fileName) {
+  std::ofstream op(fileName, std::ios::binary);
+  if (!op.is_open()) return;
+  std::vector<double> row((size_t)ncols);
+  for (int i = 0; i < nrows; i++) {
+    for (int j = 0; j < ncols; j++) row[j] = mat(i, j);
+    op.write((const char*)row.data(), sizeof(double) * (size_t)ncols);
+  }
+}
+// Reads what writeMatBin wrote.  (The reference's reader, io.cpp:291-302, reads 8 bytes into each 4-byte float
+// of the Eigen matrix; that overrun is not reproduced.)
+bool readMatBin(DenseF32& mat, int nrows, int ncols, const char* fileName) {
+  std::ifstream in(fileName, std::ios::binary);
+  if (!in.is_open()) {
+    std::cout << "\nCan't open file: " << fileName << std::endl;
+    return false;
+  }
+  mat = DenseF32(nrows, ncols);
+  std::vector<double> row((size_t)ncols);
+  for (int i = 0; i < nrows; i++) {
+    in.read((char*)row.data(), sizeof(double) * (size_t)ncols);
+    if (in.gcount() != (std::streamsize)(sizeof(double) * (size_t)ncols)) return false;
+    for (int j = 0; j < ncols; j++) mat(i, j) = (float)row[j];
+  }
+  return true;
+}
+static bool isBinMat(const char* name) {
+  const std::string s(name);
+  return s.size() > 7 && s.compare(s.size() - 7, 7, ".binmat") == 0;
+}
+
 bool readMat(DenseF32& mat, int nrows, int ncols, const char* fileName) {
+  if (isBinMat(fileName)) return readMatBin(mat, nrows, ncols, fileName);
   std::cout << "\nReading ... " << fileName << " nrows: " << nrows << " ncols: " << ncols << std::endl;
   std::ifstream in(fileName);
   if (!in.is_open()) {
@@ -193,6 +226,31 @@ void Model::saveFacs(std::string prefix) {
   const std::string iName = prefix + "_iFac_" + sign + ".mat";
   writeMat(iFac, nItems, facDim, iName.c_str());
   std::cout << "iFac Norm: " << iFac.norm() << std::endl;
+  if (getenv("MFX_SAVE_BIN")) saveBinFacs(prefix);   // lossless companion files (the text files keep 6 digits)
+}
+
+// model.cpp:131-140
+void Model::saveBinFacs(std::string prefix) {
+  if (getenv("MFX_NO_SAVE")) return;
+  syncHost();
+  const std::string sign = modelSignature();
+  writeMatBin(uFac, nUsers, facDim, (prefix + "_uFac_" + sign + ".binmat").c_str());
+  writeMatBin(iFac, nItems, facDim, (prefix + "_iFac_" + sign + ".binmat").c_str());
+}
+// model.cpp:143-159
+void Model::loadBinFacs(std::string prefix) {
+  const std::string sign = modelSignature();
+  const std::string uName = prefix + "_uFac_" + sign + ".binmat";
+  if (isFileExist(uName.c_str())) {
+    std::cout << "Loading user factors: " << uName << std::endl;
+    readMatBin(uFac, nUsers, facDim, uName.c_str());
+  }
+  const std::string iName = prefix + "_iFac_" + sign + ".binmat";
+  if (isFileExist(iName.c_str())) {
+    std::cout << "Loading item factors: " << iName << std::endl;
+    readMatBin(iFac, nItems, facDim, iName.c_str());
+  }
+  if (dev && devSnap == MFX_SNAP_CURRENT) pushToDevice();
 }
 
 void Model::loadFacs(std::string prefix) {

@@ -93,6 +93,8 @@ class Model {
   void display();
   void saveFacs(std::string prefix);                                               // model.cpp:89-101
   void loadFacs(std::string prefix);                                               // model.cpp:104-128
+  void saveBinFacs(std::string prefix);                                            // model.cpp:131-140
+  void loadBinFacs(std::string prefix);                                            // model.cpp:143-159
 
   // ---- device mirror ------------------------------------------------------------
   std::shared_ptr<MfxSession> dev;   // set while/after a trainer ran
@@ -138,6 +140,8 @@ class ModelMF : public Model {
 
 // text factor files (io.cpp:83-154)
 void writeMat(const DenseF32& mat, int nrows, int ncols, const char* fileName);
-bool readMat(DenseF32& mat, int nrows, int ncols, const char* fileName);
+bool readMat(DenseF32& mat, int nrows, int ncols, const char* fileName);     // text, or binary when the name ends in .binmat
+void writeMatBin(const DenseF32& mat, int nrows, int ncols, const char* fileName);
+bool readMatBin(DenseF32& mat, int nrows, int ncols, const char* fileName);
 bool isFileExist(const char* fileName);
 #endif

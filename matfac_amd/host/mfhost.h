@@ -44,6 +44,10 @@ int mfh_csr_read_text(const char* path, int32_t* nrows, int32_t* ncols, int64_t*
 int mfh_data_shape(const char* train, const char* test, const char* val, int32_t* nUsers, int32_t* nItems,
                    int32_t* trainNNZ);
 
+/* factor files (mf_model.cpp writeMat/readMat/writeMatBin/readMatBin) for tests; a name ending in .binmat reads binary */
+int mfh_mat_write(const char* path, const float* data, int32_t n, int32_t k, int32_t bin);
+int mfh_mat_read(const char* path, float* data, int32_t n, int32_t k);
+
 #ifdef __cplusplus
 }
 #endif

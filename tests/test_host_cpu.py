@@ -124,3 +124,20 @@ def test_parallel_reader_number_formats_and_piece_cuts(tmp_path):
     with pytest.raises(IOError) as e:
         host_read(p)
     assert "line %d" % (len(lines) + 1) in str(e.value)
+
+
+def test_factor_files_text_and_lossless_binary(tmp_path):
+    """writeMat keeps 6 significant digits (io.cpp:139-154, read back by the oracle's reader); the .binmat pair
+    (io.cpp:172-184: one double per value) is lossless and is what readMat picks by extension."""
+    lib = synth._host()
+    rng = np.random.default_rng(2)
+    M = (rng.normal(0, 1, (37, 11)) * 10.0 ** rng.integers(-6, 3, (37, 11))).astype(np.float32)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    t, b = str(tmp_path / "m.mat"), str(tmp_path / "m.binmat")
+    assert lib.mfh_mat_write(t.encode(), P(M), 37, 11, 0) == 0 and lib.mfh_mat_write(b.encode(), P(M), 37, 11, 1) == 0
+    back_t, back_b = np.empty_like(M), np.empty_like(M)
+    assert lib.mfh_mat_read(t.encode(), P(back_t), 37, 11) == 0 and lib.mfh_mat_read(b.encode(), P(back_b), 37, 11) == 0
+    assert np.array_equal(back_b.view(np.uint32), M.view(np.uint32))
+    assert np.allclose(back_t, M, rtol=1e-5) and np.array_equal(back_t, orc.read_mat(t, 37, 11))
+    assert np.array_equal(np.fromfile(b, np.float64).reshape(37, 11), M.astype(np.float64))
+    assert lib.mfh_mat_read(b.encode(), P(back_b), 38, 11) != 0          # short file
