@@ -258,6 +258,7 @@ void mfx_segs_free_internal(mfx_ctx* ctx) {
   free_segs(ctx->segs[1]);
 }
 void mfx_als_free_internal(mfx_ctx* ctx) {
+  mfx_als_wide_free_internal(ctx);
   dev_free(ctx->als_slabs);
   ctx->als_slab_cap = 0;
 }
@@ -324,9 +325,10 @@ extern "C" int mfx_als_half_sweep(mfx_ctx* ctx, int side, float reg) {
   const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
   NEED(m.present && m.has_col, MFX_E_STATE, "mfx_als_half_sweep: train matrix with column view needed");
   NEED(ctx->U, MFX_E_STATE, "mfx_als_half_sweep: no model");
-  NEED(ctx->K <= 64, MFX_E_ARG, "mfx_als_half_sweep: this build supports K <= 64 (got %d)", ctx->K);
+  NEED(ctx->K <= 256, MFX_E_ARG, "mfx_als_half_sweep: this build supports K <= 256 (got %d)", ctx->K);
   NEED(m.nrows <= ctx->nU && m.ncols <= ctx->nI, MFX_E_ARG, "mfx_als_half_sweep: matrix exceeds model");
   HIPCHK(hipSetDevice(ctx->device));
+  if (ctx->K > 64) return mfx_als_wide_half_sweep(ctx, side, reg);   // als_wide.hip
   RowSegs* sdp;
   int rc0 = mfx_get_segments(ctx, side, &sdp);
   if (rc0) return rc0;

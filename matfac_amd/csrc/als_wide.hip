@@ -1,0 +1,279 @@
+// als_wide.hip -- ALS half-sweep for 64 < K <= 256 (modelMF.cpp:805-841 users, :844-880 items).
+//
+// The 64-wide kernel of als.hip keeps the whole Gramian of a row in one wavefront's accumulators and factorises
+// it in registers; a 128..256-wide Gramian does not fit.  Here the K x K matrix is cut into 64 x 64 blocks:
+//   phase A  one wavefront per (row segment, block pair I >= J): the same gathered-row MFMA accumulation
+//            (v_mfma_f32_32x32x2_f32, two ratings per step), a from block I of y, b from block J; the
+//            right-hand side rides on the diagonal pairs.  Only the lower block triangle is formed -- the
+//            reference computes both triangles (:821-826) but they are bit-identical mirrors.
+//   phase B  one workgroup of KP threads per row: sums the row's segment partials into a packed lower
+//            triangle in LDS (K = 256: 132 KB), adds reg to the diagonal (:831-833), unpivoted LDL^T with the
+//            pivot column broadcast through a double-buffered LDS vector (one barrier per step), forward and
+//            column-oriented backward substitution.
+// Segments are processed in batches so that the partials never exceed ~8 GB whatever the matrix size.
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+
+#include "mfx_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+constexpr int BLK = 64 * 64;
+struct WideSide {
+  int32_t *wrow = nullptr, *wfirst = nullptr, *wn = nullptr;   // rows in segment order: id, first segment, segments
+  std::vector<int64_t> batch_seg, batch_row;                    // batch boundaries (segments, rows)
+  int64_t nrows = 0, nseg = 0;
+  bool built = false;
+};
+struct WideState {
+  WideSide side[2];
+  float* slabs = nullptr;
+  size_t slab_floats = 0;
+};
+WideState* wst(mfx_ctx* ctx) { return (WideState*)ctx->als_wide; }
+}  // namespace
+
+void mfx_als_wide_free_internal(mfx_ctx* ctx) {
+  WideState* s = wst(ctx);
+  if (!s) return;
+  for (WideSide& w : s->side) { dev_free(w.wrow); dev_free(w.wfirst); dev_free(w.wn); }
+  dev_free(s->slabs);
+  delete s;
+  ctx->als_wide = nullptr;
+}
+
+// ---------------------------------------------------------------------------
+// phase A
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void alsw_gram_kernel(const int64_t* __restrict__ seg_beg, const int64_t* __restrict__ seg_end,
+                                                       int64_t seg0, int64_t nseg, int npairs, const int32_t* __restrict__ ind,
+                                                       const float* __restrict__ val, const float* __restrict__ Y, int ld,
+                                                       float* __restrict__ slabs, int64_t stride) {
+  const int lane = threadIdx.x, half = lane >> 5, idx = lane & 31;
+  for (int64_t u = blockIdx.x; u < nseg * npairs; u += gridDim.x) {
+    const int64_t s = u / npairs;
+    const int p = (int)(u - s * npairs);
+    int I = 0;
+    while ((I + 1) * (I + 2) / 2 <= p) I++;
+    const int J = p - I * (I + 1) / 2;
+    const int oa = 64 * I, ob = 64 * J;
+    f32x16 t00, t01, t10, t11;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { t00[r] = 0.0f; t01[r] = 0.0f; t10[r] = 0.0f; t11[r] = 0.0f; }
+    float b0 = 0.0f, b1 = 0.0f;
+    const int64_t beg = seg_beg[seg0 + s], end = seg_end[seg0 + s];
+    for (int64_t base = beg; base < end; base += 64) {
+      const bool ok = base + lane < end;
+      const int mj = ok ? ind[base + lane] : 0;
+      const float mr = ok ? val[base + lane] : 0.0f;
+      const int n = (int)(end - base < 64 ? end - base : 64);
+      constexpr int B = 4;
+      for (int s0 = 0; s0 < n; s0 += 2 * B) {
+        float ya0[B], ya1[B], yb0[B], yb1[B], wr[B], w[B];
+#pragma unroll
+        for (int t = 0; t < B; t++) {
+          const int e = s0 + 2 * t + half;
+          const int j = __shfl(mj, e & 63, 64);
+          const float r = __shfl(mr, e & 63, 64);
+          const bool use = e < n && r > 0.0f;          // ratings <= 0 are skipped (modelMF.cpp:819,857)
+          w[t] = use ? 1.0f : 0.0f;
+          wr[t] = use ? r : 0.0f;
+          const float* y = Y + (int64_t)(e < n ? j : 0) * ld;
+          ya0[t] = y[oa + idx];
+          ya1[t] = y[oa + 32 + idx];
+          yb0[t] = y[ob + idx];
+          yb1[t] = y[ob + 32 + idx];
+        }
+#pragma unroll
+        for (int t = 0; t < B; t++) {
+          if (s0 + 2 * t < n) {   // wave-uniform
+            const float a0 = w[t] * ya0[t], a1 = w[t] * ya1[t];
+            t00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, yb0[t], t00, 0, 0, 0);
+            t01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, yb1[t], t01, 0, 0, 0);
+            t10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, yb0[t], t10, 0, 0, 0);
+            t11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, yb1[t], t11, 0, 0, 0);
+            b0 = __builtin_fmaf(wr[t], ya0[t], b0);
+            b1 = __builtin_fmaf(wr[t], ya1[t], b1);
+          }
+        }
+      }
+    }
+    float* o = slabs + s * stride + (int64_t)p * BLK + lane;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      o[(0 * 16 + r) * 64] = t00[r];
+      o[(1 * 16 + r) * 64] = t01[r];
+      o[(2 * 16 + r) * 64] = t10[r];
+      o[(3 * 16 + r) * 64] = t11[r];
+    }
+    if (I == J) {   // right-hand side of block I: even + odd rating halves
+      const float s0 = b0 + __shfl_xor(b0, 32, 64), s1 = b1 + __shfl_xor(b1, 32, 64);
+      float* ob_ = slabs + s * stride + (int64_t)npairs * BLK + 64 * I;
+      if (half == 0) { ob_[idx] = s0; ob_[32 + idx] = s1; }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// phase B
+// ---------------------------------------------------------------------------
+__global__ void alsw_solve_kernel(const int32_t* __restrict__ wrow, const int32_t* __restrict__ wfirst, const int32_t* __restrict__ wn,
+                                  int64_t row0, int64_t nrows, int64_t seg0, const float* __restrict__ slabs, int64_t stride,
+                                  int npairs, int K, int KP, int ld, float reg, float* __restrict__ X) {
+  extern __shared__ float lds[];
+  float* A = lds;                              // packed lower triangle
+  float* colbuf = A + KP * (KP + 1) / 2;       // [2][KP]
+  float* xb = colbuf + 2 * KP;                 // [2]
+  const int tid = threadIdx.x;
+  const int tri = tid * (tid + 1) / 2;
+  for (int64_t m = blockIdx.x; m < nrows; m += gridDim.x) {
+    const int row = wrow[row0 + m], n = wn[row0 + m];
+    const int64_t first = (int64_t)wfirst[row0 + m] - seg0;
+    float z = 0.0f;
+    for (int sg = 0; sg < n; sg++) {   // segment order: reproducible
+      const float* sl = slabs + (first + sg) * stride;
+      for (int off = tid; off < npairs * BLK; off += KP) {
+        const int p = off >> 12, rem = off & (BLK - 1);
+        int I = 0;
+        while ((I + 1) * (I + 2) / 2 <= p) I++;
+        const int J = p - I * (I + 1) / 2;
+        const int t = rem >> 10, r = (rem >> 6) & 15, l = rem & 63;
+        const int gi = 64 * I + 32 * (t >> 1) + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        const int gj = 64 * J + 32 * (t & 1) + (l & 31);
+        if (gj <= gi) {
+          const int at = gi * (gi + 1) / 2 + gj;
+          A[at] = sg == 0 ? sl[off] : A[at] + sl[off];
+        }
+      }
+      z += sl[(int64_t)npairs * BLK + tid];
+    }
+    __syncthreads();
+    // YTY(j,j) += reg for j < K (modelMF.cpp:831-833); padded dimensions become identity rows
+    A[tri + tid] = tid < K ? A[tri + tid] + reg : 1.0f;
+    __syncthreads();
+    // right-looking LDL^T; column k (unscaled) goes through colbuf
+    float d = 1.0f;
+    for (int k = 0; k < KP; k++) {
+      float* buf = colbuf + (k & 1) * KP;
+      if (tid >= k) buf[tid] = A[tri + k];
+      __syncthreads();
+      const float dk = buf[k];
+      if (tid == k) d = dk;
+      if (tid > k) {
+        const float lik = buf[tid] / dk;
+        float* rowp = A + tri;
+        for (int j = k + 1; j <= tid; j++) rowp[j] = rowp[j] - lik * buf[j];
+        rowp[k] = lik;
+      }
+    }
+    __syncthreads();
+    // L y = b
+    for (int k = 0; k < KP; k++) {
+      if (tid == k) xb[k & 1] = z;
+      __syncthreads();
+      const float zk = xb[k & 1];
+      if (tid > k) z = z - A[tri + k] * zk;
+    }
+    z = z / d;
+    __syncthreads();
+    // L^T x = y, one column of L^T (= row j of L) per step
+    for (int j = KP - 1; j >= 0; j--) {
+      if (tid == j) xb[j & 1] = z;
+      __syncthreads();
+      const float xj = xb[j & 1];
+      if (tid < j) z = z - A[j * (j + 1) / 2 + tid] * xj;
+    }
+    if (tid < K) X[(int64_t)row * ld + tid] = z;
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------
+static int build_wide_side(mfx_ctx* ctx, WideSide& w, const RowSegs& sd, int64_t seg_floats) {
+  std::vector<int32_t> seg_row((size_t)sd.nseg);
+  if (sd.nseg) HIPCHK(hipMemcpy(seg_row.data(), sd.seg_row, sizeof(int32_t) * seg_row.size(), hipMemcpyDeviceToHost));
+  std::vector<int32_t> wrow, wfirst, wn;
+  for (int64_t s = 0; s < sd.nseg;) {
+    int64_t e = s;
+    while (e < sd.nseg && seg_row[e] == seg_row[s]) e++;
+    wrow.push_back(seg_row[s]); wfirst.push_back((int32_t)s); wn.push_back((int32_t)(e - s));
+    s = e;
+  }
+  // batches of whole rows whose partials stay under the cap
+  static const int64_t cap_bytes = [] { const char* e = getenv("MFX_ALS_SLAB_GB"); return (int64_t)((e ? atof(e) : 8.0) * (1 << 30)); }();
+  const int64_t cap_seg = std::max<int64_t>(1, cap_bytes / (seg_floats * 4));
+  w.batch_seg.assign(1, 0);
+  w.batch_row.assign(1, 0);
+  int64_t cur = 0;
+  for (size_t r = 0; r < wrow.size(); r++) {
+    if (cur > 0 && cur + wn[r] > cap_seg) { w.batch_seg.push_back(wfirst[r]); w.batch_row.push_back((int64_t)r); cur = 0; }
+    cur += wn[r];
+  }
+  w.batch_seg.push_back(sd.nseg);
+  w.batch_row.push_back((int64_t)wrow.size());
+  int rc;
+  auto up = [&](int32_t** dst, const std::vector<int32_t>& v) -> int {
+    int r = dev_alloc(ctx, dst, v.size());
+    if (r) return r;
+    if (!v.empty()) HIPCHK(hipMemcpy(*dst, v.data(), sizeof(int32_t) * v.size(), hipMemcpyHostToDevice));
+    return MFX_OK;
+  };
+  if ((rc = up(&w.wrow, wrow)) || (rc = up(&w.wfirst, wfirst)) || (rc = up(&w.wn, wn))) return rc;
+  w.nrows = (int64_t)wrow.size();
+  w.nseg = sd.nseg;
+  w.built = true;
+  return MFX_OK;
+}
+
+int mfx_als_wide_half_sweep(mfx_ctx* ctx, int side, float reg) {
+  const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
+  const int K = ctx->K, C = (K + 63) / 64, KP = 64 * C, npairs = C * (C + 1) / 2;
+  NEED(K > 64 && K <= 256, MFX_E_ARG, "mfx_als_half_sweep: K=%d outside the wide kernel's range (64, 256]", K);
+  NEED(ctx->ld >= KP, MFX_E_STATE, "mfx_als_half_sweep: factor rows are not padded to %d", KP);
+  NEED(!(side == MFX_SIDE_ITEMS && mfx_sharded(ctx)), MFX_E_ARG, "mfx_als_half_sweep: the sharded item sweep is built for K <= 64");
+  if (!ctx->als_wide) ctx->als_wide = new WideState;
+  WideState* st = wst(ctx);
+  RowSegs* sdp;
+  int rc = mfx_get_segments(ctx, side, &sdp);
+  if (rc) return rc;
+  const int64_t stride = (int64_t)npairs * BLK + KP;
+  WideSide& w = st->side[side];
+  if (!w.built && (rc = build_wide_side(ctx, w, *sdp, stride))) return rc;
+  const int32_t* ind = side == MFX_SIDE_USERS ? m.rowind : m.colind;
+  const float* val = side == MFX_SIDE_USERS ? m.rowval : m.colval;
+  const float* Y = side == MFX_SIDE_USERS ? ctx->V : ctx->U;
+  float* X = side == MFX_SIDE_USERS ? ctx->U : ctx->V;
+  const size_t lds = ((size_t)KP * (KP + 1) / 2 + 2 * (size_t)KP + 2) * sizeof(float);
+  HIPCHK(hipFuncSetAttribute((const void*)alsw_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  for (size_t b = 0; b + 1 < w.batch_seg.size(); b++) {
+    const int64_t s0 = w.batch_seg[b], ns = w.batch_seg[b + 1] - s0;
+    const int64_t r0 = w.batch_row[b], nr = w.batch_row[b + 1] - r0;
+    if (ns == 0) continue;
+    const size_t need = (size_t)ns * (size_t)stride;
+    if (need > st->slab_floats) {
+      dev_free(st->slabs);
+      st->slab_floats = 0;
+      if ((rc = dev_alloc(ctx, &st->slabs, need))) return rc;
+      st->slab_floats = need;
+    }
+    {
+      ProfScope ps(ctx, MFX_K_ALS_GRAM);
+      const int blocks = (int)std::min<int64_t>(ns * npairs, 256 * 32);
+      hipLaunchKernelGGL(alsw_gram_kernel, dim3(blocks), dim3(64), 0, ctx->stream, sdp->seg_beg, sdp->seg_end, s0, ns, npairs, ind, val,
+                         Y, ctx->ld, st->slabs, stride);
+      HIPCHK(hipGetLastError());
+    }
+    {
+      ProfScope ps(ctx, MFX_K_ALS_SOLVE);
+      const int blocks = (int)std::min<int64_t>(nr, 256 * 8);
+      hipLaunchKernelGGL(alsw_solve_kernel, dim3(blocks), dim3(KP), lds, ctx->stream, w.wrow, w.wfirst, w.wn, r0, nr, s0, st->slabs, stride,
+                         npairs, K, KP, ctx->ld, reg, X);
+      HIPCHK(hipGetLastError());
+    }
+  }
+  return MFX_OK;
+}

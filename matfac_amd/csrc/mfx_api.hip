@@ -226,6 +226,7 @@ extern "C" int mfx_set_model(mfx_ctx* ctx, int32_t nUsers, int32_t nItems, int32
   free_model(ctx);
   mfx_ccd_free_internal(ctx);
   mfx_cd_free_internal(ctx);
+  mfx_als_wide_free_internal(ctx);
   ctx->nU = nUsers; ctx->nI = nItems; ctx->K = K;
   mfx_tree_shape(K, &ctx->L, &ctx->C);
   ctx->ld = 4 * ctx->L * ctx->C;

@@ -92,6 +92,7 @@ struct mfx_ctx {
   int32_t* colid = nullptr;
   void* ccd_cols = nullptr;   // strip-major column view (ccd_cols.hip owns the type)
   void* cd = nullptr;         // trainCCD state (cd.hip owns the type)
+  void* als_wide = nullptr;   // ALS for K > 64 (als_wide.hip owns the type)
 
   // comm
   void* comm = nullptr;      // ncclComm_t
@@ -197,6 +198,8 @@ int mfx_comm_global_col_counts(mfx_ctx* ctx, const double** out);
 void mfx_comm_drop_col_counts(mfx_ctx* ctx);
 void mfx_ccd_free_internal(mfx_ctx* ctx);
 void mfx_als_free_internal(mfx_ctx* ctx);
+void mfx_als_wide_free_internal(mfx_ctx* ctx);
+int mfx_als_wide_half_sweep(mfx_ctx* ctx, int side, float reg);
 void mfx_segs_free_internal(mfx_ctx* ctx);
 // CCD++ column view (ccd_cols.hip)
 int mfx_ccd_cols_build(mfx_ctx* ctx);

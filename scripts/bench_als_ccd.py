@@ -8,7 +8,7 @@ from matfac_amd import Ctx, mfx, synth
 
 what = os.environ.get("WHAT", "als,ccd").split(",")
 if "als" in what:
-    K = 64
+    K = int(os.environ.get("ALS_K", 64))
     shape = dict(synth.SHAPES["C2"]); shape["nnz"] = int(shape["nnz"] / 0.8)
     d = synth.make(shape, seed=1); tr, va = d["train"], d["val"]; nU, nI = d["nUsers"], shape["nI"]
     U0, V0 = synth.init_factors(1, nU, nI, K)
@@ -19,7 +19,7 @@ if "als" in what:
     reg = 5.0
     ctx.als_half_sweep(mfx.SIDE_USERS, reg); ctx.als_half_sweep(mfx.SIDE_ITEMS, reg); ctx.synchronize()
     ctx.prof_enable(True); ctx.prof_reset()
-    iters = 5
+    iters = int(os.environ.get("ALS_ITERS", 5))
     t0 = time.perf_counter(); traj = []
     for it in range(iters):
         ctx.als_half_sweep(mfx.SIDE_USERS, reg); ctx.als_half_sweep(mfx.SIDE_ITEMS, reg)
@@ -27,7 +27,7 @@ if "als" in what:
     ctx.synchronize(); wall = (time.perf_counter() - t0) / iters
     g_ms, g_n = ctx.prof_get(mfx.K_ALS_GRAM); s_ms, s_n = ctx.prof_get(mfx.K_ALS_SOLVE)
     flops = 2 * tr.nnz * (2 * K * K + 2 * K) + (nU + nI) * (K ** 3 / 3 + 2 * K * K)
-    print(json.dumps(dict(path="ALS C3", nnz=tr.nnz, K=K, ms_per_iter_events=(g_ms + s_ms) / iters, wall_ms_per_iter=wall * 1e3,
+    print(json.dumps(dict(path="ALS C3" if K == 64 else "ALS C2 matrix", nnz=tr.nnz, K=K, ms_per_iter_events=(g_ms + s_ms) / iters, wall_ms_per_iter=wall * 1e3,
                           gram_ms=g_ms / iters, reduce_ms=s_ms / iters, tflops=flops / ((g_ms + s_ms) / iters * 1e-3) / 1e12,
                           mfma_peak_tflops=157.3, rating_iters_per_s=tr.nnz / ((g_ms + s_ms) / iters * 1e-3), val_rmse=traj)), flush=True)
     ctx.close()

@@ -21,7 +21,9 @@ def _data(nU, nI, nnz, seed):
     return d, tr, (cp, ci, cv)
 
 
-@pytest.mark.parametrize("K,reg", [(64, 5.0), (64, 0.5), (64, 0.05), (32, 1.0), (10, 1.0), (48, 2.0)])
+# K > 64 runs the blocked kernels of als_wide.hip (64x64 block pairs + LDL^T in LDS)
+@pytest.mark.parametrize("K,reg", [(64, 5.0), (64, 0.5), (64, 0.05), (32, 1.0), (10, 1.0), (48, 2.0), (128, 2.0), (100, 1.0),
+                                   (192, 3.0), (256, 5.0), (65, 0.5)])
 def test_half_sweeps_match_oracle(K, reg):
     d, tr, (cp, ci, cv) = _data(1500, 400, 60000, seed=K)
     nU, nI = d["nUsers"], d["nItems"]

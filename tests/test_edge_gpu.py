@@ -76,7 +76,7 @@ def test_all_trainers_leave_invalid_rows_alone_and_match_oracle(K):
         assert np.array_equal(U[[1, 4]], U0[[1, 4]]) and np.array_equal(V[4:], V0[4:])
         assert not np.array_equal(U[0], U0[0])
         # ALS
-        if K <= 64:
+        if K <= 256:
             ctx.set_factors(U0, V0)
             ctx.als_half_sweep(mfx.SIDE_USERS, 0.7)
             ctx.als_half_sweep(mfx.SIDE_ITEMS, 0.7)
@@ -154,8 +154,8 @@ def test_single_rating_and_argument_errors():
         with pytest.raises(mfx.MfxError):
             ctx.set_model(0, 5, 4)
     with Ctx(0) as ctx:
-        ctx.set_model(4, 4, 80)
+        ctx.set_model(4, 4, 300)
         ctx.set_csr(mfx.MAT_TRAIN, 4, 4, np.arange(5), np.arange(4, dtype=np.int32), np.ones(4, np.float32))
         with pytest.raises(mfx.MfxError) as e:
-            ctx.als_half_sweep(mfx.SIDE_USERS, 1.0)            # ALS is built for K <= 64
-        assert "K <= 64" in str(e.value)
+            ctx.als_half_sweep(mfx.SIDE_USERS, 1.0)            # ALS is built for K <= 256
+        assert "K <= 256" in str(e.value)
