@@ -6,10 +6,10 @@
 //            (v_mfma_f32_32x32x2_f32, two ratings per step), a from block I of y, b from block J; the
 //            right-hand side rides on the diagonal pairs.  Only the lower block triangle is formed -- the
 //            reference computes both triangles (:821-826) but they are bit-identical mirrors.
-//   phase B  one workgroup of KP threads per row: sums the row's segment partials into a packed lower
-//            triangle in LDS (K = 256: 132 KB), adds reg to the diagonal (:831-833), unpivoted LDL^T with the
-//            pivot column broadcast through a double-buffered LDS vector (one barrier per step), forward and
-//            column-oriented backward substitution.
+//   phase B  one workgroup of (KP/8)^2 threads per row: sums the row's segment partials into a lower triangle
+//            held 2D-cyclically in registers (36 per thread), adds reg to the diagonal (:831-833), unpivoted LDL^T
+//            with the pivot column broadcast through a double-buffered LDS vector (one barrier per step), then L
+//            and D go to LDS (K = 256: 132 KB) for the forward and the column-oriented backward substitution.
 // Segments are processed in batches so that the partials never exceed ~8 GB whatever the matrix size.
 #include <algorithm>
 #include <cstdlib>
@@ -119,73 +119,150 @@ __global__ __launch_bounds__(64) void alsw_gram_kernel(const int64_t* __restrict
 // ---------------------------------------------------------------------------
 // phase B
 // ---------------------------------------------------------------------------
-__global__ void alsw_solve_kernel(const int32_t* __restrict__ wrow, const int32_t* __restrict__ wfirst, const int32_t* __restrict__ wn,
-                                  int64_t row0, int64_t nrows, int64_t seg0, const float* __restrict__ slabs, int64_t stride,
-                                  int npairs, int K, int KP, int ld, float reg, float* __restrict__ X) {
+// position of element (gi, gj), gj <= gi, inside a segment's partials (the MFMA accumulator layout of phase A)
+__device__ __forceinline__ int alsw_slab_offset(int gi, int gj) {
+  const int I = gi >> 6, J = gj >> 6, rr = gi & 63, cc = gj & 63;
+  const int p = I * (I + 1) / 2 + J, t = (rr >> 5) * 2 + (cc >> 5), r32 = rr & 31, c32 = cc & 31;
+  const int r = (r32 & 3) + 4 * (r32 >> 3), lane = c32 + 32 * ((r32 >> 2) & 1);
+  return p * BLK + (t * 16 + r) * 64 + lane;
+}
+
+// One workgroup of P*P threads per row, KP = 8P.  The lower triangle lives in REGISTERS, 2D-cyclic: thread
+// (ti, tj) owns the elements (ti + P*a, tj + P*b), a >= b -- 36 registers.  Step k of the right-looking LDL^T:
+// the owners of column k publish it (unscaled) through a double-buffered LDS vector, one barrier, then every
+// thread updates its own elements with 8 + 8 LDS reads.  The column loop is blocked by P so that every register
+// index is a compile-time constant.  L and D are then written to LDS for the two substitutions.
+template <int P>
+__global__ __launch_bounds__(P * P) void alsw_solve_kernel(const int32_t* __restrict__ wrow, const int32_t* __restrict__ wfirst,
+                                                          const int32_t* __restrict__ wn, int64_t row0, int64_t nrows, int64_t seg0,
+                                                          const float* __restrict__ slabs, int64_t stride, int npairs, int K,
+                                                          int ld, float reg, float* __restrict__ X) {
+  constexpr int KP = 8 * P;
   extern __shared__ float lds[];
-  float* A = lds;                              // packed lower triangle
-  float* colbuf = A + KP * (KP + 1) / 2;       // [2][KP]
-  float* xb = colbuf + 2 * KP;                 // [2]
-  const int tid = threadIdx.x;
-  const int tri = tid * (tid + 1) / 2;
+  float* Lp = lds;                              // packed strictly-lower L (+ unused diagonal slots)
+  float* colbuf = Lp + KP * (KP + 1) / 2;       // [2][KP]
+  float* dvec = colbuf + 2 * KP;                // [KP]
+
+  const int tid = threadIdx.x, ti = tid / P, tj = tid % P;
   for (int64_t m = blockIdx.x; m < nrows; m += gridDim.x) {
     const int row = wrow[row0 + m], n = wn[row0 + m];
     const int64_t first = (int64_t)wfirst[row0 + m] - seg0;
+    float A[8][8];
     float z = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 8; a++)
+#pragma unroll
+      for (int b = 0; b <= a; b++) A[a][b] = 0.0f;
+#pragma nounroll
     for (int sg = 0; sg < n; sg++) {   // segment order: reproducible
       const float* sl = slabs + (first + sg) * stride;
-      for (int off = tid; off < npairs * BLK; off += KP) {
-        const int p = off >> 12, rem = off & (BLK - 1);
-        int I = 0;
-        while ((I + 1) * (I + 2) / 2 <= p) I++;
-        const int J = p - I * (I + 1) / 2;
-        const int t = rem >> 10, r = (rem >> 6) & 15, l = rem & 63;
-        const int gi = 64 * I + 32 * (t >> 1) + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-        const int gj = 64 * J + 32 * (t & 1) + (l & 31);
-        if (gj <= gi) {
-          const int at = gi * (gi + 1) / 2 + gj;
-          A[at] = sg == 0 ? sl[off] : A[at] + sl[off];
+#pragma unroll
+      for (int a = 0; a < 8; a++)
+#pragma unroll
+        for (int b = 0; b <= a; b++) {
+          const int gi = ti + P * a, gj = tj + P * b;
+          if (gj <= gi) A[a][b] += sl[alsw_slab_offset(gi, gj)];
+        }
+      if (tid < KP) z += sl[(int64_t)npairs * BLK + tid];
+    }
+    // YTY(j,j) += reg for j < K (modelMF.cpp:831-833); padded dimensions become identity rows
+    if (ti == tj) {
+#pragma unroll
+      for (int a = 0; a < 8; a++) A[a][a] = (ti + P * a) < K ? A[a][a] + reg : 1.0f;
+    }
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+#pragma nounroll
+      for (int kk = 0; kk < P; kk++) {
+        const int k = b * P + kk;
+        float* buf = colbuf + (k & 1) * KP;
+        if (tj == kk) {
+#pragma unroll
+          for (int a = b; a < 8; a++) buf[ti + P * a] = A[a][b];
+        }
+        __syncthreads();
+        const float rdk = 1.0f / buf[k];
+        float li[8], cj[8];
+#pragma unroll
+        for (int a = b; a < 8; a++) li[a] = buf[ti + P * a] * rdk;
+#pragma unroll
+        for (int c = b; c < 8; c++) cj[c] = buf[tj + P * c];
+        // element (ti + P a, tj + P c) is below column k and inside the lower triangle: decided at compile time
+        // except in the block column of k (c == b: tj > kk) and on the diagonal blocks (a == c: tj <= ti)
+        const bool right_of_k = tj > kk, on_or_below = tj <= ti;
+#pragma unroll
+        for (int a = b; a < 8; a++)
+#pragma unroll
+          for (int c = b; c <= a; c++) {
+            const float upd = __builtin_fmaf(-li[a], cj[c], A[a][c]);
+            if (c > b && a > c) A[a][c] = upd;
+            else if (c > b) A[a][c] = on_or_below ? upd : A[a][c];
+            else if (a > c) A[a][c] = right_of_k ? upd : A[a][c];
+            else A[a][c] = (right_of_k && on_or_below) ? upd : A[a][c];
+          }
+        if (tj == kk) {
+#pragma unroll
+          for (int a = b; a < 8; a++)
+            if (ti + P * a > k) A[a][b] = li[a];
         }
       }
-      z += sl[(int64_t)npairs * BLK + tid];
     }
+    // L (strictly lower) and D to LDS
+#pragma unroll
+    for (int a = 0; a < 8; a++)
+#pragma unroll
+      for (int b = 0; b <= a; b++) {
+        const int gi = ti + P * a, gj = tj + P * b;
+        if (gj < gi) Lp[gi * (gi + 1) / 2 + gj] = A[a][b];
+        else if (gj == gi) dvec[gi] = A[a][b];
+      }
     __syncthreads();
-    // YTY(j,j) += reg for j < K (modelMF.cpp:831-833); padded dimensions become identity rows
-    A[tri + tid] = tid < K ? A[tri + tid] + reg : 1.0f;
+    // The substitutions run on ONE wavefront (lane l owns rows l, l+64, ...): the pivot value travels by a
+    // cross-lane read instead of a workgroup barrier per step.
+    if (tid < KP) colbuf[tid] = z;     // right-hand side, gathered from the threads that summed it
     __syncthreads();
-    // right-looking LDL^T; column k (unscaled) goes through colbuf
-    float d = 1.0f;
-    for (int k = 0; k < KP; k++) {
-      float* buf = colbuf + (k & 1) * KP;
-      if (tid >= k) buf[tid] = A[tri + k];
-      __syncthreads();
-      const float dk = buf[k];
-      if (tid == k) d = dk;
-      if (tid > k) {
-        const float lik = buf[tid] / dk;
-        float* rowp = A + tri;
-        for (int j = k + 1; j <= tid; j++) rowp[j] = rowp[j] - lik * buf[j];
-        rowp[k] = lik;
+    if (tid < 64) {
+      constexpr int Q = KP / 64;
+      float zz[Q];
+#pragma unroll
+      for (int q = 0; q < Q; q++) zz[q] = colbuf[tid + 64 * q];
+      // L y = b
+#pragma unroll
+      for (int q = 0; q < Q; q++) {
+#pragma nounroll
+        for (int kk = 0; kk < 64; kk++) {
+          const int k = 64 * q + kk;
+          const float zk = __shfl(zz[q], kk, 64);
+#pragma unroll
+          for (int q2 = q; q2 < Q; q2++) {
+            const int i = tid + 64 * q2;
+            if (i > k) zz[q2] = zz[q2] - Lp[i * (i + 1) / 2 + k] * zk;
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < Q; q++) zz[q] = zz[q] / dvec[tid + 64 * q];
+      // L^T x = y, one column of L^T (= row j of L) per step
+#pragma unroll
+      for (int q = Q - 1; q >= 0; q--) {
+#pragma nounroll
+        for (int jj = 63; jj >= 0; jj--) {
+          const int j = 64 * q + jj;
+          const float xj = __shfl(zz[q], jj, 64);
+          const float* Lj = Lp + j * (j + 1) / 2;
+#pragma unroll
+          for (int q2 = 0; q2 <= q; q2++) {
+            const int i = tid + 64 * q2;
+            if (i < j) zz[q2] = zz[q2] - Lj[i] * xj;
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < Q; q++) {
+        const int i = tid + 64 * q;
+        if (i < K) X[(int64_t)row * ld + i] = zz[q];
       }
     }
-    __syncthreads();
-    // L y = b
-    for (int k = 0; k < KP; k++) {
-      if (tid == k) xb[k & 1] = z;
-      __syncthreads();
-      const float zk = xb[k & 1];
-      if (tid > k) z = z - A[tri + k] * zk;
-    }
-    z = z / d;
-    __syncthreads();
-    // L^T x = y, one column of L^T (= row j of L) per step
-    for (int j = KP - 1; j >= 0; j--) {
-      if (tid == j) xb[j & 1] = z;
-      __syncthreads();
-      const float xj = xb[j & 1];
-      if (tid < j) z = z - A[j * (j + 1) / 2 + tid] * xj;
-    }
-    if (tid < K) X[(int64_t)row * ld + tid] = z;
     __syncthreads();
   }
 }
@@ -247,8 +324,9 @@ int mfx_als_wide_half_sweep(mfx_ctx* ctx, int side, float reg) {
   const float* val = side == MFX_SIDE_USERS ? m.rowval : m.colval;
   const float* Y = side == MFX_SIDE_USERS ? ctx->V : ctx->U;
   float* X = side == MFX_SIDE_USERS ? ctx->U : ctx->V;
-  const size_t lds = ((size_t)KP * (KP + 1) / 2 + 2 * (size_t)KP + 2) * sizeof(float);
-  HIPCHK(hipFuncSetAttribute((const void*)alsw_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const size_t lds = ((size_t)KP * (KP + 1) / 2 + 3 * (size_t)KP + 2) * sizeof(float);
+  const void* solve_fn = C == 2 ? (const void*)alsw_solve_kernel<16> : C == 3 ? (const void*)alsw_solve_kernel<24> : (const void*)alsw_solve_kernel<32>;
+  HIPCHK(hipFuncSetAttribute(solve_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   for (size_t b = 0; b + 1 < w.batch_seg.size(); b++) {
     const int64_t s0 = w.batch_seg[b], ns = w.batch_seg[b + 1] - s0;
     const int64_t r0 = w.batch_row[b], nr = w.batch_row[b + 1] - r0;
@@ -270,8 +348,11 @@ int mfx_als_wide_half_sweep(mfx_ctx* ctx, int side, float reg) {
     {
       ProfScope ps(ctx, MFX_K_ALS_SOLVE);
       const int blocks = (int)std::min<int64_t>(nr, 256 * 8);
-      hipLaunchKernelGGL(alsw_solve_kernel, dim3(blocks), dim3(KP), lds, ctx->stream, w.wrow, w.wfirst, w.wn, r0, nr, s0, st->slabs, stride,
-                         npairs, K, KP, ctx->ld, reg, X);
+#define MFX_SOLVE(PP)                                                                                                        \
+  hipLaunchKernelGGL(alsw_solve_kernel<PP>, dim3(blocks), dim3(PP * PP), lds, ctx->stream, w.wrow, w.wfirst, w.wn, r0, nr, s0, \
+                     st->slabs, stride, npairs, K, ctx->ld, reg, X)
+      if (C == 2) MFX_SOLVE(16); else if (C == 3) MFX_SOLVE(24); else MFX_SOLVE(32);
+#undef MFX_SOLVE
       HIPCHK(hipGetLastError());
     }
   }
