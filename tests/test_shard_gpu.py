@@ -82,12 +82,20 @@ def _worker(rank, world, port, out_dir):
 
 
 def test_two_shards_equal_one_context(tmp_path):
-    import torch.multiprocessing as mp
+    # stdlib multiprocessing: torch (and the HIP/RCCL copies it bundles) is loaded in the two workers only, never
+    # into this process, which already holds libmfx.so and possibly the system RCCL from other tests
+    import multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    cx = mp.get_context("spawn")
+    procs = [cx.Process(target=_worker, args=(g, 2, port, str(tmp_path))) for g in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(280)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     r = [np.load(str(tmp_path / ("r%d.npz" % g))) for g in range(2)]
     tr, nI, U0, V0 = _problem()
     with Ctx(0) as ctx:
