@@ -194,6 +194,20 @@ int mfx_ccd_end(mfx_ctx* ctx);
 /* test hook: the residuals on both views (either pointer may be NULL) */
 int mfx_debug_ccd_residuals(mfx_ctx* ctx, float* res_row, float* res_col);
 
+/* ---- ModelMF::trainSGDParSVD (modelMF.cpp:353-557) ------------------------------ */
+/* Replaces svdFrmSvdlibCSREig(trainMat, facDim, uFac, iFac, false) (svdFrmsvdlib.cpp:69-133, SVDLIBC las2):
+ * rank-K truncated SVD of the train matrix; uFac <- left, iFac <- right singular vectors (rows of items
+ * beyond the train matrix keep their values), singular[K] <- singular values, descending.  Randomized block
+ * subspace iteration: power_iters passes over R and R^T on a (K + oversample)-dimensional block.            */
+int mfx_svd_init(mfx_ctx* ctx, int32_t power_iters, int32_t oversample, uint32_t seed, float* singular);
+/* Per-dimension regulariser of the SVD variant: with reg != NULL, MFX_SGD_HOGWILD / MFX_SGD_SERIAL epochs run
+ * x_k -= lr * (-2 diff y_k + 2 reg[k] x_k) with a float diff (modelMF.cpp:494-505) on both sides and ignore
+ * opts->uReg/iReg/arith; NULL switches back.  reg[k] = (sing_a + 1) / (sing_b + sigma_k).                    */
+int mfx_sgd_set_dim_reg(mfx_ctx* ctx, const float* reg);
+/* Model::objectiveSing (model.cpp:1818-1865): as mfx_eval, with unorm2 / inorm2 = sum over valid rows of
+ * sum_k x_k^2 * w[k].                                                                                        */
+int mfx_eval_weighted(mfx_ctx* ctx, int which, int snapshot, const float* w, mfx_eval_out* out);
+
 /* ---- multi-GPU: user-row-block sharding, item-factor exchange over RCCL ------ */
 /* The reference is single-process; this is new.  Each rank owns a
  * user block (its CSR rows + U shard) and a replica of V.  After local work,

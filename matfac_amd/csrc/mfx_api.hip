@@ -99,6 +99,7 @@ void mfx_destroy(mfx_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   mfx_comm_free_internal(ctx);
+  dev_free(ctx->dimreg);
   mfx_ccd_free_internal(ctx);
   mfx_cd_free_internal(ctx);
   mfx_als_free_internal(ctx);
@@ -227,6 +228,7 @@ extern "C" int mfx_set_model(mfx_ctx* ctx, int32_t nUsers, int32_t nItems, int32
   mfx_ccd_free_internal(ctx);
   mfx_cd_free_internal(ctx);
   mfx_als_wide_free_internal(ctx);
+  dev_free(ctx->dimreg);
   ctx->nU = nUsers; ctx->nI = nItems; ctx->K = K;
   mfx_tree_shape(K, &ctx->L, &ctx->C);
   ctx->ld = 4 * ctx->L * ctx->C;
@@ -439,6 +441,8 @@ extern "C" int mfx_sgd_epoch(mfx_ctx* ctx, const mfx_sgd_opts* o) {
   NEED(m.nrows <= ctx->nU && m.ncols <= ctx->nI, MFX_E_ARG,
        "mfx_sgd_epoch: train matrix %dx%d exceeds model %dx%d", m.nrows, m.ncols, ctx->nU, ctx->nI);
   NEED(o->mode >= MFX_SGD_HOGWILD && o->mode <= MFX_SGD_TILED, MFX_E_ARG, "mfx_sgd_epoch: mode=%d", o->mode);
+  NEED(!ctx->dimreg || o->mode == MFX_SGD_HOGWILD || o->mode == MFX_SGD_SERIAL, MFX_E_ARG,
+       "mfx_sgd_epoch: per-dimension regularisation (mfx_sgd_set_dim_reg) runs on MFX_SGD_HOGWILD / MFX_SGD_SERIAL");
   NEED(o->order >= MFX_ORDER_DEVICE && o->order <= MFX_ORDER_NATURAL, MFX_E_ARG, "mfx_sgd_epoch: order=%d", o->order);
   NEED(o->arith >= MFX_ARITH_REF64 && o->arith <= MFX_ARITH_F32, MFX_E_ARG, "mfx_sgd_epoch: arith=%d", o->arith);
   HIPCHK(hipSetDevice(ctx->device));

@@ -93,6 +93,7 @@ struct mfx_ctx {
   void* ccd_cols = nullptr;   // strip-major column view (ccd_cols.hip owns the type)
   void* cd = nullptr;         // trainCCD state (cd.hip owns the type)
   void* als_wide = nullptr;   // ALS for K > 64 (als_wide.hip owns the type)
+  float* dimreg = nullptr;    // per-dimension regulariser [ld] of trainSGDParSVD (svd.hip), or NULL
 
   // comm
   void* comm = nullptr;      // ncclComm_t
@@ -186,6 +187,7 @@ static inline void mfx_tree_shape(int K, int* L, int* C) {
 int mfx_launch_sgd(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_t count);
 int mfx_launch_sgd_users(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t nusers);
 int mfx_launch_sgd_tiled(mfx_ctx* ctx, const mfx_sgd_opts* o);
+int mfx_launch_sgd_dimreg(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_t count);   // svd.hip
 int mfx_slots_materialise_order(mfx_ctx* ctx);
 void mfx_slots_free_internal(mfx_ctx* ctx);
 int mfx_launch_eval(mfx_ctx* ctx, const DevCSR& m, const float* U, const float* V,

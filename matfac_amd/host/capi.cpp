@@ -32,6 +32,7 @@ extern "C" int mfh_train(const char* method, int32_t nrows, const int64_t* tr_pt
   else if (m == "hogsgd") model.hogTrain(data, best, iu, ii);
   else if (m == "sgdu") model.trainUShuffle(data, best, iu, ii);
   else if (m == "sgdpar") model.trainSGDPar(data, best, iu, ii);
+  else if (m == "sgdparsvd") model.trainSGDParSVD(data, best, iu, ii);
   else if (m == "sgd") model.train(data, best, iu, ii);
   else return -1;
   const size_t su = sizeof(float) * (size_t)data.nUsers * K, si = sizeof(float) * (size_t)data.nItems * K;

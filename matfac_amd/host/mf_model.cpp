@@ -188,6 +188,7 @@ void Model::copyScalarsFrom(const Model& o) {
   nUsers = o.nUsers; nItems = o.nItems; facDim = o.facDim; trainSeed = o.trainSeed;
   origLearnRate = o.origLearnRate; learnRate = o.learnRate; rhoRMS = o.rhoRMS; alpha = o.alpha;
   maxIter = o.maxIter; uReg = o.uReg; iReg = o.iReg; sing_a = o.sing_a; sing_b = o.sing_b; mu = o.mu;
+  singularVals = o.singularVals;
 }
 
 std::string Model::modelSignature() {
@@ -372,8 +373,34 @@ double Model::objective(const Data& data) {
 bool Model::isTerminateModel(Model& bestModel, const Data& data, int iter, int& bestIter, double& bestObj,
                              double& prevObj, double& bestValRMSE, double& prevValRMSE, IntSet& invalidUsers,
                              IntSet& invalidItems) {
+  return terminateImpl(false, bestModel, data, iter, bestIter, bestObj, prevObj, bestValRMSE, prevValRMSE, invalidUsers,
+                       invalidItems);
+}
+// model.cpp:1543-1612: the same rules on objectiveSing
+bool Model::isTerminateModelSing(Model& bestModel, const Data& data, int iter, int& bestIter, double& bestObj,
+                                 double& prevObj, double& bestValRMSE, double& prevValRMSE, IntSet& invalidUsers,
+                                 IntSet& invalidItems) {
+  return terminateImpl(true, bestModel, data, iter, bestIter, bestObj, prevObj, bestValRMSE, prevValRMSE, invalidUsers,
+                       invalidItems);
+}
+// model.cpp:1818-1865: squared error + sum_k x_k^2 * singularVals(k) over the valid users and items
+double Model::objectiveSing(const Data& data, IntSet& invalidUsers, IntSet& invalidItems) {
+  (void)invalidUsers; (void)invalidItems;
+  const int w = dev ? dev->which(data.trainMat) : -1;
+  if (w < 0 || (int)singularVals.size() != facDim) {
+    std::cerr << "\nModel::objectiveSing: needs a device session and facDim singular values" << std::endl;
+    exit(-2);
+  }
+  mfx_eval_out o;
+  dev->check(mfx_eval_weighted(dev->ctx, w, devSnap, singularVals.data(), &o), "mfx_eval_weighted");
+  return o.sse + o.unorm2 + o.inorm2;
+}
+
+bool Model::terminateImpl(bool sing, Model& bestModel, const Data& data, int iter, int& bestIter, double& bestObj,
+                          double& prevObj, double& bestValRMSE, double& prevValRMSE, IntSet& invalidUsers,
+                          IntSet& invalidItems) {
   bool ret = false;
-  const double currObj = objective(data, invalidUsers, invalidItems);
+  const double currObj = sing ? objectiveSing(data, invalidUsers, invalidItems) : objective(data, invalidUsers, invalidItems);
   double currValRMSE = -1;
   if (data.valMat) {
     currValRMSE = RMSE(data.valMat, invalidUsers, invalidItems);
@@ -432,10 +459,7 @@ void ModelMF::trainCCDPPFreqAdap(const Data& d, Model& b, IntSet& iu, IntSet& ii
   run(K_CCDPP_FA, "trainCCDPPFreqAdap", d, b, iu, ii);
 }
 void ModelMF::trainCCD(const Data& d, Model& b, IntSet& iu, IntSet& ii) { run(K_CCD, "trainCCD", d, b, iu, ii); }
-void ModelMF::trainSGDParSVD(const Data&, Model&, IntSet&, IntSet&) {
-  // needs SVDLIBC (svdLAS2A) for the initialisation (modelMF.cpp:368); not part of this build
-  std::cerr << "\nModelMF::trainSGDParSVD needs SVDLIBC and is not available in the MI355X build" << std::endl;
-}
+void ModelMF::trainSGDParSVD(const Data& d, Model& b, IntSet& iu, IntSet& ii) { run(K_SGDPARSVD, "trainSGDParSVD", d, b, iu, ii); }
 
 void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestModel, IntSet& invalidUsers,
                   IntSet& invalidItems) {
@@ -458,6 +482,24 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
 
   std::cout << "\nObj b4 svd: " << objective(data) << " Train RMSE: " << RMSE(data.trainMat)
             << " Train nnz: " << data.trainNNZ << std::endl;
+  if (kind == K_SGDPARSVD) {
+    // singularVals = svdFrmSvdlibCSREig(data.trainMat, facDim, uFac, iFac, false) (modelMF.cpp:368): on the device
+    const auto t0 = std::chrono::system_clock::now();
+    singularVals.assign((size_t)facDim, 0.0f);
+    const char* it = getenv("MFX_SVD_ITERS");
+    dev->check(mfx_svd_init(dev->ctx, it ? atoi(it) : 10, std::max(10, facDim / 8), (uint32_t)trainSeed, singularVals.data()),
+               "mfx_svd_init");
+    hostStale = true;
+    std::cout << "Rank regs: ";
+    std::vector<float> regk((size_t)facDim);
+    for (int k = 0; k < facDim; k++) {
+      regk[k] = (sing_a + 1) / (sing_b + singularVals[k]);       // float, as the update evaluates it (:498)
+      std::cout << (1.0 + sing_a) / (sing_b + singularVals[k]) << " ";
+    }
+    std::cout << std::endl;
+    std::cout << "\nsvd duration: " << std::chrono::duration<double>(std::chrono::system_clock::now() - t0).count();
+    dev->check(mfx_sgd_set_dim_reg(dev->ctx, regk.data()), "mfx_sgd_set_dim_reg");
+  }
 
   int iter, bestIter = -1;
   double bestObj, prevObj, bestValRMSE, prevValRMSE;
@@ -522,6 +564,11 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
         o.mode = MFX_SGD_TILED; o.order = MFX_ORDER_DEVICE;
         dev->check(mfx_sgd_epoch(dev->ctx, &o), "mfx_sgd_epoch");
         break;
+      case K_SGDPARSVD:   // modelMF.cpp:474-512 with the per-dimension regulariser set above; lock-free, coherent rows
+        o.mode = exact ? MFX_SGD_SERIAL : MFX_SGD_HOGWILD;
+        o.order = exact ? MFX_ORDER_NATURAL : MFX_ORDER_DEVICE;
+        dev->check(mfx_sgd_epoch(dev->ctx, &o), "mfx_sgd_epoch");
+        break;
       case K_SGDU: {
         std::shuffle(validUsers.begin(), validUsers.end(), mt);   // modelMF.cpp:635
         if (exact) {
@@ -578,8 +625,10 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
     subIterDuration = std::chrono::duration<double>(std::chrono::system_clock::now() - start).count();
 
     if (iter % MF_OBJ_ITER == 0 || iter == maxIter - 1) {
-      if (isTerminateModel(bestModel, data, iter, bestIter, bestObj, prevObj, bestValRMSE, prevValRMSE,
-                           invalidUsers, invalidItems))
+      if (kind == K_SGDPARSVD ? isTerminateModelSing(bestModel, data, iter, bestIter, bestObj, prevObj, bestValRMSE,
+                                                     prevValRMSE, invalidUsers, invalidItems)
+                              : isTerminateModel(bestModel, data, iter, bestIter, bestObj, prevObj, bestValRMSE, prevValRMSE,
+                                                 invalidUsers, invalidItems))
         break;
       if (iter % MF_DISP_ITER == 0) {
         std::cout << "ModelMF::" << name << " trainSeed: " << trainSeed << " Iter: " << iter
@@ -597,6 +646,7 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
   std::cout << "\nBest model validation RMSE: " << bestModel.RMSE(data.valMat, invalidUsers, invalidItems);
   if (kind == K_CCDPP || kind == K_CCDPP_FA) dev->check(mfx_ccdpp_end(dev->ctx), "mfx_ccdpp_end");
   if (kind == K_CCD) dev->check(mfx_ccd_end(dev->ctx), "mfx_ccd_end");
+  if (kind == K_SGDPARSVD) dev->check(mfx_sgd_set_dim_reg(dev->ctx, nullptr), "mfx_sgd_set_dim_reg");
   syncHost();
   bestModel.syncHost();
 }

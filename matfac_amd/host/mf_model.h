@@ -59,6 +59,7 @@ class Model {
   float uReg = 0, iReg = 0, sing_a = 0, sing_b = 0;
   DenseF32 uFac, iFac;
   std::vector<float> uBias, iBias;
+  std::vector<float> singularVals;   // model.h: Eigen::VectorXf singularVals (set by trainSGDParSVD)
   double mu = 0;
 
   Model(const Params& params);                                   // model.cpp:2315-2366
@@ -88,7 +89,14 @@ class Model {
   virtual double objective(const Data& data, IntSet& invalidUsers, IntSet& invalidItems);  // :1770-1815
   bool isTerminateModel(Model& bestModel, const Data& data, int iter, int& bestIter, double& bestObj,
                         double& prevObj, double& bestValRMSE, double& prevValRMSE, IntSet& invalidUsers,
-                        IntSet& invalidItems);                                     // model.cpp:1471-1540
+                        IntSet& invalidItems);
+  bool isTerminateModelSing(Model& bestModel, const Data& data, int iter, int& bestIter, double& bestObj,
+                            double& prevObj, double& bestValRMSE, double& prevValRMSE, IntSet& invalidUsers,
+                            IntSet& invalidItems);                                  // model.cpp:1543-1612
+  double objectiveSing(const Data& data, IntSet& invalidUsers, IntSet& invalidItems);   // model.cpp:1818-1865
+  bool terminateImpl(bool sing, Model& bestModel, const Data& data, int iter, int& bestIter, double& bestObj,
+                     double& prevObj, double& bestValRMSE, double& prevValRMSE, IntSet& invalidUsers,
+                     IntSet& invalidItems);                                     // model.cpp:1471-1540
   std::string modelSignature();                                                    // model.cpp:11-19
   void display();
   void saveFacs(std::string prefix);                                               // model.cpp:89-101
@@ -133,7 +141,7 @@ class ModelMF : public Model {
   void hogTrain(const Data& data, Model& bestModel, IntSet& invalidUsers, IntSet& invalidItems) override;
 
  private:
-  enum Kind { K_SGD, K_HOG, K_SGDPAR, K_SGDU, K_ALS, K_CCDPP, K_CCDPP_FA, K_CCD };
+  enum Kind { K_SGD, K_HOG, K_SGDPAR, K_SGDU, K_ALS, K_CCDPP, K_CCDPP_FA, K_CCD, K_SGDPARSVD };
   void run(Kind kind, const char* name, const Data& data, Model& bestModel, IntSet& invalidUsers,
            IntSet& invalidItems);
 };

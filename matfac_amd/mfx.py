@@ -207,6 +207,23 @@ class Ctx:
         self._chk(self.lib.mfx_debug_residuals(self.h, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)))
         return a, b
 
+    # ---- trainSGDParSVD -------------------------------------------------------------
+    def svd_init(self, power_iters=8, oversample=10, seed=1):
+        s = np.empty(self.K, np.float32)
+        self._chk(self.lib.mfx_svd_init(self.h, C.c_int32(power_iters), C.c_int32(oversample), C.c_uint32(seed),
+                                        s.ctypes.data_as(C.c_void_p)))
+        return s
+
+    def sgd_set_dim_reg(self, reg):
+        k = _p(reg, np.float32)
+        self._chk(self.lib.mfx_sgd_set_dim_reg(self.h, k[1] if k else None))
+
+    def eval_weighted(self, which, w, snapshot=SNAP_CURRENT):
+        out = EvalOut()
+        k = _p(w, np.float32)
+        self._chk(self.lib.mfx_eval_weighted(self.h, which, snapshot, k[1], C.byref(out)))
+        return out
+
     # ---- cyclic coordinate descent (trainCCD) ---------------------------------------
     def ccd_begin(self):
         self._chk(self.lib.mfx_ccd_begin(self.h))

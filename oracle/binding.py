@@ -193,6 +193,22 @@ def sgd_pass(U, V, u, i, r, order, lr, uReg, iReg, arith=ARITH_REF64, dot_mode=D
                      C.c_float(lr), C.c_float(uReg), C.c_float(iReg), arith, dot_mode)
 
 
+def sgd_pass_dimreg(U, V, u, i, r, order, lr, regk, dot_mode=DOT_SEQ):
+    K = U.shape[1]
+    regk = np.ascontiguousarray(regk, np.float32)
+    lib.orc_sgd_pass_dimreg(K, F(U), F(V), I32(u), I32(i), F(r), U64(order) if order is not None else None,
+                            C.c_int64(len(order) if order is not None else len(u)), C.c_float(lr), F(regk), dot_mode)
+
+
+def objective_sing(U, V, nUsers, nItems, nrows, rowptr, rowind, rowval, invU, invI, sing, dot_mode=DOT_SEQ):
+    lib.orc_objective_sing.restype = C.c_double
+    sse, ur, ir = C.c_double(), C.c_double(), C.c_double()
+    sing = np.ascontiguousarray(sing, np.float32)
+    o = lib.orc_objective_sing(U.shape[1], F(U), F(V), nUsers, nItems, nrows, I64(rowptr), I32(rowind), F(rowval),
+                               U8(invU), U8(invI), F(sing), dot_mode, C.byref(sse), C.byref(ur), C.byref(ir))
+    return o, sse.value, ur.value, ir.value
+
+
 def sgd_hogwild(U, V, u, i, r, order, lr, uReg, iReg, arith=ARITH_F32, dot_mode=DOT_SEQ, nthreads=1):
     K = U.shape[1]
     lib.orc_sgd_hogwild(K, F(U), F(V), I32(u), I32(i), F(r), U64(order) if order is not None else None,

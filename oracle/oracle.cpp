@@ -297,6 +297,53 @@ void orc_sgd_pass(int K, float* U, float* V, const int32_t* u, const int32_t* i,
   }
 }
 
+// trainSGDParSVD's visit (modelMF.cpp:489-507): float dot, FLOAT diff, and the same per-dimension
+// regulariser 2.0*((sing_a + 1)/(sing_b + singularVals[i])) on the user and on the item side.
+// regk[i] = (sing_a + 1)/(sing_b + singularVals[i]) as the float the reference's expression yields.
+void orc_sgd_pass_dimreg(int K, float* U, float* V, const int32_t* u, const int32_t* i, const float* r,
+                         const uint64_t* order, int64_t n, float learnRate, const float* regk, int dot_mode) {
+  for (int64_t t = 0; t < n; t++) {
+    const int64_t ind = order ? (int64_t)order[t] : t;
+    float* p = U + (int64_t)u[ind] * K;
+    float* q = V + (int64_t)i[ind] * K;
+    const float itemRat = r[ind];
+    const float r_ui_est = dotf(p, q, K, dot_mode);
+    const float diff = itemRat - r_ui_est;
+    for (int k = 0; k < K; k++) p[k] -= learnRate * (-2.0 * diff * q[k] + 2.0 * regk[k] * p[k]);
+    for (int k = 0; k < K; k++) q[k] -= learnRate * (-2.0 * diff * p[k] + 2.0 * regk[k] * q[k]);
+  }
+}
+
+// Model::objectiveSing (model.cpp:1818-1865): squared error + sum_k x_k^2 * singularVals(k) over valid rows
+double orc_objective_sing(int K, const float* U, const float* V, int32_t nUsers, int32_t nItems, int32_t nrows,
+                          const int64_t* rowptr, const int32_t* rowind, const float* rowval, const uint8_t* invU,
+                          const uint8_t* invI, const float* sing, int dot_mode, double* sse_out, double* ureg_out,
+                          double* ireg_out) {
+  double rmse = 0, uRegErr = 0, iRegErr = 0;
+  for (int u = 0; u < nUsers; u++) {
+    if (invU[u]) continue;
+    const float* p = U + (int64_t)u * K;
+    if (u < nrows)
+      for (int64_t ii = rowptr[u]; ii < rowptr[u + 1]; ii++) {
+        const int item = rowind[ii];
+        if (invI[item]) continue;
+        const float itemRat = rowval[ii];
+        const double diff = itemRat - (double)dotf(p, V + (int64_t)item * K, K, dot_mode);
+        rmse += diff * diff;
+      }
+    for (int k = 0; k < K; k++) uRegErr += p[k] * p[k] * sing[k];
+  }
+  for (int item = 0; item < nItems; item++) {
+    if (invI[item]) continue;
+    const float* q = V + (int64_t)item * K;
+    for (int k = 0; k < K; k++) iRegErr += q[k] * q[k] * sing[k];
+  }
+  if (sse_out) *sse_out = rmse;
+  if (ureg_out) *ureg_out = uRegErr;
+  if (ireg_out) *ireg_out = iRegErr;
+  return rmse + uRegErr + iRegErr;
+}
+
 void orc_sgd_hogwild(int K, float* U, float* V, const int32_t* u, const int32_t* i,
                      const float* r, const uint64_t* order, int64_t n, float lr,
                      float uReg, float iReg, int arith, int dot_mode, int nthreads) {

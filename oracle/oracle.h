@@ -141,6 +141,14 @@ void orc_ccdpp_rank1(int K, int k, float* U, float* V, int32_t nUsers, int32_t n
                      float uReg, float iReg, int add_back, int inner,
                      float freq_thresh, int nthreads);
 
+/* ---- trainSGDParSVD pieces (modelMF.cpp:489-507, model.cpp:1818-1865) ---- */
+void orc_sgd_pass_dimreg(int K, float* U, float* V, const int32_t* u, const int32_t* i, const float* r,
+                         const uint64_t* order, int64_t n, float learnRate, const float* regk, int dot_mode);
+double orc_objective_sing(int K, const float* U, const float* V, int32_t nUsers, int32_t nItems, int32_t nrows,
+                          const int64_t* rowptr, const int32_t* rowind, const float* rowval, const uint8_t* invU,
+                          const uint8_t* invI, const float* sing, int dot_mode, double* sse_out, double* ureg_out,
+                          double* ireg_out);
+
 /* ---- CCD (modelMF.cpp:1528-1605), sequential ---------------------------- */
 void orc_ccd_iter(int K, float* U, float* V, int32_t nUsers, int32_t nItems,
                   int32_t ncols, const int64_t* rowptr, const int32_t* rowind,

@@ -81,3 +81,20 @@ if "cd" in what:      # trainCCD (a12) on the C2 matrix
                           ms_per_iter=(su + si) / iters, rating_factor_updates_per_s=2 * tr.nnz * K / ((su + si) / iters * 1e-3),
                           val_rmse=traj)), flush=True)
     ctx.ccd_end(); ctx.close()
+if "svd" in what:     # the SVD initialisation of trainSGDParSVD (a8) on the C2 matrix
+    K = int(os.environ.get("SVD_K", 64))
+    shape = dict(synth.SHAPES["C2"]); shape["nnz"] = int(shape["nnz"] / 0.8)
+    d = synth.make(shape, seed=1); tr = d["train"]; nU, nI = d["nUsers"], shape["nI"]
+    ctx = Ctx(0)
+    ctx.set_csr(mfx.MAT_TRAIN, tr.nrows, nI, tr.rowptr, tr.rowind, tr.rowval)
+    ctx.set_model(nU, nI, K); ctx.compute_invalid()
+    ctx.svd_init(1, 10, 1); ctx.synchronize()
+    t0 = time.perf_counter(); sig = ctx.svd_init(10, max(10, K // 8), 1); ctx.synchronize(); dt = time.perf_counter() - t0
+    U, V = ctx.get_factors()
+    # residual of the leading triplets: || R v_k - sigma_k u_k || through scipy
+    import scipy.sparse as sp
+    R = sp.csr_matrix((tr.rowval, tr.rowind, tr.rowptr), shape=(tr.nrows, nI))
+    res = np.linalg.norm(R @ V[:, :8] - U[:, :8] * sig[:8], axis=0) / sig[:8]
+    print(json.dumps(dict(path="SVD init C2", nnz=tr.nnz, K=K, seconds=dt, sigma_first=[float(x) for x in sig[:4]], sigma_last=float(sig[-1]),
+                          rel_residual_first8=[float(x) for x in res])), flush=True)
+    ctx.close()

@@ -126,6 +126,39 @@ def test_ccd_loop_matches_oracle_with_replayed_factor_orders_and_converges_with_
     assert f["val"] < o2["valbest"] + 3e-2 and f["test"] < o2["test"] + 3e-2 and abs(f["val"] - o2["valbest"]) < 0.1
 
 
+def test_sgdparsvd_loop_follows_a_simulation_with_numpy_svd():
+    """trainSGDParSVD (modelMF.cpp:353-557): SVD initialisation, per-dimension regulariser, objectiveSing.  The
+    checker runs the same loop with numpy's dense SVD and the oracle's visit in CSR order; singular vectors are
+    defined up to sign (which the update is invariant to), so the two runs agree to the accuracy of the SVDs."""
+    d, K, iters, lr, reg = data(), 8, 8, 0.01, 0.05
+    tr, va = d["train"], d["val"]
+    nU, nI = d["nUsers"], d["nItems"]
+    h = host_train("sgdparsvd", d, K, iters, 1, lr, reg, reg, env={"MFX_EXACT": "1", "MFX_SVD_ITERS": "30"})
+    R = np.zeros((tr.nrows, tr.ncols))
+    R[tr.rowids(), tr.rowind] = tr.rowval
+    Ud, sd, Vtd = np.linalg.svd(R, full_matrices=False)
+    U, V = orc.init_factors(1, nU, nI, K)
+    U[:tr.nrows] = Ud[:, :K]
+    V[:tr.ncols] = Vtd[:K].T
+    sing = sd[:K].astype(np.float32)
+    regk = ((np.float32(reg) + np.float32(1)) / (np.float32(reg) + sing)).astype(np.float32)
+    invU, invI = orc.invalid(tr.nrows, tr.ncols, tr.rowptr, tr.rowind, nU, nI)
+    best = (np.inf, None, None)
+    for it in range(iters):
+        orc.sgd_pass_dimreg(U, V, tr.rowids(), tr.rowind, tr.rowval, None, lr, regk)
+        v, _, _ = orc.rmse(U, V, nU, nI, va.nrows, va.rowptr, va.rowind, va.rowval, invU, invI, orc.DOT_SEQ)
+        if v < best[0]:
+            best = (v, U.copy(), V.copy())
+    print("sgdparsvd val gpu %.5f sim %.5f" % (h["val"], best[0]))
+    assert abs(h["val"] - best[0]) < 5e-3
+    # same products: U V^T of the best models agree although individual vectors may differ in sign
+    P_gpu = h["Ubest"][:50] @ h["Vbest"][:60].T
+    P_sim = best[1][:50] @ best[2][:60].T
+    assert np.abs(P_gpu - P_sim).max() < 2e-2 * max(1.0, np.abs(P_sim).max())
+    f = host_train("sgdparsvd", d, K, 30, 1, lr, reg, reg)                      # lock-free order, default SVD settings
+    assert f["val"] < h["val"] + 2e-2
+
+
 @pytest.mark.parametrize("method", ["sgd", "hogsgd", "sgdpar", "sgdu"])
 def test_fast_sgd_paths_reach_the_reference_rmse(method):
     d, K = data(3000, 2000, 300000, seed=2), 16
