@@ -80,9 +80,10 @@ template <int C, int ARITH>
 __device__ __forceinline__ void sgd_axpys(float4v (&p)[C], float4v (&q)[C], float r, float est, float lr,
                                           float uReg, float iReg) {
   if (ARITH == MFX_ARITH_F32) {
-    const double diff = (double)r - (double)est;
-    const float c1 = (float)(-2.0 * diff);
-    const float cu = (float)(2.0 * (double)uReg), ci = (float)(2.0 * (double)iReg);
+    // (float)(-2.0 * ((double)r - (double)est)): r - est is exact in double and scaling by 2 commutes with the
+    // rounding to float, so the float expression below is the same number (no f64 instructions)
+    const float c1 = -2.0f * (r - est);
+    const float cu = 2.0f * uReg, ci = 2.0f * iReg;
 #pragma unroll
     for (int c = 0; c < C; c++) {
 #pragma unroll

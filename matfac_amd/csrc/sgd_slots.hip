@@ -201,10 +201,12 @@ __device__ __forceinline__ int slot_take(int v, int g) {
 }
 
 // The L steps of one 64-rating chunk, unrolled by template recursion (the DPP controls are immediates).
-template <int L, int C, int ARITH, bool OWN_U, int S>
+// FIX: the slot's rows are in the fixed-point representation (decided per slot, so per chunk it is a template
+// argument, not a select per element).
+template <int L, int C, int ARITH, bool OWN_U, bool FIX, int S>
 struct SlotSteps {
   static __device__ __forceinline__ void run(const Rows<3>& Um, int* q_lds, int tx, int ty, int tz, int g, int j,
-                                             int nvalid, bool fix, float lr, float uReg, float iReg,
+                                             int nvalid, float lr, float uReg, float iReg,
                                              float4v (&pn)[C], int64_t& pen, float4v (&pnn)[C], int64_t& penn) {
     constexpr int G = 64 / L;
     constexpr int LD = 4 * L * C;
@@ -227,33 +229,52 @@ struct SlotSteps {
     }
     if (e < nvalid) {
       int* qrow = q_lds + li * LD + 4 * j;
-      float4v q[C], q0[C];
+      float4v q[C];
 #pragma unroll
       for (int c = 0; c < C; c++) {
         const int4 qi = *(const int4*)(qrow + c * 4 * L);
-        if (fix) q[c] = float4v{(float)qi.x * FIX_INV, (float)qi.y * FIX_INV, (float)qi.z * FIX_INV, (float)qi.w * FIX_INV};
+        if (FIX) q[c] = float4v{(float)qi.x * FIX_INV, (float)qi.y * FIX_INV, (float)qi.z * FIX_INV, (float)qi.w * FIX_INV};
         else q[c] = __builtin_bit_cast(float4v, qi);
-        q0[c] = q[c];
       }
       // p = the row from global memory, q = the owned row; the reference updates the USER row first
       // and the item row with the updated user row (modelMF.cpp:94-103) whichever side is owned
       const float est = group_dot<L, C>(p, q);
-      if (OWN_U) sgd_axpys<C, ARITH>(q, p, r, est, lr, uReg, iReg);
-      else sgd_axpys<C, ARITH>(p, q, r, est, lr, uReg, iReg);
+      if constexpr (FIX && !OWN_U && ARITH == MFX_ARITH_F32) {
+        // hogTrain's arithmetic (modelMF.cpp:1755-1762) with the item step taken as a delta: the new item
+        // row would be q - t, t = lr*(c1*p' + ci*q); the owner copy receives round(-t * 2^24) directly
+        const float c1 = -2.0f * (r - est), cu = 2.0f * uReg, ci = 2.0f * iReg;
 #pragma unroll
-      for (int c = 0; c < C; c++) {
-        Um.st(pe + c * 4 * L, p[c]);
-        if (fix) {
+        for (int c = 0; c < C; c++) {
 #pragma unroll
-          for (int x = 0; x < 4; x++)
-            atomicAdd(qrow + c * 4 * L + x, __float2int_rn((q[c][x] - q0[c][x]) * FIX_SCALE));   // ds_add_u32
-        } else {
-          *(int4*)(qrow + c * 4 * L) = __builtin_bit_cast(int4, q[c]);
+          for (int x = 0; x < 4; x++) p[c][x] = upd_f32(p[c][x], q[c][x], c1, cu, lr);
+          Um.st(pe + c * 4 * L, p[c]);
+#pragma unroll
+          for (int x = 0; x < 4; x++) {
+            const float t = lr * (c1 * p[c][x] + ci * q[c][x]);
+            atomicAdd(qrow + c * 4 * L + x, __float2int_rn(t * -FIX_SCALE));   // ds_add_u32
+          }
+        }
+      } else {
+        float4v q0[C];
+#pragma unroll
+        for (int c = 0; c < C; c++) q0[c] = q[c];
+        if (OWN_U) sgd_axpys<C, ARITH>(q, p, r, est, lr, uReg, iReg);
+        else sgd_axpys<C, ARITH>(p, q, r, est, lr, uReg, iReg);
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+          Um.st(pe + c * 4 * L, p[c]);
+          if (FIX) {
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+              atomicAdd(qrow + c * 4 * L + x, __float2int_rn((q[c][x] - q0[c][x]) * FIX_SCALE));   // ds_add_u32
+          } else {
+            *(int4*)(qrow + c * 4 * L) = __builtin_bit_cast(int4, q[c]);
+          }
         }
       }
     }
     if constexpr (S + 1 < L)
-      SlotSteps<L, C, ARITH, OWN_U, S + 1>::run(Um, q_lds, tx, ty, tz, g, j, nvalid, fix, lr, uReg, iReg, pn, pen, pnn, penn);
+      SlotSteps<L, C, ARITH, OWN_U, FIX, S + 1>::run(Um, q_lds, tx, ty, tz, g, j, nvalid, lr, uReg, iReg, pn, pen, pnn, penn);
   }
 };
 
@@ -346,8 +367,8 @@ __global__ __launch_bounds__(WG, (C == 1 ? 8 : 4)) void sgd_slots_kernel(const i
 #pragma unroll
           for (int c = 0; c < C; c++) pnn[c] = Um.ld(penn + c * 4 * L);
         }
-        SlotSteps<L, C, ARITH, OWN_U, 0>::run(Um, q_lds, tx, ty, tz, g, j, nvalid, fix, lr, uReg, iReg, pn, pen, pnn,
-                                              penn);
+        if (fix) SlotSteps<L, C, ARITH, OWN_U, true, 0>::run(Um, q_lds, tx, ty, tz, g, j, nvalid, lr, uReg, iReg, pn, pen, pnn, penn);
+        else SlotSteps<L, C, ARITH, OWN_U, false, 0>::run(Um, q_lds, tx, ty, tz, g, j, nvalid, lr, uReg, iReg, pn, pen, pnn, penn);
       }
       __syncthreads();
       // write the item rows back (this workgroup is their only owner during the round)

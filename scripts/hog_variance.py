@@ -1,0 +1,13 @@
+"""Run-to-run spread of the lock-free tiled SGD through the host classes (test_host_gpu's hogsgd case)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ["MFX_NO_SAVE"] = "1"
+from test_host_gpu import data, host_train, oracle_train
+from oracle import binding as orc
+d, K = data(3000, 2000, 300000, seed=2), 16
+o = oracle_train(orc.M_SGD, d, K, 40, 1, 0.01, 0.02, 0.02)
+print("cpu test %.5f val %.5f" % (o["test"], o["valbest"]))
+for m in ("hogsgd", "sgd", "hogsgd", "sgd", "hogsgd"):
+    h = host_train(m, d, K, 40, 1, 0.01, 0.02, 0.02)
+    print(m, "gpu test %.5f val %.5f" % (h["test"], h["val"]), flush=True)
