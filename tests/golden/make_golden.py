@@ -19,7 +19,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 from matfac_amd import synth  # noqa: E402
 from oracle import binding as orc  # noqa: E402
 
-METHODS = {"sgd": orc.M_SGD, "sgdu": orc.M_SGDU, "als": orc.M_ALS, "ccdpp": orc.M_CCDPP, "ccdpp_fa": orc.M_CCDPP_FA}
+METHODS = {"sgd": orc.M_SGD, "sgdu": orc.M_SGDU, "als": orc.M_ALS, "ccdpp": orc.M_CCDPP, "ccdpp_fa": orc.M_CCDPP_FA,
+           "ccd": orc.M_CCD}
 
 
 def tiny():
