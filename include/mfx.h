@@ -208,6 +208,18 @@ int mfx_sgd_set_dim_reg(mfx_ctx* ctx, const float* reg);
  * sum_k x_k^2 * w[k].                                                                                        */
 int mfx_eval_weighted(mfx_ctx* ctx, int which, int snapshot, const float* w, mfx_eval_out* out);
 
+/* ---- ModelInvPopMF (--algo=IFWMF): inverse-frequency-weighted MF ------------------ */
+/* Per-rating weight on the error term (modelInvPopMF.cpp:161-166): wt = invPopI[item], or invPopU[u] when
+ * itemFreq[item] > userFreq[u]; wt = 1/(1 + rhoRMS*wt).  Arrays of nUsers resp. nItems floats (the reference's
+ * doubles narrowed as `float wt = invPopI[item]` does).  With weights set, MFX_SGD_HOGWILD / MFX_SGD_SERIAL epochs
+ * run p -= lr*(-2*wt*diff*q + 2*uReg*p) etc. in the double bracket (:168-176) and ignore opts->arith.  All four
+ * pointers NULL: weights off.                                                                                   */
+int mfx_sgd_set_ifw(mfx_ctx* ctx, const float* userFreq, const float* invPopU, const float* itemFreq,
+                    const float* invPopI, float rhoRMS);
+/* ModelInvPopMF::objective (modelInvPopMF.cpp:3-55): out->sse = sum wt*diff*diff over the valid train ratings,
+ * n and the two norms as mfx_eval.                                                                              */
+int mfx_eval_ifw(mfx_ctx* ctx, int snapshot, mfx_eval_out* out);
+
 /* ---- multi-GPU: user-row-block sharding, item-factor exchange over RCCL ------ */
 /* The reference is single-process; this is new.  Each rank owns a
  * user block (its CSR rows + U shard) and a replica of V.  After local work,

@@ -100,6 +100,7 @@ void mfx_destroy(mfx_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   mfx_comm_free_internal(ctx);
   dev_free(ctx->dimreg);
+  mfx_ifw_free_internal(ctx);
   mfx_ccd_free_internal(ctx);
   mfx_cd_free_internal(ctx);
   mfx_als_free_internal(ctx);
@@ -229,6 +230,7 @@ extern "C" int mfx_set_model(mfx_ctx* ctx, int32_t nUsers, int32_t nItems, int32
   mfx_cd_free_internal(ctx);
   mfx_als_wide_free_internal(ctx);
   dev_free(ctx->dimreg);
+  mfx_ifw_free_internal(ctx);
   ctx->nU = nUsers; ctx->nI = nItems; ctx->K = K;
   mfx_tree_shape(K, &ctx->L, &ctx->C);
   ctx->ld = 4 * ctx->L * ctx->C;
@@ -443,6 +445,9 @@ extern "C" int mfx_sgd_epoch(mfx_ctx* ctx, const mfx_sgd_opts* o) {
   NEED(o->mode >= MFX_SGD_HOGWILD && o->mode <= MFX_SGD_TILED, MFX_E_ARG, "mfx_sgd_epoch: mode=%d", o->mode);
   NEED(!ctx->dimreg || o->mode == MFX_SGD_HOGWILD || o->mode == MFX_SGD_SERIAL, MFX_E_ARG,
        "mfx_sgd_epoch: per-dimension regularisation (mfx_sgd_set_dim_reg) runs on MFX_SGD_HOGWILD / MFX_SGD_SERIAL");
+  NEED(!ctx->ifw || o->mode == MFX_SGD_HOGWILD || o->mode == MFX_SGD_SERIAL, MFX_E_ARG,
+       "mfx_sgd_epoch: rating weights (mfx_sgd_set_ifw) run on MFX_SGD_HOGWILD / MFX_SGD_SERIAL");
+  NEED(!(ctx->ifw && ctx->dimreg), MFX_E_STATE, "mfx_sgd_epoch: rating weights and per-dimension regularisation are exclusive");
   NEED(o->order >= MFX_ORDER_DEVICE && o->order <= MFX_ORDER_NATURAL, MFX_E_ARG, "mfx_sgd_epoch: order=%d", o->order);
   NEED(o->arith >= MFX_ARITH_REF64 && o->arith <= MFX_ARITH_F32, MFX_E_ARG, "mfx_sgd_epoch: arith=%d", o->arith);
   HIPCHK(hipSetDevice(ctx->device));

@@ -94,6 +94,7 @@ struct mfx_ctx {
   void* cd = nullptr;         // trainCCD state (cd.hip owns the type)
   void* als_wide = nullptr;   // ALS for K > 64 (als_wide.hip owns the type)
   float* dimreg = nullptr;    // per-dimension regulariser [ld] of trainSGDParSVD (svd.hip), or NULL
+  void* ifw = nullptr;        // rating weights of ModelInvPopMF (sgd_ifw.hip owns the type), or NULL
 
   // comm
   void* comm = nullptr;      // ncclComm_t
@@ -187,6 +188,8 @@ static inline void mfx_tree_shape(int K, int* L, int* C) {
 int mfx_launch_sgd(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_t count);
 int mfx_launch_sgd_users(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t nusers);
 int mfx_launch_sgd_tiled(mfx_ctx* ctx, const mfx_sgd_opts* o);
+int mfx_launch_sgd_ifw(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_t count);      // sgd_ifw.hip
+void mfx_ifw_free_internal(mfx_ctx* ctx);
 int mfx_launch_sgd_dimreg(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_t count);   // svd.hip
 int mfx_slots_materialise_order(mfx_ctx* ctx);
 void mfx_slots_free_internal(mfx_ctx* ctx);

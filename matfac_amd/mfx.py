@@ -224,6 +224,16 @@ class Ctx:
         self._chk(self.lib.mfx_eval_weighted(self.h, which, snapshot, k[1], C.byref(out)))
         return out
 
+    # ---- ModelInvPopMF (IFWMF) --------------------------------------------------------
+    def sgd_set_ifw(self, userFreq=None, invPopU=None, itemFreq=None, invPopI=None, rho=0.0):
+        ks = [_p(a, np.float32) for a in (userFreq, invPopU, itemFreq, invPopI)]
+        self._chk(self.lib.mfx_sgd_set_ifw(self.h, *[k[1] if k else None for k in ks], C.c_float(rho)))
+
+    def eval_ifw(self, snapshot=SNAP_CURRENT):
+        out = EvalOut()
+        self._chk(self.lib.mfx_eval_ifw(self.h, snapshot, C.byref(out)))
+        return out
+
     # ---- cyclic coordinate descent (trainCCD) ---------------------------------------
     def ccd_begin(self):
         self._chk(self.lib.mfx_ccd_begin(self.h))

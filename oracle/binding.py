@@ -209,6 +209,36 @@ def objective_sing(U, V, nUsers, nItems, nrows, rowptr, rowind, rowval, invU, in
     return o, sse.value, ur.value, ir.value
 
 
+def _f64p(a):
+    assert a.dtype == np.float64 and a.flags.c_contiguous
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def ifw_pop(nrows, ncols, rowptr, rowind, invU, invI):
+    """(userFreq, itemFreq, invPopU, invPopI) as modelInvPopMF.cpp:84-113 builds them (float64)."""
+    uf, itf = np.zeros(nrows), np.zeros(ncols)
+    pu, pi = np.zeros(nrows), np.zeros(ncols)
+    lib.orc_ifw_pop(nrows, ncols, I64(rowptr), I32(rowind), U8(invU), U8(invI), _f64p(uf), _f64p(itf), _f64p(pu), _f64p(pi))
+    return uf, itf, pu, pi
+
+
+def sgd_pass_ifw(U, V, u, i, r, order, lr, uReg, iReg, pop, rho, dot_mode=DOT_SEQ):
+    uf, itf, pu, pi = pop
+    lib.orc_sgd_pass_ifw(U.shape[1], F(U), F(V), I32(u), I32(i), F(r), U64(order) if order is not None else None,
+                         C.c_int64(len(order) if order is not None else len(u)), C.c_float(lr), C.c_float(uReg),
+                         C.c_float(iReg), _f64p(uf), _f64p(itf), _f64p(pu), _f64p(pi), C.c_float(rho), dot_mode)
+
+
+def objective_ifw(U, V, nUsers, nItems, nrows, rowptr, rowind, rowval, invU, invI, uReg, iReg, pop, rho, dot_mode=DOT_SEQ):
+    uf, itf, pu, pi = pop
+    lib.orc_objective_ifw.restype = C.c_double
+    w = C.c_double()
+    o = lib.orc_objective_ifw(U.shape[1], F(U), F(V), nUsers, nItems, nrows, I64(rowptr), I32(rowind), F(rowval), U8(invU),
+                              U8(invI), C.c_float(uReg), C.c_float(iReg), _f64p(uf), _f64p(itf), _f64p(pu), _f64p(pi), C.c_float(rho),
+                              dot_mode, C.byref(w))
+    return o, w.value
+
+
 def sgd_hogwild(U, V, u, i, r, order, lr, uReg, iReg, arith=ARITH_F32, dot_mode=DOT_SEQ, nthreads=1):
     K = U.shape[1]
     lib.orc_sgd_hogwild(K, F(U), F(V), I32(u), I32(i), F(r), U64(order) if order is not None else None,

@@ -344,6 +344,78 @@ double orc_objective_sing(int K, const float* U, const float* V, int32_t nUsers,
   return rmse + uRegErr + iRegErr;
 }
 
+// ---- ModelInvPopMF (IFWMF) ---------------------------------------------------------------
+// modelInvPopMF.cpp:84-113: popularity scores of the valid users and items, each normalised to sum 1
+void orc_ifw_pop(int32_t nrows, int32_t ncols, const int64_t* rowptr, const int32_t* rowind, const uint8_t* invU,
+                 const uint8_t* invI, double* userFreq, double* itemFreq, double* invPopU, double* invPopI) {
+  for (int u = 0; u < nrows; u++) userFreq[u] = 0;
+  for (int i = 0; i < ncols; i++) itemFreq[i] = 0;
+  for (int u = 0; u < nrows; u++)           // getRowColFreq, util.cpp:555-569
+    for (int64_t ii = rowptr[u]; ii < rowptr[u + 1]; ii++) { userFreq[u] += 1; itemFreq[rowind[ii]] += 1; }
+  int nTrainUsers = 0, nTrainItems = 0;
+  for (int u = 0; u < nrows; u++) if (!invU[u]) nTrainUsers++;
+  for (int i = 0; i < ncols; i++) if (!invI[i]) nTrainItems++;
+  double sumPopScore = 0;
+  for (int u = 0; u < nrows; u++) { invPopU[u] = 0; if (!invU[u]) { invPopU[u] = userFreq[u] / ((double)nTrainItems); sumPopScore += invPopU[u]; } }
+  for (int u = 0; u < nrows; u++) if (!invU[u]) invPopU[u] = invPopU[u] / sumPopScore;
+  sumPopScore = 0;
+  for (int i = 0; i < ncols; i++) { invPopI[i] = 0; if (!invI[i]) { invPopI[i] = itemFreq[i] / ((double)nTrainUsers); sumPopScore += invPopI[i]; } }
+  for (int i = 0; i < ncols; i++) if (!invI[i]) invPopI[i] = invPopI[i] / sumPopScore;
+}
+static inline float ifw_weight(int u, int item, const double* userFreq, const double* itemFreq, const double* invPopU,
+                               const double* invPopI, float rhoRMS) {
+  float wt = invPopI[item];                          // modelInvPopMF.cpp:161-166
+  if (itemFreq[item] > userFreq[u]) wt = invPopU[u];
+  wt = (1.0 / (1.0 + rhoRMS * wt));
+  return wt;
+}
+// modelInvPopMF.cpp:152-178
+void orc_sgd_pass_ifw(int K, float* U, float* V, const int32_t* u, const int32_t* i, const float* r, const uint64_t* order,
+                      int64_t n, float learnRate, float uReg, float iReg, const double* userFreq, const double* itemFreq,
+                      const double* invPopU, const double* invPopI, float rhoRMS, int dot_mode) {
+  for (int64_t t = 0; t < n; t++) {
+    const int64_t ind = order ? (int64_t)order[t] : t;
+    float* p = U + (int64_t)u[ind] * K;
+    float* q = V + (int64_t)i[ind] * K;
+    const float itemRat = r[ind];
+    const double r_ui_est = dotf(p, q, K, dot_mode);
+    const double diff = itemRat - r_ui_est;
+    const float wt = ifw_weight(u[ind], i[ind], userFreq, itemFreq, invPopU, invPopI, rhoRMS);
+    for (int k = 0; k < K; k++) p[k] -= learnRate * (-2.0 * wt * diff * q[k] + 2.0 * uReg * p[k]);
+    for (int k = 0; k < K; k++) q[k] -= learnRate * (-2.0 * wt * diff * p[k] + 2.0 * iReg * q[k]);
+  }
+}
+// modelInvPopMF.cpp:3-55
+double orc_objective_ifw(int K, const float* U, const float* V, int32_t nUsers, int32_t nItems, int32_t nrows,
+                         const int64_t* rowptr, const int32_t* rowind, const float* rowval, const uint8_t* invU,
+                         const uint8_t* invI, float uReg, float iReg, const double* userFreq, const double* itemFreq,
+                         const double* invPopU, const double* invPopI, float rhoRMS, int dot_mode, double* wsse_out) {
+  double rmse = 0, uRegErr = 0, iRegErr = 0;
+  for (int u = 0; u < nUsers; u++) {
+    if (invU[u]) continue;
+    const float* p = U + (int64_t)u * K;
+    if (u < nrows)
+      for (int64_t ii = rowptr[u]; ii < rowptr[u + 1]; ii++) {
+        const int item = rowind[ii];
+        if (invI[item]) continue;
+        const float wt = ifw_weight(u, item, userFreq, itemFreq, invPopU, invPopI, rhoRMS);
+        const float itemRat = rowval[ii];
+        const double diff = itemRat - (double)dotf(p, V + (int64_t)item * K, K, dot_mode);
+        rmse += wt * diff * diff;
+      }
+    uRegErr += dotf(p, p, K, dot_mode);
+  }
+  uRegErr = uRegErr * uReg;
+  for (int item = 0; item < nItems; item++) {
+    if (invI[item]) continue;
+    const float* q = V + (int64_t)item * K;
+    iRegErr += dotf(q, q, K, dot_mode);
+  }
+  iRegErr = iRegErr * iReg;
+  if (wsse_out) *wsse_out = rmse;
+  return rmse + uRegErr + iRegErr;
+}
+
 void orc_sgd_hogwild(int K, float* U, float* V, const int32_t* u, const int32_t* i,
                      const float* r, const uint64_t* order, int64_t n, float lr,
                      float uReg, float iReg, int arith, int dot_mode, int nthreads) {

@@ -149,6 +149,17 @@ double orc_objective_sing(int K, const float* U, const float* V, int32_t nUsers,
                           const uint8_t* invI, const float* sing, int dot_mode, double* sse_out, double* ureg_out,
                           double* ireg_out);
 
+/* ---- ModelInvPopMF / IFWMF (modelInvPopMF.cpp:3-55, 84-113, 152-178) ---- */
+void orc_ifw_pop(int32_t nrows, int32_t ncols, const int64_t* rowptr, const int32_t* rowind, const uint8_t* invU,
+                 const uint8_t* invI, double* userFreq, double* itemFreq, double* invPopU, double* invPopI);
+void orc_sgd_pass_ifw(int K, float* U, float* V, const int32_t* u, const int32_t* i, const float* r, const uint64_t* order,
+                      int64_t n, float learnRate, float uReg, float iReg, const double* userFreq, const double* itemFreq,
+                      const double* invPopU, const double* invPopI, float rhoRMS, int dot_mode);
+double orc_objective_ifw(int K, const float* U, const float* V, int32_t nUsers, int32_t nItems, int32_t nrows,
+                         const int64_t* rowptr, const int32_t* rowind, const float* rowval, const uint8_t* invU,
+                         const uint8_t* invI, float uReg, float iReg, const double* userFreq, const double* itemFreq,
+                         const double* invPopU, const double* invPopI, float rhoRMS, int dot_mode, double* wsse_out);
+
 /* ---- CCD (modelMF.cpp:1528-1605), sequential ---------------------------- */
 void orc_ccd_iter(int K, float* U, float* V, int32_t nUsers, int32_t nItems,
                   int32_t ncols, const int64_t* rowptr, const int32_t* rowind,
