@@ -6,6 +6,7 @@
 #include <string>
 
 #include "mf_model.h"
+#include "model_invpop.h"
 #include "mfhost.h"
 
 extern "C" int mfh_train(const char* method, int32_t nrows, const int64_t* tr_ptr, const int32_t* tr_ind,
@@ -22,10 +23,23 @@ extern "C" int mfh_train(const char* method, int32_t nrows, const int64_t* tr_pt
             csr_from_arrays(nrows, va_ncols, va_ptr, va_ind, va_val), pfx.c_str());
   params.nUsers = data.nUsers;
   params.nItems = data.nItems;
-  ModelMF model(params, params.seed), best(params, params.seed);
-  std::unordered_set<int> iu, ii;
   const std::string m = method;
-  if (m == "ccd++") model.trainCCDPPFreqAdap(data, best, iu, ii);
+  std::unique_ptr<ModelMF> pm, pb;
+  if (m.rfind("ifwmf:", 0) == 0) {       // "ifwmf:<rhoRMS>": ModelInvPopMF as main.cpp:1361-1366 builds it
+    params.rhoRMS = (float)atof(m.c_str() + 6);
+    std::vector<double> uf((size_t)data.trainMat->nrows, 0.0), itf((size_t)data.trainMat->ncols, 0.0);
+    for (int u = 0; u < data.trainMat->nrows; u++)
+      for (int64_t e2 = data.trainMat->rowptr[u]; e2 < data.trainMat->rowptr[u + 1]; e2++) { uf[u] += 1; itf[data.trainMat->rowind[e2]] += 1; }
+    pm.reset(new ModelInvPopMF(params, params.seed, uf, itf));
+    pb.reset(new ModelInvPopMF(params, params.seed, uf, itf));
+  } else {
+    pm.reset(new ModelMF(params, params.seed));
+    pb.reset(new ModelMF(params, params.seed));
+  }
+  ModelMF &model = *pm, &best = *pb;
+  std::unordered_set<int> iu, ii;
+  if (m.rfind("ifwmf:", 0) == 0) model.train(data, best, iu, ii);
+  else if (m == "ccd++") model.trainCCDPPFreqAdap(data, best, iu, ii);
   else if (m == "ccdpp") model.trainCCDPP(data, best, iu, ii);
   else if (m == "ccd") model.trainCCD(data, best, iu, ii);
   else if (m == "als") model.trainALS(data, best, iu, ii);

@@ -9,6 +9,7 @@
 #include <string>
 
 #include "mf_model.h"
+#include "model_invpop.h"
 
 #include <algorithm>
 #include <fstream>
@@ -150,8 +151,8 @@ int main(int argc, char** argv) {
   params.nItems = data.nItems;
   params.display();
 
-  if (flags["algo"] != "mf") {
-    std::cerr << "Invalid algo input: " << flags["algo"] << " (this build implements --algo=mf)" << std::endl;
+  if (flags["algo"] != "mf" && flags["algo"] != "IFWMF") {
+    std::cerr << "Invalid algo input: " << flags["algo"] << " (this build implements --algo=mf and --algo=IFWMF)" << std::endl;
     exit(0);
   }
   Partition partItems, partUsers;
@@ -168,7 +169,12 @@ int main(int argc, char** argv) {
     bestModel.reset(new ModelMF(params, params.seed));
   }
   const std::string m = flags["mf_method"];
-  if (m == "ccd++") mfModel->trainCCDPPFreqAdap(data, *bestModel, invalidUsers, invalidItems);
+  if (flags["algo"] == "IFWMF") {       // main.cpp:1361-1366
+    auto rowColFreq = getRowColFreq(data.trainMat);
+    mfModel.reset(new ModelInvPopMF(params, params.seed, rowColFreq.first, rowColFreq.second));
+    bestModel.reset(new ModelInvPopMF(params, params.seed, rowColFreq.first, rowColFreq.second));
+    mfModel->train(data, *bestModel, invalidUsers, invalidItems);
+  } else if (m == "ccd++") mfModel->trainCCDPPFreqAdap(data, *bestModel, invalidUsers, invalidItems);
   else if (m == "ccdpp") mfModel->trainCCDPP(data, *bestModel, invalidUsers, invalidItems);   // reachable only programmatically in the reference
   else if (m == "ccd") mfModel->trainCCD(data, *bestModel, invalidUsers, invalidItems);
   else if (m == "als") mfModel->trainALS(data, *bestModel, invalidUsers, invalidItems);

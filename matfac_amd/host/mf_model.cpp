@@ -504,6 +504,7 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
   int iter, bestIter = -1;
   double bestObj, prevObj, bestValRMSE, prevValRMSE;
   deviceInvalid(data, invalidUsers, invalidItems);   // getInvalidUsersItems + modelMF.cpp:40-45
+  beforeLoop(kind, data, invalidUsers, invalidItems);
   prevObj = objective(data, invalidUsers, invalidItems);
   bestObj = prevObj;
   bestValRMSE = prevValRMSE = RMSE(data.valMat, invalidUsers, invalidItems);
@@ -519,7 +520,7 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
   std::vector<size_t> uiRatingInds;
   std::vector<uint64_t> userPerm;
   std::vector<size_t> validUsers;
-  if ((kind == K_SGD || kind == K_HOG) && exact) {
+  if ((kind == K_SGD || kind == K_HOG || kind == K_IFW) && exact) {
     uiRatingInds.resize((size_t)nRatings);
     std::iota(uiRatingInds.begin(), uiRatingInds.end(), 0);
   }
@@ -549,6 +550,7 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
     switch (kind) {
       case K_SGD:
       case K_HOG:
+      case K_IFW:     // ModelInvPopMF::train: the same sequential loop with the weights beforeLoop() installed
         if (exact) {
           // modelMF.cpp:76-81: std::shuffle every epoch on one thread (parBlockShuffle with one
           // OpenMP thread is a plain std::shuffle; the reference is only reproducible that way)
@@ -556,7 +558,7 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
           dev->check(mfx_sgd_set_order(dev->ctx, (const uint64_t*)uiRatingInds.data(), nRatings), "set_order");
           o.mode = MFX_SGD_SERIAL; o.order = MFX_ORDER_HOST;
         } else {
-          o.mode = MFX_SGD_TILED; o.order = MFX_ORDER_DEVICE;
+          o.mode = kind == K_IFW ? MFX_SGD_HOGWILD : MFX_SGD_TILED; o.order = MFX_ORDER_DEVICE;
         }
         dev->check(mfx_sgd_epoch(dev->ctx, &o), "mfx_sgd_epoch");
         break;
@@ -647,6 +649,7 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
   if (kind == K_CCDPP || kind == K_CCDPP_FA) dev->check(mfx_ccdpp_end(dev->ctx), "mfx_ccdpp_end");
   if (kind == K_CCD) dev->check(mfx_ccd_end(dev->ctx), "mfx_ccd_end");
   if (kind == K_SGDPARSVD) dev->check(mfx_sgd_set_dim_reg(dev->ctx, nullptr), "mfx_sgd_set_dim_reg");
+  afterLoop(kind);
   syncHost();
   bestModel.syncHost();
 }

@@ -140,10 +140,13 @@ class ModelMF : public Model {
   void trainCCD(const Data& data, Model& bestModel, IntSet& invalidUsers, IntSet& invalidItems) override;
   void hogTrain(const Data& data, Model& bestModel, IntSet& invalidUsers, IntSet& invalidItems) override;
 
- private:
-  enum Kind { K_SGD, K_HOG, K_SGDPAR, K_SGDU, K_ALS, K_CCDPP, K_CCDPP_FA, K_CCD, K_SGDPARSVD };
+ protected:
+  enum Kind { K_SGD, K_HOG, K_SGDPAR, K_SGDU, K_ALS, K_CCDPP, K_CCDPP_FA, K_CCD, K_SGDPARSVD, K_IFW };
   void run(Kind kind, const char* name, const Data& data, Model& bestModel, IntSet& invalidUsers,
            IntSet& invalidItems);
+  // called once the invalid sets are known and before the first objective: sibling models set their state here
+  virtual void beforeLoop(Kind, const Data&, IntSet&, IntSet&) {}
+  virtual void afterLoop(Kind) {}
 };
 
 // text factor files (io.cpp:83-154)

@@ -159,6 +159,32 @@ def test_sgdparsvd_loop_follows_a_simulation_with_numpy_svd():
     assert f["val"] < h["val"] + 2e-2
 
 
+def test_ifwmf_loop_is_bit_exact_with_replayed_orders():
+    """ModelInvPopMF::train (--algo=IFWMF): with MFX_EXACT the host replays std::shuffle(uiRatingInds, mt) every
+    epoch; the checker runs the oracle's weighted visit over the same orders with the best-validation bookkeeping."""
+    d, K, iters, lr, reg, rho = data(), 8, 6, 0.004, 0.02, 500.0
+    tr, va = d["train"], d["val"]
+    nU, nI = d["nUsers"], d["nItems"]
+    h = host_train("ifwmf:%g" % rho, d, K, iters, 1, lr, reg, reg, env={"MFX_EXACT": "1"})
+    U, V = orc.init_factors(1, nU, nI, K)
+    invU, invI = orc.invalid(tr.nrows, tr.ncols, tr.rowptr, tr.rowind, nU, nI)
+    pop = orc.ifw_pop(tr.nrows, tr.ncols, tr.rowptr, tr.rowind, invU[:tr.nrows].copy(), invI[:tr.ncols].copy())
+    mt = orc.MT(1)
+    order = np.arange(tr.nnz, dtype=np.uint64)
+    best = (np.inf, None, None)
+    for it in range(iters):
+        mt.shuffle_u64(order)                       # one thread: parBlockShuffle is a plain std::shuffle too
+        orc.sgd_pass_ifw(U, V, tr.rowids(), tr.rowind, tr.rowval, order, lr, reg, reg, pop, rho, orc.DOT_TREE)
+        v, _, _ = orc.rmse(U, V, nU, nI, va.nrows, va.rowptr, va.rowind, va.rowval, invU, invI, orc.DOT_TREE)
+        if v < best[0]:
+            best = (v, U.copy(), V.copy())
+    assert np.array_equal(h["U"], U) and np.array_equal(h["V"], V)
+    assert np.array_equal(h["Ubest"], best[1]) and abs(h["val"] - best[0]) < 1e-12
+    f = host_train("ifwmf:%g" % rho, d, K, 40, 1, lr, reg, reg)              # lock-free order
+    e = host_train("ifwmf:%g" % rho, d, K, 40, 1, lr, reg, reg, env={"MFX_EXACT": "1"})
+    assert abs(f["val"] - e["val"]) < 3e-2
+
+
 @pytest.mark.parametrize("method", ["sgd", "hogsgd", "sgdpar", "sgdu"])
 def test_fast_sgd_paths_reach_the_reference_rmse(method):
     d, K = data(3000, 2000, 300000, seed=2), 16
@@ -228,6 +254,11 @@ def test_mf_cli_end_to_end(tmp_path):
     assert sum(got_items[0::2]) == sum(got_users[0::2])
     part_file = open(prefix + "_itemPartition.txt").read().split()
     assert len(part_file) == 2 * int((~invI[:tr.ncols]).sum())
+    # --algo=IFWMF goes through ModelInvPopMF (main.cpp:1361-1366)
+    ifw = subprocess.run(cmd[:6] + ["--prefix=" + prefix + "_ifw", "--facdim=%d" % K, "--maxiter=5", "--algo=IFWMF", "--rhorms=200",
+                                    "--learnrate=0.004", "--seed=1"], capture_output=True, text=True, timeout=300)
+    assert ifw.returncode == 0, ifw.stderr
+    assert "ModelMF::train trainSeed" in ifw.stdout and float(re.search(r"Test RMSE: ([0-9.eE+-]+)", ifw.stdout).group(1)) < 5.0
     # missing flags exit with -1 like the reference (main.cpp:53-64)
     bad = subprocess.run([cmd[0], "--facdim=4"], capture_output=True, text=True)
     assert bad.returncode != 0 and "Missing" in bad.stderr
