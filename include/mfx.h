@@ -220,6 +220,15 @@ int mfx_sgd_set_ifw(mfx_ctx* ctx, const float* userFreq, const float* invPopU, c
  * n and the two norms as mfx_eval.                                                                              */
 int mfx_eval_ifw(mfx_ctx* ctx, int snapshot, mfx_eval_out* out);
 
+/* ---- ModelDropoutSigmoid (--algo=TMF): truncated-rank MF ---------------------------- */
+/* Every rating uses only the first `rank` dimensions, rank = userRank[u] when userFreq[u] < itemFreq[item], else
+ * itemRank[item] (modelDropoutSigmoid.cpp:158-188; the caller evaluates ceil(sigmoid(..)*facDim) per user and per
+ * item, ranks in [1, K]).  With the table set, MFX_SGD_HOGWILD / MFX_SGD_SERIAL epochs update those dimensions only
+ * (float diff, double bracket) and mfx_eval / mfx_eval_filtered use the truncated estimate (the class's estRating
+ * override, :5-24).  All four pointers NULL: off.                                                                */
+int mfx_set_tmf(mfx_ctx* ctx, const float* userFreq, const int32_t* userRank, const float* itemFreq,
+                const int32_t* itemRank);
+
 /* ---- multi-GPU: user-row-block sharding, item-factor exchange over RCCL ------ */
 /* The reference is single-process; this is new.  Each rank owns a
  * user block (its CSR rows + U shard) and a replica of V.  After local work,

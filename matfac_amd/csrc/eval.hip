@@ -49,14 +49,30 @@ __device__ __forceinline__ T block_combine(T wave_val, T* sh) {
   return tot;
 }
 
+// truncated-rank estimate (ModelDropoutSigmoid::estRating, modelDropoutSigmoid.cpp:5-24): elements k < rank only
 template <int L, int C>
+__device__ __forceinline__ float row_dot_trunc(const float* __restrict__ a, const float* __restrict__ b, int j, int rank) {
+  float s = 0.0f;
+#pragma unroll
+  for (int c = 0; c < C; c++) {
+    const float4v x = *(const float4v*)(a + c * 4 * L);
+    const float4v y = *(const float4v*)(b + c * 4 * L);
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+      if (c * 4 * L + 4 * j + e < rank) s = __builtin_fmaf(x[e], y[e], s);
+  }
+  return group_sum<L>(s);
+}
+
+template <int L, int C, bool TMF>
 __global__ __launch_bounds__(256) void eval_sse_kernel(const int32_t* __restrict__ ru,
                                                        const int32_t* __restrict__ ri,
                                                        const float* __restrict__ rr, int64_t n,
                                                        const float* __restrict__ U, const float* __restrict__ V,
                                                        const uint8_t* __restrict__ invU,
                                                        const uint8_t* __restrict__ invI, int32_t nU, int32_t nI,
-                                                       double* __restrict__ part_d, int64_t* __restrict__ part_i) {
+                                                       double* __restrict__ part_d, int64_t* __restrict__ part_i,
+                                                       const int2* __restrict__ tu, const int2* __restrict__ ti) {
   constexpr int G = 64 / L;
   constexpr int LD = 4 * L * C;
   __shared__ double shd[4];
@@ -83,7 +99,14 @@ __global__ __launch_bounds__(256) void eval_sse_kernel(const int32_t* __restrict
       bool use = e < nvalid && u < nU && it < nI;
       if (use) use = !invU[u] && !invI[it];
       if (use) {
-        const float est = row_dot<L, C>(U + (int64_t)u * LD + 4 * j, V + (int64_t)it * LD + 4 * j);
+        float est;
+        if (TMF) {
+          const int2 a = tu[u], b = ti[it];
+          est = row_dot_trunc<L, C>(U + (int64_t)u * LD + 4 * j, V + (int64_t)it * LD + 4 * j, j,
+                                    __int_as_float(a.x) < __int_as_float(b.x) ? a.y : b.y);
+        } else {
+          est = row_dot<L, C>(U + (int64_t)u * LD + 4 * j, V + (int64_t)it * LD + 4 * j);
+        }
         const double diff = (double)r - (double)est;
         if (j == 0) { acc += diff * diff; cnt++; }
       }
@@ -165,8 +188,13 @@ static int eval_lc(mfx_ctx* ctx, const DevCSR& m, const float* U, const float* V
                    int nbu, int nbi) {
   ProfScope ps(ctx, MFX_K_EVAL);
   double* pd = ctx->red_d;
-  hipLaunchKernelGGL((eval_sse_kernel<L, C>), dim3(nb), dim3(256), 0, ctx->stream, m.rowid, m.rowind, m.rowval,
-                     m.nnz, U, V, ctx->invU, ctx->invI, ctx->nU, ctx->nI, pd, ctx->red_i);
+  if (ctx->tmf_u)
+    hipLaunchKernelGGL((eval_sse_kernel<L, C, true>), dim3(nb), dim3(256), 0, ctx->stream, m.rowid, m.rowind, m.rowval,
+                       m.nnz, U, V, ctx->invU, ctx->invI, ctx->nU, ctx->nI, pd, ctx->red_i, ctx->tmf_u, ctx->tmf_i);
+  else
+    hipLaunchKernelGGL((eval_sse_kernel<L, C, false>), dim3(nb), dim3(256), 0, ctx->stream, m.rowid, m.rowind, m.rowval,
+                       m.nnz, U, V, ctx->invU, ctx->invI, ctx->nU, ctx->nI, pd, ctx->red_i, (const int2*)nullptr,
+                       (const int2*)nullptr);
   if (with_norms) {
     hipLaunchKernelGGL((eval_norm_kernel<L, C>), dim3(nbu), dim3(256), 0, ctx->stream, U, ctx->nU, ctx->invU,
                        pd + nb);

@@ -101,6 +101,7 @@ void mfx_destroy(mfx_ctx* ctx) {
   mfx_comm_free_internal(ctx);
   dev_free(ctx->dimreg);
   mfx_ifw_free_internal(ctx);
+  mfx_tmf_free_internal(ctx);
   mfx_ccd_free_internal(ctx);
   mfx_cd_free_internal(ctx);
   mfx_als_free_internal(ctx);
@@ -231,6 +232,7 @@ extern "C" int mfx_set_model(mfx_ctx* ctx, int32_t nUsers, int32_t nItems, int32
   mfx_als_wide_free_internal(ctx);
   dev_free(ctx->dimreg);
   mfx_ifw_free_internal(ctx);
+  mfx_tmf_free_internal(ctx);
   ctx->nU = nUsers; ctx->nI = nItems; ctx->K = K;
   mfx_tree_shape(K, &ctx->L, &ctx->C);
   ctx->ld = 4 * ctx->L * ctx->C;
@@ -448,6 +450,9 @@ extern "C" int mfx_sgd_epoch(mfx_ctx* ctx, const mfx_sgd_opts* o) {
   NEED(!ctx->ifw || o->mode == MFX_SGD_HOGWILD || o->mode == MFX_SGD_SERIAL, MFX_E_ARG,
        "mfx_sgd_epoch: rating weights (mfx_sgd_set_ifw) run on MFX_SGD_HOGWILD / MFX_SGD_SERIAL");
   NEED(!(ctx->ifw && ctx->dimreg), MFX_E_STATE, "mfx_sgd_epoch: rating weights and per-dimension regularisation are exclusive");
+  NEED(!ctx->tmf_u || o->mode == MFX_SGD_HOGWILD || o->mode == MFX_SGD_SERIAL, MFX_E_ARG,
+       "mfx_sgd_epoch: truncated ranks (mfx_set_tmf) run on MFX_SGD_HOGWILD / MFX_SGD_SERIAL");
+  NEED(!(ctx->tmf_u && (ctx->ifw || ctx->dimreg)), MFX_E_STATE, "mfx_sgd_epoch: truncated ranks exclude the other SGD variants");
   NEED(o->order >= MFX_ORDER_DEVICE && o->order <= MFX_ORDER_NATURAL, MFX_E_ARG, "mfx_sgd_epoch: order=%d", o->order);
   NEED(o->arith >= MFX_ARITH_REF64 && o->arith <= MFX_ARITH_F32, MFX_E_ARG, "mfx_sgd_epoch: arith=%d", o->arith);
   HIPCHK(hipSetDevice(ctx->device));

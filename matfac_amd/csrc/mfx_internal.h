@@ -95,6 +95,7 @@ struct mfx_ctx {
   void* als_wide = nullptr;   // ALS for K > 64 (als_wide.hip owns the type)
   float* dimreg = nullptr;    // per-dimension regulariser [ld] of trainSGDParSVD (svd.hip), or NULL
   void* ifw = nullptr;        // rating weights of ModelInvPopMF (sgd_ifw.hip owns the type), or NULL
+  int2 *tmf_u = nullptr, *tmf_i = nullptr;   // (train frequency bits, truncated rank) per user / item (sgd_tmf.hip), or NULL
 
   // comm
   void* comm = nullptr;      // ncclComm_t
@@ -190,6 +191,8 @@ int mfx_launch_sgd_users(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t nusers);
 int mfx_launch_sgd_tiled(mfx_ctx* ctx, const mfx_sgd_opts* o);
 int mfx_launch_sgd_ifw(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_t count);      // sgd_ifw.hip
 void mfx_ifw_free_internal(mfx_ctx* ctx);
+int mfx_launch_sgd_tmf(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_t count);      // sgd_tmf.hip
+void mfx_tmf_free_internal(mfx_ctx* ctx);
 int mfx_launch_sgd_dimreg(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_t count);   // svd.hip
 int mfx_slots_materialise_order(mfx_ctx* ctx);
 void mfx_slots_free_internal(mfx_ctx* ctx);

@@ -216,6 +216,7 @@ static int launch_any(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_
 int mfx_launch_sgd(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_t count) {
   if (ctx->dimreg) return mfx_launch_sgd_dimreg(ctx, o, first, count);   // trainSGDParSVD's regulariser (svd.hip)
   if (ctx->ifw) return mfx_launch_sgd_ifw(ctx, o, first, count);         // ModelInvPopMF's rating weights (sgd_ifw.hip)
+  if (ctx->tmf_u) return mfx_launch_sgd_tmf(ctx, o, first, count);       // ModelDropoutSigmoid's truncated ranks (sgd_tmf.hip)
   return launch_any(ctx, o, first, count, 0);
 }
 int mfx_launch_sgd_users(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t nusers) {

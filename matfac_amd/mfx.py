@@ -234,6 +234,11 @@ class Ctx:
         self._chk(self.lib.mfx_eval_ifw(self.h, snapshot, C.byref(out)))
         return out
 
+    # ---- ModelDropoutSigmoid (TMF) ------------------------------------------------------
+    def set_tmf(self, userFreq=None, userRank=None, itemFreq=None, itemRank=None):
+        ks = [_p(userFreq, np.float32), _p(userRank, np.int32), _p(itemFreq, np.float32), _p(itemRank, np.int32)]
+        self._chk(self.lib.mfx_set_tmf(self.h, *[k[1] if k else None for k in ks]))
+
     # ---- cyclic coordinate descent (trainCCD) ---------------------------------------
     def ccd_begin(self):
         self._chk(self.lib.mfx_ccd_begin(self.h))

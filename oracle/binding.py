@@ -239,6 +239,27 @@ def objective_ifw(U, V, nUsers, nItems, nrows, rowptr, rowind, rowval, invU, inv
     return o, w.value
 
 
+def tmf_ranks(freq, meanFreq, stdFreq, rho, alpha, K):
+    freq = np.ascontiguousarray(freq, np.float64)
+    out = np.zeros(len(freq), np.int32)
+    lib.orc_tmf_ranks(len(freq), _f64p(freq), C.c_double(meanFreq), C.c_double(stdFreq), C.c_float(rho), C.c_float(alpha), K, I32(out))
+    return out
+
+
+def sgd_pass_tmf(U, V, u, i, r, order, lr, uReg, iReg, uf, itf, ru, ri, dot_mode=DOT_SEQ):
+    lib.orc_sgd_pass_tmf(U.shape[1], F(U), F(V), I32(u), I32(i), F(r), U64(order) if order is not None else None,
+                         C.c_int64(len(order) if order is not None else len(u)), C.c_float(lr), C.c_float(uReg), C.c_float(iReg),
+                         _f64p(uf), _f64p(itf), I32(ru), I32(ri), dot_mode)
+
+
+def rmse_tmf(U, V, nUsers, nItems, nrows, rowptr, rowind, rowval, invU, invI, uf, itf, ru, ri, dot_mode=DOT_SEQ):
+    lib.orc_rmse_tmf.restype = C.c_double
+    sse, cnt = C.c_double(), C.c_int64()
+    r = lib.orc_rmse_tmf(U.shape[1], F(U), F(V), nUsers, nItems, nrows, I64(rowptr), I32(rowind), F(rowval), U8(invU), U8(invI),
+                         _f64p(uf), _f64p(itf), I32(ru), I32(ri), dot_mode, C.byref(sse), C.byref(cnt))
+    return r, sse.value, cnt.value
+
+
 def sgd_hogwild(U, V, u, i, r, order, lr, uReg, iReg, arith=ARITH_F32, dot_mode=DOT_SEQ, nthreads=1):
     K = U.shape[1]
     lib.orc_sgd_hogwild(K, F(U), F(V), I32(u), I32(i), F(r), U64(order) if order is not None else None,

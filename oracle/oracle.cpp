@@ -416,6 +416,74 @@ double orc_objective_ifw(int K, const float* U, const float* V, int32_t nUsers, 
   return rmse + uRegErr + iRegErr;
 }
 
+// ---- ModelDropoutSigmoid (TMF) -------------------------------------------------------------
+// adapDotProd (util.cpp:1067-1074) over the first `rank` dimensions; in device order the masked elements
+// simply contribute nothing to their lane's chain
+static inline float dotf_trunc(const float* p, const float* q, int K, int rank, int mode) {
+  if (mode != ORC_DOT_TREE) {
+    float prod = 0;
+    for (int k = 0; k < rank; k++) prod += p[k] * q[k];
+    return prod;
+  }
+  std::vector<float> qm(q, q + K), pm(p, p + K);
+  for (int k = rank; k < K; k++) { qm[k] = 0.0f; pm[k] = 0.0f; }    // fma(0, 0, a) == a
+  return dot_tree(pm.data(), qm.data(), K);
+}
+// modelDropoutSigmoid.cpp:158-172 (train) / :7-18 (estRating): the rank of a frequency.  The class's
+// meanFreq/stdFreq are meanStdDev (util.cpp:278-294) of userFreq ++ itemFreq.
+void orc_tmf_ranks(int32_t n, const double* freq, double meanFreq, double stdFreq, float rhoRMS, float alpha, int facDim,
+                   int32_t* rank) {
+  for (int i = 0; i < n; i++) {
+    const double scaleFreq = (freq[i] - meanFreq) / stdFreq;
+    const double sigmPc = 1.0 / (1.0 + exp(-rhoRMS * (scaleFreq - alpha)));
+    int updMinRank = std::ceil(sigmPc * ((double)facDim));
+    if (updMinRank < 1e-5) updMinRank = 1;        // train (:165-167); estRating asserts > 0 instead
+    if (updMinRank > facDim) updMinRank = facDim;
+    rank[i] = updMinRank;
+  }
+}
+static inline int tmf_rank(int u, int item, const double* userFreq, const double* itemFreq, const int32_t* ru, const int32_t* ri) {
+  return userFreq[u] < itemFreq[item] ? ru[u] : ri[item];       // isUMinFreq
+}
+// modelDropoutSigmoid.cpp:152-188 for a list of ratings
+void orc_sgd_pass_tmf(int K, float* U, float* V, const int32_t* u, const int32_t* i, const float* r, const uint64_t* order,
+                      int64_t n, float learnRate, float uReg, float iReg, const double* userFreq, const double* itemFreq,
+                      const int32_t* ru, const int32_t* ri, int dot_mode) {
+  for (int64_t t = 0; t < n; t++) {
+    const int64_t ind = order ? (int64_t)order[t] : t;
+    float* p = U + (int64_t)u[ind] * K;
+    float* q = V + (int64_t)i[ind] * K;
+    const int updMinRank = tmf_rank(u[ind], i[ind], userFreq, itemFreq, ru, ri);
+    const float itemRat = r[ind];
+    const float r_ui_est = dotf_trunc(p, q, K, updMinRank, dot_mode);
+    const float diff = itemRat - r_ui_est;
+    for (int k = 0; k < updMinRank; k++) p[k] -= learnRate * (-2.0 * diff * q[k] + 2.0 * uReg * p[k]);
+    for (int k = 0; k < updMinRank; k++) q[k] -= learnRate * (-2.0 * diff * p[k] + 2.0 * iReg * q[k]);
+  }
+}
+// Model::RMSE (model.cpp:214-251) through ModelDropoutSigmoid::estRating; also returns the squared error sum
+double orc_rmse_tmf(int K, const float* U, const float* V, int32_t nUsers, int32_t nItems, int32_t nrows,
+                    const int64_t* rowptr, const int32_t* rowind, const float* rowval, const uint8_t* invU,
+                    const uint8_t* invI, const double* userFreq, const double* itemFreq, const int32_t* ru,
+                    const int32_t* ri, int dot_mode, double* sse_out, int64_t* cnt) {
+  int64_t nnz = 0;
+  double rmse = 0;
+  for (int u = 0; u < nUsers && u < nrows; u++) {
+    if (invU[u]) continue;
+    for (int64_t ii = rowptr[u]; ii < rowptr[u + 1]; ii++) {
+      const int item = rowind[ii];
+      if (item >= nItems || invI[item]) continue;
+      const double r_ui_est = dotf_trunc(U + (int64_t)u * K, V + (int64_t)item * K, K, tmf_rank(u, item, userFreq, itemFreq, ru, ri), dot_mode);
+      const double diff = rowval[ii] - r_ui_est;
+      rmse += diff * diff;
+      nnz++;
+    }
+  }
+  if (sse_out) *sse_out = rmse;
+  if (cnt) *cnt = nnz;
+  return sqrt(rmse / nnz);
+}
+
 void orc_sgd_hogwild(int K, float* U, float* V, const int32_t* u, const int32_t* i,
                      const float* r, const uint64_t* order, int64_t n, float lr,
                      float uReg, float iReg, int arith, int dot_mode, int nthreads) {

@@ -160,6 +160,17 @@ double orc_objective_ifw(int K, const float* U, const float* V, int32_t nUsers, 
                          const uint8_t* invI, float uReg, float iReg, const double* userFreq, const double* itemFreq,
                          const double* invPopU, const double* invPopI, float rhoRMS, int dot_mode, double* wsse_out);
 
+/* ---- ModelDropoutSigmoid / TMF (modelDropoutSigmoid.cpp:5-24, 152-188) ---- */
+void orc_tmf_ranks(int32_t n, const double* freq, double meanFreq, double stdFreq, float rhoRMS, float alpha, int facDim,
+                   int32_t* rank);
+void orc_sgd_pass_tmf(int K, float* U, float* V, const int32_t* u, const int32_t* i, const float* r, const uint64_t* order,
+                      int64_t n, float learnRate, float uReg, float iReg, const double* userFreq, const double* itemFreq,
+                      const int32_t* ru, const int32_t* ri, int dot_mode);
+double orc_rmse_tmf(int K, const float* U, const float* V, int32_t nUsers, int32_t nItems, int32_t nrows,
+                    const int64_t* rowptr, const int32_t* rowind, const float* rowval, const uint8_t* invU,
+                    const uint8_t* invI, const double* userFreq, const double* itemFreq, const int32_t* ru,
+                    const int32_t* ri, int dot_mode, double* sse_out, int64_t* cnt);
+
 /* ---- CCD (modelMF.cpp:1528-1605), sequential ---------------------------- */
 void orc_ccd_iter(int K, float* U, float* V, int32_t nUsers, int32_t nItems,
                   int32_t ncols, const int64_t* rowptr, const int32_t* rowind,

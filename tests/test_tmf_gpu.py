@@ -1,0 +1,73 @@
+"""ModelDropoutSigmoid (--algo=TMF, modelDropoutSigmoid.cpp): rank truncated per rating by the frequency of its
+rarer side.  Device visit and truncated evaluation against the oracle, bit-exact in list order."""
+import numpy as np
+import pytest
+
+from matfac_amd import Ctx, mfx, synth
+from oracle import binding as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("K,rho,alpha", [(5, 1.0, 0.0), (16, 2.0, -0.5), (40, 0.5, 0.3), (64, 1.0, 0.0), (100, 3.0, 0.2)])
+def test_truncated_rank_visit_and_evaluation(K, rho, alpha):
+    d = synth.make(dict(nU=400, nI=150, nnz=12000, K=K), seed=K + 1)
+    tr, te = d["train"], d["test"]
+    nU, nI = d["nUsers"], max(d["nItems"], tr.ncols)
+    rng = np.random.default_rng(K)
+    U0 = rng.normal(0, 0.4, (nU, K)).astype(np.float32)
+    V0 = rng.normal(0, 0.4, (nI, K)).astype(np.float32)
+    oU, oI = orc.invalid(tr.nrows, tr.ncols, tr.rowptr, tr.rowind, nU, nI)
+    uf = np.zeros(nU); uf[:tr.nrows] = np.diff(tr.rowptr)
+    itf = np.zeros(nI); itf[:tr.ncols] = np.bincount(tr.rowind, minlength=tr.ncols)
+    both = np.concatenate([uf[:tr.nrows], itf[:tr.ncols]])
+    mean, std = both.mean(), np.sqrt(((both - both.mean()) ** 2).sum() / len(both))        # meanStdDev, util.cpp:278-294
+    ru, ri = orc.tmf_ranks(uf, mean, std, rho, alpha, K), orc.tmf_ranks(itf, mean, std, rho, alpha, K)
+    assert ru.min() >= 1 and ru.max() <= K and len(np.unique(np.concatenate([ru, ri]))) > 1           # ranks really vary
+    order = np.arange(tr.nnz, dtype=np.uint64)
+    orc.MT(4).shuffle_u64(order)
+    with Ctx(0) as ctx:
+        ctx.set_csr(mfx.MAT_TRAIN, tr.nrows, tr.ncols, tr.rowptr, tr.rowind, tr.rowval)
+        ctx.set_csr(mfx.MAT_TEST, te.nrows, nI, te.rowptr, te.rowind, te.rowval)
+        ctx.set_model(nU, nI, K)
+        ctx.set_factors(U0, V0)
+        ctx.compute_invalid()
+        full = ctx.eval(mfx.MAT_TEST)
+        ctx.set_tmf(uf.astype(np.float32), ru, itf.astype(np.float32), ri)
+        e0 = ctx.eval(mfx.MAT_TEST)
+        ctx.sgd_set_order(order)
+        ctx.sgd_epoch(0.004, 0.05, 0.03, mode=mfx.SGD_SERIAL, order=mfx.ORDER_HOST)
+        U, V = ctx.get_factors()
+        e1 = ctx.eval(mfx.MAT_TRAIN)
+        keep_i = (np.arange(nI) % 2).astype(np.uint8)
+        ef = ctx.eval_filtered(mfx.MAT_TEST, None, keep_i)
+        with pytest.raises(mfx.MfxError):
+            ctx.sgd_epoch(0.004, 0.05, 0.03, mode=mfx.SGD_TILED)
+        ctx.set_factors(U0, V0)
+        first = np.unique(tr.rowids(), return_index=True)[1]
+        keep = first[np.unique(tr.rowind[first], return_index=True)[1]].astype(np.uint64)
+        ctx.sgd_set_order(keep)
+        ctx.sgd_epoch(0.004, 0.05, 0.03, mode=mfx.SGD_HOGWILD, order=mfx.ORDER_HOST)
+        Uh, Vh = ctx.get_factors()
+        ctx.set_tmf()
+        ctx.set_factors(U0, V0)
+        again = ctx.eval(mfx.MAT_TEST)
+    _, s0, n0 = orc.rmse_tmf(U0, V0, nU, nI, te.nrows, te.rowptr, te.rowind, te.rowval, oU, oI, uf, itf, ru, ri, orc.DOT_TREE)
+    assert e0.n == n0 and abs(e0.sse - s0) <= 1e-12 * s0 and e0.sse != full.sse
+    assert (again.n, again.sse) == (full.n, full.sse)
+    Uo, Vo = U0.copy(), V0.copy()
+    orc.sgd_pass_tmf(Uo, Vo, tr.rowids(), tr.rowind, tr.rowval, order, 0.004, 0.05, 0.03, uf, itf, ru, ri, orc.DOT_TREE)
+    assert np.isfinite(Uo).all() and np.array_equal(U, Uo) and np.array_equal(V, Vo)
+    _, s1, n1 = orc.rmse_tmf(Uo, Vo, nU, nI, tr.nrows, tr.rowptr, tr.rowind, tr.rowval, oU, oI, uf, itf, ru, ri, orc.DOT_TREE)
+    assert e1.n == n1 and abs(e1.sse - s1) <= 1e-12 * s1
+    _, sf, nf = orc.rmse_tmf(Uo, Vo, nU, nI, te.nrows, te.rowptr, te.rowind, te.rowval, oU, (oI | (1 - keep_i)).astype(np.uint8), uf, itf,
+                             ru, ri, orc.DOT_TREE)
+    assert ef.n == nf and abs(ef.sse - sf) <= 1e-12 * sf
+    Uc, Vc = U0.copy(), V0.copy()
+    orc.sgd_pass_tmf(Uc, Vc, tr.rowids(), tr.rowind, tr.rowval, keep, 0.004, 0.05, 0.03, uf, itf, ru, ri, orc.DOT_TREE)
+    assert np.array_equal(Uh, Uc) and np.array_equal(Vh, Vc)
+    # dimensions beyond a row's largest rank are never touched
+    top_u = np.zeros(nU, int)
+    np.maximum.at(top_u, tr.rowids(), np.where(uf[tr.rowids()] < itf[tr.rowind], ru[tr.rowids()], ri[tr.rowind]))
+    for u in range(0, nU, 37):
+        assert np.array_equal(U[u, top_u[u]:], U0[u, top_u[u]:])
