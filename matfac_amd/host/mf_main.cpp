@@ -10,6 +10,7 @@
 
 #include "mf_model.h"
 #include "model_invpop.h"
+#include "model_tmf.h"
 
 #include <algorithm>
 #include <fstream>
@@ -151,8 +152,8 @@ int main(int argc, char** argv) {
   params.nItems = data.nItems;
   params.display();
 
-  if (flags["algo"] != "mf" && flags["algo"] != "IFWMF") {
-    std::cerr << "Invalid algo input: " << flags["algo"] << " (this build implements --algo=mf and --algo=IFWMF)" << std::endl;
+  if (flags["algo"] != "mf" && flags["algo"] != "IFWMF" && flags["algo"] != "TMF") {
+    std::cerr << "Invalid algo input: " << flags["algo"] << " (this build implements --algo=mf, IFWMF and TMF)" << std::endl;
     exit(0);
   }
   Partition partItems, partUsers;
@@ -173,6 +174,12 @@ int main(int argc, char** argv) {
     auto rowColFreq = getRowColFreq(data.trainMat);
     mfModel.reset(new ModelInvPopMF(params, params.seed, rowColFreq.first, rowColFreq.second));
     bestModel.reset(new ModelInvPopMF(params, params.seed, rowColFreq.first, rowColFreq.second));
+    mfModel->train(data, *bestModel, invalidUsers, invalidItems);
+  } else if (flags["algo"] == "TMF") {   // main.cpp:1349-1354 (userRankPc / itemRankPc are carried, not used by train)
+    auto rowColFreq = getRowColFreq(data.trainMat);
+    std::vector<double> userRankPc, itemRankPc;
+    mfModel.reset(new ModelDropoutSigmoid(params, params.seed, userRankPc, itemRankPc, rowColFreq.first, rowColFreq.second));
+    bestModel.reset(new ModelDropoutSigmoid(params, params.seed, userRankPc, itemRankPc, rowColFreq.first, rowColFreq.second));
     mfModel->train(data, *bestModel, invalidUsers, invalidItems);
   } else if (m == "ccd++") mfModel->trainCCDPPFreqAdap(data, *bestModel, invalidUsers, invalidItems);
   else if (m == "ccdpp") mfModel->trainCCDPP(data, *bestModel, invalidUsers, invalidItems);   // reachable only programmatically in the reference

@@ -566,6 +566,12 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
         o.mode = MFX_SGD_TILED; o.order = MFX_ORDER_DEVICE;
         dev->check(mfx_sgd_epoch(dev->ctx, &o), "mfx_sgd_epoch");
         break;
+      case K_TMF:         // modelDropoutSigmoid.cpp:140-192 with the rank table beforeLoop() installed; float diff
+        o.arith = MFX_ARITH_REF64F;
+        o.mode = exact ? MFX_SGD_SERIAL : MFX_SGD_HOGWILD;
+        o.order = exact ? MFX_ORDER_NATURAL : MFX_ORDER_DEVICE;
+        dev->check(mfx_sgd_epoch(dev->ctx, &o), "mfx_sgd_epoch");
+        break;
       case K_SGDPARSVD:   // modelMF.cpp:474-512 with the per-dimension regulariser set above; lock-free, coherent rows
         o.mode = exact ? MFX_SGD_SERIAL : MFX_SGD_HOGWILD;
         o.order = exact ? MFX_ORDER_NATURAL : MFX_ORDER_DEVICE;
