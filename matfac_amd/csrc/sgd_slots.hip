@@ -174,8 +174,9 @@ static int build_slots(mfx_ctx* ctx, SlotList* S, int rows, int side) {
 // ---------------------------------------------------------------------------
 // kernel
 // ---------------------------------------------------------------------------
-template <int C>
-struct SlotRows { static constexpr int value = 64 / C < 8 ? 8 : 64 / C; };
+// owned rows per slot: 16 KB of LDS per workgroup, at most 64 and at least 8 rows
+template <int LD>
+struct SlotRows { static constexpr int value = 4096 / LD > 64 ? 64 : (4096 / LD < 8 ? 8 : 4096 / LD); };
 
 __device__ __forceinline__ int64_t slot_perm(int64_t t, int64_t R, uint32_t k0, uint32_t k1) {
   int bits = 2;
@@ -280,7 +281,7 @@ struct SlotSteps {
 
 // C = 1 (K <= 64): 2 workgroups per CU (<= 64 VGPRs); wider ranks keep 1 workgroup per CU and get 128 VGPRs
 template <int L, int C, int ARITH, bool SWEEP, bool OWN_U>
-__global__ __launch_bounds__(WG, (C == 1 ? 8 : 4)) void sgd_slots_kernel(const int4* __restrict__ rec,
+__global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kernel(const int4* __restrict__ rec,
                                                            const int64_t* __restrict__ slot_beg,
                                                            const int32_t* __restrict__ slot_ibeg,
                                                            const int32_t* __restrict__ slot_items,
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(WG, (C == 1 ? 8 : 4)) void sgd_slots_kernel(const i
   constexpr int G = 64 / L;
   constexpr int LD = 4 * L * C;
   constexpr int LD4 = LD / 4;
-  constexpr int ROWS = SlotRows<C>::value;
+  constexpr int ROWS = SlotRows<4 * L * C>::value;
   __shared__ __attribute__((aligned(16))) int q_lds[ROWS * LD];
   __shared__ int s_slot, s_bad;
   // Oth: the lock-free side (user rows when item rows are owned, and vice versa); Own: staged in LDS
@@ -465,7 +466,7 @@ int mfx_launch_sgd_tiled(mfx_ctx* ctx, const mfx_sgd_opts* o) {
   SlotState* st = state(ctx);
   if (!st) { st = new SlotState; ctx->slots = st; }
   SlotList* S = &st->side[side];
-  const int rows = ctx->C <= 8 ? (64 / ctx->C < 8 ? 8 : 64 / ctx->C) : 8;
+  const int rows = std::min(64, std::max(8, 4096 / ctx->ld));
   if (!S->built || S->rows != rows || S->nnz != ctx->mat[MFX_MAT_TRAIN].nnz) {
     int rc = build_slots(ctx, S, rows, side);
     if (rc) return rc;
@@ -482,7 +483,7 @@ int mfx_launch_sgd_tiled(mfx_ctx* ctx, const mfx_sgd_opts* o) {
   if (L == 4) return launch_arith<4, 1>(ctx, S, side, o, blocks, k0, k1);
   if (L == 8) return launch_arith<8, 1>(ctx, S, side, o, blocks, k0, k1);
   switch (C) {
-    case 1: return launch_arith<16, 1>(ctx, S, side, o, blocks, k0, k1);
+    case 1: return launch_arith<16, 1>(ctx, S, side, o, blocks, k0, k1);   // (8 lanes x 2 chunks was tried: 64 VGPRs do not hold it, 2.5x slower)
     case 2: return launch_arith<16, 2>(ctx, S, side, o, blocks, k0, k1);
     case 3: return launch_arith<16, 3>(ctx, S, side, o, blocks, k0, k1);
     case 4: return launch_arith<16, 4>(ctx, S, side, o, blocks, k0, k1);
