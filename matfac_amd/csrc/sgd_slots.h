@@ -34,6 +34,21 @@ struct SlotState {
   int last_side = 0;
 };
 
+// position t of a slot's visiting order (Feistel permutation of [0, R) keyed per epoch and slot)
+__device__ __forceinline__ int64_t slot_perm(int64_t t, int64_t R, uint32_t k0, uint32_t k1) {
+  int bits = 2;
+  while (((int64_t)1 << bits) < R) bits++;
+  const int ab = bits / 2;
+  return mfx_perm_index(t, R, ab, bits - ab, k0, k1);
+}
+
+// the kernel launchers, one per rank shape (sgd_slots_inst_<L>x<C>.hip)
+#define MFX_SLOTS_DECL(LL, CC) \
+  int mfx_slots_launch_##LL##x##CC(mfx_ctx* ctx, SlotList* S, int side, const mfx_sgd_opts* o, int blocks, uint32_t k0, uint32_t k1);
+MFX_SLOTS_DECL(4, 1) MFX_SLOTS_DECL(8, 1) MFX_SLOTS_DECL(16, 1) MFX_SLOTS_DECL(16, 2) MFX_SLOTS_DECL(16, 3) MFX_SLOTS_DECL(16, 4)
+MFX_SLOTS_DECL(16, 5) MFX_SLOTS_DECL(16, 6) MFX_SLOTS_DECL(16, 7) MFX_SLOTS_DECL(16, 8)
+#undef MFX_SLOTS_DECL
+
 // builds S on the device from the train matrix (setup.hip); same lists as the host builder in sgd_slots.hip
 int mfx_slots_build_device(mfx_ctx* ctx, SlotList* S, int rows, int side);
 

@@ -1,0 +1,4 @@
+// MFX_SGD_TILED kernel for the rank shape L=16 lanes x C=4 chunks (see sgd_slots_kernel.h)
+#include "sgd_slots_kernel.h"
+
+MFX_SLOTS_INSTANCE(16, 4)

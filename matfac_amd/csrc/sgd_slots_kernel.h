@@ -1,0 +1,280 @@
+// sgd_slots_kernel.h -- the MFX_SGD_TILED kernel and its launch templates.  Included by one small translation
+// unit per rank shape (sgd_slots_inst_*.hip) so that the shapes compile in parallel; see sgd_slots.hip for the
+// schedule and the slot lists.
+#ifndef MFX_SGD_SLOTS_KERNEL_H_
+#define MFX_SGD_SLOTS_KERNEL_H_
+
+#include <algorithm>
+
+#include "sgd_common.h"
+#include "sgd_slots.h"
+
+// ---------------------------------------------------------------------------
+// kernel
+// ---------------------------------------------------------------------------
+// owned rows per slot: 16 KB of LDS per workgroup, at most 64 and at least 8 rows
+template <int LD>
+struct SlotRows { static constexpr int value = 4096 / LD > 64 ? 64 : (4096 / LD < 8 ? 8 : 4096 / LD); };
+
+
+// Item rows of a slot live in LDS as Q = round(q * 2^24) (int32).  A visit reads q = float(Q) * 2^-24,
+// computes q_new with the reference's arithmetic and adds round((q_new - q) * 2^24) with ds_add_u32:
+// no item update is lost and every group reads the freshest row.  (ds_add_f32 was measured 7x slower
+// than the whole rest of the kernel; the integer add is free.)  Resolution 6e-8, range +-128; a slot
+// whose staged rows are not finite or exceed the range falls back to float rows with plain stores, and a
+// row that leaves the range while being updated is written back as NaN, so Model::isTerminateModel's NaN
+// guard (model.cpp:1486-1498) still sees a diverged model.
+constexpr float FIX_SCALE = 16777216.0f, FIX_INV = 1.0f / 16777216.0f, FIX_MAX = 127.0f;
+
+// entry S*G+g of the chunk: row_share broadcast of the transposed chunk (L == 16) or a cross-lane read
+template <int L, int S>
+__device__ __forceinline__ int slot_take(int v, int g) {
+  if constexpr (L == 16) return __builtin_amdgcn_update_dpp(0, v, 0x150 + S, 0xF, 0xF, false);   // row_share:S
+  else return __shfl(v, S * (64 / L) + g, 64);
+}
+
+// The L steps of one 64-rating chunk, unrolled by template recursion (the DPP controls are immediates).
+// FIX: the slot's rows are in the fixed-point representation (decided per slot, so per chunk it is a template
+// argument, not a select per element).
+template <int L, int C, int ARITH, bool OWN_U, bool FIX, int S>
+struct SlotSteps {
+  static __device__ __forceinline__ void run(const Rows<3>& Um, int* q_lds, int tx, int ty, int tz, int g, int j,
+                                             int nvalid, float lr, float uReg, float iReg,
+                                             float4v (&pn)[C], int64_t& pen, float4v (&pnn)[C], int64_t& penn) {
+    constexpr int G = 64 / L;
+    constexpr int LD = 4 * L * C;
+    const int e = S * G + g;
+    const int li = slot_take<L, S>(ty, g);
+    const float r = __builtin_bit_cast(float, slot_take<L, S>(tz, g));
+    // rows of steps S+1 and S+2 are already requested; take S, shift, request S+2
+    float4v p[C];
+    const int64_t pe = pen;
+#pragma unroll
+    for (int c = 0; c < C; c++) { p[c] = pn[c]; pn[c] = pnn[c]; }
+    pen = penn;
+    if constexpr (S + 2 < L) {
+      const int un = slot_take<L, S + 2>(tx, g);
+      if (e + 2 * G < nvalid) {
+        penn = (int64_t)un * LD + 4 * j;
+#pragma unroll
+        for (int c = 0; c < C; c++) pnn[c] = Um.ld(penn + c * 4 * L);
+      }
+    }
+    if (e < nvalid) {
+      int* qrow = q_lds + li * LD + 4 * j;
+      float4v q[C];
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        const int4 qi = *(const int4*)(qrow + c * 4 * L);
+        if (FIX) q[c] = float4v{(float)qi.x * FIX_INV, (float)qi.y * FIX_INV, (float)qi.z * FIX_INV, (float)qi.w * FIX_INV};
+        else q[c] = __builtin_bit_cast(float4v, qi);
+      }
+      // p = the row from global memory, q = the owned row; the reference updates the USER row first
+      // and the item row with the updated user row (modelMF.cpp:94-103) whichever side is owned
+      const float est = group_dot<L, C>(p, q);
+      if constexpr (FIX && !OWN_U && ARITH == MFX_ARITH_F32) {
+        // hogTrain's arithmetic (modelMF.cpp:1755-1762) with the item step taken as a delta: the new item
+        // row would be q - t, t = lr*(c1*p' + ci*q); the owner copy receives round(-t * 2^24) directly
+        const float c1 = -2.0f * (r - est), cu = 2.0f * uReg, ci = 2.0f * iReg;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+#pragma unroll
+          for (int x = 0; x < 4; x++) p[c][x] = upd_f32(p[c][x], q[c][x], c1, cu, lr);
+          Um.st(pe + c * 4 * L, p[c]);
+#pragma unroll
+          for (int x = 0; x < 4; x++) {
+            const float t = lr * (c1 * p[c][x] + ci * q[c][x]);
+            atomicAdd(qrow + c * 4 * L + x, __float2int_rn(t * -FIX_SCALE));   // ds_add_u32
+          }
+        }
+      } else {
+        float4v q0[C];
+#pragma unroll
+        for (int c = 0; c < C; c++) q0[c] = q[c];
+        if (OWN_U) sgd_axpys<C, ARITH>(q, p, r, est, lr, uReg, iReg);
+        else sgd_axpys<C, ARITH>(p, q, r, est, lr, uReg, iReg);
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+          Um.st(pe + c * 4 * L, p[c]);
+          if (FIX) {
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+              atomicAdd(qrow + c * 4 * L + x, __float2int_rn((q[c][x] - q0[c][x]) * FIX_SCALE));   // ds_add_u32
+          } else {
+            *(int4*)(qrow + c * 4 * L) = __builtin_bit_cast(int4, q[c]);
+          }
+        }
+      }
+    }
+    if constexpr (S + 1 < L)
+      SlotSteps<L, C, ARITH, OWN_U, FIX, S + 1>::run(Um, q_lds, tx, ty, tz, g, j, nvalid, lr, uReg, iReg, pn, pen, pnn, penn);
+  }
+};
+
+// C = 1 (K <= 64): 2 workgroups per CU (<= 64 VGPRs); wider ranks keep 1 workgroup per CU and get 128 VGPRs
+template <int L, int C, int ARITH, bool SWEEP, bool OWN_U>
+__global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kernel(const int4* __restrict__ rec,
+                                                           const int64_t* __restrict__ slot_beg,
+                                                           const int32_t* __restrict__ slot_ibeg,
+                                                           const int32_t* __restrict__ slot_items,
+                                                           const int32_t* __restrict__ tile_slot, unsigned* ctr,
+                                                           int round, float* Oth, float* Own, uint32_t obytes,
+                                                           float lr, float uReg, float iReg, uint32_t k0,
+                                                           uint32_t k1) {
+  constexpr int G = 64 / L;
+  constexpr int LD = 4 * L * C;
+  constexpr int LD4 = LD / 4;
+  constexpr int ROWS = SlotRows<4 * L * C>::value;
+  __shared__ __attribute__((aligned(16))) int q_lds[ROWS * LD];
+  __shared__ int s_slot, s_bad;
+  // Oth: the lock-free side (user rows when item rows are owned, and vice versa); Own: staged in LDS
+  const Rows<3> Um(Oth, obytes);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane / L, j = lane % L;
+  const int xcc = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7);  // HW_REG_XCC_ID[3:0]
+  // round r: XCD x takes user block x*SUB + r%SUB and item block (x + r/SUB) mod 8
+  const int t_first = SWEEP ? 0 : (xcc * SUB + round % SUB) * 8 + ((xcc + round / SUB) & 7);
+  const int t_last = SWEEP ? NTILE - 1 : t_first;
+  int4* q4 = (int4*)q_lds;
+  for (int tile = t_first; tile <= t_last; tile++) {
+    const int s0 = tile_slot[tile], ns = tile_slot[tile + 1] - s0;
+    if (SWEEP) {  // nothing left in this tile (the normal case): do not queue on its counter
+      if (tid == 0) s_slot = (int)__hip_atomic_load(&ctr[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      const int seen = s_slot;
+      __syncthreads();
+      if (seen >= ns) continue;
+    }
+    for (;;) {
+      if (tid == 0) { s_slot = (int)atomicAdd(&ctr[tile], 1u); s_bad = 0; }
+      __syncthreads();
+      const int sl = s_slot;
+      __syncthreads();
+      if (sl >= ns) break;
+      const int slot = s0 + sl;
+      const int64_t rb = slot_beg[slot], R = slot_beg[slot + 1] - rb;
+      const int ib = slot_ibeg[slot], ni = slot_ibeg[slot + 1] - ib;
+      // stage the slot's item rows (as floats first, to decide the representation)
+      bool mybad = false;
+      for (int x = tid; x < ni * LD4; x += WG) {
+        const int row = x / LD4, c4 = x % LD4;
+        const float4v v = *(const float4v*)(Own + (int64_t)slot_items[ib + row] * LD + 4 * c4);
+#pragma unroll
+        for (int e = 0; e < 4; e++) mybad |= !(__builtin_fabsf(v[e]) <= FIX_MAX);   // also true for NaN
+        q4[row * LD4 + c4] = __builtin_bit_cast(int4, v);
+      }
+      if (mybad) s_bad = 1;
+      __syncthreads();
+      const bool fix = s_bad == 0;
+      if (fix) {
+        for (int x = tid; x < ni * LD4; x += WG) {
+          const float4v v = __builtin_bit_cast(float4v, q4[x]);
+          q4[x] = make_int4(__float2int_rn(v.x * FIX_SCALE), __float2int_rn(v.y * FIX_SCALE),
+                            __float2int_rn(v.z * FIX_SCALE), __float2int_rn(v.w * FIX_SCALE));
+        }
+      }
+      __syncthreads();
+      const uint32_t ks0 = k0 + (uint32_t)slot * 0x632be5abU, ks1 = k1 ^ mfx_mix32((uint32_t)slot + 77U);
+      for (int64_t cb = (int64_t)wave * 64; cb < R; cb += (WG / 64) * 64) {
+        const int64_t t = cb + lane;
+        const bool ok = t < R;
+        int4 rc4 = make_int4(0, 0, 0, 0);
+        if (ok) rc4 = rec[rb + slot_perm(t, R, ks0, ks1)];
+        const int nvalid = (int)(R - cb < 64 ? R - cb : 64);
+        // L == 16: a group is one DPP row.  Transpose the chunk once (3 ds_bpermute) so that lane s of row g
+        // holds entry s*G+g; every step then takes its entry with a row_share broadcast (no LDS traffic).
+        int tx = rc4.x, ty = rc4.y, tz = rc4.z;
+        if (L == 16) {
+          const int src = (lane & 15) * G + (lane >> 4);
+          tx = __shfl(rc4.x, src, 64); ty = __shfl(rc4.y, src, 64); tz = __shfl(rc4.z, src, 64);
+        }
+        // software pipeline: the lock-free rows of steps s+1 and s+2 are requested before step s is computed
+        float4v pn[C], pnn[C];
+        int64_t pen = (int64_t)slot_take<L, 0>(tx, g) * LD + 4 * j;
+        int64_t penn = (int64_t)slot_take<L, 1>(tx, g) * LD + 4 * j;
+        if (g < nvalid) {
+#pragma unroll
+          for (int c = 0; c < C; c++) pn[c] = Um.ld(pen + c * 4 * L);
+        }
+        if (G + g < nvalid) {
+#pragma unroll
+          for (int c = 0; c < C; c++) pnn[c] = Um.ld(penn + c * 4 * L);
+        }
+        if (fix) SlotSteps<L, C, ARITH, OWN_U, true, 0>::run(Um, q_lds, tx, ty, tz, g, j, nvalid, lr, uReg, iReg, pn, pen, pnn, penn);
+        else SlotSteps<L, C, ARITH, OWN_U, false, 0>::run(Um, q_lds, tx, ty, tz, g, j, nvalid, lr, uReg, iReg, pn, pen, pnn, penn);
+      }
+      __syncthreads();
+      // write the item rows back (this workgroup is their only owner during the round)
+      for (int x = tid; x < ni * LD4; x += WG) {
+        const int row = x / LD4, c4 = x % LD4;
+        const int4 qi = q4[x];
+        float* vrow = Own + (int64_t)slot_items[ib + row] * LD + 4 * c4;
+        float4v v;
+        if (fix) {
+          // new row = staged fp32 row + the accumulated fixed-point delta: an untouched row is
+          // written back bit for bit, a touched one carries only the rounding of its updates
+          const float4v v0 = *(const float4v*)vrow;
+          const int lim = 0x7f000000;   // |q| beyond ~127: the row left the fixed-point range => diverged
+          const float nanv = __builtin_nanf("");
+          const int qa[4] = {qi.x, qi.y, qi.z, qi.w};
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const int q0i = __float2int_rn(v0[e] * FIX_SCALE);
+            v[e] = (qa[e] > lim || qa[e] < -lim) ? nanv : v0[e] + (float)(qa[e] - q0i) * FIX_INV;
+          }
+        } else {
+          v = __builtin_bit_cast(float4v, qi);
+        }
+        *(float4v*)vrow = v;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// launch
+// ---------------------------------------------------------------------------
+template <int L, int C, int ARITH, bool OWN_U>
+static int launch_slots(mfx_ctx* ctx, SlotList* S, const mfx_sgd_opts* o, int blocks, uint32_t k0, uint32_t k1) {
+  float* oth = OWN_U ? ctx->V : ctx->U;
+  float* own = OWN_U ? ctx->U : ctx->V;
+  const uint64_t ob = (uint64_t)(OWN_U ? ctx->nI : ctx->nU) * ctx->ld * 4;
+  HIPCHK(hipMemsetAsync(S->ctr, 0, NTILE * sizeof(unsigned), ctx->stream));
+  for (int round = 0; round < NUB; round++) {
+    ProfScope ps(ctx, MFX_K_SGD);
+    hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, false, OWN_U>), dim3(blocks), dim3(WG), 0, ctx->stream,
+                       (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->tile_slot, S->ctr, round,
+                       oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1);
+  }
+  {
+    ProfScope ps(ctx, MFX_K_SGD_SWEEP);
+    hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, true, OWN_U>), dim3(256), dim3(WG), 0, ctx->stream,
+                       (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->tile_slot, S->ctr, -1,
+                       oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1);
+  }
+  HIPCHK(hipGetLastError());
+  return MFX_OK;
+}
+
+template <int L, int C>
+static int launch_arith(mfx_ctx* ctx, SlotList* S, int side, const mfx_sgd_opts* o, int blocks, uint32_t k0,
+                        uint32_t k1) {
+#define MFX_SIDE(A) \
+  (side ? launch_slots<L, C, A, true>(ctx, S, o, blocks, k0, k1) : launch_slots<L, C, A, false>(ctx, S, o, blocks, k0, k1))
+  switch (o->arith) {
+    case MFX_ARITH_REF64: return MFX_SIDE(MFX_ARITH_REF64);
+    case MFX_ARITH_REF64F: return MFX_SIDE(MFX_ARITH_REF64F);
+    default: return MFX_SIDE(MFX_ARITH_F32);
+  }
+#undef MFX_SIDE
+}
+
+// one entry point per rank shape, defined by MFX_SLOTS_INSTANCE in sgd_slots_inst_<L>x<C>.hip
+#define MFX_SLOTS_INSTANCE(LL, CC)                                                                                      \
+  int mfx_slots_launch_##LL##x##CC(mfx_ctx* ctx, SlotList* S, int side, const mfx_sgd_opts* o, int blocks, uint32_t k0, \
+                                   uint32_t k1) {                                                                       \
+    return launch_arith<LL, CC>(ctx, S, side, o, blocks, k0, k1);                                                       \
+  }
+
+#endif
