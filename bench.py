@@ -54,11 +54,18 @@ def main():
 
     dist = None
     force_dist = os.environ.get("BENCH_FORCE_DIST") == "1"   # rehearse the N > 1 code path with one rank
+    # BENCH_COMM=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks -- the ranks share the
+    # visible GPUs and the exchange goes through mfx_comm_init_external + gloo instead of RCCL (never the driver's mode)
+    use_gloo = os.environ.get("BENCH_COMM") == "gloo"
     if N > 1 or force_dist:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if use_gloo:
+            local_rank = local_rank % max(1, torch.cuda.device_count())
+            dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from matfac_amd import Ctx, mfx, synth
 
@@ -83,9 +90,12 @@ def main():
     ctx.compute_invalid()
     if N > 1 or force_dist:
         import torch
-        uid = [Ctx.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        ctx.comm_init(N, rank, uid[0])
+        if use_gloo:
+            ctx.comm_init_external(N, rank, lambda a: dist.all_reduce(torch.from_numpy(a), op=dist.ReduceOp.SUM))
+        else:
+            uid = [Ctx.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            ctx.comm_init(N, rank, uid[0])
         ctx.comm_mark_synced()
 
     # main.cpp:29-31 defaults are learnrate 0.005, ureg = ireg = 0.01.  On ML-20M-skewed data the
@@ -107,7 +117,8 @@ def main():
         if N > 1 or force_dist:
             import torch
             dist.barrier()
-            torch.cuda.synchronize()
+            if not use_gloo:
+                torch.cuda.synchronize()
 
     for ep in range(args.warmup):
         step(ep)
@@ -128,7 +139,7 @@ def main():
     total_nnz = nnz
     if N > 1 or force_dist:
         import torch
-        t = torch.tensor([elapsed, float(nnz)], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, float(nnz)], dtype=torch.float64, device="cpu" if use_gloo else "cuda")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
