@@ -281,7 +281,8 @@ static int build_wide_side(mfx_ctx* ctx, WideSide& w, const RowSegs& sd, int64_t
     s = e;
   }
   // batches of whole rows whose partials stay under the cap
-  static const int64_t cap_bytes = [] { const char* e = getenv("MFX_ALS_SLAB_GB"); return (int64_t)((e ? atof(e) : 8.0) * (1 << 30)); }();
+  const char* cap_env = getenv("MFX_ALS_SLAB_GB");
+  const int64_t cap_bytes = (int64_t)((cap_env ? atof(cap_env) : 8.0) * (1 << 30));
   const int64_t cap_seg = std::max<int64_t>(1, cap_bytes / (seg_floats * 4));
   w.batch_seg.assign(1, 0);
   w.batch_row.assign(1, 0);

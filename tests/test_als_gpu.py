@@ -112,3 +112,23 @@ def test_nonpositive_ratings_are_skipped():
     orc.als_half(0, Uo, Vo, tr.nrows, tr.rowptr, tr.rowind, tr.rowval, invU, reg)
     rel = np.linalg.norm(U1 - Uo, axis=1) / np.maximum(np.linalg.norm(Uo, axis=1), 1e-6)
     assert rel.max() < 2e-4
+
+
+def test_wide_als_in_several_batches_equals_one_batch(monkeypatch):
+    """als_wide.hip caps the segment partials (default 8 GB) and sweeps the rows in batches; a tiny cap forces many."""
+    K, reg = 128, 1.5
+    d, tr, _ = _data(900, 300, 40000, seed=21)
+    nU, nI = d["nUsers"], d["nItems"]
+    rng = np.random.default_rng(2)
+    U0 = rng.normal(0, 0.3, (nU, K)).astype(np.float32)
+    V0 = rng.normal(0, 0.3, (nI, K)).astype(np.float32)
+    res = []
+    for cap in (None, "0.002"):                   # 2 MB: about 40 segments of 49 KB per batch
+        if cap:
+            monkeypatch.setenv("MFX_ALS_SLAB_GB", cap)
+        with Ctx(0) as ctx:
+            load_ctx(ctx, d, K, U0, V0)
+            ctx.als_half_sweep(mfx.SIDE_USERS, reg)
+            ctx.als_half_sweep(mfx.SIDE_ITEMS, reg)
+            res.append(ctx.get_factors())
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
