@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void eval_sse_kernel(const int32_t* __restrict
         if (TMF) {
           const int2 a = tu[u], b = ti[it];
           est = row_dot_trunc<L, C>(U + (int64_t)u * LD + 4 * j, V + (int64_t)it * LD + 4 * j, j,
-                                    __int_as_float(a.x) < __int_as_float(b.x) ? a.y : b.y);
+                                    mfx_tmf_rank(a, b));
         } else {
           est = row_dot<L, C>(U + (int64_t)u * LD + 4 * j, V + (int64_t)it * LD + 4 * j);
         }

@@ -447,11 +447,11 @@ extern "C" int mfx_sgd_epoch(mfx_ctx* ctx, const mfx_sgd_opts* o) {
   NEED(o->mode >= MFX_SGD_HOGWILD && o->mode <= MFX_SGD_TILED, MFX_E_ARG, "mfx_sgd_epoch: mode=%d", o->mode);
   NEED(!ctx->dimreg || o->mode == MFX_SGD_HOGWILD || o->mode == MFX_SGD_SERIAL, MFX_E_ARG,
        "mfx_sgd_epoch: per-dimension regularisation (mfx_sgd_set_dim_reg) runs on MFX_SGD_HOGWILD / MFX_SGD_SERIAL");
-  NEED(!ctx->ifw || o->mode == MFX_SGD_HOGWILD || o->mode == MFX_SGD_SERIAL, MFX_E_ARG,
-       "mfx_sgd_epoch: rating weights (mfx_sgd_set_ifw) run on MFX_SGD_HOGWILD / MFX_SGD_SERIAL");
+  NEED(!ctx->ifw || o->mode == MFX_SGD_HOGWILD || o->mode == MFX_SGD_SERIAL || o->mode == MFX_SGD_TILED, MFX_E_ARG,
+       "mfx_sgd_epoch: rating weights (mfx_sgd_set_ifw) run on MFX_SGD_HOGWILD / MFX_SGD_SERIAL / MFX_SGD_TILED");
   NEED(!(ctx->ifw && ctx->dimreg), MFX_E_STATE, "mfx_sgd_epoch: rating weights and per-dimension regularisation are exclusive");
-  NEED(!ctx->tmf_u || o->mode == MFX_SGD_HOGWILD || o->mode == MFX_SGD_SERIAL, MFX_E_ARG,
-       "mfx_sgd_epoch: truncated ranks (mfx_set_tmf) run on MFX_SGD_HOGWILD / MFX_SGD_SERIAL");
+  NEED(!ctx->tmf_u || o->mode == MFX_SGD_HOGWILD || o->mode == MFX_SGD_SERIAL || o->mode == MFX_SGD_TILED, MFX_E_ARG,
+       "mfx_sgd_epoch: truncated ranks (mfx_set_tmf) run on MFX_SGD_HOGWILD / MFX_SGD_SERIAL / MFX_SGD_TILED");
   NEED(!(ctx->tmf_u && (ctx->ifw || ctx->dimreg)), MFX_E_STATE, "mfx_sgd_epoch: truncated ranks exclude the other SGD variants");
   NEED(o->order >= MFX_ORDER_DEVICE && o->order <= MFX_ORDER_NATURAL, MFX_E_ARG, "mfx_sgd_epoch: order=%d", o->order);
   NEED(o->arith >= MFX_ARITH_REF64 && o->arith <= MFX_ARITH_F32, MFX_E_ARG, "mfx_sgd_epoch: arith=%d", o->arith);

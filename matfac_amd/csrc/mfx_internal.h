@@ -95,6 +95,7 @@ struct mfx_ctx {
   void* als_wide = nullptr;   // ALS for K > 64 (als_wide.hip owns the type)
   float* dimreg = nullptr;    // per-dimension regulariser [ld] of trainSGDParSVD (svd.hip), or NULL
   void* ifw = nullptr;        // rating weights of ModelInvPopMF (sgd_ifw.hip owns the type), or NULL
+  uint64_t var_gen = 0;       // bumped whenever the rating weights / rank tables change
   int2 *tmf_u = nullptr, *tmf_i = nullptr;   // (train frequency bits, truncated rank) per user / item (sgd_tmf.hip), or NULL
 
   // comm
@@ -191,6 +192,8 @@ int mfx_launch_sgd_users(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t nusers);
 int mfx_launch_sgd_tiled(mfx_ctx* ctx, const mfx_sgd_opts* o);
 int mfx_launch_sgd_ifw(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_t count);      // sgd_ifw.hip
 void mfx_ifw_free_internal(mfx_ctx* ctx);
+// (freq, score) pairs and rhoRMS of the installed weights (sgd_ifw.hip)
+void mfx_ifw_tables(mfx_ctx* ctx, const float2** ua, const float2** ia, float* rho);
 int mfx_launch_sgd_tmf(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_t count);      // sgd_tmf.hip
 void mfx_tmf_free_internal(mfx_ctx* ctx);
 int mfx_launch_sgd_dimreg(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_t count);   // svd.hip

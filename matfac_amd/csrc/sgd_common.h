@@ -107,4 +107,16 @@ __device__ __forceinline__ void sgd_axpys(float4v (&p)[C], float4v (&q)[C], floa
   }
 }
 
+// ---- per-rating attributes of the sibling models, derived from one pair per user and one per item ----
+// ModelInvPopMF (modelInvPopMF.cpp:161-166): (freq, score) pairs -> float wt = 1/(1 + rhoRMS*score of the rarer side)
+__device__ __forceinline__ float mfx_ifw_weight(float2 ua, float2 ia, float rho) {
+  float wt = ia.y;                       // float wt = invPopI[item]
+  if (ia.x > ua.x) wt = ua.y;            // itemFreq[item] > userFreq[u]
+  return (float)(1.0 / (1.0 + (double)(rho * wt)));
+}
+// ModelDropoutSigmoid (modelDropoutSigmoid.cpp:158-160): (freq bits, rank) pairs -> rank of the rarer side
+__device__ __forceinline__ int mfx_tmf_rank(int2 ua, int2 ia) {
+  return __int_as_float(ua.x) < __int_as_float(ia.x) ? ua.y : ia.y;
+}
+
 #endif

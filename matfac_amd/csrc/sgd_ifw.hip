@@ -23,11 +23,6 @@ struct IfwState {
 };
 IfwState* ifw(mfx_ctx* ctx) { return (IfwState*)ctx->ifw; }
 
-__device__ __forceinline__ float ifw_weight(float2 ua, float2 ia, float rho) {
-  float wt = ia.y;                       // float wt = invPopI[item]
-  if (ia.x > ua.x) wt = ua.y;            // itemFreq[item] > userFreq[u]
-  return (float)(1.0 / (1.0 + (double)(rho * wt)));
-}
 __device__ __forceinline__ double wave_sum_dd(double v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
@@ -35,7 +30,13 @@ __device__ __forceinline__ double wave_sum_dd(double v) {
 }
 }  // namespace
 
+void mfx_ifw_tables(mfx_ctx* ctx, const float2** ua, const float2** ia, float* rho) {
+  IfwState* s = ifw(ctx);
+  *ua = s ? s->ua : nullptr; *ia = s ? s->ia : nullptr; *rho = s ? s->rho : 0.0f;
+}
+
 void mfx_ifw_free_internal(mfx_ctx* ctx) {
+  ctx->var_gen++;
   IfwState* s = ifw(ctx);
   if (!s) return;
   dev_free(s->ua); dev_free(s->ia);
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256) void sgd_ifw_kernel(const int32_t* __restrict_
     const Rows<0> Um(U, 0), Vm(V, 0);
     for (int64_t t = 0; t < count; t++) {
       const int u = eu[first + t], it = ei[first + t];
-      visit_ifw<L, C, 0>(Um, Vm, (int64_t)u * LD + 4 * j, (int64_t)it * LD + 4 * j, er[first + t], ifw_weight(ua[u], ia[it], rho), lr,
+      visit_ifw<L, C, 0>(Um, Vm, (int64_t)u * LD + 4 * j, (int64_t)it * LD + 4 * j, er[first + t], mfx_ifw_weight(ua[u], ia[it], rho), lr,
                          uReg, iReg);
     }
     return;
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(256) void sgd_ifw_kernel(const int32_t* __restrict_
     const int mu = ok ? eu[first + base + lane] : 0;
     const int mi = ok ? ei[first + base + lane] : 0;
     const float mr = ok ? er[first + base + lane] : 0.0f;
-    const float mw = ok ? ifw_weight(ua[mu], ia[mi], rho) : 0.0f;      // one weight per lane, then broadcast like (u, i, r)
+    const float mw = ok ? mfx_ifw_weight(ua[mu], ia[mi], rho) : 0.0f;      // one weight per lane, then broadcast like (u, i, r)
 #pragma unroll 1
     for (int s = 0; s < L; s++) {
       const int e = s * G + g;
@@ -131,7 +132,7 @@ static int launch_ifw(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_
 
 int mfx_launch_sgd_ifw(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_t count) {
   NEED(o->mode == MFX_SGD_HOGWILD || o->mode == MFX_SGD_SERIAL, MFX_E_ARG,
-       "rating weights (mfx_sgd_set_ifw) run on MFX_SGD_HOGWILD / MFX_SGD_SERIAL (mode=%d)", o->mode);
+       "rating weights (mfx_sgd_set_ifw): this launcher serves MFX_SGD_HOGWILD / MFX_SGD_SERIAL (mode=%d)", o->mode);
   const int L = ctx->L, C = ctx->C;
   if (L == 4) return launch_ifw<4, 1>(ctx, o, first, count);
   if (L == 8) return launch_ifw<8, 1>(ctx, o, first, count);
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(256) void ifw_sse_kernel(const int32_t* __restrict_
         }
         const float est = group_dot<L, C>(p, q);
         const double diff = (double)r - (double)est;
-        if (j == 0) acc += ((double)ifw_weight(ua[u], ia[it], rho) * diff) * diff;     // rmse += wt*diff*diff
+        if (j == 0) acc += ((double)mfx_ifw_weight(ua[u], ia[it], rho) * diff) * diff;     // rmse += wt*diff*diff
       }
     }
   }

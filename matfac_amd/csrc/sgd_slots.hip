@@ -35,7 +35,7 @@ void mfx_slots_free_internal(mfx_ctx* ctx) {
   SlotState* st = state(ctx);
   if (!st) return;
   for (SlotList& s : st->side) {
-    dev_free(s.rec); dev_free(s.slot_beg); dev_free(s.slot_ibeg); dev_free(s.slot_items);
+    dev_free(s.rec); dev_free(s.slot_beg); dev_free(s.slot_ibeg); dev_free(s.slot_items); dev_free(s.attr);
     dev_free(s.tile_slot); dev_free(s.ctr);
   }
   delete st;
@@ -196,6 +196,16 @@ static int env_blocks() {
 }
 
 
+// weight bits (var 1) or rank (var 2) of every rating in slot order, from the installed attribute tables
+__global__ void slots_attr_kernel(const int4* __restrict__ rec, int64_t nnz, int var, const float2* __restrict__ ua,
+                                  const float2* __restrict__ ia, float rho, const int2* __restrict__ tu, const int2* __restrict__ ti,
+                                  int32_t* __restrict__ attr) {
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < nnz; t += (int64_t)gridDim.x * blockDim.x) {
+    const int4 r = rec[t];                 // owned item rows: x = user, w = item
+    attr[t] = var == 1 ? __float_as_int(mfx_ifw_weight(ua[r.x], ia[r.w], rho)) : mfx_tmf_rank(tu[r.x], ti[r.w]);
+  }
+}
+
 int mfx_launch_sgd_tiled(mfx_ctx* ctx, const mfx_sgd_opts* o) {
   // which side is owned this epoch: o->own = 0 item rows (default), 1 user rows, 2 alternate
   const int side = o->own == 1 ? 1 : o->own == 2 ? (o->epoch & 1) : 0;
@@ -209,6 +219,21 @@ int mfx_launch_sgd_tiled(mfx_ctx* ctx, const mfx_sgd_opts* o) {
     int rc = build_slots(ctx, S, rows, side);
     if (rc) return rc;
   }
+  // sibling models: the weight / rank of every rating rides next to its record
+  const int var = ctx->ifw ? 1 : (ctx->tmf_u ? 2 : 0);
+  NEED(var == 0 || side == 0, MFX_E_ARG, "MFX_SGD_TILED: rating weights / truncated ranks need own = 0 (item rows owned)");
+  if (var != 0 && (S->var != var || S->attr_gen != ctx->var_gen || !S->attr)) {
+    int rc;
+    if (!S->attr && (rc = dev_alloc(ctx, &S->attr, (size_t)S->nnz))) return rc;
+    const float2 *ua = nullptr, *ia = nullptr;
+    float rho = 0.0f;
+    mfx_ifw_tables(ctx, &ua, &ia, &rho);
+    hipLaunchKernelGGL(slots_attr_kernel, dim3(4096), dim3(256), 0, ctx->stream, (const int4*)S->rec, S->nnz, var, ua, ia, rho,
+                       ctx->tmf_u, ctx->tmf_i, S->attr);
+    HIPCHK(hipGetLastError());
+    S->attr_gen = ctx->var_gen;
+  }
+  S->var = var;
   const uint32_t k0 = mfx_mix32(o->seed ^ 0x3c6ef372U) + (uint32_t)o->epoch * 0x9e3779b9U;
   const uint32_t k1 = mfx_mix32(o->seed * 0x85ebca6bU + 0xdaa66d2bU) ^ mfx_mix32((uint32_t)o->epoch + 0x1b873593U);
   st->last_k0 = k0; st->last_k1 = k1; st->last_side = side;

@@ -36,9 +36,11 @@ __device__ __forceinline__ int slot_take(int v, int g) {
 // The L steps of one 64-rating chunk, unrolled by template recursion (the DPP controls are immediates).
 // FIX: the slot's rows are in the fixed-point representation (decided per slot, so per chunk it is a template
 // argument, not a select per element).
-template <int L, int C, int ARITH, bool OWN_U, bool FIX, int S>
+// VAR: 0 the plain update; 1 ModelInvPopMF's weight on the error term (tw = float bits of wt, sgd_ifw.hip);
+// 2 ModelDropoutSigmoid's truncated rank (tw = rank, sgd_tmf.hip).
+template <int L, int C, int ARITH, bool OWN_U, bool FIX, int VAR, int S>
 struct SlotSteps {
-  static __device__ __forceinline__ void run(const Rows<3>& Um, int* q_lds, int tx, int ty, int tz, int g, int j,
+  static __device__ __forceinline__ void run(const Rows<3>& Um, int* q_lds, int tx, int ty, int tz, int tw, int g, int j,
                                              int nvalid, float lr, float uReg, float iReg,
                                              float4v (&pn)[C], int64_t& pen, float4v (&pnn)[C], int64_t& penn) {
     constexpr int G = 64 / L;
@@ -46,6 +48,7 @@ struct SlotSteps {
     const int e = S * G + g;
     const int li = slot_take<L, S>(ty, g);
     const float r = __builtin_bit_cast(float, slot_take<L, S>(tz, g));
+    const int var = VAR != 0 ? slot_take<L, S>(tw, g) : 0;   // (cross-lane reads stay outside the divergent part)
     // rows of steps S+1 and S+2 are already requested; take S, shift, request S+2
     float4v p[C];
     const int64_t pe = pen;
@@ -71,8 +74,49 @@ struct SlotSteps {
       }
       // p = the row from global memory, q = the owned row; the reference updates the USER row first
       // and the item row with the updated user row (modelMF.cpp:94-103) whichever side is owned
-      const float est = group_dot<L, C>(p, q);
-      if constexpr (FIX && !OWN_U && ARITH == MFX_ARITH_F32) {
+      float est;
+      if constexpr (VAR == 2) {            // dimensions k < rank only (modelDropoutSigmoid.cpp:174)
+        float a = 0.0f;
+#pragma unroll
+        for (int c = 0; c < C; c++)
+#pragma unroll
+          for (int x = 0; x < 4; x++)
+            if (c * 4 * L + 4 * j + x < var) a = __builtin_fmaf(p[c][x], q[c][x], a);
+        est = group_sum<L>(a);
+      } else {
+        est = group_dot<L, C>(p, q);
+      }
+      if constexpr (VAR != 0) {
+        static_assert(VAR == 0 || !OWN_U, "the sibling models run with owned item rows");
+        float4v q0[C];
+#pragma unroll
+        for (int c = 0; c < C; c++) q0[c] = q[c];
+        double m2;
+        if constexpr (VAR == 1) m2 = (-2.0 * (double)__builtin_bit_cast(float, var)) * ((double)r - (double)est);   // -2.0*wt*diff
+        else { const float d = r - est; m2 = -2.0 * (double)d; }                                                  // float diff
+        const double ru = 2.0 * (double)uReg, ri = 2.0 * (double)iReg, lrd = (double)lr;
+        const int lim = VAR == 2 ? var : 4 * L * C;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+#pragma unroll
+          for (int x = 0; x < 4; x++)
+            if (c * 4 * L + 4 * j + x < lim) p[c][x] = upd_ref64(p[c][x], q[c][x], m2, ru, lrd);
+#pragma unroll
+          for (int x = 0; x < 4; x++)
+            if (c * 4 * L + 4 * j + x < lim) q[c][x] = upd_ref64(q[c][x], p[c][x], m2, ri, lrd);
+          if (c * 4 * L + 4 * j < lim) {
+            Um.st(pe + c * 4 * L, p[c]);
+            if (FIX) {
+#pragma unroll
+              for (int x = 0; x < 4; x++)
+                if (c * 4 * L + 4 * j + x < lim)
+                  atomicAdd(qrow + c * 4 * L + x, __float2int_rn((q[c][x] - q0[c][x]) * FIX_SCALE));   // ds_add_u32
+            } else {
+              *(int4*)(qrow + c * 4 * L) = __builtin_bit_cast(int4, q[c]);
+            }
+          }
+        }
+      } else if constexpr (FIX && !OWN_U && ARITH == MFX_ARITH_F32) {
         // hogTrain's arithmetic (modelMF.cpp:1755-1762) with the item step taken as a delta: the new item
         // row would be q - t, t = lr*(c1*p' + ci*q); the owner copy receives round(-t * 2^24) directly
         const float c1 = -2.0f * (r - est), cu = 2.0f * uReg, ci = 2.0f * iReg;
@@ -107,12 +151,12 @@ struct SlotSteps {
       }
     }
     if constexpr (S + 1 < L)
-      SlotSteps<L, C, ARITH, OWN_U, FIX, S + 1>::run(Um, q_lds, tx, ty, tz, g, j, nvalid, lr, uReg, iReg, pn, pen, pnn, penn);
+      SlotSteps<L, C, ARITH, OWN_U, FIX, VAR, S + 1>::run(Um, q_lds, tx, ty, tz, tw, g, j, nvalid, lr, uReg, iReg, pn, pen, pnn, penn);
   }
 };
 
 // C = 1 (K <= 64): 2 workgroups per CU (<= 64 VGPRs); wider ranks keep 1 workgroup per CU and get 128 VGPRs
-template <int L, int C, int ARITH, bool SWEEP, bool OWN_U>
+template <int L, int C, int ARITH, bool SWEEP, bool OWN_U, int VAR>
 __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kernel(const int4* __restrict__ rec,
                                                            const int64_t* __restrict__ slot_beg,
                                                            const int32_t* __restrict__ slot_ibeg,
@@ -120,7 +164,7 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
                                                            const int32_t* __restrict__ tile_slot, unsigned* ctr,
                                                            int round, float* Oth, float* Own, uint32_t obytes,
                                                            float lr, float uReg, float iReg, uint32_t k0,
-                                                           uint32_t k1) {
+                                                           uint32_t k1, const int32_t* __restrict__ attr) {
   constexpr int G = 64 / L;
   constexpr int LD = 4 * L * C;
   constexpr int LD4 = LD / 4;
@@ -179,7 +223,12 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
         const int64_t t = cb + lane;
         const bool ok = t < R;
         int4 rc4 = make_int4(0, 0, 0, 0);
-        if (ok) rc4 = rec[rb + slot_perm(t, R, ks0, ks1)];
+        int tw = 0;
+        if (ok) {
+          const int64_t src = rb + slot_perm(t, R, ks0, ks1);
+          rc4 = rec[src];
+          if (VAR != 0) tw = attr[src];
+        }
         const int nvalid = (int)(R - cb < 64 ? R - cb : 64);
         // L == 16: a group is one DPP row.  Transpose the chunk once (3 ds_bpermute) so that lane s of row g
         // holds entry s*G+g; every step then takes its entry with a row_share broadcast (no LDS traffic).
@@ -187,6 +236,7 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
         if (L == 16) {
           const int src = (lane & 15) * G + (lane >> 4);
           tx = __shfl(rc4.x, src, 64); ty = __shfl(rc4.y, src, 64); tz = __shfl(rc4.z, src, 64);
+          if (VAR != 0) tw = __shfl(tw, src, 64);
         }
         // software pipeline: the lock-free rows of steps s+1 and s+2 are requested before step s is computed
         float4v pn[C], pnn[C];
@@ -200,8 +250,8 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
 #pragma unroll
           for (int c = 0; c < C; c++) pnn[c] = Um.ld(penn + c * 4 * L);
         }
-        if (fix) SlotSteps<L, C, ARITH, OWN_U, true, 0>::run(Um, q_lds, tx, ty, tz, g, j, nvalid, lr, uReg, iReg, pn, pen, pnn, penn);
-        else SlotSteps<L, C, ARITH, OWN_U, false, 0>::run(Um, q_lds, tx, ty, tz, g, j, nvalid, lr, uReg, iReg, pn, pen, pnn, penn);
+        if (fix) SlotSteps<L, C, ARITH, OWN_U, true, VAR, 0>::run(Um, q_lds, tx, ty, tz, tw, g, j, nvalid, lr, uReg, iReg, pn, pen, pnn, penn);
+        else SlotSteps<L, C, ARITH, OWN_U, false, VAR, 0>::run(Um, q_lds, tx, ty, tz, tw, g, j, nvalid, lr, uReg, iReg, pn, pen, pnn, penn);
       }
       __syncthreads();
       // write the item rows back (this workgroup is their only owner during the round)
@@ -235,7 +285,7 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
 // ---------------------------------------------------------------------------
 // launch
 // ---------------------------------------------------------------------------
-template <int L, int C, int ARITH, bool OWN_U>
+template <int L, int C, int ARITH, bool OWN_U, int VAR>
 static int launch_slots(mfx_ctx* ctx, SlotList* S, const mfx_sgd_opts* o, int blocks, uint32_t k0, uint32_t k1) {
   float* oth = OWN_U ? ctx->V : ctx->U;
   float* own = OWN_U ? ctx->U : ctx->V;
@@ -243,15 +293,15 @@ static int launch_slots(mfx_ctx* ctx, SlotList* S, const mfx_sgd_opts* o, int bl
   HIPCHK(hipMemsetAsync(S->ctr, 0, NTILE * sizeof(unsigned), ctx->stream));
   for (int round = 0; round < NUB; round++) {
     ProfScope ps(ctx, MFX_K_SGD);
-    hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, false, OWN_U>), dim3(blocks), dim3(WG), 0, ctx->stream,
+    hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, false, OWN_U, VAR>), dim3(blocks), dim3(WG), 0, ctx->stream,
                        (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->tile_slot, S->ctr, round,
-                       oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1);
+                       oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1, VAR ? S->attr : (const int32_t*)nullptr);
   }
   {
     ProfScope ps(ctx, MFX_K_SGD_SWEEP);
-    hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, true, OWN_U>), dim3(256), dim3(WG), 0, ctx->stream,
+    hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, true, OWN_U, VAR>), dim3(256), dim3(WG), 0, ctx->stream,
                        (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->tile_slot, S->ctr, -1,
-                       oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1);
+                       oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1, VAR ? S->attr : (const int32_t*)nullptr);
   }
   HIPCHK(hipGetLastError());
   return MFX_OK;
@@ -260,8 +310,15 @@ static int launch_slots(mfx_ctx* ctx, SlotList* S, const mfx_sgd_opts* o, int bl
 template <int L, int C>
 static int launch_arith(mfx_ctx* ctx, SlotList* S, int side, const mfx_sgd_opts* o, int blocks, uint32_t k0,
                         uint32_t k1) {
+  // sibling models (S->var): owned item rows only, their own arithmetic
+  if constexpr (C <= 4) {      // K <= 256, as the flat kernels of sgd_ifw.hip / sgd_tmf.hip
+    if (S->var == 1) return launch_slots<L, C, MFX_ARITH_REF64, false, 1>(ctx, S, o, blocks, k0, k1);
+    if (S->var == 2) return launch_slots<L, C, MFX_ARITH_REF64F, false, 2>(ctx, S, o, blocks, k0, k1);
+  } else if (S->var != 0) {
+    return mfx_fail(ctx, MFX_E_ARG, "MFX_SGD_TILED: rating weights / truncated ranks are built for K <= 256");
+  }
 #define MFX_SIDE(A) \
-  (side ? launch_slots<L, C, A, true>(ctx, S, o, blocks, k0, k1) : launch_slots<L, C, A, false>(ctx, S, o, blocks, k0, k1))
+  (side ? launch_slots<L, C, A, true, 0>(ctx, S, o, blocks, k0, k1) : launch_slots<L, C, A, false, 0>(ctx, S, o, blocks, k0, k1))
   switch (o->arith) {
     case MFX_ARITH_REF64: return MFX_SIDE(MFX_ARITH_REF64);
     case MFX_ARITH_REF64F: return MFX_SIDE(MFX_ARITH_REF64F);

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void sgd_tmf_kernel(const int32_t* __restrict_
     for (int64_t t = 0; t < count; t++) {
       const int u = eu[first + t], it = ei[first + t];
       const int2 a = tu[u], b = ti[it];
-      const int rank = __int_as_float(a.x) < __int_as_float(b.x) ? a.y : b.y;
+      const int rank = mfx_tmf_rank(a, b);
       visit_tmf<L, C, 0>(Um, Vm, (int64_t)u * LD + 4 * j, (int64_t)it * LD + 4 * j, er[first + t], rank, j, lr, uReg, iReg);
     }
     return;
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void sgd_tmf_kernel(const int32_t* __restrict_
     const int mi = ok ? ei[first + base + lane] : 0;
     const float mr = ok ? er[first + base + lane] : 0.0f;
     int mk = 0;
-    if (ok) { const int2 a = tu[mu], b = ti[mi]; mk = __int_as_float(a.x) < __int_as_float(b.x) ? a.y : b.y; }
+    if (ok) { const int2 a = tu[mu], b = ti[mi]; mk = mfx_tmf_rank(a, b); }
 #pragma unroll 1
     for (int s = 0; s < L; s++) {
       const int e = s * G + g;
@@ -127,7 +127,7 @@ int mfx_launch_sgd_tmf(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64
   return mfx_fail(ctx, MFX_E_ARG, "truncated-rank sgd: K <= 256");
 }
 
-void mfx_tmf_free_internal(mfx_ctx* ctx) { dev_free(ctx->tmf_u); dev_free(ctx->tmf_i); }
+void mfx_tmf_free_internal(mfx_ctx* ctx) { ctx->var_gen++; dev_free(ctx->tmf_u); dev_free(ctx->tmf_i); }
 
 extern "C" int mfx_set_tmf(mfx_ctx* ctx, const float* userFreq, const int32_t* userRank, const float* itemFreq,
                            const int32_t* itemRank) {

@@ -558,7 +558,7 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
           dev->check(mfx_sgd_set_order(dev->ctx, (const uint64_t*)uiRatingInds.data(), nRatings), "set_order");
           o.mode = MFX_SGD_SERIAL; o.order = MFX_ORDER_HOST;
         } else {
-          o.mode = kind == K_IFW ? MFX_SGD_HOGWILD : MFX_SGD_TILED; o.order = MFX_ORDER_DEVICE;
+          o.mode = MFX_SGD_TILED; o.order = MFX_ORDER_DEVICE;   // (K_IFW: the tiled kernel's weighted variant)
         }
         dev->check(mfx_sgd_epoch(dev->ctx, &o), "mfx_sgd_epoch");
         break;
@@ -568,7 +568,7 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
         break;
       case K_TMF:         // modelDropoutSigmoid.cpp:140-192 with the rank table beforeLoop() installed; float diff
         o.arith = MFX_ARITH_REF64F;
-        o.mode = exact ? MFX_SGD_SERIAL : MFX_SGD_HOGWILD;
+        o.mode = exact ? MFX_SGD_SERIAL : MFX_SGD_TILED;       // the tiled kernel's truncated-rank variant
         o.order = exact ? MFX_ORDER_NATURAL : MFX_ORDER_DEVICE;
         dev->check(mfx_sgd_epoch(dev->ctx, &o), "mfx_sgd_epoch");
         break;

@@ -38,7 +38,7 @@ def test_weighted_visit_and_objective(K, rho):
         U, V = ctx.get_factors()
         e1 = ctx.eval_ifw()
         with pytest.raises(mfx.MfxError):
-            ctx.sgd_epoch(0.004, 0.05, 0.03, mode=mfx.SGD_TILED)
+            ctx.sgd_epoch(0.004, 0.05, 0.03, mode=mfx.SGD_USERS, order=mfx.ORDER_NATURAL)
         # parallel kernel on a conflict-free batch
         ctx.set_factors(U0, V0)
         first = np.unique(tr.rowids(), return_index=True)[1]

@@ -42,7 +42,7 @@ def test_truncated_rank_visit_and_evaluation(K, rho, alpha):
         keep_i = (np.arange(nI) % 2).astype(np.uint8)
         ef = ctx.eval_filtered(mfx.MAT_TEST, None, keep_i)
         with pytest.raises(mfx.MfxError):
-            ctx.sgd_epoch(0.004, 0.05, 0.03, mode=mfx.SGD_TILED)
+            ctx.sgd_epoch(0.004, 0.05, 0.03, mode=mfx.SGD_USERS, order=mfx.ORDER_NATURAL)
         ctx.set_factors(U0, V0)
         first = np.unique(tr.rowids(), return_index=True)[1]
         keep = first[np.unique(tr.rowind[first], return_index=True)[1]].astype(np.uint64)
@@ -71,3 +71,58 @@ def test_truncated_rank_visit_and_evaluation(K, rho, alpha):
     np.maximum.at(top_u, tr.rowids(), np.where(uf[tr.rowids()] < itf[tr.rowind], ru[tr.rowids()], ri[tr.rowind]))
     for u in range(0, nU, 37):
         assert np.array_equal(U[u, top_u[u]:], U0[u, top_u[u]:])
+
+
+def _perm_matrix(n, seed):
+    """n x n with one rating per user and per item: every visit of an epoch is conflict-free in any order."""
+    rng = np.random.default_rng(seed)
+    cols = rng.permutation(n).astype(np.int32)
+    vals = (rng.integers(1, 11, n) * 0.5).astype(np.float32)
+    return synth.CSR(n, n, np.arange(n + 1, dtype=np.int64), cols, vals)
+
+
+@pytest.mark.parametrize("K", [10, 64, 128])
+def test_tiled_kernel_with_truncated_ranks_and_with_weights(K):
+    """The sibling models on MFX_SGD_TILED: on a conflict-free matrix the epoch equals the oracle's list-order pass
+    up to the fixed-point representation of the owned item rows (2e-7), whatever order the slots are visited in."""
+    n = 3000
+    tr = _perm_matrix(n, K)
+    rng = np.random.default_rng(K)
+    U0 = rng.normal(0, 0.3, (n, K)).astype(np.float32)
+    V0 = rng.normal(0, 0.3, (n, K)).astype(np.float32)
+    # artificial popularity tables (the matrix itself has one rating per row): what matters is that they vary
+    uf = rng.integers(1, 400, n).astype(np.float64)
+    itf = rng.integers(1, 400, n).astype(np.float64)
+    both = np.concatenate([uf, itf])
+    ru, ri = orc.tmf_ranks(uf, both.mean(), both.std(), 1.0, 0.0, K), orc.tmf_ranks(itf, both.mean(), both.std(), 1.0, 0.0, K)
+    pu, pi = uf / uf.sum(), itf / itf.sum()
+    with Ctx(0) as ctx:
+        ctx.set_csr(mfx.MAT_TRAIN, n, n, tr.rowptr, tr.rowind, tr.rowval)
+        ctx.set_model(n, n, K)
+        ctx.set_factors(U0, V0)
+        ctx.set_tmf(uf.astype(np.float32), ru, itf.astype(np.float32), ri)
+        ctx.sgd_epoch(0.01, 0.05, 0.02, mode=mfx.SGD_TILED, seed=3, epoch=1)
+        Ut, Vt = ctx.get_factors()
+        ctx.set_tmf()
+        ctx.set_factors(U0, V0)
+        ctx.sgd_set_ifw(uf.astype(np.float32), pu.astype(np.float32), itf.astype(np.float32), pi.astype(np.float32), 2000.0)
+        ctx.sgd_epoch(0.01, 0.05, 0.02, mode=mfx.SGD_TILED, seed=3, epoch=1)
+        Uw, Vw = ctx.get_factors()
+        ctx.sgd_set_ifw()
+        ctx.set_factors(U0, V0)
+        ctx.sgd_epoch(0.01, 0.05, 0.02, mode=mfx.SGD_TILED, seed=3, epoch=1, arith=mfx.ARITH_REF64)    # plain again
+        Up, Vp = ctx.get_factors()
+    Uo, Vo = U0.copy(), V0.copy()
+    orc.sgd_pass_tmf(Uo, Vo, tr.rowids(), tr.rowind, tr.rowval, None, 0.01, 0.05, 0.02, uf, itf, ru, ri, orc.DOT_TREE)
+    assert np.abs(Ut - Uo).max() <= 2e-7 and np.abs(Vt - Vo).max() <= 2e-7
+    rank = np.where(uf < itf[tr.rowind], ru, ri[tr.rowind])                      # user u's only rating decides its rank
+    for u in range(0, n, 97):
+        assert np.array_equal(Ut[u, rank[u]:], U0[u, rank[u]:])                  # dimensions beyond the rank: bit for bit
+    Uo, Vo = U0.copy(), V0.copy()
+    pop = (uf, itf, pu.astype(np.float32).astype(np.float64), pi.astype(np.float32).astype(np.float64))
+    orc.sgd_pass_ifw(Uo, Vo, tr.rowids(), tr.rowind, tr.rowval, None, 0.01, 0.05, 0.02, pop, 2000.0, orc.DOT_TREE)
+    assert np.abs(Uw - Uo).max() <= 2e-7 and np.abs(Vw - Vo).max() <= 2e-7
+    assert np.abs(Uw - Ut).max() > 1e-4                                          # and the two models differ
+    Uo, Vo = U0.copy(), V0.copy()
+    orc.sgd_pass(Uo, Vo, tr.rowids(), tr.rowind, tr.rowval, None, 0.01, 0.05, 0.02, orc.ARITH_REF64, orc.DOT_TREE)
+    assert np.abs(Up - Uo).max() <= 2e-7 and np.abs(Vp - Vo).max() <= 2e-7
