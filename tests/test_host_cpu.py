@@ -141,3 +141,32 @@ def test_factor_files_text_and_lossless_binary(tmp_path):
     assert np.allclose(back_t, M, rtol=1e-5) and np.array_equal(back_t, orc.read_mat(t, 37, 11))
     assert np.array_equal(np.fromfile(b, np.float64).reshape(37, 11), M.astype(np.float64))
     assert lib.mfh_mat_read(b.encode(), P(back_b), 38, 11) != 0          # short file
+
+
+def test_dropin_example_compiles_and_links_against_the_class_surface(tmp_path):
+    """INTEGRATION.md section A as a program (examples/dropin_main.cpp): the reference's main() for --algo=mf against
+    this repo's headers.  No GPU needed to compile and link; without a device it must fail loudly, not fall back."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "dropin")
+    cmd = ["g++", "-std=c++17", "-I" + os.path.join(root, "include"), "-I" + os.path.join(root, "matfac_amd", "host"),
+           os.path.join(root, "examples", "dropin_main.cpp"), "-L" + os.path.join(root, "matfac_amd"), "-lmfhost", "-lmfx",
+           "-Wl,-rpath," + os.path.join(root, "matfac_amd"), "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert subprocess.run([exe], capture_output=True, text=True).returncode != 0       # usage
+    from matfac_amd import mfx
+    try:
+        mfx.Ctx(0).close()
+        has_gpu = True
+    except mfx.MfxError:
+        has_gpu = False
+    if not has_gpu:
+        files = []
+        for name in ("tr", "te", "va"):
+            p = str(tmp_path / name)
+            open(p, "w").write("0 4.0 1 3.0\n1 2.0\n")
+            files.append(p)
+        run = subprocess.run([exe] + files + [str(tmp_path / "run"), "sgd", "2", "1"], capture_output=True, text=True, timeout=120)
+        assert run.returncode != 0 and "mfx_create failed" in run.stderr            # no CPU fallback
