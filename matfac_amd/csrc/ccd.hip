@@ -154,21 +154,17 @@ __global__ __launch_bounds__(1024) void ccd_pass_kernel(const int32_t* __restric
   for (int64_t s = grp; s < nseg; s += ngrp) {
     const int64_t b = seg_beg[s], e = seg_end[s];
     double num = 0.0, den = 0.0;
-    int64_t t = b + j;
-    // 4 independent 16-rating strides per trip: the loads of one trip are all in flight together
-    for (; t + 48 < e; t += 64) {
-      const int i0 = ind[t], i1 = ind[t + 16], i2 = ind[t + 32], i3 = ind[t + 48];
-      const float r0 = res[t], r1 = res[t + 16], r2 = res[t + 32], r3 = res[t + 48];
-      const float o0 = other[i0], o1 = other[i1], o2 = other[i2], o3 = other[i3];
+    // 4 independent 16-rating strides per trip, the trailing ones masked: the loads of one trip are all in flight
+    // together (a separate tail loop serialised up to three dependent loads per short row); a masked entry adds +0.0
+    for (int64_t t = b + j; t < e; t += 64) {
+      const bool v1 = t + 16 < e, v2 = t + 32 < e, v3 = t + 48 < e;
+      const int i0 = ind[t], i1 = v1 ? ind[t + 16] : 0, i2 = v2 ? ind[t + 32] : 0, i3 = v3 ? ind[t + 48] : 0;
+      const float r0 = res[t], r1 = v1 ? res[t + 16] : 0.0f, r2 = v2 ? res[t + 32] : 0.0f, r3 = v3 ? res[t + 48] : 0.0f;
+      const float o0 = other[i0], o1 = v1 ? other[i1] : 0.0f, o2 = v2 ? other[i2] : 0.0f, o3 = v3 ? other[i3] : 0.0f;
       num += (double)(r0 * o0); den += (double)(o0 * o0);   // float products (modelMF.cpp:1069-1070)
       num += (double)(r1 * o1); den += (double)(o1 * o1);
       num += (double)(r2 * o2); den += (double)(o2 * o2);
       num += (double)(r3 * o3); den += (double)(o3 * o3);
-    }
-    for (; t < e; t += 16) {
-      const float o = other[ind[t]];
-      num += (double)(res[t] * o);
-      den += (double)(o * o);
     }
     num = group16_sum(num);
     den = group16_sum(den);

@@ -228,19 +228,17 @@ __global__ __launch_bounds__(1024) void colpass_kernel(const int32_t* __restrict
   for (int s = pw_s0[blockIdx.x] + grp; s < pw_s1[blockIdx.x]; s += 64) {
     const int64_t beg = seg_beg[s], end = seg_end[s];
     double num = 0.0, den = 0.0;
-    int64_t t = beg + j;
-    for (; t + 48 < end; t += 64) {
-      const float o0 = su[buser[t]], o1 = su[buser[t + 16]], o2 = su[buser[t + 32]], o3 = su[buser[t + 48]];
-      const float r0 = res[t], r1 = res[t + 16], r2 = res[t + 32], r3 = res[t + 48];
+    // 4 strides of 16 entries per trip, the trailing ones masked: all loads of a trip are in flight together (a
+    // separate tail loop made a 95-entry segment wait for three dependent loads in a row); a masked entry adds +0.0
+    for (int64_t t = beg + j; t < end; t += 64) {
+      const bool v1 = t + 16 < end, v2 = t + 32 < end, v3 = t + 48 < end;
+      const int i0 = buser[t], i1 = v1 ? buser[t + 16] : 0, i2 = v2 ? buser[t + 32] : 0, i3 = v3 ? buser[t + 48] : 0;
+      const float r0 = res[t], r1 = v1 ? res[t + 16] : 0.0f, r2 = v2 ? res[t + 32] : 0.0f, r3 = v3 ? res[t + 48] : 0.0f;
+      const float o0 = su[i0], o1 = v1 ? su[i1] : 0.0f, o2 = v2 ? su[i2] : 0.0f, o3 = v3 ? su[i3] : 0.0f;
       num += (double)(r0 * o0); den += (double)(o0 * o0);   // float products (modelMF.cpp:1085-1086)
       num += (double)(r1 * o1); den += (double)(o1 * o1);
       num += (double)(r2 * o2); den += (double)(o2 * o2);
       num += (double)(r3 * o3); den += (double)(o3 * o3);
-    }
-    for (; t < end; t += 16) {
-      const float o = su[buser[t]];
-      num += (double)(res[t] * o);
-      den += (double)(o * o);
     }
     num = g16_sum(num);
     den = g16_sum(den);
