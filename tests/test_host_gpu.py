@@ -296,3 +296,24 @@ def test_mf_cli_end_to_end(tmp_path):
     # missing flags exit with -1 like the reference (main.cpp:53-64)
     bad = subprocess.run([cmd[0], "--facdim=4"], capture_output=True, text=True)
     assert bad.returncode != 0 and "Missing" in bad.stderr
+
+
+def test_dropin_example_trains_on_the_gpu(tmp_path):
+    """examples/dropin_main.cpp (the reference's main() for --algo=mf on this repo's headers) run for real."""
+    d, K = data(400, 300, 15000, seed=9), 8
+    files = []
+    for name in ("train", "test", "val"):
+        m = d[name]
+        files.append(str(tmp_path / (name + ".csr")))
+        orc.write_csr_text(files[-1], m.nrows, m.rowptr, m.rowind, m.rowval)
+    exe = str(tmp_path / "dropin")
+    build = subprocess.run(["g++", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "matfac_amd", "host"),
+                            os.path.join(ROOT, "examples", "dropin_main.cpp"), "-L" + os.path.join(ROOT, "matfac_amd"), "-lmfhost",
+                            "-lmfx", "-Wl,-rpath," + os.path.join(ROOT, "matfac_amd"), "-o", exe], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr
+    for method in ("hogsgd", "als", "ccd++", "ccd", "sgdparsvd"):
+        out = subprocess.run([exe] + files + [str(tmp_path / ("run_" + method)), method, str(K), "8"], capture_output=True, text=True,
+                             timeout=300)
+        assert out.returncode == 0, (method, out.stderr[-400:])
+        test_rmse = float(re.search(r"Test RMSE: ([0-9.eE+-]+)", out.stdout).group(1))
+        assert np.isfinite(test_rmse) and test_rmse < 4.0, (method, test_rmse)
