@@ -159,3 +159,57 @@ def test_single_rating_and_argument_errors():
         with pytest.raises(mfx.MfxError) as e:
             ctx.als_half_sweep(mfx.SIDE_USERS, 1.0)            # ALS is built for K <= 256
         assert "K <= 256" in str(e.value)
+
+
+def test_contexts_give_their_device_memory_back():
+    """Every trainer run once in a context, then mfx_destroy: free device memory returns to where it was
+    (hipMemGetInfo through the HIP runtime libmfx.so is linked against)."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    free, total = C.c_size_t(), C.c_size_t()
+
+    def free_now():
+        assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+        return free.value
+
+    d = synth.make(dict(nU=3000, nI=800, nnz=120000, K=16), seed=5)
+    tr, va = d["train"], d["val"]
+    nU, nI = d["nUsers"], max(d["nItems"], tr.ncols)
+    U0, V0 = synth.init_factors(1, nU, nI, 16)
+
+    def once(K):
+        with Ctx(0) as ctx:
+            ctx.set_csr(mfx.MAT_TRAIN, tr.nrows, nI, tr.rowptr, tr.rowind, tr.rowval)
+            ctx.set_csr(mfx.MAT_VAL, va.nrows, nI, va.rowptr, va.rowind, va.rowval)
+            ctx.set_model(nU, nI, K)
+            ctx.compute_invalid()
+            for mode in (mfx.SGD_TILED, mfx.SGD_HOGWILD):
+                ctx.sgd_epoch(0.002, 0.01, 0.01, mode=mode, seed=1, epoch=0)
+            ctx.als_half_sweep(mfx.SIDE_USERS, 1.0)
+            ctx.als_half_sweep(mfx.SIDE_ITEMS, 1.0)
+            ctx.ccdpp_begin()
+            ctx.ccdpp_rank1(0, 0.5, 0.5, add_back=False)
+            ctx.ccdpp_end()
+            ctx.ccd_begin()
+            ctx.ccd_sweep(mfx.SIDE_USERS, 0.5)
+            ctx.ccd_end()
+            sig = ctx.svd_init(2, 4, 1)
+            ctx.sgd_set_dim_reg(1.0 / (1.0 + sig))
+            ctx.sgd_epoch(0.002, 0, 0, mode=mfx.SGD_HOGWILD)
+            ctx.sgd_set_dim_reg(None)
+            f = np.ones(nU, np.float32)
+            ctx.set_tmf(f, np.full(nU, K, np.int32), np.ones(nI, np.float32), np.full(nI, max(1, K // 2), np.int32))
+            ctx.sgd_epoch(0.002, 0.01, 0.01, mode=mfx.SGD_TILED, seed=1, epoch=1)
+            ctx.rmse(mfx.MAT_VAL)
+
+    once(16)                       # warm up allocator pools, code objects
+    once(128)
+    series = [free_now()]
+    for rep in range(4):
+        for K in (16, 128, 16):
+            once(K)
+        series.append(free_now())
+    print("free device memory after each batch of 3 contexts:", series)
+    # the runtime grows its own pools in 16 MB steps now and then; a leak would take memory with EVERY batch
+    drops = [a - b for a, b in zip(series, series[1:])]
+    assert sum(1 for x in drops if x > 0) <= 2 and series[0] - series[-1] <= 64 << 20, series
