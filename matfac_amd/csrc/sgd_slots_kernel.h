@@ -49,18 +49,32 @@ struct SlotSteps {
     const int li = slot_take<L, S>(ty, g);
     const float r = __builtin_bit_cast(float, slot_take<L, S>(tz, g));
     const int var = VAR != 0 ? slot_take<L, S>(tw, g) : 0;   // (cross-lane reads stay outside the divergent part)
-    // rows of steps S+1 and S+2 are already requested; take S, shift, request S+2
+    // K <= 128: rows of steps S+1 and S+2 are already requested; take S, shift, request S+2.
+    // Wider rows: one step ahead only (two buffers of 4C registers each do not fit next to the rows themselves
+    // under the 128-VGPR cap of a 1024-thread workgroup: measured spills, -6 % at K = 256)
+    constexpr bool DEEP = C <= 2;
     float4v p[C];
     const int64_t pe = pen;
 #pragma unroll
-    for (int c = 0; c < C; c++) { p[c] = pn[c]; pn[c] = pnn[c]; }
-    pen = penn;
-    if constexpr (S + 2 < L) {
-      const int un = slot_take<L, S + 2>(tx, g);
-      if (e + 2 * G < nvalid) {
-        penn = (int64_t)un * LD + 4 * j;
+    for (int c = 0; c < C; c++) p[c] = pn[c];
+    if constexpr (DEEP) {
 #pragma unroll
-        for (int c = 0; c < C; c++) pnn[c] = Um.ld(penn + c * 4 * L);
+      for (int c = 0; c < C; c++) pn[c] = pnn[c];
+      pen = penn;
+      if constexpr (S + 2 < L) {
+        const int un = slot_take<L, S + 2>(tx, g);
+        if (e + 2 * G < nvalid) {
+          penn = (int64_t)un * LD + 4 * j;
+#pragma unroll
+          for (int c = 0; c < C; c++) pnn[c] = Um.ld(penn + c * 4 * L);
+        }
+      }
+    } else if constexpr (S + 1 < L) {
+      const int un = slot_take<L, S + 1>(tx, g);
+      if (e + G < nvalid) {
+        pen = (int64_t)un * LD + 4 * j;
+#pragma unroll
+        for (int c = 0; c < C; c++) pn[c] = Um.ld(pen + c * 4 * L);
       }
     }
     if (e < nvalid) {
@@ -246,7 +260,7 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
 #pragma unroll
           for (int c = 0; c < C; c++) pn[c] = Um.ld(pen + c * 4 * L);
         }
-        if (G + g < nvalid) {
+        if (C <= 2 && G + g < nvalid) {      // the second buffer is used by the two-steps-ahead pipeline only
 #pragma unroll
           for (int c = 0; c < C; c++) pnn[c] = Um.ld(penn + c * 4 * L);
         }
