@@ -52,7 +52,10 @@ struct SlotSteps {
     // K <= 128: rows of steps S+1 and S+2 are already requested; take S, shift, request S+2.
     // Wider rows: one step ahead only (two buffers of 4C registers each do not fit next to the rows themselves
     // under the 128-VGPR cap of a 1024-thread workgroup: measured spills, -6 % at K = 256)
-    constexpr bool DEEP = C <= 2;
+    // LEAN: the hogTrain path on wide rows re-reads the owned row chunk by chunk from LDS instead of holding it, which
+    // leaves room for the two-steps-ahead pipeline (at 125 M ratings / K = 256 the shallow one cost 6 %)
+    constexpr bool LEAN = C > 2 && FIX && !OWN_U && ARITH == MFX_ARITH_F32 && VAR == 0;
+    constexpr bool DEEP = C <= 2 || LEAN;
     float4v p[C];
     const int64_t pe = pen;
 #pragma unroll
@@ -77,7 +80,35 @@ struct SlotSteps {
         for (int c = 0; c < C; c++) pn[c] = Um.ld(pen + c * 4 * L);
       }
     }
-    if (e < nvalid) {
+    if constexpr (LEAN) {
+      if (e < nvalid) {
+        int* qrow = q_lds + li * LD + 4 * j;
+        float a = 0.0f;
+#pragma unroll
+        for (int c = 0; c < C; c++) {          // pass 1: the dot, same per-lane chain as group_dot
+          const int4 qi = *(const int4*)(qrow + c * 4 * L);
+          a = __builtin_fmaf(p[c].x, (float)qi.x * FIX_INV, a);
+          a = __builtin_fmaf(p[c].y, (float)qi.y * FIX_INV, a);
+          a = __builtin_fmaf(p[c].z, (float)qi.z * FIX_INV, a);
+          a = __builtin_fmaf(p[c].w, (float)qi.w * FIX_INV, a);
+        }
+        const float est = group_sum<L>(a);
+        const float c1 = -2.0f * (r - est), cu = 2.0f * uReg, ci = 2.0f * iReg;
+#pragma unroll
+        for (int c = 0; c < C; c++) {          // pass 2: both steps of this chunk
+          const int4 qi = *(const int4*)(qrow + c * 4 * L);
+          const float4v q = float4v{(float)qi.x * FIX_INV, (float)qi.y * FIX_INV, (float)qi.z * FIX_INV, (float)qi.w * FIX_INV};
+#pragma unroll
+          for (int x = 0; x < 4; x++) p[c][x] = upd_f32(p[c][x], q[x], c1, cu, lr);
+          Um.st(pe + c * 4 * L, p[c]);
+#pragma unroll
+          for (int x = 0; x < 4; x++) {
+            const float t = lr * (c1 * p[c][x] + ci * q[x]);
+            atomicAdd(qrow + c * 4 * L + x, __float2int_rn(t * -FIX_SCALE));   // ds_add_u32
+          }
+        }
+      }
+    } else if (e < nvalid) {
       int* qrow = q_lds + li * LD + 4 * j;
       float4v q[C];
 #pragma unroll
@@ -260,7 +291,7 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
 #pragma unroll
           for (int c = 0; c < C; c++) pn[c] = Um.ld(pen + c * 4 * L);
         }
-        if (C <= 2 && G + g < nvalid) {      // the second buffer is used by the two-steps-ahead pipeline only
+        if ((C <= 2 || (!OWN_U && ARITH == MFX_ARITH_F32 && VAR == 0)) && G + g < nvalid) {   // two-steps-ahead pipelines only
 #pragma unroll
           for (int c = 0; c < C; c++) pnn[c] = Um.ld(penn + c * 4 * L);
         }
