@@ -539,7 +539,11 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
 
   mfx_sgd_opts o;
   o.uReg = uReg; o.iReg = iReg; o.seed = (uint32_t)trainSeed; o.blocks = 0; o.own = 0; o.first = 0; o.count = 0;
+  // Arithmetic of the bracket: the reference's own per trainer when its order is replayed (MFX_EXACT), hogTrain's
+  // float row expressions otherwise -- on the lock-free schedule the 1e-7 relative difference between the double
+  // and the float bracket is far below the effect of the visiting order, and the float one runs 1.5x faster.
   o.arith = kind == K_HOG ? MFX_ARITH_F32 : kind == K_SGDPAR ? MFX_ARITH_REF64F : MFX_ARITH_REF64;
+  if (!exact && (kind == K_SGD || kind == K_SGDPAR)) o.arith = MFX_ARITH_F32;
 
   double subIterDuration = 0;
   const auto loopStart = std::chrono::steady_clock::now();
