@@ -229,6 +229,12 @@ int mfx_eval_ifw(mfx_ctx* ctx, int snapshot, mfx_eval_out* out);
 int mfx_set_tmf(mfx_ctx* ctx, const float* userFreq, const int32_t* userRank, const float* itemFreq,
                 const int32_t* itemRank);
 
+/* ModelPoissonDropout (--algo=TMFDropout, modelPoissonDropout.cpp:186-221): on top of mfx_set_tmf (whose ranks then
+ * serve the evaluation: cdfRanks, :5-23), every SGD visit uses Poisson(lambda) dimensions, clipped to [1, K], lambda =
+ * userLambda[u] when userFreq[u] < itemFreq[item], else itemLambda[item].  The draw is a pure function of
+ * (seed, opts->epoch, u, item) -- the reference's per-thread mt19937 streams depend on the thread count.  NULLs: off.  */
+int mfx_set_tmf_dropout(mfx_ctx* ctx, const int32_t* userLambda, const int32_t* itemLambda, uint32_t seed);
+
 /* ---- multi-GPU: user-row-block sharding, item-factor exchange over RCCL ------ */
 /* The reference is single-process; this is new.  Each rank owns a
  * user block (its CSR rows + U shard) and a replica of V.  After local work,

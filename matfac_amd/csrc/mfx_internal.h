@@ -96,6 +96,9 @@ struct mfx_ctx {
   float* dimreg = nullptr;    // per-dimension regulariser [ld] of trainSGDParSVD (svd.hip), or NULL
   void* ifw = nullptr;        // rating weights of ModelInvPopMF (sgd_ifw.hip owns the type), or NULL
   uint64_t var_gen = 0;       // bumped whenever the rating weights / rank tables change
+  int32_t *tmfd_u = nullptr, *tmfd_i = nullptr;   // ModelPoissonDropout: lambda per user / item, or NULL
+  double* tmfd_exp = nullptr;                     // exp(-lambda), lambda = 0..K
+  uint32_t tmfd_seed = 0;
   int2 *tmf_u = nullptr, *tmf_i = nullptr;   // (train frequency bits, truncated rank) per user / item (sgd_tmf.hip), or NULL
 
   // comm

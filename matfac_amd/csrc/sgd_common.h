@@ -118,5 +118,27 @@ __device__ __forceinline__ float mfx_ifw_weight(float2 ua, float2 ia, float rho)
 __device__ __forceinline__ int mfx_tmf_rank(int2 ua, int2 ia) {
   return __int_as_float(ua.x) < __int_as_float(ia.x) ? ua.y : ia.y;
 }
+// ModelPoissonDropout (modelPoissonDropout.cpp:199-207): the update rank of a visit is a Poisson(lambda) draw clipped to
+// [1, K].  The reference draws from std::poisson_distribution on one mt19937 per OpenMP thread, i.e. a stream that
+// depends on the thread count; here the draw is a pure function of (seed, epoch, user, item): a 32-bit hash mapped to
+// (0,1) and inverted through the Poisson CDF by sequential search in double (expneg = exp(-lambda) from the host, so
+// host and device run the same IEEE operations).
+__host__ __device__ static inline uint32_t mfx_draw_hash(uint32_t seed, uint32_t epoch, uint32_t u, uint32_t item) {
+  uint32_t h = mfx_mix32(seed * 0x9e3779b1U + epoch * 0x85ebca6bU + 0x2545f491U);
+  h = mfx_mix32(h ^ (u * 0xc2b2ae35U + 0x27d4eb2fU));
+  h = mfx_mix32(h ^ (item * 0x165667b1U + 0x9e3779b9U));
+  return h;
+}
+__host__ __device__ static inline int mfx_poisson_rank(int lambda, double expneg, uint32_t h, int K) {
+  const double x = ((double)h + 0.5) * (1.0 / 4294967296.0);
+  double p = expneg, F = p;
+  int k = 0;
+  while (x > F && k < 4 * K + 64) {      // the bound only guards against a CDF that stalls below x by round-off
+    k++;
+    p = p * (double)lambda / (double)k;
+    F += p;
+  }
+  return k < 1 ? 1 : (k > K ? K : k);     // updRank > facDim -> facDim; updRank < EPS -> 1 (:202-207)
+}
 
 #endif

@@ -199,10 +199,18 @@ static int env_blocks() {
 // weight bits (var 1) or rank (var 2) of every rating in slot order, from the installed attribute tables
 __global__ void slots_attr_kernel(const int4* __restrict__ rec, int64_t nnz, int var, const float2* __restrict__ ua,
                                   const float2* __restrict__ ia, float rho, const int2* __restrict__ tu, const int2* __restrict__ ti,
-                                  int32_t* __restrict__ attr) {
+                                  const int32_t* __restrict__ du, const int32_t* __restrict__ di, const double* __restrict__ dexp,
+                                  uint32_t seed, uint32_t epoch, int K, int32_t* __restrict__ attr) {
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < nnz; t += (int64_t)gridDim.x * blockDim.x) {
     const int4 r = rec[t];                 // owned item rows: x = user, w = item
-    attr[t] = var == 1 ? __float_as_int(mfx_ifw_weight(ua[r.x], ia[r.w], rho)) : mfx_tmf_rank(tu[r.x], ti[r.w]);
+    if (var == 1) { attr[t] = __float_as_int(mfx_ifw_weight(ua[r.x], ia[r.w], rho)); continue; }
+    const int2 a = tu[r.x], b = ti[r.w];
+    int rank = mfx_tmf_rank(a, b);
+    if (du) {                              // ModelPoissonDropout: a fresh Poisson(lambda) draw per visit, i.e. per epoch
+      const int lam = __int_as_float(a.x) < __int_as_float(b.x) ? du[r.x] : di[r.w];
+      rank = mfx_poisson_rank(lam, dexp[lam], mfx_draw_hash(seed, epoch, (uint32_t)r.x, (uint32_t)r.w), K);
+    }
+    attr[t] = rank;
   }
 }
 
@@ -222,14 +230,15 @@ int mfx_launch_sgd_tiled(mfx_ctx* ctx, const mfx_sgd_opts* o) {
   // sibling models: the weight / rank of every rating rides next to its record
   const int var = ctx->ifw ? 1 : (ctx->tmf_u ? 2 : 0);
   NEED(var == 0 || side == 0, MFX_E_ARG, "MFX_SGD_TILED: rating weights / truncated ranks need own = 0 (item rows owned)");
-  if (var != 0 && (S->var != var || S->attr_gen != ctx->var_gen || !S->attr)) {
+  if (var != 0 && (S->var != var || S->attr_gen != ctx->var_gen || !S->attr || (var == 2 && ctx->tmfd_u))) {
     int rc;
     if (!S->attr && (rc = dev_alloc(ctx, &S->attr, (size_t)S->nnz))) return rc;
     const float2 *ua = nullptr, *ia = nullptr;
     float rho = 0.0f;
     mfx_ifw_tables(ctx, &ua, &ia, &rho);
     hipLaunchKernelGGL(slots_attr_kernel, dim3(4096), dim3(256), 0, ctx->stream, (const int4*)S->rec, S->nnz, var, ua, ia, rho,
-                       ctx->tmf_u, ctx->tmf_i, S->attr);
+                       ctx->tmf_u, ctx->tmf_i, ctx->tmfd_u, ctx->tmfd_i, ctx->tmfd_exp, ctx->tmfd_seed, (uint32_t)o->epoch, ctx->K,
+                       S->attr);
     HIPCHK(hipGetLastError());
     S->attr_gen = ctx->var_gen;
   }

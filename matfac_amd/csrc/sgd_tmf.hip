@@ -8,6 +8,7 @@
 // kernels (eval.hip) use the same truncated estimate, which is what the class's estRating override does to
 // Model::RMSE / objective.
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -55,7 +56,9 @@ template <int L, int C, bool SERIAL>
 __global__ __launch_bounds__(256) void sgd_tmf_kernel(const int32_t* __restrict__ eu, const int32_t* __restrict__ ei,
                                                       const float* __restrict__ er, int64_t first, int64_t count, float* U, float* V,
                                                       uint32_t ubytes, uint32_t vbytes, float lr, float uReg, float iReg,
-                                                      const int2* __restrict__ tu, const int2* __restrict__ ti) {
+                                                      const int2* __restrict__ tu, const int2* __restrict__ ti,
+                                                      const int32_t* __restrict__ du, const int32_t* __restrict__ di,
+                                                      const double* __restrict__ dexp, uint32_t seed, uint32_t epoch, int K) {
   constexpr int G = 64 / L;
   constexpr int LD = 4 * L * C;
   const int lane = threadIdx.x & 63, g = lane / L, j = lane % L;
@@ -65,7 +68,11 @@ __global__ __launch_bounds__(256) void sgd_tmf_kernel(const int32_t* __restrict_
     for (int64_t t = 0; t < count; t++) {
       const int u = eu[first + t], it = ei[first + t];
       const int2 a = tu[u], b = ti[it];
-      const int rank = mfx_tmf_rank(a, b);
+      int rank = mfx_tmf_rank(a, b);
+      if (du) {                               // ModelPoissonDropout: Poisson(lambda of the rarer side)
+        const int lam = __int_as_float(a.x) < __int_as_float(b.x) ? du[u] : di[it];
+        rank = mfx_poisson_rank(lam, dexp[lam], mfx_draw_hash(seed, epoch, (uint32_t)u, (uint32_t)it), K);
+      }
       visit_tmf<L, C, 0>(Um, Vm, (int64_t)u * LD + 4 * j, (int64_t)it * LD + 4 * j, er[first + t], rank, j, lr, uReg, iReg);
     }
     return;
@@ -80,7 +87,14 @@ __global__ __launch_bounds__(256) void sgd_tmf_kernel(const int32_t* __restrict_
     const int mi = ok ? ei[first + base + lane] : 0;
     const float mr = ok ? er[first + base + lane] : 0.0f;
     int mk = 0;
-    if (ok) { const int2 a = tu[mu], b = ti[mi]; mk = mfx_tmf_rank(a, b); }
+    if (ok) {
+      const int2 a = tu[mu], b = ti[mi];
+      mk = mfx_tmf_rank(a, b);
+      if (du) {
+        const int lam = __int_as_float(a.x) < __int_as_float(b.x) ? du[mu] : di[mi];
+        mk = mfx_poisson_rank(lam, dexp[lam], mfx_draw_hash(seed, epoch, (uint32_t)mu, (uint32_t)mi), K);
+      }
+    }
 #pragma unroll 1
     for (int s = 0; s < L; s++) {
       const int e = s * G + g;
@@ -100,13 +114,15 @@ static int launch_tmf(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_
   NEED(ub < (1ull << 32) && vb < (1ull << 32), MFX_E_ARG, "truncated-rank sgd: factor matrices must be < 4 GiB");
   if (o->mode == MFX_SGD_SERIAL) {
     hipLaunchKernelGGL((sgd_tmf_kernel<L, C, true>), dim3(1), dim3(64), 0, ctx->stream, ctx->eu, ctx->ei, ctx->er, first, count, ctx->U,
-                       ctx->V, (uint32_t)ub, (uint32_t)vb, o->learnRate, o->uReg, o->iReg, ctx->tmf_u, ctx->tmf_i);
+                       ctx->V, (uint32_t)ub, (uint32_t)vb, o->learnRate, o->uReg, o->iReg, ctx->tmf_u, ctx->tmf_i, ctx->tmfd_u, ctx->tmfd_i,
+                       ctx->tmfd_exp, ctx->tmfd_seed, (uint32_t)o->epoch, ctx->K);
   } else {
     const int64_t waves = (count + 63) / 64;
     const int cap = o->blocks > 0 ? std::min(o->blocks, 8192) : std::max(8, std::min(2048, std::min(ctx->nU, ctx->nI) / 64));
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((waves + 3) / 4, cap));
     hipLaunchKernelGGL((sgd_tmf_kernel<L, C, false>), dim3(blocks), dim3(256), 0, ctx->stream, ctx->eu, ctx->ei, ctx->er, first, count,
-                       ctx->U, ctx->V, (uint32_t)ub, (uint32_t)vb, o->learnRate, o->uReg, o->iReg, ctx->tmf_u, ctx->tmf_i);
+                       ctx->U, ctx->V, (uint32_t)ub, (uint32_t)vb, o->learnRate, o->uReg, o->iReg, ctx->tmf_u, ctx->tmf_i,
+                       ctx->tmfd_u, ctx->tmfd_i, ctx->tmfd_exp, ctx->tmfd_seed, (uint32_t)o->epoch, ctx->K);
   }
   HIPCHK(hipGetLastError());
   return MFX_OK;
@@ -127,7 +143,37 @@ int mfx_launch_sgd_tmf(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64
   return mfx_fail(ctx, MFX_E_ARG, "truncated-rank sgd: K <= 256");
 }
 
-void mfx_tmf_free_internal(mfx_ctx* ctx) { ctx->var_gen++; dev_free(ctx->tmf_u); dev_free(ctx->tmf_i); }
+void mfx_tmf_free_internal(mfx_ctx* ctx) {
+  ctx->var_gen++;
+  dev_free(ctx->tmf_u); dev_free(ctx->tmf_i);
+  dev_free(ctx->tmfd_u); dev_free(ctx->tmfd_i); dev_free(ctx->tmfd_exp);
+}
+
+extern "C" int mfx_set_tmf_dropout(mfx_ctx* ctx, const int32_t* userLambda, const int32_t* itemLambda, uint32_t seed) {
+  if (!ctx) return MFX_E_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->var_gen++;
+  dev_free(ctx->tmfd_u); dev_free(ctx->tmfd_i); dev_free(ctx->tmfd_exp);
+  if (!userLambda && !itemLambda) return MFX_OK;
+  NEED(ctx->tmf_u, MFX_E_STATE, "mfx_set_tmf_dropout: set the evaluation ranks first (mfx_set_tmf)");
+  NEED(userLambda && itemLambda, MFX_E_ARG, "mfx_set_tmf_dropout: both arrays or none");
+  for (int u = 0; u < ctx->nU; u++)
+    NEED(userLambda[u] >= 1 && userLambda[u] <= ctx->K, MFX_E_ARG, "mfx_set_tmf_dropout: userLambda[%d]=%d outside [1,%d]", u, userLambda[u], ctx->K);
+  for (int i = 0; i < ctx->nI; i++)
+    NEED(itemLambda[i] >= 1 && itemLambda[i] <= ctx->K, MFX_E_ARG, "mfx_set_tmf_dropout: itemLambda[%d]=%d outside [1,%d]", i, itemLambda[i], ctx->K);
+  std::vector<double> e((size_t)ctx->K + 1);
+  for (int l = 0; l <= ctx->K; l++) e[l] = exp(-(double)l);
+  int rc;
+  if ((rc = dev_alloc(ctx, &ctx->tmfd_u, (size_t)ctx->nU)) || (rc = dev_alloc(ctx, &ctx->tmfd_i, (size_t)ctx->nI)) ||
+      (rc = dev_alloc(ctx, &ctx->tmfd_exp, e.size())))
+    return rc;
+  HIPCHK(hipMemcpy(ctx->tmfd_u, userLambda, sizeof(int32_t) * (size_t)ctx->nU, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(ctx->tmfd_i, itemLambda, sizeof(int32_t) * (size_t)ctx->nI, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(ctx->tmfd_exp, e.data(), sizeof(double) * e.size(), hipMemcpyHostToDevice));
+  ctx->tmfd_seed = seed;
+  return MFX_OK;
+}
 
 extern "C" int mfx_set_tmf(mfx_ctx* ctx, const float* userFreq, const int32_t* userRank, const float* itemFreq,
                            const int32_t* itemRank) {

@@ -33,6 +33,15 @@ extern "C" int mfh_train(const char* method, int32_t nrows, const int64_t* tr_pt
       for (int64_t e2 = data.trainMat->rowptr[u]; e2 < data.trainMat->rowptr[u + 1]; e2++) { uf[u] += 1; itf[data.trainMat->rowind[e2]] += 1; }
     pm.reset(new ModelInvPopMF(params, params.seed, uf, itf));
     pb.reset(new ModelInvPopMF(params, params.seed, uf, itf));
+  } else if (m.rfind("tmfd:", 0) == 0) {  // "tmfd:<rhoRMS>:<alpha>": ModelPoissonDropout (main.cpp:1355-1360)
+    params.rhoRMS = (float)atof(m.c_str() + 5);
+    const size_t c2 = m.find(':', 5);
+    params.alpha = c2 == std::string::npos ? 0.0f : (float)atof(m.c_str() + c2 + 1);
+    std::vector<double> uf((size_t)data.trainMat->nrows, 0.0), itf((size_t)data.trainMat->ncols, 0.0), none;
+    for (int u = 0; u < data.trainMat->nrows; u++)
+      for (int64_t e2 = data.trainMat->rowptr[u]; e2 < data.trainMat->rowptr[u + 1]; e2++) { uf[u] += 1; itf[data.trainMat->rowind[e2]] += 1; }
+    pm.reset(new ModelPoissonDropout(params, params.seed, none, none, uf, itf));
+    pb.reset(new ModelPoissonDropout(params, params.seed, none, none, uf, itf));
   } else if (m.rfind("tmf:", 0) == 0) {  // "tmf:<rhoRMS>:<alpha>": ModelDropoutSigmoid as main.cpp:1349-1354 builds it
     params.rhoRMS = (float)atof(m.c_str() + 4);
     const size_t c2 = m.find(':', 4);
@@ -48,7 +57,7 @@ extern "C" int mfh_train(const char* method, int32_t nrows, const int64_t* tr_pt
   }
   ModelMF &model = *pm, &best = *pb;
   std::unordered_set<int> iu, ii;
-  if (m.rfind("ifwmf:", 0) == 0 || m.rfind("tmf:", 0) == 0) model.train(data, best, iu, ii);
+  if (m.rfind("ifwmf:", 0) == 0 || m.rfind("tmf:", 0) == 0 || m.rfind("tmfd:", 0) == 0) model.train(data, best, iu, ii);
   else if (m == "ccd++") model.trainCCDPPFreqAdap(data, best, iu, ii);
   else if (m == "ccdpp") model.trainCCDPP(data, best, iu, ii);
   else if (m == "ccd") model.trainCCD(data, best, iu, ii);

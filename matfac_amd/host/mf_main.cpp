@@ -152,8 +152,8 @@ int main(int argc, char** argv) {
   params.nItems = data.nItems;
   params.display();
 
-  if (flags["algo"] != "mf" && flags["algo"] != "IFWMF" && flags["algo"] != "TMF") {
-    std::cerr << "Invalid algo input: " << flags["algo"] << " (this build implements --algo=mf, IFWMF and TMF)" << std::endl;
+  if (flags["algo"] != "mf" && flags["algo"] != "IFWMF" && flags["algo"] != "TMF" && flags["algo"] != "TMFDropout") {
+    std::cerr << "Invalid algo input: " << flags["algo"] << " (this build implements --algo=mf, IFWMF, TMF and TMFDropout)" << std::endl;
     exit(0);
   }
   Partition partItems, partUsers;
@@ -174,6 +174,12 @@ int main(int argc, char** argv) {
     auto rowColFreq = getRowColFreq(data.trainMat);
     mfModel.reset(new ModelInvPopMF(params, params.seed, rowColFreq.first, rowColFreq.second));
     bestModel.reset(new ModelInvPopMF(params, params.seed, rowColFreq.first, rowColFreq.second));
+    mfModel->train(data, *bestModel, invalidUsers, invalidItems);
+  } else if (flags["algo"] == "TMFDropout") {   // main.cpp:1355-1360
+    auto rowColFreq = getRowColFreq(data.trainMat);
+    std::vector<double> userRankPc, itemRankPc;
+    mfModel.reset(new ModelPoissonDropout(params, params.seed, userRankPc, itemRankPc, rowColFreq.first, rowColFreq.second));
+    bestModel.reset(new ModelPoissonDropout(params, params.seed, userRankPc, itemRankPc, rowColFreq.first, rowColFreq.second));
     mfModel->train(data, *bestModel, invalidUsers, invalidItems);
   } else if (flags["algo"] == "TMF") {   // main.cpp:1349-1354 (userRankPc / itemRankPc are carried, not used by train)
     auto rowColFreq = getRowColFreq(data.trainMat);

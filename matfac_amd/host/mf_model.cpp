@@ -570,6 +570,7 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
         o.mode = MFX_SGD_TILED; o.order = MFX_ORDER_DEVICE;
         dev->check(mfx_sgd_epoch(dev->ctx, &o), "mfx_sgd_epoch");
         break;
+      case K_TMFD:        // modelPoissonDropout.cpp:170-224: K_TMF with the draws mfx_set_tmf_dropout installed
       case K_TMF:         // modelDropoutSigmoid.cpp:140-192 with the rank table beforeLoop() installed; float diff
         o.arith = MFX_ARITH_REF64F;
         o.mode = exact ? MFX_SGD_SERIAL : MFX_SGD_TILED;       // the tiled kernel's truncated-rank variant

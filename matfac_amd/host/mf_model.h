@@ -141,7 +141,7 @@ class ModelMF : public Model {
   void hogTrain(const Data& data, Model& bestModel, IntSet& invalidUsers, IntSet& invalidItems) override;
 
  protected:
-  enum Kind { K_SGD, K_HOG, K_SGDPAR, K_SGDU, K_ALS, K_CCDPP, K_CCDPP_FA, K_CCD, K_SGDPARSVD, K_IFW, K_TMF };
+  enum Kind { K_SGD, K_HOG, K_SGDPAR, K_SGDU, K_ALS, K_CCDPP, K_CCDPP_FA, K_CCD, K_SGDPARSVD, K_IFW, K_TMF, K_TMFD };
   void run(Kind kind, const char* name, const Data& data, Model& bestModel, IntSet& invalidUsers,
            IntSet& invalidItems);
   // called once the invalid sets are known and before the first objective: sibling models set their state here

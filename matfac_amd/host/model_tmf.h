@@ -26,4 +26,22 @@ class ModelDropoutSigmoid : public ModelMF {
   void beforeLoop(Kind kind, const Data& data, IntSet& invalidUsers, IntSet& invalidItems) override;
 };
 
+
+// ModelPoissonDropout (--algo=TMFDropout, modelPoissonDropout.h): TMF whose update rank is a Poisson(lambda) draw per
+// visit, lambda = the TMF rank of the rarer side; estimates use the dimensions 0..cdfRanks[lambda-1].
+class ModelPoissonDropout : public ModelDropoutSigmoid {
+ public:
+  std::vector<double> factorial;
+  std::vector<int> cdfRanks;
+
+  ModelPoissonDropout(const Params& params, int seed, std::vector<double>& userRankMap, std::vector<double>& itemRankMap,
+                      std::vector<double>& userFreq, std::vector<double>& itemFreq);
+  void initCDFRanks();                                                                                    // modelPoissonDropout.cpp:25-47
+  void train(const Data& data, Model& bestModel, IntSet& invalidUsers, IntSet& invalidItems) override;   // :50-290
+  double estRating(int user, int item) override;                                                          // :5-23
+
+ protected:
+  void beforeLoop(Kind kind, const Data& data, IntSet& invalidUsers, IntSet& invalidItems) override;
+};
+
 #endif

@@ -239,6 +239,10 @@ class Ctx:
         ks = [_p(userFreq, np.float32), _p(userRank, np.int32), _p(itemFreq, np.float32), _p(itemRank, np.int32)]
         self._chk(self.lib.mfx_set_tmf(self.h, *[k[1] if k else None for k in ks]))
 
+    def set_tmf_dropout(self, userLambda=None, itemLambda=None, seed=1):
+        ks = [_p(userLambda, np.int32), _p(itemLambda, np.int32)]
+        self._chk(self.lib.mfx_set_tmf_dropout(self.h, *[k[1] if k else None for k in ks], C.c_uint32(seed)))
+
     # ---- cyclic coordinate descent (trainCCD) ---------------------------------------
     def ccd_begin(self):
         self._chk(self.lib.mfx_ccd_begin(self.h))

@@ -260,6 +260,22 @@ def rmse_tmf(U, V, nUsers, nItems, nrows, rowptr, rowind, rowval, invU, invI, uf
     return r, sse.value, cnt.value
 
 
+def cdf_ranks(K):
+    out = np.zeros(K, np.int32)
+    lib.orc_cdf_ranks(K, I32(out))
+    return out
+
+
+def poisson_rank(lam, seed, epoch, u, item, K):
+    return lib.orc_poisson_rank(int(lam), C.c_uint32(seed), C.c_uint32(epoch), C.c_uint32(u), C.c_uint32(item), K)
+
+
+def sgd_pass_tmfd(U, V, u, i, r, order, lr, uReg, iReg, uf, itf, lu, li, seed, epoch, dot_mode=DOT_SEQ):
+    lib.orc_sgd_pass_tmfd(U.shape[1], F(U), F(V), I32(u), I32(i), F(r), U64(order) if order is not None else None,
+                          C.c_int64(len(order) if order is not None else len(u)), C.c_float(lr), C.c_float(uReg), C.c_float(iReg),
+                          _f64p(uf), _f64p(itf), I32(lu), I32(li), C.c_uint32(seed), C.c_uint32(epoch), dot_mode)
+
+
 def sgd_hogwild(U, V, u, i, r, order, lr, uReg, iReg, arith=ARITH_F32, dot_mode=DOT_SEQ, nthreads=1):
     K = U.shape[1]
     lib.orc_sgd_hogwild(K, F(U), F(V), I32(u), I32(i), F(r), U64(order) if order is not None else None,

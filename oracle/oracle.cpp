@@ -484,6 +484,59 @@ double orc_rmse_tmf(int K, const float* U, const float* V, int32_t nUsers, int32
   return sqrt(rmse / nnz);
 }
 
+// ---- ModelPoissonDropout (TMF + Dropout) ---------------------------------------------------------
+// initCDFRanks (modelPoissonDropout.cpp:25-47): for lambda = 1..facDim the smallest k whose Poisson(lambda) CDF over
+// 0..k+1 reaches 0.99; estRating uses dimensions 0..cdfRanks[lambda-1] (:17).  factorial as the class builds it.
+void orc_cdf_ranks(int facDim, int32_t* cdfRanks) {
+  std::vector<double> factorial;
+  factorial.push_back(1);
+  for (int i = 1; i <= facDim + 1; i++) factorial.push_back(factorial.back() * ((double)i));
+  for (int lambda = 1; lambda <= facDim; lambda++) {
+    double cdf = std::exp(-lambda) * (std::pow(lambda, 0) / factorial[0]);
+    int k = 0;
+    for (k = 0; k < facDim; k++) {
+      const double wt = std::exp(-lambda) * (std::pow(lambda, k + 1) / factorial[k + 1]);
+      cdf += wt;
+      if (cdf >= 0.99) break;
+    }
+    cdfRanks[lambda - 1] = k;
+    if (k == facDim) cdfRanks[lambda - 1] = k - 1;
+  }
+}
+// The draw of this build (include/mfx.h, mfx_set_tmf_dropout): hash of (seed, epoch, user, item) -> (0,1) -> inverse
+// Poisson CDF by sequential search in double, clipped to [1, K] as :202-207 clip std::poisson_distribution's draw.
+static inline uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+int32_t orc_poisson_rank(int32_t lambda, uint32_t seed, uint32_t epoch, uint32_t u, uint32_t item, int32_t K) {
+  uint32_t h = mix32(seed * 0x9e3779b1U + epoch * 0x85ebca6bU + 0x2545f491U);
+  h = mix32(h ^ (u * 0xc2b2ae35U + 0x27d4eb2fU));
+  h = mix32(h ^ (item * 0x165667b1U + 0x9e3779b9U));
+  const double x = ((double)h + 0.5) * (1.0 / 4294967296.0);
+  double p = exp(-(double)lambda), F = p;
+  int k = 0;
+  while (x > F && k < 4 * K + 64) { k++; p = p * (double)lambda / (double)k; F += p; }
+  return k < 1 ? 1 : (k > K ? K : k);
+}
+// modelPoissonDropout.cpp:186-221 for a list of ratings: lambda of the rarer side, updRank drawn, truncated visit
+void orc_sgd_pass_tmfd(int K, float* U, float* V, const int32_t* u, const int32_t* i, const float* r, const uint64_t* order,
+                       int64_t n, float learnRate, float uReg, float iReg, const double* userFreq, const double* itemFreq,
+                       const int32_t* lu, const int32_t* li, uint32_t seed, uint32_t epoch, int dot_mode) {
+  for (int64_t t = 0; t < n; t++) {
+    const int64_t ind = order ? (int64_t)order[t] : t;
+    float* p = U + (int64_t)u[ind] * K;
+    float* q = V + (int64_t)i[ind] * K;
+    const int lambda = userFreq[u[ind]] < itemFreq[i[ind]] ? lu[u[ind]] : li[i[ind]];
+    const int updRank = orc_poisson_rank(lambda, seed, epoch, (uint32_t)u[ind], (uint32_t)i[ind], K);
+    const float itemRat = r[ind];
+    const float r_ui_est = dotf_trunc(p, q, K, updRank, dot_mode);
+    const float diff = itemRat - r_ui_est;
+    for (int k = 0; k < updRank; k++) p[k] -= learnRate * (-2.0 * diff * q[k] + 2.0 * uReg * p[k]);
+    for (int k = 0; k < updRank; k++) q[k] -= learnRate * (-2.0 * diff * p[k] + 2.0 * iReg * q[k]);
+  }
+}
+
 void orc_sgd_hogwild(int K, float* U, float* V, const int32_t* u, const int32_t* i,
                      const float* r, const uint64_t* order, int64_t n, float lr,
                      float uReg, float iReg, int arith, int dot_mode, int nthreads) {

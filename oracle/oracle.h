@@ -171,6 +171,13 @@ double orc_rmse_tmf(int K, const float* U, const float* V, int32_t nUsers, int32
                     const uint8_t* invI, const double* userFreq, const double* itemFreq, const int32_t* ru,
                     const int32_t* ri, int dot_mode, double* sse_out, int64_t* cnt);
 
+/* ---- ModelPoissonDropout / TMFDropout (modelPoissonDropout.cpp:5-47, 186-221) ---- */
+void orc_cdf_ranks(int facDim, int32_t* cdfRanks);
+int32_t orc_poisson_rank(int32_t lambda, uint32_t seed, uint32_t epoch, uint32_t u, uint32_t item, int32_t K);
+void orc_sgd_pass_tmfd(int K, float* U, float* V, const int32_t* u, const int32_t* i, const float* r, const uint64_t* order,
+                       int64_t n, float learnRate, float uReg, float iReg, const double* userFreq, const double* itemFreq,
+                       const int32_t* lu, const int32_t* li, uint32_t seed, uint32_t epoch, int dot_mode);
+
 /* ---- CCD (modelMF.cpp:1528-1605), sequential ---------------------------- */
 void orc_ccd_iter(int K, float* U, float* V, int32_t nUsers, int32_t nItems,
                   int32_t ncols, const int64_t* rowptr, const int32_t* rowind,

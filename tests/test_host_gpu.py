@@ -215,6 +215,33 @@ def test_tmf_loop_is_bit_exact_in_list_order():
     assert abs(f["val"] - e["val"]) < 0.1 and f["val"] < 1.2
 
 
+def test_tmf_dropout_loop_is_bit_exact_in_list_order():
+    """ModelPoissonDropout::train (--algo=TMFDropout): Poisson-drawn update ranks (a function of seed, epoch, user, item in
+    this build), cdfRanks in every estimate."""
+    d, K, iters, lr, reg, rho, alpha = data(), 8, 6, 0.004, 0.02, 1.5, -0.2
+    tr, va = d["train"], d["val"]
+    nU, nI = d["nUsers"], d["nItems"]
+    h = host_train("tmfd:%g:%g" % (rho, alpha), d, K, iters, 1, lr, reg, reg, env={"MFX_EXACT": "1"})
+    uf = np.zeros(nU); uf[:tr.nrows] = np.diff(tr.rowptr)
+    itf = np.zeros(nI); itf[:tr.ncols] = np.bincount(tr.rowind, minlength=tr.ncols)
+    both = np.concatenate([uf[:tr.nrows], itf[:tr.ncols]])
+    mean, std = both.mean(), np.sqrt(((both - both.mean()) ** 2).sum() / len(both))
+    lu, li = orc.tmf_ranks(uf, mean, std, rho, alpha, K), orc.tmf_ranks(itf, mean, std, rho, alpha, K)
+    cdf = orc.cdf_ranks(K)
+    eu, ei = np.minimum(cdf[lu - 1] + 1, K).astype(np.int32), np.minimum(cdf[li - 1] + 1, K).astype(np.int32)
+    U, V = orc.init_factors(1, nU, nI, K)
+    invU, invI = orc.invalid(tr.nrows, tr.ncols, tr.rowptr, tr.rowind, nU, nI)
+    best = (np.inf, None, None)
+    for it in range(iters):
+        orc.sgd_pass_tmfd(U, V, tr.rowids(), tr.rowind, tr.rowval, None, lr, reg, reg, uf, itf, lu, li, 1, it, orc.DOT_TREE)
+        v, _, _ = orc.rmse_tmf(U, V, nU, nI, va.nrows, va.rowptr, va.rowind, va.rowval, invU, invI, uf, itf, eu, ei, orc.DOT_TREE)
+        if v < best[0]:
+            best = (v, U.copy(), V.copy())
+    assert np.array_equal(h["U"], U) and np.array_equal(h["Ubest"], best[1]) and abs(h["val"] - best[0]) < 1e-12
+    f = host_train("tmfd:%g:%g" % (rho, alpha), d, K, 40, 1, lr, reg, reg)
+    assert np.isfinite(f["val"]) and f["val"] < 1.3
+
+
 @pytest.mark.parametrize("method", ["sgd", "hogsgd", "sgdpar", "sgdu"])
 def test_fast_sgd_paths_reach_the_reference_rmse(method):
     d, K = data(3000, 2000, 300000, seed=2), 16
@@ -293,6 +320,10 @@ def test_mf_cli_end_to_end(tmp_path):
                                     "--alpha=-0.2", "--learnrate=0.004", "--seed=1"], capture_output=True, text=True, timeout=300)
     assert tmf.returncode == 0, tmf.stderr
     assert "minFreq:" in tmf.stdout and float(re.search(r"Test RMSE: ([0-9.eE+-]+)", tmf.stdout).group(1)) < 5.0
+    tmfd = subprocess.run(cmd[:6] + ["--prefix=" + prefix + "_tmfd", "--facdim=%d" % K, "--maxiter=5", "--algo=TMFDropout", "--rhorms=1.5",
+                                     "--alpha=-0.2", "--learnrate=0.004", "--seed=1"], capture_output=True, text=True, timeout=300)
+    assert tmfd.returncode == 0, tmfd.stderr
+    assert float(re.search(r"Test RMSE: ([0-9.eE+-]+)", tmfd.stdout).group(1)) < 5.0
     # missing flags exit with -1 like the reference (main.cpp:53-64)
     bad = subprocess.run([cmd[0], "--facdim=4"], capture_output=True, text=True)
     assert bad.returncode != 0 and "Missing" in bad.stderr

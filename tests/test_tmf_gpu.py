@@ -126,3 +126,52 @@ def test_tiled_kernel_with_truncated_ranks_and_with_weights(K):
     Uo, Vo = U0.copy(), V0.copy()
     orc.sgd_pass(Uo, Vo, tr.rowids(), tr.rowind, tr.rowval, None, 0.01, 0.05, 0.02, orc.ARITH_REF64, orc.DOT_TREE)
     assert np.abs(Up - Uo).max() <= 2e-7 and np.abs(Vp - Vo).max() <= 2e-7
+
+
+def test_poisson_dropout_visits_match_oracle_and_draws_look_poisson():
+    """ModelPoissonDropout (--algo=TMFDropout): the rank of a visit is a Poisson(lambda) draw -- here a pure function of
+    (seed, epoch, user, item), the same on the flat kernels, on the tiled kernel and in the oracle."""
+    K = 40
+    # the sampler itself: mean and variance of Poisson(lambda) before clipping effects matter
+    for lam in (3, 12, 30):
+        d = np.array([orc.poisson_rank(lam, 7, e, u, 5 * u + 1, 400) for e in range(4) for u in range(2500)], float)
+        assert abs(d.mean() - lam) < 0.15 * np.sqrt(lam) and abs(d.var() - lam) < 0.15 * lam, (lam, d.mean(), d.var())
+    cdf = orc.cdf_ranks(K)
+    assert np.all(np.diff(cdf) >= 0) and cdf[0] >= 1 and cdf[-1] == K - 1
+    n = 3000
+    tr = _perm_matrix(n, 77)
+    rng = np.random.default_rng(5)
+    U0 = rng.normal(0, 0.3, (n, K)).astype(np.float32)
+    V0 = rng.normal(0, 0.3, (n, K)).astype(np.float32)
+    uf = rng.integers(1, 400, n).astype(np.float64)
+    itf = rng.integers(1, 400, n).astype(np.float64)
+    both = np.concatenate([uf, itf])
+    lu, li = orc.tmf_ranks(uf, both.mean(), both.std(), 1.0, 0.0, K), orc.tmf_ranks(itf, both.mean(), both.std(), 1.0, 0.0, K)
+    eu, ei = np.minimum(cdf[lu - 1] + 1, K).astype(np.int32), np.minimum(cdf[li - 1] + 1, K).astype(np.int32)   # estRating's count
+    outs = {}
+    with Ctx(0) as ctx:
+        ctx.set_csr(mfx.MAT_TRAIN, n, n, tr.rowptr, tr.rowind, tr.rowval)
+        ctx.set_model(n, n, K)
+        ctx.compute_invalid()
+        with pytest.raises(mfx.MfxError):
+            ctx.set_tmf_dropout(lu, li, 9)                       # needs the evaluation ranks first
+        ctx.set_tmf(uf.astype(np.float32), eu, itf.astype(np.float32), ei)
+        ctx.set_tmf_dropout(lu, li, 9)
+        for name, mode, order in (("serial", mfx.SGD_SERIAL, mfx.ORDER_NATURAL), ("flat", mfx.SGD_HOGWILD, mfx.ORDER_DEVICE),
+                                  ("tiled", mfx.SGD_TILED, mfx.ORDER_DEVICE)):
+            ctx.set_factors(U0, V0)
+            for ep in (0, 1):
+                ctx.sgd_epoch(0.01, 0.05, 0.02, mode=mode, order=order, seed=3, epoch=ep)
+            outs[name] = ctx.get_factors()
+        e = ctx.eval(mfx.MAT_TRAIN)
+        ctx.set_tmf_dropout()
+    Uo, Vo = U0.copy(), V0.copy()
+    for ep in (0, 1):
+        orc.sgd_pass_tmfd(Uo, Vo, tr.rowids(), tr.rowind, tr.rowval, None, 0.01, 0.05, 0.02, uf, itf, lu, li, 9, ep, orc.DOT_TREE)
+    assert np.array_equal(outs["serial"][0], Uo) and np.array_equal(outs["serial"][1], Vo)
+    assert np.array_equal(outs["flat"][0], Uo) and np.array_equal(outs["flat"][1], Vo)           # conflict-free matrix
+    assert np.abs(outs["tiled"][0] - Uo).max() <= 4e-7 and np.abs(outs["tiled"][1] - Vo).max() <= 4e-7
+    # the evaluation uses the cdf ranks, not a draw
+    oU, oI = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+    _, s, cnt = orc.rmse_tmf(outs["tiled"][0], outs["tiled"][1], n, n, n, tr.rowptr, tr.rowind, tr.rowval, oU, oI, uf, itf, eu, ei, orc.DOT_TREE)
+    assert e.n == cnt and abs(e.sse - s) <= 1e-12 * s
