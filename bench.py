@@ -159,9 +159,10 @@ def main():
             "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: ML-20M-shape synthetic CSR %dx%d per GPU, train nnz=%d per GPU, rank=%d, "
+            "config": {"workload": "%s: %s synthetic CSR %dx%d per GPU, train nnz=%d per GPU, rank=%d, "
                                    "%s Hogwild SGD epoch (device reshuffle + update kernel%s)"
-                                   % (args.workload, nU, nI, nnz, K, "XCD-tiled" if mode == mfx.SGD_TILED else "flat",
+                                   % (args.workload, {"C1": "ML-100K-shape", "C2": "ML-20M-shape", "C4": "Netflix-shape"}.get(args.workload, ""),
+                                      nU, nI, nnz, K, "XCD-tiled" if mode == mfx.SGD_TILED else "flat",
                                       ", RCCL item-factor all-reduce" if N > 1 else ""),
                        "learnrate": lr, "ureg": ureg, "ireg": ireg, "arith": args.arith,
                        "parallelism": "user-block x%d" % N},
