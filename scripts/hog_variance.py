@@ -11,3 +11,9 @@ print("cpu test %.5f val %.5f" % (o["test"], o["valbest"]))
 for m in ("hogsgd", "sgd", "hogsgd", "sgd", "hogsgd"):
     h = host_train(m, d, K, 40, 1, 0.01, 0.02, 0.02)
     print(m, "gpu test %.5f val %.5f" % (h["test"], h["val"]), flush=True)
+print("--- sibling models, 40 iterations on the small matrix of test_host_gpu: lock-free default vs MFX_EXACT")
+d2 = data()
+for m in ("ifwmf:500", "tmf:1.5:-0.2", "tmfd:1.5:-0.2"):
+    e = host_train(m, d2, 8, 40, 1, 0.004, 0.02, 0.02, env={"MFX_EXACT": "1"})
+    vals = [host_train(m, d2, 8, 40, 1, 0.004, 0.02, 0.02)["val"] for _ in range(4)]
+    print(m, "exact val %.5f" % e["val"], "lock-free", " ".join("%.5f" % v for v in vals), flush=True)

@@ -182,7 +182,7 @@ def test_ifwmf_loop_is_bit_exact_with_replayed_orders():
     assert np.array_equal(h["Ubest"], best[1]) and abs(h["val"] - best[0]) < 1e-12
     f = host_train("ifwmf:%g" % rho, d, K, 40, 1, lr, reg, reg)              # lock-free order
     e = host_train("ifwmf:%g" % rho, d, K, 40, 1, lr, reg, reg, env={"MFX_EXACT": "1"})
-    assert abs(f["val"] - e["val"]) < 3e-2
+    assert abs(f["val"] - e["val"]) < 5e-2          # measured 2.3e-2 +- 1e-3 (scripts/hog_variance.py)
 
 
 def test_tmf_loop_is_bit_exact_in_list_order():
