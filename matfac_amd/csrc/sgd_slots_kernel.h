@@ -29,7 +29,8 @@ constexpr float FIX_SCALE = 16777216.0f, FIX_INV = 1.0f / 16777216.0f, FIX_MAX =
 // entry S*G+g of the chunk: row_share broadcast of the transposed chunk (L == 16) or a cross-lane read
 template <int L, int S>
 __device__ __forceinline__ int slot_take(int v, int g) {
-  if constexpr (L == 16) return __builtin_amdgcn_update_dpp(0, v, 0x150 + S, 0xF, 0xF, false);   // row_share:S
+  // row_share:S writes every lane: the form without an "old" operand needs no initialising move
+  if constexpr (L == 16) return __builtin_amdgcn_mov_dpp(v, 0x150 + S, 0xF, 0xF, true);
   else return __shfl(v, S * (64 / L) + g, 64);
 }
 
