@@ -591,10 +591,15 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
           dev->check(mfx_sgd_set_order(dev->ctx, (const uint64_t*)uiRatingInds.data(), (int64_t)uiRatingInds.size()),
                      "set_order");
           o.mode = MFX_SGD_SERIAL; o.order = MFX_ORDER_HOST;
-        } else {
+        } else if (getenv("MFX_SGDU_USERS_KERNEL")) {
+          // one group per user, the user row kept in registers over the user's ratings (closest to the reference's
+          // order; 12x slower than the tiled schedule at the ML-20M shape)
           dev->check(mfx_sgd_set_order(dev->ctx, (const uint64_t*)validUsers.data(), (int64_t)validUsers.size()),
                      "set_order");
           o.mode = MFX_SGD_USERS; o.order = MFX_ORDER_HOST;
+        } else {
+          // like train / hogTrain: the lock-free tiled schedule (the order of the users is then the kernel's business)
+          o.mode = MFX_SGD_TILED; o.order = MFX_ORDER_DEVICE; o.arith = MFX_ARITH_F32;
         }
         dev->check(mfx_sgd_epoch(dev->ctx, &o), "mfx_sgd_epoch");
         break;
