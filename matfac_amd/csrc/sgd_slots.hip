@@ -228,9 +228,9 @@ int mfx_launch_sgd_tiled(mfx_ctx* ctx, const mfx_sgd_opts* o) {
     if (rc) return rc;
   }
   // sibling models: the weight / rank of every rating rides next to its record
-  const int var = ctx->ifw ? 1 : (ctx->tmf_u ? 2 : 0);
-  NEED(var == 0 || side == 0, MFX_E_ARG, "MFX_SGD_TILED: rating weights / truncated ranks need own = 0 (item rows owned)");
-  if (var != 0 && (S->var != var || S->attr_gen != ctx->var_gen || !S->attr || (var == 2 && ctx->tmfd_u))) {
+  const int var = ctx->ifw ? 1 : (ctx->tmf_u ? 2 : (ctx->dimreg ? 3 : 0));
+  NEED(var == 0 || side == 0, MFX_E_ARG, "MFX_SGD_TILED: the SGD variants need own = 0 (item rows owned)");
+  if ((var == 1 || var == 2) && (S->var != var || S->attr_gen != ctx->var_gen || !S->attr || (var == 2 && ctx->tmfd_u))) {
     int rc;
     if (!S->attr && (rc = dev_alloc(ctx, &S->attr, (size_t)S->nnz))) return rc;
     const float2 *ua = nullptr, *ia = nullptr;

@@ -38,18 +38,19 @@ __device__ __forceinline__ int slot_take(int v, int g) {
 // FIX: the slot's rows are in the fixed-point representation (decided per slot, so per chunk it is a template
 // argument, not a select per element).
 // VAR: 0 the plain update; 1 ModelInvPopMF's weight on the error term (tw = float bits of wt, sgd_ifw.hip);
-// 2 ModelDropoutSigmoid's truncated rank (tw = rank, sgd_tmf.hip).
+// 2 ModelDropoutSigmoid's truncated rank (tw = rank, sgd_tmf.hip); 3 trainSGDParSVD's per-dimension regulariser
+// (regk = the ld values of mfx_sgd_set_dim_reg, svd.hip; no per-rating attribute).
 template <int L, int C, int ARITH, bool OWN_U, bool FIX, int VAR, int S>
 struct SlotSteps {
-  static __device__ __forceinline__ void run(const Rows<3>& Um, int* q_lds, int tx, int ty, int tz, int tw, int g, int j,
-                                             int nvalid, float lr, float uReg, float iReg,
+  static __device__ __forceinline__ void run(const Rows<3>& Um, int* q_lds, int tx, int ty, int tz, int tw, const float* regk,
+                                             int g, int j, int nvalid, float lr, float uReg, float iReg,
                                              float4v (&pn)[C], int64_t& pen, float4v (&pnn)[C], int64_t& penn) {
     constexpr int G = 64 / L;
     constexpr int LD = 4 * L * C;
     const int e = S * G + g;
     const int li = slot_take<L, S>(ty, g);
     const float r = __builtin_bit_cast(float, slot_take<L, S>(tz, g));
-    const int var = VAR != 0 ? slot_take<L, S>(tw, g) : 0;   // (cross-lane reads stay outside the divergent part)
+    const int var = (VAR == 1 || VAR == 2) ? slot_take<L, S>(tw, g) : 0;   // (cross-lane reads stay outside the divergent part)
     // K <= 128: rows of steps S+1 and S+2 are already requested; take S, shift, request S+2.
     // Wider rows: one step ahead only (two buffers of 4C registers each do not fit next to the rows themselves
     // under the 128-VGPR cap of a 1024-thread workgroup: measured spills, -6 % at K = 256)
@@ -144,12 +145,14 @@ struct SlotSteps {
         const int lim = VAR == 2 ? var : 4 * L * C;
 #pragma unroll
         for (int c = 0; c < C; c++) {
+          float4v rk = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+          if constexpr (VAR == 3) rk = *(const float4v*)(regk + c * 4 * L + 4 * j);   // 2.0*((sing_a+1)/(sing_b+sigma_k)), both sides
 #pragma unroll
           for (int x = 0; x < 4; x++)
-            if (c * 4 * L + 4 * j + x < lim) p[c][x] = upd_ref64(p[c][x], q[c][x], m2, ru, lrd);
+            if (c * 4 * L + 4 * j + x < lim) p[c][x] = upd_ref64(p[c][x], q[c][x], m2, VAR == 3 ? 2.0 * (double)rk[x] : ru, lrd);
 #pragma unroll
           for (int x = 0; x < 4; x++)
-            if (c * 4 * L + 4 * j + x < lim) q[c][x] = upd_ref64(q[c][x], p[c][x], m2, ri, lrd);
+            if (c * 4 * L + 4 * j + x < lim) q[c][x] = upd_ref64(q[c][x], p[c][x], m2, VAR == 3 ? 2.0 * (double)rk[x] : ri, lrd);
           if (c * 4 * L + 4 * j < lim) {
             Um.st(pe + c * 4 * L, p[c]);
             if (FIX) {
@@ -197,7 +200,7 @@ struct SlotSteps {
       }
     }
     if constexpr (S + 1 < L)
-      SlotSteps<L, C, ARITH, OWN_U, FIX, VAR, S + 1>::run(Um, q_lds, tx, ty, tz, tw, g, j, nvalid, lr, uReg, iReg, pn, pen, pnn, penn);
+      SlotSteps<L, C, ARITH, OWN_U, FIX, VAR, S + 1>::run(Um, q_lds, tx, ty, tz, tw, regk, g, j, nvalid, lr, uReg, iReg, pn, pen, pnn, penn);
   }
 };
 
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
         if (ok) {
           const int64_t src = rb + slot_perm(t, R, ks0, ks1);
           rc4 = rec[src];
-          if (VAR != 0) tw = attr[src];
+          if (VAR == 1 || VAR == 2) tw = attr[src];
         }
         const int nvalid = (int)(R - cb < 64 ? R - cb : 64);
         // L == 16: a group is one DPP row.  Transpose the chunk once (3 ds_bpermute) so that lane s of row g
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
         if (L == 16) {
           const int src = (lane & 15) * G + (lane >> 4);
           tx = __shfl(rc4.x, src, 64); ty = __shfl(rc4.y, src, 64); tz = __shfl(rc4.z, src, 64);
-          if (VAR != 0) tw = __shfl(tw, src, 64);
+          if (VAR == 1 || VAR == 2) tw = __shfl(tw, src, 64);
         }
         // software pipeline: the lock-free rows of steps s+1 and s+2 are requested before step s is computed
         float4v pn[C], pnn[C];
@@ -296,8 +299,9 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
 #pragma unroll
           for (int c = 0; c < C; c++) pnn[c] = Um.ld(penn + c * 4 * L);
         }
-        if (fix) SlotSteps<L, C, ARITH, OWN_U, true, VAR, 0>::run(Um, q_lds, tx, ty, tz, tw, g, j, nvalid, lr, uReg, iReg, pn, pen, pnn, penn);
-        else SlotSteps<L, C, ARITH, OWN_U, false, VAR, 0>::run(Um, q_lds, tx, ty, tz, tw, g, j, nvalid, lr, uReg, iReg, pn, pen, pnn, penn);
+        const float* regk = VAR == 3 ? (const float*)attr : nullptr;
+        if (fix) SlotSteps<L, C, ARITH, OWN_U, true, VAR, 0>::run(Um, q_lds, tx, ty, tz, tw, regk, g, j, nvalid, lr, uReg, iReg, pn, pen, pnn, penn);
+        else SlotSteps<L, C, ARITH, OWN_U, false, VAR, 0>::run(Um, q_lds, tx, ty, tz, tw, regk, g, j, nvalid, lr, uReg, iReg, pn, pen, pnn, penn);
       }
       __syncthreads();
       // write the item rows back (this workgroup is their only owner during the round)
@@ -341,13 +345,15 @@ static int launch_slots(mfx_ctx* ctx, SlotList* S, const mfx_sgd_opts* o, int bl
     ProfScope ps(ctx, MFX_K_SGD);
     hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, false, OWN_U, VAR>), dim3(blocks), dim3(WG), 0, ctx->stream,
                        (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->tile_slot, S->ctr, round,
-                       oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1, VAR ? S->attr : (const int32_t*)nullptr);
+                       oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1,
+                       VAR == 3 ? (const int32_t*)ctx->dimreg : (VAR ? S->attr : (const int32_t*)nullptr));
   }
   {
     ProfScope ps(ctx, MFX_K_SGD_SWEEP);
     hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, true, OWN_U, VAR>), dim3(256), dim3(WG), 0, ctx->stream,
                        (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->tile_slot, S->ctr, -1,
-                       oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1, VAR ? S->attr : (const int32_t*)nullptr);
+                       oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1,
+                       VAR == 3 ? (const int32_t*)ctx->dimreg : (VAR ? S->attr : (const int32_t*)nullptr));
   }
   HIPCHK(hipGetLastError());
   return MFX_OK;
@@ -360,6 +366,7 @@ static int launch_arith(mfx_ctx* ctx, SlotList* S, int side, const mfx_sgd_opts*
   if constexpr (C <= 4) {      // K <= 256, as the flat kernels of sgd_ifw.hip / sgd_tmf.hip
     if (S->var == 1) return launch_slots<L, C, MFX_ARITH_REF64, false, 1>(ctx, S, o, blocks, k0, k1);
     if (S->var == 2) return launch_slots<L, C, MFX_ARITH_REF64F, false, 2>(ctx, S, o, blocks, k0, k1);
+    if (S->var == 3) return launch_slots<L, C, MFX_ARITH_REF64F, false, 3>(ctx, S, o, blocks, k0, k1);
   } else if (S->var != 0) {
     return mfx_fail(ctx, MFX_E_ARG, "MFX_SGD_TILED: rating weights / truncated ranks are built for K <= 256");
   }

@@ -578,7 +578,7 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
         dev->check(mfx_sgd_epoch(dev->ctx, &o), "mfx_sgd_epoch");
         break;
       case K_SGDPARSVD:   // modelMF.cpp:474-512 with the per-dimension regulariser set above; lock-free, coherent rows
-        o.mode = exact ? MFX_SGD_SERIAL : MFX_SGD_HOGWILD;
+        o.mode = exact ? MFX_SGD_SERIAL : MFX_SGD_TILED;       // the tiled kernel's per-dimension-regulariser variant
         o.order = exact ? MFX_ORDER_NATURAL : MFX_ORDER_DEVICE;
         dev->check(mfx_sgd_epoch(dev->ctx, &o), "mfx_sgd_epoch");
         break;

@@ -85,7 +85,7 @@ def test_dimreg_sgd_serial_is_bit_exact_and_objective_sing_matches(K):
         U, V = ctx.get_factors()
         e = ctx.eval_weighted(mfx.MAT_TRAIN, sing)
         with pytest.raises(mfx.MfxError):
-            ctx.sgd_epoch(0.01, 0, 0, mode=mfx.SGD_TILED)
+            ctx.sgd_epoch(0.01, 0, 0, mode=mfx.SGD_USERS, order=mfx.ORDER_NATURAL)
         # the parallel kernel: a conflict-free batch is exact too
         ctx.set_factors(U0, V0)
         n = min(nU, nI)
@@ -109,3 +109,26 @@ def test_dimreg_sgd_serial_is_bit_exact_and_objective_sing_matches(K):
     Uq, Vq = U0.copy(), V0.copy()                                       # clearing the regulariser restores the scalar path
     orc.sgd_pass(Uq, Vq, tr.rowids(), tr.rowind, tr.rowval, None, 0.01, 0.5, 0.5, orc.ARITH_REF64F, orc.DOT_TREE)
     assert np.array_equal(Up, Uq)
+
+
+@pytest.mark.parametrize("K", [10, 64, 128])
+def test_dimreg_on_the_tiled_kernel(K):
+    """The per-dimension regulariser as a variant of MFX_SGD_TILED: on a conflict-free matrix the epoch equals the oracle's
+    list-order pass up to the fixed-point item rows (2e-7)."""
+    n = 3000
+    rng = np.random.default_rng(K)
+    tr = synth.CSR(n, n, np.arange(n + 1, dtype=np.int64), rng.permutation(n).astype(np.int32), (rng.integers(1, 11, n) * 0.5).astype(np.float32))
+    U0 = rng.normal(0, 0.3, (n, K)).astype(np.float32)
+    V0 = rng.normal(0, 0.3, (n, K)).astype(np.float32)
+    regk = (np.float32(1.01) / (np.float32(0.02) + np.sort(rng.uniform(1, 300, K)).astype(np.float32)[::-1])).astype(np.float32)
+    with Ctx(0) as ctx:
+        ctx.set_csr(mfx.MAT_TRAIN, n, n, tr.rowptr, tr.rowind, tr.rowval)
+        ctx.set_model(n, n, K)
+        ctx.set_factors(U0, V0)
+        ctx.sgd_set_dim_reg(regk)
+        ctx.sgd_epoch(0.01, 9.0, 9.0, mode=mfx.SGD_TILED, seed=3, epoch=1)
+        U, V = ctx.get_factors()
+        ctx.sgd_set_dim_reg(None)
+    Uo, Vo = U0.copy(), V0.copy()
+    orc.sgd_pass_dimreg(Uo, Vo, tr.rowids(), tr.rowind, tr.rowval, None, 0.01, regk, orc.DOT_TREE)
+    assert np.abs(U - Uo).max() <= 2e-7 and np.abs(V - Vo).max() <= 2e-7 and np.abs(U - U0).max() > 1e-4
