@@ -156,6 +156,10 @@ typedef struct {
 /* objective = sse + uReg*unorm2 + iReg*inorm2 ; RMSE = sqrt(sse/n).
  * with_norms != 0 also fills unorm2/inorm2.                                     */
 int mfx_eval(mfx_ctx* ctx, int which, int snapshot, int with_norms, mfx_eval_out* out);
+/* Two evaluations with one copy back and one synchronisation: what Model::isTerminateModel needs every iteration
+ * (objective on train with the norms, RMSE on validation; model.cpp:1476-1480).                                  */
+int mfx_eval2(mfx_ctx* ctx, int whichA, int with_normsA, int whichB, int with_normsB, int snapshot,
+              mfx_eval_out* outA, mfx_eval_out* outB);
 /* Model::RMSE(mat, filtItems, ...) (model.cpp:348-394) and Model::RMSEU(mat, filtUsers, ...) (:446-486): the
  * evaluation restricted to the users / items whose keep flag is non-zero (either array may be NULL = keep
  * all; keepUsers has nUsers entries, keepItems nItems).  out->sse and out->n as mfx_eval, no norms.          */

@@ -205,22 +205,24 @@ static int eval_lc(mfx_ctx* ctx, const DevCSR& m, const float* U, const float* V
   return MFX_OK;
 }
 
-int mfx_launch_eval(mfx_ctx* ctx, const DevCSR& m, const float* U, const float* V, int with_norms,
-                    mfx_eval_out* out) {
+// block counts of one evaluation
+static void eval_blocks(const mfx_ctx* ctx, const DevCSR& m, int* nb, int* nbu, int* nbi) {
+  const int G = 64 / ctx->L;
+  *nb = (int)std::max<int64_t>(1, std::min<int64_t>(((m.nnz + 63) / 64 + 3) / 4, 2048));
+  *nbu = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)ctx->nU + 4 * G - 1) / (4 * G), 1024));
+  *nbi = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)ctx->nI + 4 * G - 1) / (4 * G), 1024));
+}
+
+// launches the kernels of one evaluation into the partial-sum region starting at `base` and its 4 results into
+// dout[0..3]; nothing is copied back yet
+static int eval_enqueue(mfx_ctx* ctx, const DevCSR& m, const float* U, const float* V, int with_norms, int base, double* dout) {
   const int L = ctx->L, C = ctx->C;
-  const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(((m.nnz + 63) / 64 + 3) / 4, 2048));
-  const int G = 64 / L;
-  const int nbu = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)ctx->nU + 4 * G - 1) / (4 * G), 1024));
-  const int nbi = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)ctx->nI + 4 * G - 1) / (4 * G), 1024));
-  const int need = nb + nbu + nbi;
-  if (ctx->red_blocks < need) {
-    dev_free(ctx->red_d);
-    dev_free(ctx->red_i);
-    int rc;
-    if ((rc = dev_alloc(ctx, &ctx->red_d, (size_t)need + 8))) return rc;
-    if ((rc = dev_alloc(ctx, &ctx->red_i, (size_t)need))) return rc;
-    ctx->red_blocks = need;
-  }
+  int nb, nbu, nbi;
+  eval_blocks(ctx, m, &nb, &nbu, &nbi);
+  double* save_d = ctx->red_d;
+  int64_t* save_i = ctx->red_i;
+  ctx->red_d += base;          // eval_lc addresses the region through the context
+  ctx->red_i += base;
   int rc = MFX_E_ARG;
   if (L == 4) rc = eval_lc<4, 1>(ctx, m, U, V, with_norms, nb, nbu, nbi);
   else if (L == 8) rc = eval_lc<8, 1>(ctx, m, U, V, with_norms, nb, nbu, nbi);
@@ -234,16 +236,60 @@ int mfx_launch_eval(mfx_ctx* ctx, const DevCSR& m, const float* U, const float* 
     case 7: rc = eval_lc<16, 7>(ctx, m, U, V, with_norms, nb, nbu, nbi); break;
     case 8: rc = eval_lc<16, 8>(ctx, m, U, V, with_norms, nb, nbu, nbi); break;
   }
+  if (!rc) {
+    hipLaunchKernelGGL(eval_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->red_d, nb, ctx->red_i, ctx->red_d + nb,
+                       with_norms ? nbu : 0, ctx->red_d + nb + nbu, with_norms ? nbi : 0, dout);
+    if (hipGetLastError() != hipSuccess) rc = mfx_fail(ctx, MFX_E_HIP, "eval: launch failed");
+  }
+  ctx->red_d = save_d;
+  ctx->red_i = save_i;
+  return rc;
+}
+
+// room for `count` evaluations side by side (+ 8 result doubles)
+static int eval_reserve(mfx_ctx* ctx, int need_total) {
+  if (ctx->red_blocks >= need_total) return MFX_OK;
+  dev_free(ctx->red_d);
+  dev_free(ctx->red_i);
+  ctx->red_blocks = 0;
+  int rc;
+  if ((rc = dev_alloc(ctx, &ctx->red_d, (size_t)need_total + 8))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->red_i, (size_t)need_total))) return rc;
+  ctx->red_blocks = need_total;
+  return MFX_OK;
+}
+static void eval_unpack(const double* r, mfx_eval_out* out) {
+  out->sse = r[0]; out->n = (int64_t)r[1]; out->unorm2 = r[2]; out->inorm2 = r[3];
+}
+
+int mfx_launch_eval(mfx_ctx* ctx, const DevCSR& m, const float* U, const float* V, int with_norms, mfx_eval_out* out) {
+  int nb, nbu, nbi;
+  eval_blocks(ctx, m, &nb, &nbu, &nbi);
+  int rc = eval_reserve(ctx, nb + nbu + nbi);
   if (rc) return rc;
-  double* dout = ctx->red_d + need;  // 4 doubles of the +8 tail
-  hipLaunchKernelGGL(eval_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->red_d, nb, ctx->red_i,
-                     ctx->red_d + nb, with_norms ? nbu : 0, ctx->red_d + nb + nbu, with_norms ? nbi : 0, dout);
-  HIPCHK(hipGetLastError());
+  double* dout = ctx->red_d + ctx->red_blocks;
+  if ((rc = eval_enqueue(ctx, m, U, V, with_norms, 0, dout))) return rc;
   HIPCHK(hipMemcpyAsync(ctx->red_out, dout, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  out->sse = ctx->red_out[0];
-  out->n = (int64_t)ctx->red_out[1];
-  out->unorm2 = ctx->red_out[2];
-  out->inorm2 = ctx->red_out[3];
+  eval_unpack(ctx->red_out, out);
+  return MFX_OK;
+}
+
+// two evaluations, one copy back, one synchronisation (the objective + validation RMSE of every iteration)
+int mfx_launch_eval2(mfx_ctx* ctx, const DevCSR& ma, int norms_a, const DevCSR& mb, int norms_b, const float* U, const float* V,
+                     mfx_eval_out* out_a, mfx_eval_out* out_b) {
+  int nb, nbu, nbi, nb2, nbu2, nbi2;
+  eval_blocks(ctx, ma, &nb, &nbu, &nbi);
+  eval_blocks(ctx, mb, &nb2, &nbu2, &nbi2);
+  const int need_a = nb + nbu + nbi;
+  int rc = eval_reserve(ctx, need_a + nb2 + nbu2 + nbi2);
+  if (rc) return rc;
+  double* dout = ctx->red_d + ctx->red_blocks;
+  if ((rc = eval_enqueue(ctx, ma, U, V, norms_a, 0, dout))) return rc;
+  if ((rc = eval_enqueue(ctx, mb, U, V, norms_b, need_a, dout + 4))) return rc;
+  HIPCHK(hipMemcpyAsync(ctx->red_out, dout, 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  eval_unpack(ctx->red_out, out_a);
+  eval_unpack(ctx->red_out + 4, out_b);
   return MFX_OK;
 }

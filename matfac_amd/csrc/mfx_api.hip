@@ -554,6 +554,20 @@ extern "C" int mfx_eval(mfx_ctx* ctx, int which, int snapshot, int with_norms, m
                          with_norms, out);
 }
 
+extern "C" int mfx_eval2(mfx_ctx* ctx, int whichA, int normsA, int whichB, int normsB, int snapshot, mfx_eval_out* outA,
+                         mfx_eval_out* outB) {
+  if (!ctx) return MFX_E_ARG;
+  NEED(outA && outB, MFX_E_ARG, "mfx_eval2: out NULL");
+  NEED(whichA >= 0 && whichA < 3 && whichB >= 0 && whichB < 3, MFX_E_ARG, "mfx_eval2: which=%d,%d", whichA, whichB);
+  NEED(ctx->mat[whichA].present && ctx->mat[whichB].present, MFX_E_STATE, "mfx_eval2: matrix not set");
+  NEED(ctx->U, MFX_E_STATE, "mfx_eval2: no model");
+  NEED(ctx->have_invalid, MFX_E_STATE, "mfx_eval2: call mfx_compute_invalid first");
+  NEED(snapshot == MFX_SNAP_CURRENT || snapshot == MFX_SNAP_BEST, MFX_E_ARG, "mfx_eval2: snapshot");
+  HIPCHK(hipSetDevice(ctx->device));
+  return mfx_launch_eval2(ctx, ctx->mat[whichA], normsA, ctx->mat[whichB], normsB, snapshot ? ctx->Ubest : ctx->U,
+                          snapshot ? ctx->Vbest : ctx->V, outA, outB);
+}
+
 __global__ void mask_combine_kernel(const uint8_t* __restrict__ inv, const uint8_t* __restrict__ keep, int32_t n, uint8_t* __restrict__ out) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < n) out[t] = inv[t] | (keep[t] ? 0 : 1);

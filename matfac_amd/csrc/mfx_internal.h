@@ -204,6 +204,8 @@ int mfx_slots_materialise_order(mfx_ctx* ctx);
 void mfx_slots_free_internal(mfx_ctx* ctx);
 int mfx_launch_eval(mfx_ctx* ctx, const DevCSR& m, const float* U, const float* V,
                     int with_norms, mfx_eval_out* out);
+int mfx_launch_eval2(mfx_ctx* ctx, const DevCSR& ma, int norms_a, const DevCSR& mb, int norms_b, const float* U, const float* V,
+                     mfx_eval_out* out_a, mfx_eval_out* out_b);
 int mfx_comm_free_internal(mfx_ctx* ctx);
 int mfx_comm_allreduce(mfx_ctx* ctx, void* dev, size_t count, int dtype);   // sum over ranks, dtype 0 f32 / 1 f64
 static inline bool mfx_sharded(const mfx_ctx* ctx);

@@ -400,13 +400,22 @@ bool Model::terminateImpl(bool sing, Model& bestModel, const Data& data, int ite
                           double& prevObj, double& bestValRMSE, double& prevValRMSE, IntSet& invalidUsers,
                           IntSet& invalidItems) {
   bool ret = false;
-  const double currObj = sing ? objectiveSing(data, invalidUsers, invalidItems) : objective(data, invalidUsers, invalidItems);
-  double currValRMSE = -1;
-  if (data.valMat) {
-    currValRMSE = RMSE(data.valMat, invalidUsers, invalidItems);
+  double currObj, currValRMSE = -1;
+  const int wt = dev ? dev->which(data.trainMat) : -1, wv = dev && data.valMat ? dev->which(data.valMat) : -1;
+  if (!sing && baseObjective() && wt >= 0 && wv >= 0) {
+    // objective(data, ...) and RMSE(valMat, ...) from one device round trip
+    mfx_eval_out ot, ov;
+    dev->check(mfx_eval2(dev->ctx, wt, 1, wv, 0, devSnap, &ot, &ov), "mfx_eval2");
+    currObj = ot.sse + ot.unorm2 * uReg + ot.inorm2 * iReg;
+    currValRMSE = std::sqrt(ov.sse / (double)ov.n);
   } else {
-    std::cerr << "\nNo validation data" << std::endl;
-    exit(0);
+    currObj = sing ? objectiveSing(data, invalidUsers, invalidItems) : objective(data, invalidUsers, invalidItems);
+    if (data.valMat) {
+      currValRMSE = RMSE(data.valMat, invalidUsers, invalidItems);
+    } else {
+      std::cerr << "\nNo validation data" << std::endl;
+      exit(0);
+    }
   }
   if (currObj != currObj || currValRMSE != currValRMSE) {
     std::cout << "Found nan " << std::endl;
@@ -639,8 +648,12 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
       }
     }
     hostStale = true;
-    dev->check(mfx_synchronize(dev->ctx), "mfx_synchronize");
-    subIterDuration = std::chrono::duration<double>(std::chrono::system_clock::now() - start).count();
+    // subIterDuration is only printed every MF_DISP_ITER iterations (modelMF.cpp:116-123): wait for the device just for
+    // those; otherwise the evaluation below is the first thing that needs the epoch to have finished
+    if (iter % MF_DISP_ITER == 0) {
+      dev->check(mfx_synchronize(dev->ctx), "mfx_synchronize");
+      subIterDuration = std::chrono::duration<double>(std::chrono::system_clock::now() - start).count();
+    }
 
     if (iter % MF_OBJ_ITER == 0 || iter == maxIter - 1) {
       if (kind == K_SGDPARSVD ? isTerminateModelSing(bestModel, data, iter, bestIter, bestObj, prevObj, bestValRMSE,

@@ -121,6 +121,9 @@ class Model {
   // getInvalidUsersItems + modelMF.cpp:40-45 on the device, returned as sets
   void deviceInvalid(const Data& data, IntSet& invalidUsers, IntSet& invalidItems);
   void evalDevice(const csr_t* mat, int withNorms, mfx_eval_out* out);
+  // true while objective() is the base formula, so that isTerminateModel may take the objective and the
+  // validation RMSE from one mfx_eval2 call; a class that overrides objective() returns false
+  virtual bool baseObjective() const { return true; }
 };
 
 class ModelMF : public Model {

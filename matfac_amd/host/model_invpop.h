@@ -27,6 +27,7 @@ class ModelInvPopMF : public ModelMF {
  protected:
   void beforeLoop(Kind kind, const Data& data, IntSet& invalidUsers, IntSet& invalidItems) override;
   void afterLoop(Kind kind) override;
+  bool baseObjective() const override { return false; }
   bool weightsOn = false;
 };
 

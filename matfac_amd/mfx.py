@@ -172,6 +172,11 @@ class Ctx:
         self._chk(self.lib.mfx_eval(self.h, which, snapshot, int(with_norms), C.byref(out)))
         return out
 
+    def eval2(self, whichA, normsA, whichB, normsB=False, snapshot=SNAP_CURRENT):
+        a, b = EvalOut(), EvalOut()
+        self._chk(self.lib.mfx_eval2(self.h, whichA, int(normsA), whichB, int(normsB), snapshot, C.byref(a), C.byref(b)))
+        return a, b
+
     def eval_filtered(self, which, keep_users=None, keep_items=None, snapshot=SNAP_CURRENT):
         out = EvalOut()
         ku, ki = _p(keep_users, np.uint8), _p(keep_items, np.uint8)

@@ -21,7 +21,7 @@ def declared_symbols():
 def test_header_declares_the_expected_surface():
     names = declared_symbols()
     for must in ["mfx_create", "mfx_destroy", "mfx_set_csr", "mfx_set_model", "mfx_set_factors", "mfx_get_factors",
-                 "mfx_compute_invalid", "mfx_sgd_epoch", "mfx_eval", "mfx_als_half_sweep", "mfx_ccdpp_rank1",
+                 "mfx_compute_invalid", "mfx_sgd_epoch", "mfx_eval", "mfx_eval2", "mfx_als_half_sweep", "mfx_ccdpp_rank1",
                  "mfx_snapshot_best", "mfx_allreduce_item_factors", "mfx_prof_get"]:
         assert must in names
 

@@ -130,6 +130,19 @@ def test_filtered_evaluation_matches_oracle_masks():
             assert e.n == n and 0 < n < full.n and abs(e.sse - sse) <= 1e-12 * sse
         again = ctx.eval(mfx.MAT_TEST)                      # the filter does not stick
         assert (again.n, again.sse) == (full.n, full.sse)
+        # the fused pair of isTerminateModel (objective on train + RMSE on another matrix) = the two single calls, bit for bit
+        for K2 in (8, 64, 200):
+            U2 = rng.normal(0, 0.3, (nU, K2)).astype(np.float32)
+            V2 = rng.normal(0, 0.3, (nI, K2)).astype(np.float32)
+            ctx.set_model(nU, nI, K2)
+            ctx.set_factors(U2, V2)
+            ctx.compute_invalid()
+            a1, b1 = ctx.eval(mfx.MAT_TRAIN, with_norms=True), ctx.eval(mfx.MAT_TEST)
+            a2, b2 = ctx.eval2(mfx.MAT_TRAIN, True, mfx.MAT_TEST, False)
+            assert (a1.sse, a1.n, a1.unorm2, a1.inorm2) == (a2.sse, a2.n, a2.unorm2, a2.inorm2)
+            assert (b1.sse, b1.n) == (b2.sse, b2.n)
+            a3 = ctx.eval(mfx.MAT_TRAIN, with_norms=True)   # and the single call after the pair still reads its own region
+            assert (a3.sse, a3.unorm2) == (a1.sse, a1.unorm2)
 
 
 def test_single_rating_and_argument_errors():
