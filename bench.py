@@ -88,14 +88,45 @@ def main():
     _, V0 = synth.init_factors(1, 1, nI, K, want_u=False)            # V replica: identical everywhere
     ctx.set_factors(U0, V0)
     ctx.compute_invalid()
+    exchange = "RCCL item-factor all-reduce"
     if N > 1 or force_dist:
         import torch
         if use_gloo:
+            exchange = "gloo all-reduce staged through the host (rehearsal)"
             ctx.comm_init_external(N, rank, lambda a: dist.all_reduce(torch.from_numpy(a), op=dist.ReduceOp.SUM))
         else:
-            uid = [Ctx.comm_unique_id() if rank == 0 else None]
+            # the library's own RCCL communicator (device buffers, on its stream).  Every rank reports whether it came
+            # up; if any did not, all of them fall back to the host-staged external reducer over torch's communicator,
+            # so that the run still completes (slower, and named as such in config.exchange).
+            ok = 1
+            uid = [None]
+            if rank == 0:
+                try:
+                    uid = [Ctx.comm_unique_id()]
+                except Exception as e:                               # noqa: BLE001
+                    print("rank 0: mfx_comm_unique_id failed: %s" % e, file=sys.stderr)
             dist.broadcast_object_list(uid, src=0)
-            ctx.comm_init(N, rank, uid[0])
+            try:
+                if uid[0] is None:
+                    raise RuntimeError("no unique id")
+                if os.environ.get("BENCH_BREAK_RCCL") == "1":        # rehearsal of the fallback below
+                    raise RuntimeError("BENCH_BREAK_RCCL=1")
+                ctx.comm_init(N, rank, uid[0])
+            except Exception as e:                                   # noqa: BLE001 -- reported, then agreed on below
+                print("rank %d: mfx_comm_init failed: %s" % (rank, e), file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag[0]) == 0:
+                exchange = "torch.distributed all-reduce staged through the host (library RCCL init failed)"
+                if ok:
+                    ctx.comm_destroy()
+
+                def staged(a):
+                    t = torch.from_numpy(a).cuda()
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                    a[...] = t.cpu().numpy()
+                ctx.comm_init_external(N, rank, staged)
         ctx.comm_mark_synced()
 
     # main.cpp:29-31 defaults are learnrate 0.005, ureg = ireg = 0.01.  On ML-20M-skewed data the
@@ -163,7 +194,7 @@ def main():
                                    "%s Hogwild SGD epoch (device reshuffle + update kernel%s)"
                                    % (args.workload, {"C1": "ML-100K-shape", "C2": "ML-20M-shape", "C4": "Netflix-shape"}.get(args.workload, ""),
                                       nU, nI, nnz, K, "XCD-tiled" if mode == mfx.SGD_TILED else "flat",
-                                      ", RCCL item-factor all-reduce" if N > 1 else ""),
+                                      ", " + exchange if N > 1 or force_dist else ""),
                        "learnrate": lr, "ureg": ureg, "ireg": ireg, "arith": args.arith,
                        "parallelism": "user-block x%d" % N},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
