@@ -50,103 +50,157 @@ __device__ __forceinline__ void gram_zero(GramAcc& g) {
   g.b0 = g.b1 = 0.0f;
 }
 
-// accumulate ratings [beg,end) of one row: ind[] = counterpart index, val[] = rating
-__device__ __forceinline__ void gram_accumulate(GramAcc& g, const float* __restrict__ Y,
-                                                const int32_t* __restrict__ ind,
-                                                const float* __restrict__ val, int64_t beg, int64_t end,
-                                                int lane, int ld) {
+// accumulate ratings [beg,end) of one row: ind[] = counterpart index, val[] = rating.
+// Batches of B steps (2 ratings each); the 2B gathered row loads of batch q+1 are issued before the 4B MFMAs of
+// batch q, so the MFMA pipe works through one batch while the next one's rows are in flight.
+namespace {
+constexpr int GB = 8;
+struct GramBatch {
+  float y0[GB], y1[GB], w[GB], wr[GB];
+};
+}  // namespace
+
+__device__ __forceinline__ void gram_load_batch(GramBatch& b, int q, int len, int mj, float mr, const float* __restrict__ Y, int lane,
+                                                int ld) {
   const int half = lane >> 5, idx = lane & 31;
-  for (int64_t base = beg; base < end; base += 64) {
-    const bool ok = base + lane < end;
-    const int mj = ok ? ind[base + lane] : 0;
-    const float mr = ok ? val[base + lane] : 0.0f;
-    const int n = (int)(end - base < 64 ? end - base : 64);
-    // batches of B steps (2 ratings each): all 2B row loads of a batch are issued before its 4B MFMAs,
-    // so ~16 gathered rows per wave are in flight instead of 2 (the loop was latency-bound)
-    constexpr int B = 8;
-    for (int s0 = 0; s0 < n; s0 += 2 * B) {
-      float y0[B], y1[B], wr[B], w[B];
 #pragma unroll
-      for (int t = 0; t < B; t++) {
-        const int e = s0 + 2 * t + half;
-        const int j = __shfl(mj, e & 63, 64);
-        const float r = __shfl(mr, e & 63, 64);
-        // ratings <= 0 are skipped (modelMF.cpp:819,857); a missing partner contributes 0
-        const bool use = e < n && r > 0.0f;
-        w[t] = use ? 1.0f : 0.0f;
-        wr[t] = use ? r : 0.0f;
-        const float* y = Y + (int64_t)(e < n ? j : 0) * ld;
-        y0[t] = idx < ld ? y[idx] : 0.0f;
-        y1[t] = 32 + idx < ld ? y[32 + idx] : 0.0f;
-      }
+  for (int t = 0; t < GB; t++) {
+    const int e = q * (2 * GB) + 2 * t + half;     // rating number within the row; its index block is e / 64
+    const int j = __shfl(mj, e & 63, 64);
+    const float r = __shfl(mr, e & 63, 64);
+    // ratings <= 0 are skipped (modelMF.cpp:819,857); a missing partner contributes 0
+    const bool use = e < len && r > 0.0f;
+    b.w[t] = use ? 1.0f : 0.0f;
+    b.wr[t] = use ? r : 0.0f;
+    const float* y = Y + (int64_t)(e < len ? j : 0) * ld;
+    b.y0[t] = idx < ld ? y[idx] : 0.0f;
+    b.y1[t] = 32 + idx < ld ? y[32 + idx] : 0.0f;
+  }
+}
+__device__ __forceinline__ void gram_mfma_batch(GramAcc& g, const GramBatch& b, int q, int len) {
 #pragma unroll
-      for (int t = 0; t < B; t++) {
-        if (s0 + 2 * t < n) {   // wave-uniform
-          const float a0 = w[t] * y0[t], a1 = w[t] * y1[t];
-          g.t[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, y0[t], g.t[0][0], 0, 0, 0);
-          g.t[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, y1[t], g.t[0][1], 0, 0, 0);
-          g.t[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, y0[t], g.t[1][0], 0, 0, 0);
-          g.t[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, y1[t], g.t[1][1], 0, 0, 0);
-          g.b0 = __builtin_fmaf(wr[t], y0[t], g.b0);
-          g.b1 = __builtin_fmaf(wr[t], y1[t], g.b1);
-        }
-      }
+  for (int t = 0; t < GB; t++) {
+    if (q * (2 * GB) + 2 * t < len) {   // wave-uniform
+      const float a0 = b.w[t] * b.y0[t], a1 = b.w[t] * b.y1[t];
+      g.t[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b.y0[t], g.t[0][0], 0, 0, 0);
+      g.t[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b.y1[t], g.t[0][1], 0, 0, 0);
+      g.t[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b.y0[t], g.t[1][0], 0, 0, 0);
+      g.t[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b.y1[t], g.t[1][1], 0, 0, 0);
+      g.b0 = __builtin_fmaf(b.wr[t], b.y0[t], g.b0);
+      g.b1 = __builtin_fmaf(b.wr[t], b.y1[t], g.b1);
     }
   }
 }
 
+__device__ __forceinline__ void gram_accumulate(GramAcc& g, const float* __restrict__ Y,
+                                                const int32_t* __restrict__ ind,
+                                                const float* __restrict__ val, int64_t beg, int64_t end,
+                                                int lane, int ld) {
+  if (end <= beg) return;
+  const int len = (int)(end - beg);                 // a segment is at most SEG ratings
+  const int nbatch = (len + 2 * GB - 1) / (2 * GB);
+  // index blocks of 64 ratings: the current one and the one after it
+  int mj, mjn = 0;
+  float mr, mrn = 0.0f;
+  {
+    const bool ok = lane < len;
+    mj = ok ? ind[beg + lane] : 0;
+    mr = ok ? val[beg + lane] : 0.0f;
+    const bool ok2 = 64 + lane < len;
+    mjn = ok2 ? ind[beg + 64 + lane] : 0;
+    mrn = ok2 ? val[beg + 64 + lane] : 0.0f;
+  }
+  // entering batch p: when it starts a new index block, the prefetched block becomes current and the next is requested
+  auto advance = [&](int p) {
+    if ((p & 3) == 0) {
+      mj = mjn;
+      mr = mrn;
+      const int64_t off = (int64_t)(p / 4 + 1) * 64 + lane;
+      const bool ok = off < len;
+      mjn = ok ? ind[beg + off] : 0;
+      mrn = ok ? val[beg + off] : 0.0f;
+    }
+  };
+  GramBatch ba, bb;
+  gram_load_batch(ba, 0, len, mj, mr, Y, lane, ld);
+  for (int q = 0; q < nbatch; q += 2) {
+    if (q + 1 < nbatch) {
+      advance(q + 1);
+      gram_load_batch(bb, q + 1, len, mj, mr, Y, lane, ld);
+    }
+    gram_mfma_batch(g, ba, q, len);
+    if (q + 1 < nbatch) {
+      if (q + 2 < nbatch) {
+        advance(q + 2);
+        gram_load_batch(ba, q + 2, len, mj, mr, Y, lane, ld);
+      }
+      gram_mfma_batch(g, bb, q + 1, len);
+    }
+  }
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 // Turn the tile layout into "lane i owns row i", add reg, solve, return x_i in lane i.
 __device__ __forceinline__ float gram_solve(const GramAcc& g, int K, float reg, int lane) {
-  const int h = lane >> 5;
-  float a[64];
-  // lane l holds, of columns c and 32+c (c = l&31), the rows whose bit 2 equals h; its
-  // partner l^32 holds the other rows.  Keep column 32h+c, trade the rest.
+  // a[2p], a[2p+1] = A(lane, 2p), A(lane, 2p+1): pairs, so that the trailing update is one packed fma per two columns
+  f32x2 a[32];
+  // Of columns c and 32+c (c = l&31) lane l holds the rows whose bit 2 equals l>>5, its partner l^32 the others.
+  // v_permlane32_swap trades the upper half of the first tile column with the lower half of the second: afterwards
+  // the first register is row I0 and the second row I0+4 of the lane's own column 32*(l>>5)+c (= row, A is symmetric).
+  // (inline asm: the compiler's own handling of the builtin merged most of the 33 swaps of this function into three.
+  //  The accumulators were written by MFMAs and asm operands are invisible to the hazard recogniser, hence the nops:
+  //  18 wait states cover a 16-pass MFMA result read by a VALU instruction.)
+  asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
 #pragma unroll
   for (int ti = 0; ti < 2; ti++)
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-      const float own = h ? g.t[ti][1][r] : g.t[ti][0][r];
-      const float send = h ? g.t[ti][0][r] : g.t[ti][1][r];
-      const float recv = __shfl_xor(send, 32, 64);
-      const int I0 = 32 * ti + (r & 3) + 8 * (r >> 2);  // row with bit 2 clear; I0+4 has it set
-      a[I0] = h ? recv : own;
-      a[I0 + 4] = h ? own : recv;
+      const int I0 = 32 * ti + (r & 3) + 8 * (r >> 2);   // row with bit 2 clear; I0+4 has it set
+      float lo = g.t[ti][0][r], hi = g.t[ti][1][r];
+      asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+      a[I0 >> 1][I0 & 1] = lo;
+      a[(I0 + 4) >> 1][I0 & 1] = hi;
     }
-  const float bt0 = g.b0 + __shfl_xor(g.b0, 32, 64);
-  const float bt1 = g.b1 + __shfl_xor(g.b1, 32, 64);
-  float z = h ? bt1 : bt0;
-  // YTY(j,j) += reg for j < K (modelMF.cpp:831-833); padded dimensions become identity rows
+  float z0 = g.b0, z1 = g.b1;
+  asm volatile("v_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(z0), "+v"(z1));
+  float z = z0 + z1;
+  // YTY(j,j) += reg for j < K (modelMF.cpp:831-833); padded dimensions (all zero) become identity rows
+  const float regv = lane < K ? reg : 1.0f;
 #pragma unroll
-  for (int I = 0; I < 64; I++) {
-    if (I == lane) a[I] = I < K ? a[I] + reg : 1.0f;
-  }
-  // right-looking LDL^T, row i of A in lane i.  The pivot's reciprocal is formed once per step and the trailing
-  // update is one fused multiply-add per element (the reference's Eigen LDLT is a different operation order anyway;
-  // the comparison with the oracle is to eps * cond(A))
+  for (int I = 0; I < 64; I++) a[I >> 1][I & 1] += lane == I ? regv : 0.0f;
+  // Right-looking LDL^T, row i of A in lane i, no pivoting (A + reg*I is SPD).  Step k: lanes i > k form l_ik =
+  // a_ik / d_k and subtract l_ik * (pivot row k, read from lane k) from their row; lanes <= k stand still, so that
+  // lane k keeps d_k in a[k] and the pivot row d_k * l_jk (j > k) in a[j] -- column k of L, which the back
+  // substitution below wants in one lane.  The right-hand side rides along as one more column (L y = b).
   float d = 1.0f;
 #pragma unroll
   for (int k = 0; k < 64; k++) {
-    const float dk = rdlane(a[k], k);
-    const float lik = a[k] * (1.0f / dk);
+    const float dk = rdlane(a[k >> 1][k & 1], k);
+    float rk = __builtin_amdgcn_rcpf(dk);
+    rk = __builtin_fmaf(__builtin_fmaf(-dk, rk, 1.0f), rk, rk);
+    const float lik = lane > k ? a[k >> 1][k & 1] * rk : 0.0f;
+    if ((k & 1) == 0) a[k >> 1][1] = __builtin_fmaf(-lik, rdlane(a[k >> 1][1], k), a[k >> 1][1]);
+    const f32x2 l2 = {lik, lik};
 #pragma unroll
-    for (int j = k + 1; j < 64; j++) a[j] = __builtin_fmaf(-lik, rdlane(a[j], k), a[j]);
-    a[k] = lik;
-    if (lane == k) d = dk;
+    for (int p = (k >> 1) + 1; p < 32; p++) {
+      const f32x2 row = {rdlane(a[p][0], k), rdlane(a[p][1], k)};
+      a[p] = __builtin_elementwise_fma(-l2, row, a[p]);   // v_pk_fma_f32 with the scalar pair as one source
+    }
+    z = __builtin_fmaf(-lik, rdlane(z, k), z);
+    a[k >> 1][k & 1] = lane > k ? lik : a[k >> 1][k & 1];
+    d = lane == k ? dk : d;
+    __builtin_amdgcn_sched_barrier(0);   // keep the steps apart: interleaved, each column becomes one dependent chain
   }
-  // L y = b
+  // L^T x = D^-1 y from the last row up: x_j is final in lane j; lanes k < j subtract (d_k l_jk) x_j before their division
+  float rd = __builtin_amdgcn_rcpf(d);
+  rd = __builtin_fmaf(__builtin_fmaf(-d, rd, 1.0f), rd, rd);
+  float acc = z, x = 0.0f;
 #pragma unroll
-  for (int k = 0; k < 64; k++) {
-    const float zk = rdlane(z, k);
-    if (lane > k) z = __builtin_fmaf(-a[k], zk, z);
-  }
-  z = z / d;
-  // L^T x = y
-  float x = z;
-#pragma unroll
-  for (int i = 63; i >= 0; i--) {
-    const float t = lane > i ? a[i] * x : 0.0f;
-    const float s = wave_sum_f(t);
-    if (lane == i) x = x - s;
+  for (int j = 63; j >= 0; j--) {
+    const float xv = acc * rd;
+    x = lane == j ? xv : x;
+    acc = __builtin_fmaf(-a[j >> 1][j & 1], rdlane(xv, j), acc);
   }
   return x;
 }
@@ -176,7 +230,7 @@ __device__ __forceinline__ void gram_add(GramAcc& g, const float* o) {
 // SOLVE 1: solve single-segment rows in place; 0: timing probe; 2 (sharded item sweep): emit every row's
 // accumulators to grow[row] for the all-reduce over the ranks
 template <int SOLVE>
-__global__ __launch_bounds__(64) void als_segment_kernel(const int32_t* __restrict__ seg_row,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void als_segment_kernel(const int32_t* __restrict__ seg_row,
                                                          const int64_t* __restrict__ seg_beg,
                                                          const int64_t* __restrict__ seg_end,
                                                          const int32_t* __restrict__ seg_slab, int64_t nseg,
