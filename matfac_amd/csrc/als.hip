@@ -21,6 +21,7 @@
 #include "mfx_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 constexpr int SLAB = 66 * 64;     // floats per partial: 4 tiles x 16 regs + 2 rhs, per lane
@@ -51,51 +52,80 @@ __device__ __forceinline__ void gram_zero(GramAcc& g) {
 }
 
 // accumulate ratings [beg,end) of one row: ind[] = counterpart index, val[] = rating.
-// Batches of B steps (2 ratings each); the 2B gathered row loads of batch q+1 are issued before the 4B MFMAs of
-// batch q, so the MFMA pipe works through one batch while the next one's rows are in flight.
+// Batches of GB steps (2 ratings each); the 2*GB gathered row loads of batch q+1 are issued before the 4*GB MFMAs of
+// batch q, so the MFMA pipe works through one batch while the next one's rows are in flight.  LD (the row stride:
+// 16, 32 or 64 floats) is a template parameter: the row address is a shift, no load sits behind a lane predicate
+// (a predicated load becomes its own basic block and the waits around it can no longer be counted), and for
+// LD <= 32 only the first 32x32 tile exists.
 namespace {
 constexpr int GB = 8;
 struct GramBatch {
-  float y0[GB], y1[GB], w[GB], wr[GB];
+  float y0[GB], y1[GB], r[GB];
 };
 }  // namespace
 
-__device__ __forceinline__ void gram_load_batch(GramBatch& b, int q, int len, int mj, float mr, const float* __restrict__ Y, int lane,
-                                                int ld) {
+// BIG: the factor table is 4 GB or more and needs 64-bit row offsets; otherwise a row's byte offset is one 32-bit shift
+// and the loads use the scalar-base + 32-bit-offset form.  (The f32 MFMA shares the SIMD's issue slots with ordinary
+// vector instructions -- measured: their times add -- so every instruction saved per step is MFMA time gained.)
+template <int LD, bool BIG>
+__device__ __forceinline__ void gram_load_batch(GramBatch& b, int q, int mj, float mr, const float* __restrict__ Y, int lane) {
   const int half = lane >> 5, idx = lane & 31;
+  int j[GB];
+  // ratings past the end of the row read index 0 / rating 0 from the block registers (see gram_accumulate)
 #pragma unroll
   for (int t = 0; t < GB; t++) {
-    const int e = q * (2 * GB) + 2 * t + half;     // rating number within the row; its index block is e / 64
-    const int j = __shfl(mj, e & 63, 64);
-    const float r = __shfl(mr, e & 63, 64);
-    // ratings <= 0 are skipped (modelMF.cpp:819,857); a missing partner contributes 0
-    const bool use = e < len && r > 0.0f;
-    b.w[t] = use ? 1.0f : 0.0f;
-    b.wr[t] = use ? r : 0.0f;
-    const float* y = Y + (int64_t)(e < len ? j : 0) * ld;
-    b.y0[t] = idx < ld ? y[idx] : 0.0f;
-    b.y1[t] = 32 + idx < ld ? y[32 + idx] : 0.0f;
+    const int src = (q * (2 * GB) + 2 * t + half) & 63;     // position in the current block of 64 ratings
+    j[t] = __shfl(mj, src, 64);
+    b.r[t] = __shfl(mr, src, 64);
+  }
+#pragma unroll
+  for (int t = 0; t < GB; t++) {
+    const float* y;
+    if (BIG) y = Y + (uint64_t)(uint32_t)j[t] * LD;
+    else y = (const float*)((const char*)Y + (uint32_t)((uint32_t)j[t] * (uint32_t)(LD * sizeof(float))));
+    if (LD == 64) {
+      b.y0[t] = y[idx];
+      b.y1[t] = y[32 + idx];
+    } else if (LD == 32) {
+      b.y0[t] = y[idx];
+      b.y1[t] = 0.0f;
+    } else {
+      const float v = y[idx & (LD - 1)];
+      b.y0[t] = idx < LD ? v : 0.0f;
+      b.y1[t] = 0.0f;
+    }
   }
 }
+// TAIL: the last batch of a row stops at the row's last step; full batches run straight through
+template <int LD, bool TAIL>
 __device__ __forceinline__ void gram_mfma_batch(GramAcc& g, const GramBatch& b, int q, int len) {
 #pragma unroll
   for (int t = 0; t < GB; t++) {
-    if (q * (2 * GB) + 2 * t < len) {   // wave-uniform
-      const float a0 = b.w[t] * b.y0[t], a1 = b.w[t] * b.y1[t];
-      g.t[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b.y0[t], g.t[0][0], 0, 0, 0);
-      g.t[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b.y1[t], g.t[0][1], 0, 0, 0);
-      g.t[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b.y0[t], g.t[1][0], 0, 0, 0);
-      g.t[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b.y1[t], g.t[1][1], 0, 0, 0);
-      g.b0 = __builtin_fmaf(b.wr[t], b.y0[t], g.b0);
-      g.b1 = __builtin_fmaf(b.wr[t], b.y1[t], g.b1);
+    if (!TAIL || q * (2 * GB) + 2 * t < len) {   // wave-uniform
+      // ratings <= 0 are skipped (modelMF.cpp:819,857): their row enters as zeros
+      const bool use = b.r[t] > 0.0f;
+      f32x2 a = {use ? b.y0[t] : 0.0f, LD > 32 && use ? b.y1[t] : 0.0f};
+      g.t[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b.y0[t], g.t[0][0], 0, 0, 0);
+      if (LD > 32) {
+        g.t[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b.y1[t], g.t[0][1], 0, 0, 0);
+        g.t[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b.y0[t], g.t[1][0], 0, 0, 0);
+        g.t[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b.y1[t], g.t[1][1], 0, 0, 0);
+        const f32x2 rr = {b.r[t], b.r[t]}, bb = {g.b0, g.b1};
+        const f32x2 nb = __builtin_elementwise_fma(rr, a, bb);
+        g.b0 = nb[0];
+        g.b1 = nb[1];
+      } else {
+        g.b0 = __builtin_fmaf(b.r[t], a[0], g.b0);
+      }
     }
   }
 }
 
+template <int LD, bool BIG>
 __device__ __forceinline__ void gram_accumulate(GramAcc& g, const float* __restrict__ Y,
                                                 const int32_t* __restrict__ ind,
                                                 const float* __restrict__ val, int64_t beg, int64_t end,
-                                                int lane, int ld) {
+                                                int lane) {
   if (end <= beg) return;
   const int len = (int)(end - beg);                 // a segment is at most SEG ratings
   const int nbatch = (len + 2 * GB - 1) / (2 * GB);
@@ -122,24 +152,26 @@ __device__ __forceinline__ void gram_accumulate(GramAcc& g, const float* __restr
     }
   };
   GramBatch ba, bb;
-  gram_load_batch(ba, 0, len, mj, mr, Y, lane, ld);
-  for (int q = 0; q < nbatch; q += 2) {
-    if (q + 1 < nbatch) {
-      advance(q + 1);
-      gram_load_batch(bb, q + 1, len, mj, mr, Y, lane, ld);
-    }
-    gram_mfma_batch(g, ba, q, len);
-    if (q + 1 < nbatch) {
-      if (q + 2 < nbatch) {
-        advance(q + 2);
-        gram_load_batch(ba, q + 2, len, mj, mr, Y, lane, ld);
-      }
-      gram_mfma_batch(g, bb, q + 1, len);
-    }
+  gram_load_batch<LD, BIG>(ba, 0, mj, mr, Y, lane);
+  int q = 0;
+  for (; q + 2 < nbatch; q += 2) {      // two full batches per turn, the loads one batch ahead of the MFMAs
+    advance(q + 1);
+    gram_load_batch<LD, BIG>(bb, q + 1, mj, mr, Y, lane);
+    gram_mfma_batch<LD, false>(g, ba, q, len);
+    advance(q + 2);
+    gram_load_batch<LD, BIG>(ba, q + 2, mj, mr, Y, lane);
+    gram_mfma_batch<LD, false>(g, bb, q + 1, len);
+  }
+  if (q + 1 < nbatch) {                 // two batches left: a full one and the tail
+    advance(q + 1);
+    gram_load_batch<LD, BIG>(bb, q + 1, mj, mr, Y, lane);
+    gram_mfma_batch<LD, false>(g, ba, q, len);
+    gram_mfma_batch<LD, true>(g, bb, q + 1, len);
+  } else {
+    gram_mfma_batch<LD, true>(g, ba, q, len);
   }
 }
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Turn the tile layout into "lane i owns row i", add reg, solve, return x_i in lane i.
 __device__ __forceinline__ float gram_solve(const GramAcc& g, int K, float reg, int lane) {
@@ -229,7 +261,7 @@ __device__ __forceinline__ void gram_add(GramAcc& g, const float* o) {
 
 // SOLVE 1: solve single-segment rows in place; 0: timing probe; 2 (sharded item sweep): emit every row's
 // accumulators to grow[row] for the all-reduce over the ranks
-template <int SOLVE>
+template <int SOLVE, int LD, bool BIG>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void als_segment_kernel(const int32_t* __restrict__ seg_row,
                                                          const int64_t* __restrict__ seg_beg,
                                                          const int64_t* __restrict__ seg_end,
@@ -243,7 +275,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   for (int64_t s = blockIdx.x; s < nseg; s += gridDim.x) {
     GramAcc g;
     gram_zero(g);
-    gram_accumulate(g, Y, ind, val, seg_beg[s], seg_end[s], lane, ld);
+    gram_accumulate<LD, BIG>(g, Y, ind, val, seg_beg[s], seg_end[s], lane);
     const int slab = seg_slab[s];
     if (slab < 0) {
       if (SOLVE == 2) {
@@ -375,6 +407,32 @@ int mfx_get_segments(mfx_ctx* ctx, int side, RowSegs** out) {
   return MFX_OK;
 }
 
+// one launch of the accumulation kernel for the context's row stride
+template <int SOLVE>
+static int launch_segments(mfx_ctx* ctx, const RowSegs& sd, const int32_t* ind, const float* val, const float* Y, int64_t yrows,
+                           float* X, float reg, float* grow) {
+  const int blocks = (int)std::min<int64_t>(sd.nseg, 256 * 16);
+  const bool big = yrows * ctx->ld * (int64_t)sizeof(float) >= ((int64_t)1 << 32);   // gathered table of 4 GB or more
+#define MFX_ALS_LAUNCH1(LDV, BIGV)                                                                                              \
+  hipLaunchKernelGGL((als_segment_kernel<SOLVE, LDV, BIGV>), dim3(blocks), dim3(64), 0, ctx->stream, sd.seg_row, sd.seg_beg,     \
+                     sd.seg_end, sd.seg_slab, sd.nseg, ind, val, Y, X, ctx->als_slabs, ctx->K, ctx->ld, reg, grow)
+#define MFX_ALS_LAUNCH(LDV)                                \
+  do {                                                     \
+    if (big) MFX_ALS_LAUNCH1(LDV, true);                   \
+    else MFX_ALS_LAUNCH1(LDV, false);                      \
+  } while (0)
+  switch (ctx->ld) {
+    case 16: MFX_ALS_LAUNCH(16); break;
+    case 32: MFX_ALS_LAUNCH(32); break;
+    case 64: MFX_ALS_LAUNCH(64); break;
+    default: return mfx_fail(ctx, MFX_E_STATE, "ALS (K <= 64): unexpected row stride %d", ctx->ld);
+  }
+#undef MFX_ALS_LAUNCH
+#undef MFX_ALS_LAUNCH1
+  HIPCHK(hipGetLastError());
+  return MFX_OK;
+}
+
 extern "C" int mfx_als_half_sweep(mfx_ctx* ctx, int side, float reg) {
   if (!ctx) return MFX_E_ARG;
   NEED(side == MFX_SIDE_USERS || side == MFX_SIDE_ITEMS, MFX_E_ARG, "mfx_als_half_sweep: side=%d", side);
@@ -399,6 +457,7 @@ extern "C" int mfx_als_half_sweep(mfx_ctx* ctx, int side, float reg) {
   const float* val = side == MFX_SIDE_USERS ? m.rowval : m.colval;
   const float* Y = side == MFX_SIDE_USERS ? ctx->V : ctx->U;
   float* X = side == MFX_SIDE_USERS ? ctx->U : ctx->V;
+  const int64_t yrows = side == MFX_SIDE_USERS ? ctx->nI : ctx->nU;
   if (side == MFX_SIDE_ITEMS && mfx_sharded(ctx)) {
     // An item's users live on several ranks (user-block sharding): every rank accumulates (A, b) over ITS users,
     // the accumulators are summed over the ranks, and every rank solves every item (V stays replicated).
@@ -410,10 +469,7 @@ extern "C" int mfx_als_half_sweep(mfx_ctx* ctx, int side, float reg) {
     HIPCHK(hipMemsetAsync(ctx->als_global, 0, gn * sizeof(float), ctx->stream));
     if (sd.nseg > 0) {
       ProfScope ps(ctx, MFX_K_ALS_GRAM);
-      hipLaunchKernelGGL(als_segment_kernel<2>, dim3((int)std::min<int64_t>(sd.nseg, 256 * 16)), dim3(64), 0, ctx->stream,
-                         sd.seg_row, sd.seg_beg, sd.seg_end, sd.seg_slab, sd.nseg, ind, val, Y, X, ctx->als_slabs, ctx->K,
-                         ctx->ld, reg, ctx->als_global);
-      HIPCHK(hipGetLastError());
+      if ((rc = launch_segments<2>(ctx, sd, ind, val, Y, yrows, X, reg, ctx->als_global))) return rc;
     }
     if (sd.nmrow > 0) {
       hipLaunchKernelGGL(als_reduce_kernel<true>, dim3((int)std::min<int64_t>(sd.nmrow, 256 * 16)), dim3(64), 0, ctx->stream,
@@ -431,15 +487,9 @@ extern "C" int mfx_als_half_sweep(mfx_ctx* ctx, int side, float reg) {
   }
   if (sd.nseg > 0) {
     ProfScope ps(ctx, MFX_K_ALS_GRAM);
-    const int blocks = (int)std::min<int64_t>(sd.nseg, 256 * 16);
     static const bool nosolve = getenv("MFX_ALS_NOSOLVE") != nullptr;   // timing probe only
-    if (nosolve)
-      hipLaunchKernelGGL(als_segment_kernel<0>, dim3(blocks), dim3(64), 0, ctx->stream, sd.seg_row, sd.seg_beg,
-                         sd.seg_end, sd.seg_slab, sd.nseg, ind, val, Y, X, ctx->als_slabs, ctx->K, ctx->ld, reg, (float*)nullptr);
-    else
-      hipLaunchKernelGGL(als_segment_kernel<1>, dim3(blocks), dim3(64), 0, ctx->stream, sd.seg_row, sd.seg_beg,
-                         sd.seg_end, sd.seg_slab, sd.nseg, ind, val, Y, X, ctx->als_slabs, ctx->K, ctx->ld, reg, (float*)nullptr);
-    HIPCHK(hipGetLastError());
+    int rc = nosolve ? launch_segments<0>(ctx, sd, ind, val, Y, yrows, X, reg, nullptr) : launch_segments<1>(ctx, sd, ind, val, Y, yrows, X, reg, nullptr);
+    if (rc) return rc;
   }
   if (sd.nmrow > 0) {
     ProfScope ps(ctx, MFX_K_ALS_SOLVE);
