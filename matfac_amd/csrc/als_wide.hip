@@ -47,10 +47,116 @@ void mfx_als_wide_free_internal(mfx_ctx* ctx) {
 // ---------------------------------------------------------------------------
 // phase A
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void alsw_gram_kernel(const int64_t* __restrict__ seg_beg, const int64_t* __restrict__ seg_end,
-                                                       int64_t seg0, int64_t nseg, int npairs, const int32_t* __restrict__ ind,
-                                                       const float* __restrict__ val, const float* __restrict__ Y, int ld,
-                                                       float* __restrict__ slabs, int64_t stride) {
+// The accumulation is the software-pipelined loop of als.hip (gram_accumulate): batches of WB steps, the gathered
+// loads of batch q+1 in flight while the MFMAs of batch q run, no load behind a lane predicate, 32-bit row offsets
+// unless the table is 4 GB or more (BIG).  DIAG: a == b (pairs on the block diagonal), half the loads, and the
+// right-hand side rides along.
+namespace {
+constexpr int WB = 8;
+struct WideBatch {
+  float a0[WB], a1[WB], b0[WB], b1[WB], r[WB];
+};
+struct WideAcc {
+  f32x16 t00, t01, t10, t11;
+  float b0, b1;
+};
+}  // namespace
+
+template <bool DIAG, bool BIG>
+__device__ __forceinline__ void alsw_load_batch(WideBatch& w, int q, int mj, float mr, const float* __restrict__ Y, int ldbytes, int oa,
+                                                int ob, int lane) {
+  const int half = lane >> 5, idx = lane & 31;
+  int j[WB];
+#pragma unroll
+  for (int t = 0; t < WB; t++) {
+    const int src = (q * (2 * WB) + 2 * t + half) & 63;
+    j[t] = __shfl(mj, src, 64);
+    w.r[t] = __shfl(mr, src, 64);
+  }
+#pragma unroll
+  for (int t = 0; t < WB; t++) {
+    const float* y;
+    if (BIG) y = (const float*)((const char*)Y + (uint64_t)(uint32_t)j[t] * (uint32_t)ldbytes);
+    else y = (const float*)((const char*)Y + (uint32_t)((uint32_t)j[t] * (uint32_t)ldbytes));
+    w.a0[t] = y[oa + idx];
+    w.a1[t] = y[oa + 32 + idx];
+    if (!DIAG) {
+      w.b0[t] = y[ob + idx];
+      w.b1[t] = y[ob + 32 + idx];
+    }
+  }
+}
+template <bool DIAG, bool TAIL>
+__device__ __forceinline__ void alsw_mfma_batch(WideAcc& g, const WideBatch& w, int q, int len) {
+#pragma unroll
+  for (int t = 0; t < WB; t++) {
+    if (!TAIL || q * (2 * WB) + 2 * t < len) {   // wave-uniform
+      const bool use = w.r[t] > 0.0f;              // ratings <= 0 are skipped (modelMF.cpp:819,857)
+      const float a0 = use ? w.a0[t] : 0.0f, a1 = use ? w.a1[t] : 0.0f;
+      const float y0 = DIAG ? w.a0[t] : w.b0[t], y1 = DIAG ? w.a1[t] : w.b1[t];
+      g.t00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, y0, g.t00, 0, 0, 0);
+      g.t01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, y1, g.t01, 0, 0, 0);
+      g.t10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, y0, g.t10, 0, 0, 0);
+      g.t11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, y1, g.t11, 0, 0, 0);
+      if (DIAG) {
+        g.b0 = __builtin_fmaf(w.r[t], a0, g.b0);
+        g.b1 = __builtin_fmaf(w.r[t], a1, g.b1);
+      }
+    }
+  }
+}
+template <bool DIAG, bool BIG>
+__device__ __forceinline__ void alsw_accumulate(WideAcc& g, const float* __restrict__ Y, const int32_t* __restrict__ ind,
+                                                const float* __restrict__ val, int64_t beg, int64_t end, int ldbytes, int oa, int ob,
+                                                int lane) {
+  if (end <= beg) return;
+  const int len = (int)(end - beg);
+  const int nbatch = (len + 2 * WB - 1) / (2 * WB);
+  int mj, mjn;
+  float mr, mrn;
+  {
+    const bool ok = lane < len, ok2 = 64 + lane < len;
+    mj = ok ? ind[beg + lane] : 0;
+    mr = ok ? val[beg + lane] : 0.0f;
+    mjn = ok2 ? ind[beg + 64 + lane] : 0;
+    mrn = ok2 ? val[beg + 64 + lane] : 0.0f;
+  }
+  auto advance = [&](int p) {
+    if ((p & 3) == 0) {
+      mj = mjn;
+      mr = mrn;
+      const int64_t off = (int64_t)(p / 4 + 1) * 64 + lane;
+      const bool ok = off < len;
+      mjn = ok ? ind[beg + off] : 0;
+      mrn = ok ? val[beg + off] : 0.0f;
+    }
+  };
+  WideBatch wa, wb;
+  alsw_load_batch<DIAG, BIG>(wa, 0, mj, mr, Y, ldbytes, oa, ob, lane);
+  int q = 0;
+  for (; q + 2 < nbatch; q += 2) {
+    advance(q + 1);
+    alsw_load_batch<DIAG, BIG>(wb, q + 1, mj, mr, Y, ldbytes, oa, ob, lane);
+    alsw_mfma_batch<DIAG, false>(g, wa, q, len);
+    advance(q + 2);
+    alsw_load_batch<DIAG, BIG>(wa, q + 2, mj, mr, Y, ldbytes, oa, ob, lane);
+    alsw_mfma_batch<DIAG, false>(g, wb, q + 1, len);
+  }
+  if (q + 1 < nbatch) {
+    advance(q + 1);
+    alsw_load_batch<DIAG, BIG>(wb, q + 1, mj, mr, Y, ldbytes, oa, ob, lane);
+    alsw_mfma_batch<DIAG, false>(g, wa, q, len);
+    alsw_mfma_batch<DIAG, true>(g, wb, q + 1, len);
+  } else {
+    alsw_mfma_batch<DIAG, true>(g, wa, q, len);
+  }
+}
+
+template <bool BIG>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void alsw_gram_kernel(
+    const int64_t* __restrict__ seg_beg, const int64_t* __restrict__ seg_end, int64_t seg0, int64_t nseg, int npairs,
+    const int32_t* __restrict__ ind, const float* __restrict__ val, const float* __restrict__ Y, int ld, float* __restrict__ slabs,
+    int64_t stride) {
   const int lane = threadIdx.x, half = lane >> 5, idx = lane & 31;
   for (int64_t u = blockIdx.x; u < nseg * npairs; u += gridDim.x) {
     const int64_t s = u / npairs;
@@ -58,58 +164,23 @@ __global__ __launch_bounds__(64) void alsw_gram_kernel(const int64_t* __restrict
     int I = 0;
     while ((I + 1) * (I + 2) / 2 <= p) I++;
     const int J = p - I * (I + 1) / 2;
-    const int oa = 64 * I, ob = 64 * J;
-    f32x16 t00, t01, t10, t11;
+    WideAcc g;
 #pragma unroll
-    for (int r = 0; r < 16; r++) { t00[r] = 0.0f; t01[r] = 0.0f; t10[r] = 0.0f; t11[r] = 0.0f; }
-    float b0 = 0.0f, b1 = 0.0f;
+    for (int r = 0; r < 16; r++) { g.t00[r] = 0.0f; g.t01[r] = 0.0f; g.t10[r] = 0.0f; g.t11[r] = 0.0f; }
+    g.b0 = g.b1 = 0.0f;
     const int64_t beg = seg_beg[seg0 + s], end = seg_end[seg0 + s];
-    for (int64_t base = beg; base < end; base += 64) {
-      const bool ok = base + lane < end;
-      const int mj = ok ? ind[base + lane] : 0;
-      const float mr = ok ? val[base + lane] : 0.0f;
-      const int n = (int)(end - base < 64 ? end - base : 64);
-      constexpr int B = 4;
-      for (int s0 = 0; s0 < n; s0 += 2 * B) {
-        float ya0[B], ya1[B], yb0[B], yb1[B], wr[B], w[B];
-#pragma unroll
-        for (int t = 0; t < B; t++) {
-          const int e = s0 + 2 * t + half;
-          const int j = __shfl(mj, e & 63, 64);
-          const float r = __shfl(mr, e & 63, 64);
-          const bool use = e < n && r > 0.0f;          // ratings <= 0 are skipped (modelMF.cpp:819,857)
-          w[t] = use ? 1.0f : 0.0f;
-          wr[t] = use ? r : 0.0f;
-          const float* y = Y + (int64_t)(e < n ? j : 0) * ld;
-          ya0[t] = y[oa + idx];
-          ya1[t] = y[oa + 32 + idx];
-          yb0[t] = y[ob + idx];
-          yb1[t] = y[ob + 32 + idx];
-        }
-#pragma unroll
-        for (int t = 0; t < B; t++) {
-          if (s0 + 2 * t < n) {   // wave-uniform
-            const float a0 = w[t] * ya0[t], a1 = w[t] * ya1[t];
-            t00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, yb0[t], t00, 0, 0, 0);
-            t01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, yb1[t], t01, 0, 0, 0);
-            t10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, yb0[t], t10, 0, 0, 0);
-            t11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, yb1[t], t11, 0, 0, 0);
-            b0 = __builtin_fmaf(wr[t], ya0[t], b0);
-            b1 = __builtin_fmaf(wr[t], ya1[t], b1);
-          }
-        }
-      }
-    }
+    if (I == J) alsw_accumulate<true, BIG>(g, Y, ind, val, beg, end, ld * (int)sizeof(float), 64 * I, 64 * J, lane);
+    else alsw_accumulate<false, BIG>(g, Y, ind, val, beg, end, ld * (int)sizeof(float), 64 * I, 64 * J, lane);
     float* o = slabs + s * stride + (int64_t)p * BLK + lane;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-      o[(0 * 16 + r) * 64] = t00[r];
-      o[(1 * 16 + r) * 64] = t01[r];
-      o[(2 * 16 + r) * 64] = t10[r];
-      o[(3 * 16 + r) * 64] = t11[r];
+      o[(0 * 16 + r) * 64] = g.t00[r];
+      o[(1 * 16 + r) * 64] = g.t01[r];
+      o[(2 * 16 + r) * 64] = g.t10[r];
+      o[(3 * 16 + r) * 64] = g.t11[r];
     }
     if (I == J) {   // right-hand side of block I: even + odd rating halves
-      const float s0 = b0 + __shfl_xor(b0, 32, 64), s1 = b1 + __shfl_xor(b1, 32, 64);
+      const float s0 = g.b0 + __shfl_xor(g.b0, 32, 64), s1 = g.b1 + __shfl_xor(g.b1, 32, 64);
       float* ob_ = slabs + s * stride + (int64_t)npairs * BLK + 64 * I;
       if (half == 0) { ob_[idx] = s0; ob_[32 + idx] = s1; }
     }
@@ -342,8 +413,13 @@ int mfx_als_wide_half_sweep(mfx_ctx* ctx, int side, float reg) {
     {
       ProfScope ps(ctx, MFX_K_ALS_GRAM);
       const int blocks = (int)std::min<int64_t>(ns * npairs, 256 * 32);
-      hipLaunchKernelGGL(alsw_gram_kernel, dim3(blocks), dim3(64), 0, ctx->stream, sdp->seg_beg, sdp->seg_end, s0, ns, npairs, ind, val,
-                         Y, ctx->ld, st->slabs, stride);
+      const int64_t yrows = side == MFX_SIDE_USERS ? ctx->nI : ctx->nU;
+      if (yrows * ctx->ld * (int64_t)sizeof(float) >= ((int64_t)1 << 32))
+        hipLaunchKernelGGL(alsw_gram_kernel<true>, dim3(blocks), dim3(64), 0, ctx->stream, sdp->seg_beg, sdp->seg_end, s0, ns, npairs, ind,
+                           val, Y, ctx->ld, st->slabs, stride);
+      else
+        hipLaunchKernelGGL(alsw_gram_kernel<false>, dim3(blocks), dim3(64), 0, ctx->stream, sdp->seg_beg, sdp->seg_end, s0, ns, npairs, ind,
+                           val, Y, ctx->ld, st->slabs, stride);
       HIPCHK(hipGetLastError());
     }
     {
