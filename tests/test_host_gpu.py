@@ -245,11 +245,13 @@ def test_tmf_dropout_loop_is_bit_exact_in_list_order():
 @pytest.mark.parametrize("method", ["sgd", "hogsgd", "sgdpar", "sgdu"])
 def test_fast_sgd_paths_reach_the_reference_rmse(method):
     d, K = data(3000, 2000, 300000, seed=2), 16
-    h = host_train(method, d, K, 40, 1, 0.01, 0.02, 0.02)
-    o = oracle_train(orc.M_SGD, d, K, 40, 1, 0.01, 0.02, 0.02)
+    h = host_train(method, d, K, 120, 1, 0.01, 0.02, 0.02)
+    o = oracle_train(orc.M_SGD, d, K, 120, 1, 0.01, 0.02, 0.02)
     print(method, "test RMSE gpu %.5f cpu %.5f | val gpu %.5f cpu %.5f" % (h["test"], o["test"], h["val"], o["valbest"]))
-    # lock-free: the result moves by ~5e-3 from run to run around a ~2e-2 gap (scripts/hog_variance.py)
-    assert abs(h["test"] - o["test"]) < 4e-2
+    # Lock-free: after 120 iterations the best-validation models agree to -0.006..-0.002 over repeated runs
+    # (scripts/sgd_gap_variance.py).  At 40 iterations the gap is still 0.017-0.019 and a first-epoch NaN (racing updates
+    # at this learning rate on a 3000 x 2000 matrix; the reference's guard halves the rate) can double it.
+    assert abs(h["test"] - o["test"]) < 1.5e-2
 
 
 def test_mf_cli_end_to_end(tmp_path):
