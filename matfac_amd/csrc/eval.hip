@@ -64,7 +64,11 @@ __device__ __forceinline__ float row_dot_trunc(const float* __restrict__ a, cons
   return group_sum<L>(s);
 }
 
-template <int L, int C, bool TMF>
+// MASKS = false when no user and no item is invalid (the usual case): the two mask bytes per rating are not fetched.
+// Four ratings per group are in flight at a time: their indices are clamped instead of branched on, so the row loads
+// of all four are issued before the first dot product (the loop was a chain of dependent L2 round trips).  The sums
+// are accumulated per lane in the same rating order as before.
+template <int L, int C, bool TMF, bool MASKS>
 __global__ __launch_bounds__(256) void eval_sse_kernel(const int32_t* __restrict__ ru,
                                                        const int32_t* __restrict__ ri,
                                                        const float* __restrict__ rr, int64_t n,
@@ -75,6 +79,7 @@ __global__ __launch_bounds__(256) void eval_sse_kernel(const int32_t* __restrict
                                                        const int2* __restrict__ tu, const int2* __restrict__ ti) {
   constexpr int G = 64 / L;
   constexpr int LD = 4 * L * C;
+  constexpr int UN = 4;                      // L is 4, 8 or 16
   __shared__ double shd[4];
   __shared__ long long shi[4];
   const int lane = threadIdx.x & 63;
@@ -90,25 +95,37 @@ __global__ __launch_bounds__(256) void eval_sse_kernel(const int32_t* __restrict
     const float mr = ok ? rr[base + lane] : 0.0f;
     const int nvalid = (int)(n - base < 64 ? n - base : 64);
 #pragma unroll 1
-    for (int s = 0; s < L; s++) {
-      const int e = s * G + g;
-      const int u = __shfl(mu, e, 64);
-      const int it = __shfl(mi, e, 64);
-      const float r = __shfl(mr, e, 64);
-      // Model::RMSE: u < nUsers, user valid, item < nItems and valid (model.cpp:223-237)
-      bool use = e < nvalid && u < nU && it < nI;
-      if (use) use = !invU[u] && !invI[it];
-      if (use) {
-        float est;
+    for (int s0 = 0; s0 < L; s0 += UN) {
+      int u[UN], it[UN];
+      float r[UN], est[UN];
+      bool use[UN];
+#pragma unroll
+      for (int x = 0; x < UN; x++) {
+        const int e = (s0 + x) * G + g;
+        u[x] = __shfl(mu, e, 64);
+        it[x] = __shfl(mi, e, 64);
+        r[x] = __shfl(mr, e, 64);
+        // Model::RMSE: u < nUsers, user valid, item < nItems and valid (model.cpp:223-237)
+        use[x] = e < nvalid && u[x] < nU && it[x] < nI;
+        if (!use[x]) { u[x] = 0; it[x] = 0; }
+      }
+      if (MASKS) {
+#pragma unroll
+        for (int x = 0; x < UN; x++) use[x] = use[x] && !invU[u[x]] && !invI[it[x]];
+      }
+#pragma unroll
+      for (int x = 0; x < UN; x++) {
         if (TMF) {
-          const int2 a = tu[u], b = ti[it];
-          est = row_dot_trunc<L, C>(U + (int64_t)u * LD + 4 * j, V + (int64_t)it * LD + 4 * j, j,
-                                    mfx_tmf_rank(a, b));
+          const int2 a = tu[u[x]], b = ti[it[x]];
+          est[x] = row_dot_trunc<L, C>(U + (int64_t)u[x] * LD + 4 * j, V + (int64_t)it[x] * LD + 4 * j, j, mfx_tmf_rank(a, b));
         } else {
-          est = row_dot<L, C>(U + (int64_t)u * LD + 4 * j, V + (int64_t)it * LD + 4 * j);
+          est[x] = row_dot<L, C>(U + (int64_t)u[x] * LD + 4 * j, V + (int64_t)it[x] * LD + 4 * j);
         }
-        const double diff = (double)r - (double)est;
-        if (j == 0) { acc += diff * diff; cnt++; }
+      }
+#pragma unroll
+      for (int x = 0; x < UN; x++) {
+        const double diff = (double)r[x] - (double)est[x];
+        if (use[x] && j == 0) { acc += diff * diff; cnt++; }
       }
     }
   }
@@ -188,13 +205,17 @@ static int eval_lc(mfx_ctx* ctx, const DevCSR& m, const float* U, const float* V
                    int nbu, int nbi) {
   ProfScope ps(ctx, MFX_K_EVAL);
   double* pd = ctx->red_d;
-  if (ctx->tmf_u)
-    hipLaunchKernelGGL((eval_sse_kernel<L, C, true>), dim3(nb), dim3(256), 0, ctx->stream, m.rowid, m.rowind, m.rowval,
-                       m.nnz, U, V, ctx->invU, ctx->invI, ctx->nU, ctx->nI, pd, ctx->red_i, ctx->tmf_u, ctx->tmf_i);
-  else
-    hipLaunchKernelGGL((eval_sse_kernel<L, C, false>), dim3(nb), dim3(256), 0, ctx->stream, m.rowid, m.rowind, m.rowval,
-                       m.nnz, U, V, ctx->invU, ctx->invI, ctx->nU, ctx->nI, pd, ctx->red_i, (const int2*)nullptr,
-                       (const int2*)nullptr);
+  // the mask bytes are needed when something is invalid, or while mfx_eval_filtered has its own masks in place
+  const bool masks = ctx->n_invalid != 0 || ctx->force_masks;
+#define MFX_EVAL_SSE(TMFV, MASKV)                                                                                              \
+  hipLaunchKernelGGL((eval_sse_kernel<L, C, TMFV, MASKV>), dim3(nb), dim3(256), 0, ctx->stream, m.rowid, m.rowind, m.rowval, m.nnz, \
+                     U, V, ctx->invU, ctx->invI, ctx->nU, ctx->nI, pd, ctx->red_i, ctx->tmf_u, ctx->tmf_i)
+  if (ctx->tmf_u) {
+    if (masks) MFX_EVAL_SSE(true, true); else MFX_EVAL_SSE(true, false);
+  } else {
+    if (masks) MFX_EVAL_SSE(false, true); else MFX_EVAL_SSE(false, false);
+  }
+#undef MFX_EVAL_SSE
   if (with_norms) {
     hipLaunchKernelGGL((eval_norm_kernel<L, C>), dim3(nbu), dim3(256), 0, ctx->stream, U, ctx->nU, ctx->invU,
                        pd + nb);

@@ -92,6 +92,7 @@ static void free_model(mfx_ctx* ctx) {
   dev_free(ctx->U); dev_free(ctx->V); dev_free(ctx->Ubest); dev_free(ctx->Vbest);
   dev_free(ctx->Vsync); dev_free(ctx->invU); dev_free(ctx->invI);
   ctx->have_invalid = false;
+  ctx->n_invalid = -1;
 }
 
 void mfx_destroy(mfx_ctx* ctx) {
@@ -199,7 +200,7 @@ extern "C" int mfx_set_csr(mfx_ctx* ctx, int which, int32_t nrows, int32_t ncols
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));  // host buffers are borrowed for this call only
   m.present = true;
-  if (which == MFX_MAT_TRAIN) ctx->have_invalid = false;
+  if (which == MFX_MAT_TRAIN) { ctx->have_invalid = false; ctx->n_invalid = -1; }
   return MFX_OK;
 }
 
@@ -339,6 +340,13 @@ __global__ void invalid_items_global_kernel(const double* __restrict__ gcol, int
   if (t < n) inv[t] = (t >= ncols) || (gcol[t] == 0.0);
 }
 
+// number of set bytes, added to *out (the evaluation skips its mask loads when nothing is invalid)
+__global__ void mask_count_kernel(const uint8_t* __restrict__ inv, int32_t n, unsigned long long* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long b = __ballot(t < n && inv[t] != 0);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(out, (unsigned long long)__popcll(b));
+}
+
 extern "C" int mfx_compute_invalid(mfx_ctx* ctx, uint8_t* invalidUsers, uint8_t* invalidItems) {
   if (!ctx) return MFX_E_ARG;
   const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
@@ -358,9 +366,20 @@ extern "C" int mfx_compute_invalid(mfx_ctx* ctx, uint8_t* invalidUsers, uint8_t*
                        m.colptr, m.ncols, ctx->nI, ctx->invI);
   }
   HIPCHK(hipGetLastError());
+  ctx->n_invalid = -1;
+  unsigned long long* dcount = nullptr;
+  int rcnt = dev_alloc(ctx, &dcount, (size_t)1);
+  if (rcnt) return rcnt;
+  HIPCHK(hipMemsetAsync(dcount, 0, sizeof(unsigned long long), ctx->stream));
+  hipLaunchKernelGGL(mask_count_kernel, dim3((ctx->nU + 255) / 256), dim3(256), 0, ctx->stream, ctx->invU, ctx->nU, dcount);
+  hipLaunchKernelGGL(mask_count_kernel, dim3((ctx->nI + 255) / 256), dim3(256), 0, ctx->stream, ctx->invI, ctx->nI, dcount);
+  unsigned long long hcount = 0;
+  HIPCHK(hipMemcpyAsync(&hcount, dcount, sizeof(hcount), hipMemcpyDeviceToHost, ctx->stream));
   if (invalidUsers) HIPCHK(hipMemcpyAsync(invalidUsers, ctx->invU, (size_t)ctx->nU, hipMemcpyDeviceToHost, ctx->stream));
   if (invalidItems) HIPCHK(hipMemcpyAsync(invalidItems, ctx->invI, (size_t)ctx->nI, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  dev_free(dcount);
+  ctx->n_invalid = (int64_t)hcount;
   ctx->have_invalid = true;
   return MFX_OK;
 }
@@ -603,7 +622,9 @@ extern "C" int mfx_eval_filtered(mfx_ctx* ctx, int which, int snapshot, const ui
   if (!rc) {
     if (mu) ctx->invU = mu;
     if (mi) ctx->invI = mi;
+    ctx->force_masks = true;
     rc = mfx_launch_eval(ctx, ctx->mat[which], snapshot ? ctx->Ubest : ctx->U, snapshot ? ctx->Vbest : ctx->V, 0, out);
+    ctx->force_masks = false;
     ctx->invU = saveU;
     ctx->invI = saveI;
   }

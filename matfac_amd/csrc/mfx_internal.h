@@ -59,6 +59,8 @@ struct mfx_ctx {
   float *U = nullptr, *V = nullptr, *Ubest = nullptr, *Vbest = nullptr, *Vsync = nullptr;
   uint8_t *invU = nullptr, *invI = nullptr;
   bool have_invalid = false;
+  int64_t n_invalid = -1;        // invalid users + items after mfx_compute_invalid (-1: unknown, treated as some)
+  bool force_masks = false;      // mfx_eval_filtered has swapped its own masks in
 
   // epoch rating list (visiting order) and host-provided permutation
   int32_t *eu = nullptr, *ei = nullptr;
