@@ -22,6 +22,8 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int GT_STRIDE = 36;   // row stride of the transposition tile in LDS (floats): 16-byte aligned rows, banks staggered
 
 namespace {
 constexpr int SLAB = 66 * 64;     // floats per partial: 4 tiles x 16 regs + 2 rhs, per lane
@@ -107,8 +109,9 @@ __device__ __forceinline__ void gram_mfma_batch(GramAcc& g, const GramBatch& b, 
       f32x2 a = {use ? b.y0[t] : 0.0f, LD > 32 && use ? b.y1[t] : 0.0f};
       g.t[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b.y0[t], g.t[0][0], 0, 0, 0);
       if (LD > 32) {
+        // the lower-left tile would be the bit-identical mirror of the upper-right one (same products, same order):
+        // it is not accumulated; gram_solve reads it out of t[0][1] transposed
         g.t[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b.y1[t], g.t[0][1], 0, 0, 0);
-        g.t[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b.y0[t], g.t[1][0], 0, 0, 0);
         g.t[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b.y1[t], g.t[1][1], 0, 0, 0);
         const f32x2 rr = {b.r[t], b.r[t]}, bb = {g.b0, g.b1};
         const f32x2 nb = __builtin_elementwise_fma(rr, a, bb);
@@ -174,7 +177,7 @@ __device__ __forceinline__ void gram_accumulate(GramAcc& g, const float* __restr
 
 
 // Turn the tile layout into "lane i owns row i", add reg, solve, return x_i in lane i.
-__device__ __forceinline__ float gram_solve(const GramAcc& g, int K, float reg, int lane) {
+__device__ __forceinline__ float gram_solve(const GramAcc& g, int K, float reg, int lane, float* tr) {
   // a[2p], a[2p+1] = A(lane, 2p), A(lane, 2p+1): pairs, so that the trailing update is one packed fma per two columns
   f32x2 a[32];
   // Of columns c and 32+c (c = l&31) lane l holds the rows whose bit 2 equals l>>5, its partner l^32 the others.
@@ -183,17 +186,40 @@ __device__ __forceinline__ float gram_solve(const GramAcc& g, int K, float reg, 
   // (inline asm: the compiler's own handling of the builtin merged most of the 33 swaps of this function into three.
   //  The accumulators were written by MFMAs and asm operands are invisible to the hazard recogniser, hence the nops:
   //  18 wait states cover a 16-pass MFMA result read by a VALU instruction.)
+  // Rows 32..63 of the columns < 32 (the tile that was not accumulated) are the transpose of t[0][1]: it goes through
+  // LDS (tr: 32 rows of GT_STRIDE floats, one wavefront per workgroup) -- element (row, col) of t[0][1] is written at
+  // tr[row][col], lane (h, c) reads row c, columns 8q + 4h .. + 3: the rows 32 + 8q + 4h + e of its own column.
+  {
+    const int h = lane >> 5, c = lane & 31;
+#pragma unroll
+    for (int r = 0; r < 16; r++) tr[((r & 3) + 8 * (r >> 2) + 4 * h) * GT_STRIDE + c] = g.t[0][1][r];
+  }
+  __syncthreads();
+  float tx[16];
+  {
+    const int h = lane >> 5, c = lane & 31;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const f32x4 v = *(const f32x4*)(tr + c * GT_STRIDE + 8 * q + 4 * h);
+      tx[4 * q + 0] = v[0]; tx[4 * q + 1] = v[1]; tx[4 * q + 2] = v[2]; tx[4 * q + 3] = v[3];
+    }
+  }
+  __syncthreads();   // tr is reused by the next row of this workgroup
   asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
 #pragma unroll
-  for (int ti = 0; ti < 2; ti++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int I0 = 32 * ti + (r & 3) + 8 * (r >> 2);   // row with bit 2 clear; I0+4 has it set
-      float lo = g.t[ti][0][r], hi = g.t[ti][1][r];
-      asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
-      a[I0 >> 1][I0 & 1] = lo;
-      a[(I0 + 4) >> 1][I0 & 1] = hi;
-    }
+  for (int r = 0; r < 16; r++) {
+    const int I0 = (r & 3) + 8 * (r >> 2);   // row with bit 2 clear; I0+4 has it set
+    float lo = g.t[0][0][r], hi = g.t[0][1][r];
+    asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+    a[I0 >> 1][I0 & 1] = lo;
+    a[(I0 + 4) >> 1][I0 & 1] = hi;
+    // rows 32 + I0 and 32 + I0 + 4: the lanes of the first 32 columns bring the transposed values (register r of a lane
+    // in the lower half is row 32 + I0 of its column, in the upper half row 32 + I0 + 4 of the partner's), the others t[1][1]
+    float lo2 = tx[r], hi2 = g.t[1][1][r];
+    asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(lo2), "+v"(hi2));
+    a[(32 + I0) >> 1][I0 & 1] = lo2;
+    a[(32 + I0 + 4) >> 1][I0 & 1] = hi2;
+  }
   float z0 = g.b0, z1 = g.b1;
   asm volatile("v_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(z0), "+v"(z1));
   float z = z0 + z1;
@@ -242,9 +268,11 @@ __device__ __forceinline__ void gram_store(const GramAcc& g, float* o) {
 #pragma unroll
   for (int i = 0; i < 2; i++)
 #pragma unroll
-    for (int j = 0; j < 2; j++)
+    for (int j = 0; j < 2; j++) {
+      if (i == 1 && j == 0) continue;   // not accumulated (mirror of tile (0,1)); its slab slot stays unused
 #pragma unroll
       for (int r = 0; r < 16; r++) o[((i * 2 + j) * 16 + r) * 64] = g.t[i][j][r];
+    }
   o[64 * 64] = g.b0;
   o[65 * 64] = g.b1;
 }
@@ -252,9 +280,11 @@ __device__ __forceinline__ void gram_add(GramAcc& g, const float* o) {
 #pragma unroll
   for (int i = 0; i < 2; i++)
 #pragma unroll
-    for (int j = 0; j < 2; j++)
+    for (int j = 0; j < 2; j++) {
+      if (i == 1 && j == 0) continue;
 #pragma unroll
       for (int r = 0; r < 16; r++) g.t[i][j][r] += o[((i * 2 + j) * 16 + r) * 64];
+    }
   g.b0 += o[64 * 64];
   g.b1 += o[65 * 64];
 }
@@ -271,6 +301,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                                                          const float* __restrict__ Y, float* __restrict__ X,
                                                          float* __restrict__ slabs, int K, int ld, float reg,
                                                          float* __restrict__ grow) {
+  __shared__ __attribute__((aligned(16))) float tr[32 * GT_STRIDE];   // gram_solve's transposition tile
   const int lane = threadIdx.x;
   for (int64_t s = blockIdx.x; s < nseg; s += gridDim.x) {
     GramAcc g;
@@ -281,7 +312,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       if (SOLVE == 2) {
         gram_store(g, grow + (int64_t)seg_row[s] * SLAB + lane);
       } else if (SOLVE == 1) {
-        const float x = gram_solve(g, K, reg, lane);
+        const float x = gram_solve(g, K, reg, lane, tr);
         if (lane < K) X[(int64_t)seg_row[s] * ld + lane] = x;
       } else if (lane < K) {   // timing probe (MFX_ALS_NOSOLVE): keep the accumulators alive, skip the solve
         X[(int64_t)seg_row[s] * ld + lane] = g.t[0][0][0] + g.t[0][1][1] + g.t[1][0][2] + g.t[1][1][3] + g.b0 + g.b1;
@@ -298,6 +329,7 @@ __global__ __launch_bounds__(64) void als_reduce_kernel(const int32_t* __restric
                                                         const int32_t* __restrict__ mrow_n, int64_t nmrow,
                                                         const float* __restrict__ slabs, float* __restrict__ X,
                                                         int K, int ld, float reg, float* __restrict__ grow) {
+  __shared__ __attribute__((aligned(16))) float tr[32 * GT_STRIDE];   // gram_solve's transposition tile
   const int lane = threadIdx.x;
   for (int64_t m = blockIdx.x; m < nmrow; m += gridDim.x) {
     GramAcc g;
@@ -306,20 +338,21 @@ __global__ __launch_bounds__(64) void als_reduce_kernel(const int32_t* __restric
     for (int s = 0; s < n; s++)   // fixed segment order: reproducible
       gram_add(g, slabs + (int64_t)(first + s) * SLAB + lane);
     if (EMIT) { gram_store(g, grow + (int64_t)mrow[m] * SLAB + lane); continue; }
-    const float x = gram_solve(g, K, reg, lane);
+    const float x = gram_solve(g, K, reg, lane, tr);
     if (lane < K) X[(int64_t)mrow[m] * ld + lane] = x;
   }
 }
 // sharded item sweep: solve every item some rank has ratings for, from the accumulators summed over the ranks
 __global__ __launch_bounds__(64) void als_global_solve_kernel(const float* __restrict__ grow, const double* __restrict__ gcol,
                                                               int32_t nrows, float* __restrict__ X, int K, int ld, float reg) {
+  __shared__ __attribute__((aligned(16))) float tr[32 * GT_STRIDE];   // gram_solve's transposition tile
   const int lane = threadIdx.x;
   for (int64_t r = blockIdx.x; r < nrows; r += gridDim.x) {
     if (gcol[r] == 0.0) continue;
     GramAcc g;
     gram_zero(g);
     gram_add(g, grow + r * SLAB + lane);
-    const float x = gram_solve(g, K, reg, lane);
+    const float x = gram_solve(g, K, reg, lane, tr);
     if (lane < K) X[r * ld + lane] = x;
   }
 }
