@@ -95,7 +95,7 @@ __device__ __forceinline__ void alsw_mfma_batch(WideAcc& g, const WideBatch& w, 
       const float a0 = use ? w.a0[t] : 0.0f, a1 = use ? w.a1[t] : 0.0f;
       const float y0 = DIAG ? w.a0[t] : w.b0[t], y1 = DIAG ? w.a1[t] : w.b1[t];
       g.t00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, y0, g.t00, 0, 0, 0);
-      g.t01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, y1, g.t01, 0, 0, 0);
+      if (!DIAG) g.t01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, y1, g.t01, 0, 0, 0);   // above the diagonal: never read
       g.t10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, y0, g.t10, 0, 0, 0);
       g.t11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, y1, g.t11, 0, 0, 0);
       if (DIAG) {
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
     for (int r = 0; r < 16; r++) {
       o[(0 * 16 + r) * 64] = g.t00[r];
-      o[(1 * 16 + r) * 64] = g.t01[r];
+      if (I != J) o[(1 * 16 + r) * 64] = g.t01[r];
       o[(2 * 16 + r) * 64] = g.t10[r];
       o[(3 * 16 + r) * 64] = g.t11[r];
     }
