@@ -62,7 +62,8 @@ __device__ __forceinline__ void gram_zero(GramAcc& g) {
 namespace {
 constexpr int GB = 8;
 struct GramBatch {
-  float y0[GB], y1[GB], r[GB];
+  f32x2 y[GB];     // (y_j[idx], y_j[32 + idx]) of the step's rating
+  float r[GB];
 };
 }  // namespace
 
@@ -73,12 +74,13 @@ template <int LD, bool BIG>
 __device__ __forceinline__ void gram_load_batch(GramBatch& b, int q, int mj, float mr, const float* __restrict__ Y, int lane) {
   const int half = lane >> 5, idx = lane & 31;
   int j[GB];
-  // ratings past the end of the row read index 0 / rating 0 from the block registers (see gram_accumulate)
+  // Step t takes lanes 2t (lower half) and 2t+1 (upper half) of the batch's quarter of the index block: one address,
+  // constant offsets.
+  const int addr = ((((q * (2 * GB)) & 63) + half) << 2);
 #pragma unroll
   for (int t = 0; t < GB; t++) {
-    const int src = (q * (2 * GB) + 2 * t + half) & 63;     // position in the current block of 64 ratings
-    j[t] = __shfl(mj, src, 64);
-    b.r[t] = __shfl(mr, src, 64);
+    j[t] = __builtin_amdgcn_ds_bpermute(addr + 8 * t, mj);
+    b.r[t] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr + 8 * t, __builtin_bit_cast(int, mr)));
   }
 #pragma unroll
   for (int t = 0; t < GB; t++) {
@@ -86,72 +88,66 @@ __device__ __forceinline__ void gram_load_batch(GramBatch& b, int q, int mj, flo
     if (BIG) y = Y + (uint64_t)(uint32_t)j[t] * LD;
     else y = (const float*)((const char*)Y + (uint32_t)((uint32_t)j[t] * (uint32_t)(LD * sizeof(float))));
     if (LD == 64) {
-      b.y0[t] = y[idx];
-      b.y1[t] = y[32 + idx];
+      b.y[t][0] = y[idx];
+      b.y[t][1] = y[32 + idx];
     } else if (LD == 32) {
-      b.y0[t] = y[idx];
-      b.y1[t] = 0.0f;
+      b.y[t][0] = y[idx];
+      b.y[t][1] = 0.0f;
     } else {
       const float v = y[idx & (LD - 1)];
-      b.y0[t] = idx < LD ? v : 0.0f;
-      b.y1[t] = 0.0f;
+      b.y[t][0] = idx < LD ? v : 0.0f;
+      b.y[t][1] = 0.0f;
     }
   }
 }
-// TAIL: the last batch of a row stops at the row's last step; full batches run straight through
-template <int LD, bool TAIL>
-__device__ __forceinline__ void gram_mfma_batch(GramAcc& g, const GramBatch& b, int q, int len) {
+// NS steps of a batch, no compare and no select: a rating that must not count was pointed at the zero row
+template <int LD, int NS>
+__device__ __forceinline__ void gram_mfma_batch(GramAcc& g, const GramBatch& b) {
+  f32x2 bb = {g.b0, g.b1};
 #pragma unroll
-  for (int t = 0; t < GB; t++) {
-    if (!TAIL || q * (2 * GB) + 2 * t < len) {   // wave-uniform
-      // ratings <= 0 are skipped (modelMF.cpp:819,857): their row enters as zeros
-      const bool use = b.r[t] > 0.0f;
-      f32x2 a = {use ? b.y0[t] : 0.0f, LD > 32 && use ? b.y1[t] : 0.0f};
-      g.t[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b.y0[t], g.t[0][0], 0, 0, 0);
-      if (LD > 32) {
-        // the lower-left tile would be the bit-identical mirror of the upper-right one (same products, same order):
-        // it is not accumulated; gram_solve reads it out of t[0][1] transposed
-        g.t[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b.y1[t], g.t[0][1], 0, 0, 0);
-        g.t[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b.y1[t], g.t[1][1], 0, 0, 0);
-        const f32x2 rr = {b.r[t], b.r[t]}, bb = {g.b0, g.b1};
-        const f32x2 nb = __builtin_elementwise_fma(rr, a, bb);
-        g.b0 = nb[0];
-        g.b1 = nb[1];
-      } else {
-        g.b0 = __builtin_fmaf(b.r[t], a[0], g.b0);
-      }
+  for (int t = 0; t < NS; t++) {
+    const f32x2 y = b.y[t];
+    g.t[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(y[0], y[0], g.t[0][0], 0, 0, 0);
+    if (LD > 32) {
+      // the lower-left tile would be the bit-identical mirror of the upper-right one (same products, same order):
+      // it is not accumulated; gram_solve reads it out of t[0][1] transposed
+      g.t[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(y[0], y[1], g.t[0][1], 0, 0, 0);
+      g.t[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(y[1], y[1], g.t[1][1], 0, 0, 0);
     }
+    bb = __builtin_elementwise_fma(f32x2{b.r[t], b.r[t]}, y, bb);
   }
+  g.b0 = bb[0];
+  g.b1 = bb[1];
 }
 
+// zrow: index of the all-zero row behind the table.  Ratings <= 0 are skipped (modelMF.cpp:819,857) and a row's last
+// index block is padded: both read the zero row with rating 0, so they add exact zeros to A and b.
 template <int LD, bool BIG>
 __device__ __forceinline__ void gram_accumulate(GramAcc& g, const float* __restrict__ Y,
                                                 const int32_t* __restrict__ ind,
                                                 const float* __restrict__ val, int64_t beg, int64_t end,
-                                                int lane) {
+                                                int lane, int zrow) {
   if (end <= beg) return;
   const int len = (int)(end - beg);                 // a segment is at most SEG ratings
   const int nbatch = (len + 2 * GB - 1) / (2 * GB);
   // index blocks of 64 ratings: the current one and the one after it
-  int mj, mjn = 0;
-  float mr, mrn = 0.0f;
-  {
-    const bool ok = lane < len;
-    mj = ok ? ind[beg + lane] : 0;
-    mr = ok ? val[beg + lane] : 0.0f;
-    const bool ok2 = 64 + lane < len;
-    mjn = ok2 ? ind[beg + 64 + lane] : 0;
-    mrn = ok2 ? val[beg + 64 + lane] : 0.0f;
-  }
+  int mj, mjn;
+  float mr, mrn;
+  auto load_block = [&](int64_t off, int& j, float& r) {
+    const bool ok = off < len;
+    const float v = ok ? val[beg + off] : 0.0f;
+    const bool use = v > 0.0f;
+    j = use ? ind[beg + (ok ? off : 0)] : zrow;
+    r = use ? v : 0.0f;
+  };
+  load_block(lane, mj, mr);
+  load_block(64 + lane, mjn, mrn);
   // entering batch p: when it starts a new index block, the prefetched block becomes current and the next is requested
   auto advance = [&](int p) {
     if ((p & 3) == 0) {
       mj = mjn;
       mr = mrn;
-      const int64_t off = (int64_t)(p / 4 + 1) * 64 + lane;
-      const bool ok = off < len;
-      mjn = ok ? ind[beg + off] : 0;
-      mrn = ok ? val[beg + off] : 0.0f;
+      load_block((int64_t)(p / 4 + 1) * 64 + lane, mjn, mrn);
     }
   };
   GramBatch ba, bb;
@@ -160,21 +156,24 @@ __device__ __forceinline__ void gram_accumulate(GramAcc& g, const float* __restr
   for (; q + 2 < nbatch; q += 2) {      // two full batches per turn, the loads one batch ahead of the MFMAs
     advance(q + 1);
     gram_load_batch<LD, BIG>(bb, q + 1, mj, mr, Y, lane);
-    gram_mfma_batch<LD, false>(g, ba, q, len);
+    gram_mfma_batch<LD, GB>(g, ba);
     advance(q + 2);
     gram_load_batch<LD, BIG>(ba, q + 2, mj, mr, Y, lane);
-    gram_mfma_batch<LD, false>(g, bb, q + 1, len);
+    gram_mfma_batch<LD, GB>(g, bb);
   }
-  if (q + 1 < nbatch) {                 // two batches left: a full one and the tail
+  // the row's last batch runs 4 or 8 steps (its unused steps add zeros)
+  const bool short_tail = len - (nbatch - 1) * (2 * GB) <= GB;   // wave-uniform
+  if (q + 1 < nbatch) {
     advance(q + 1);
     gram_load_batch<LD, BIG>(bb, q + 1, mj, mr, Y, lane);
-    gram_mfma_batch<LD, false>(g, ba, q, len);
-    gram_mfma_batch<LD, true>(g, bb, q + 1, len);
+    gram_mfma_batch<LD, GB>(g, ba);
+    if (short_tail) gram_mfma_batch<LD, GB / 2>(g, bb);
+    else gram_mfma_batch<LD, GB>(g, bb);
   } else {
-    gram_mfma_batch<LD, true>(g, ba, q, len);
+    if (short_tail) gram_mfma_batch<LD, GB / 2>(g, ba);
+    else gram_mfma_batch<LD, GB>(g, ba);
   }
 }
-
 
 // Turn the tile layout into "lane i owns row i", add reg, solve, return x_i in lane i.
 __device__ __forceinline__ float gram_solve(const GramAcc& g, int K, float reg, int lane, float* tr) {
@@ -300,13 +299,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                                                          const float* __restrict__ val,
                                                          const float* __restrict__ Y, float* __restrict__ X,
                                                          float* __restrict__ slabs, int K, int ld, float reg,
-                                                         float* __restrict__ grow) {
+                                                         float* __restrict__ grow, int zrow) {
   __shared__ __attribute__((aligned(16))) float tr[32 * GT_STRIDE];   // gram_solve's transposition tile
   const int lane = threadIdx.x;
   for (int64_t s = blockIdx.x; s < nseg; s += gridDim.x) {
     GramAcc g;
     gram_zero(g);
-    gram_accumulate<LD, BIG>(g, Y, ind, val, seg_beg[s], seg_end[s], lane);
+    gram_accumulate<LD, BIG>(g, Y, ind, val, seg_beg[s], seg_end[s], lane, zrow);
     const int slab = seg_slab[s];
     if (slab < 0) {
       if (SOLVE == 2) {
@@ -445,10 +444,10 @@ template <int SOLVE>
 static int launch_segments(mfx_ctx* ctx, const RowSegs& sd, const int32_t* ind, const float* val, const float* Y, int64_t yrows,
                            float* X, float reg, float* grow) {
   const int blocks = (int)std::min<int64_t>(sd.nseg, 256 * 16);
-  const bool big = yrows * ctx->ld * (int64_t)sizeof(float) >= ((int64_t)1 << 32);   // gathered table of 4 GB or more
+  const bool big = (yrows + 1) * ctx->ld * (int64_t)sizeof(float) >= ((int64_t)1 << 32);   // gathered table of 4 GB or more
 #define MFX_ALS_LAUNCH1(LDV, BIGV)                                                                                              \
   hipLaunchKernelGGL((als_segment_kernel<SOLVE, LDV, BIGV>), dim3(blocks), dim3(64), 0, ctx->stream, sd.seg_row, sd.seg_beg,     \
-                     sd.seg_end, sd.seg_slab, sd.nseg, ind, val, Y, X, ctx->als_slabs, ctx->K, ctx->ld, reg, grow)
+                     sd.seg_end, sd.seg_slab, sd.nseg, ind, val, Y, X, ctx->als_slabs, ctx->K, ctx->ld, reg, grow, (int)yrows)
 #define MFX_ALS_LAUNCH(LDV)                                \
   do {                                                     \
     if (big) MFX_ALS_LAUNCH1(LDV, true);                   \

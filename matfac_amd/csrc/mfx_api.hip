@@ -237,7 +237,9 @@ extern "C" int mfx_set_model(mfx_ctx* ctx, int32_t nUsers, int32_t nItems, int32
   ctx->nU = nUsers; ctx->nI = nItems; ctx->K = K;
   mfx_tree_shape(K, &ctx->L, &ctx->C);
   ctx->ld = 4 * ctx->L * ctx->C;
-  const size_t su = (size_t)nUsers * ctx->ld, si = (size_t)nItems * ctx->ld;
+  // one extra, always-zero row behind each factor table: the ALS accumulation gathers it for ratings it must skip
+  // (<= 0, or past the end of a row) instead of masking every step
+  const size_t su = ((size_t)nUsers + 1) * ctx->ld, si = ((size_t)nItems + 1) * ctx->ld;
   int rc;
   if ((rc = dev_alloc(ctx, &ctx->U, su))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->V, si))) return rc;
