@@ -67,11 +67,11 @@ __device__ __forceinline__ void alsw_load_batch(WideBatch& w, int q, int mj, flo
                                                 int ob, int lane) {
   const int half = lane >> 5, idx = lane & 31;
   int j[WB];
+  const int addr = ((((q * (2 * WB)) & 63) + half) << 2);     // one address per batch, the steps are constant offsets
 #pragma unroll
   for (int t = 0; t < WB; t++) {
-    const int src = (q * (2 * WB) + 2 * t + half) & 63;
-    j[t] = __shfl(mj, src, 64);
-    w.r[t] = __shfl(mr, src, 64);
+    j[t] = __builtin_amdgcn_ds_bpermute(addr + 8 * t, mj);
+    w.r[t] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr + 8 * t, __builtin_bit_cast(int, mr)));
   }
 #pragma unroll
   for (int t = 0; t < WB; t++) {
@@ -86,49 +86,47 @@ __device__ __forceinline__ void alsw_load_batch(WideBatch& w, int q, int mj, flo
     }
   }
 }
-template <bool DIAG, bool TAIL>
-__device__ __forceinline__ void alsw_mfma_batch(WideAcc& g, const WideBatch& w, int q, int len) {
+// NS steps, no compare and no select: a rating that must not count was pointed at the table's zero row (als.hip)
+template <bool DIAG, int NS>
+__device__ __forceinline__ void alsw_mfma_batch(WideAcc& g, const WideBatch& w) {
 #pragma unroll
-  for (int t = 0; t < WB; t++) {
-    if (!TAIL || q * (2 * WB) + 2 * t < len) {   // wave-uniform
-      const bool use = w.r[t] > 0.0f;              // ratings <= 0 are skipped (modelMF.cpp:819,857)
-      const float a0 = use ? w.a0[t] : 0.0f, a1 = use ? w.a1[t] : 0.0f;
-      const float y0 = DIAG ? w.a0[t] : w.b0[t], y1 = DIAG ? w.a1[t] : w.b1[t];
-      g.t00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, y0, g.t00, 0, 0, 0);
-      if (!DIAG) g.t01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, y1, g.t01, 0, 0, 0);   // above the diagonal: never read
-      g.t10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, y0, g.t10, 0, 0, 0);
-      g.t11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, y1, g.t11, 0, 0, 0);
-      if (DIAG) {
-        g.b0 = __builtin_fmaf(w.r[t], a0, g.b0);
-        g.b1 = __builtin_fmaf(w.r[t], a1, g.b1);
-      }
+  for (int t = 0; t < NS; t++) {
+    const float a0 = w.a0[t], a1 = w.a1[t];
+    const float y0 = DIAG ? w.a0[t] : w.b0[t], y1 = DIAG ? w.a1[t] : w.b1[t];
+    g.t00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, y0, g.t00, 0, 0, 0);
+    if (!DIAG) g.t01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, y1, g.t01, 0, 0, 0);   // above the diagonal: never read
+    g.t10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, y0, g.t10, 0, 0, 0);
+    g.t11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, y1, g.t11, 0, 0, 0);
+    if (DIAG) {
+      g.b0 = __builtin_fmaf(w.r[t], a0, g.b0);
+      g.b1 = __builtin_fmaf(w.r[t], a1, g.b1);
     }
   }
 }
 template <bool DIAG, bool BIG>
 __device__ __forceinline__ void alsw_accumulate(WideAcc& g, const float* __restrict__ Y, const int32_t* __restrict__ ind,
                                                 const float* __restrict__ val, int64_t beg, int64_t end, int ldbytes, int oa, int ob,
-                                                int lane) {
+                                                int lane, int zrow) {
   if (end <= beg) return;
   const int len = (int)(end - beg);
   const int nbatch = (len + 2 * WB - 1) / (2 * WB);
   int mj, mjn;
   float mr, mrn;
-  {
-    const bool ok = lane < len, ok2 = 64 + lane < len;
-    mj = ok ? ind[beg + lane] : 0;
-    mr = ok ? val[beg + lane] : 0.0f;
-    mjn = ok2 ? ind[beg + 64 + lane] : 0;
-    mrn = ok2 ? val[beg + 64 + lane] : 0.0f;
-  }
+  // ratings <= 0 are skipped (modelMF.cpp:819,857) and the last index block is padded: both gather the zero row
+  auto load_block = [&](int64_t off, int& j, float& r) {
+    const bool ok = off < len;
+    const float v = ok ? val[beg + off] : 0.0f;
+    const bool use = v > 0.0f;
+    j = use ? ind[beg + (ok ? off : 0)] : zrow;
+    r = use ? v : 0.0f;
+  };
+  load_block(lane, mj, mr);
+  load_block(64 + lane, mjn, mrn);
   auto advance = [&](int p) {
     if ((p & 3) == 0) {
       mj = mjn;
       mr = mrn;
-      const int64_t off = (int64_t)(p / 4 + 1) * 64 + lane;
-      const bool ok = off < len;
-      mjn = ok ? ind[beg + off] : 0;
-      mrn = ok ? val[beg + off] : 0.0f;
+      load_block((int64_t)(p / 4 + 1) * 64 + lane, mjn, mrn);
     }
   };
   WideBatch wa, wb;
@@ -137,18 +135,21 @@ __device__ __forceinline__ void alsw_accumulate(WideAcc& g, const float* __restr
   for (; q + 2 < nbatch; q += 2) {
     advance(q + 1);
     alsw_load_batch<DIAG, BIG>(wb, q + 1, mj, mr, Y, ldbytes, oa, ob, lane);
-    alsw_mfma_batch<DIAG, false>(g, wa, q, len);
+    alsw_mfma_batch<DIAG, WB>(g, wa);
     advance(q + 2);
     alsw_load_batch<DIAG, BIG>(wa, q + 2, mj, mr, Y, ldbytes, oa, ob, lane);
-    alsw_mfma_batch<DIAG, false>(g, wb, q + 1, len);
+    alsw_mfma_batch<DIAG, WB>(g, wb);
   }
+  const bool short_tail = len - (nbatch - 1) * (2 * WB) <= WB;   // the last batch runs 4 or 8 steps (unused ones add zeros)
   if (q + 1 < nbatch) {
     advance(q + 1);
     alsw_load_batch<DIAG, BIG>(wb, q + 1, mj, mr, Y, ldbytes, oa, ob, lane);
-    alsw_mfma_batch<DIAG, false>(g, wa, q, len);
-    alsw_mfma_batch<DIAG, true>(g, wb, q + 1, len);
+    alsw_mfma_batch<DIAG, WB>(g, wa);
+    if (short_tail) alsw_mfma_batch<DIAG, WB / 2>(g, wb);
+    else alsw_mfma_batch<DIAG, WB>(g, wb);
   } else {
-    alsw_mfma_batch<DIAG, true>(g, wa, q, len);
+    if (short_tail) alsw_mfma_batch<DIAG, WB / 2>(g, wa);
+    else alsw_mfma_batch<DIAG, WB>(g, wa);
   }
 }
 
@@ -156,7 +157,7 @@ template <bool BIG>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void alsw_gram_kernel(
     const int64_t* __restrict__ seg_beg, const int64_t* __restrict__ seg_end, int64_t seg0, int64_t nseg, int npairs,
     const int32_t* __restrict__ ind, const float* __restrict__ val, const float* __restrict__ Y, int ld, float* __restrict__ slabs,
-    int64_t stride) {
+    int64_t stride, int zrow) {
   const int lane = threadIdx.x, half = lane >> 5, idx = lane & 31;
   for (int64_t u = blockIdx.x; u < nseg * npairs; u += gridDim.x) {
     const int64_t s = u / npairs;
@@ -169,8 +170,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     for (int r = 0; r < 16; r++) { g.t00[r] = 0.0f; g.t01[r] = 0.0f; g.t10[r] = 0.0f; g.t11[r] = 0.0f; }
     g.b0 = g.b1 = 0.0f;
     const int64_t beg = seg_beg[seg0 + s], end = seg_end[seg0 + s];
-    if (I == J) alsw_accumulate<true, BIG>(g, Y, ind, val, beg, end, ld * (int)sizeof(float), 64 * I, 64 * J, lane);
-    else alsw_accumulate<false, BIG>(g, Y, ind, val, beg, end, ld * (int)sizeof(float), 64 * I, 64 * J, lane);
+    if (I == J) alsw_accumulate<true, BIG>(g, Y, ind, val, beg, end, ld * (int)sizeof(float), 64 * I, 64 * J, lane, zrow);
+    else alsw_accumulate<false, BIG>(g, Y, ind, val, beg, end, ld * (int)sizeof(float), 64 * I, 64 * J, lane, zrow);
     float* o = slabs + s * stride + (int64_t)p * BLK + lane;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
@@ -414,12 +415,12 @@ int mfx_als_wide_half_sweep(mfx_ctx* ctx, int side, float reg) {
       ProfScope ps(ctx, MFX_K_ALS_GRAM);
       const int blocks = (int)std::min<int64_t>(ns * npairs, 256 * 32);
       const int64_t yrows = side == MFX_SIDE_USERS ? ctx->nI : ctx->nU;
-      if (yrows * ctx->ld * (int64_t)sizeof(float) >= ((int64_t)1 << 32))
+      if ((yrows + 1) * ctx->ld * (int64_t)sizeof(float) >= ((int64_t)1 << 32))
         hipLaunchKernelGGL(alsw_gram_kernel<true>, dim3(blocks), dim3(64), 0, ctx->stream, sdp->seg_beg, sdp->seg_end, s0, ns, npairs, ind,
-                           val, Y, ctx->ld, st->slabs, stride);
+                           val, Y, ctx->ld, st->slabs, stride, (int)yrows);
       else
         hipLaunchKernelGGL(alsw_gram_kernel<false>, dim3(blocks), dim3(64), 0, ctx->stream, sdp->seg_beg, sdp->seg_end, s0, ns, npairs, ind,
-                           val, Y, ctx->ld, st->slabs, stride);
+                           val, Y, ctx->ld, st->slabs, stride, (int)yrows);
       HIPCHK(hipGetLastError());
     }
     {
