@@ -18,6 +18,7 @@
 #include "mfx_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2s __attribute__((ext_vector_type(2)));
 
 namespace {
 constexpr int BLK = 64 * 64;
@@ -219,12 +220,13 @@ __global__ __launch_bounds__(P * P) void alsw_solve_kernel(const int32_t* __rest
   for (int64_t m = blockIdx.x; m < nrows; m += gridDim.x) {
     const int row = wrow[row0 + m], n = wn[row0 + m];
     const int64_t first = (int64_t)wfirst[row0 + m] - seg0;
-    float A[8][8];
+    f32x2s A2[8][4];   // A(a, c) = element (ti + P a, tj + P c), c <= a; pairs of columns for v_pk_fma_f32
+#define A(a, c) A2[a][(c) >> 1][(c) & 1]
     float z = 0.0f;
 #pragma unroll
     for (int a = 0; a < 8; a++)
 #pragma unroll
-      for (int b = 0; b <= a; b++) A[a][b] = 0.0f;
+      for (int b = 0; b <= a; b++) A(a, b) = 0.0f;
 #pragma nounroll
     for (int sg = 0; sg < n; sg++) {   // segment order: reproducible
       const float* sl = slabs + (first + sg) * stride;
@@ -233,14 +235,14 @@ __global__ __launch_bounds__(P * P) void alsw_solve_kernel(const int32_t* __rest
 #pragma unroll
         for (int b = 0; b <= a; b++) {
           const int gi = ti + P * a, gj = tj + P * b;
-          if (gj <= gi) A[a][b] += sl[alsw_slab_offset(gi, gj)];
+          if (gj <= gi) A(a, b) += sl[alsw_slab_offset(gi, gj)];
         }
       if (tid < KP) z += sl[(int64_t)npairs * BLK + tid];
     }
     // YTY(j,j) += reg for j < K (modelMF.cpp:831-833); padded dimensions become identity rows
     if (ti == tj) {
 #pragma unroll
-      for (int a = 0; a < 8; a++) A[a][a] = (ti + P * a) < K ? A[a][a] + reg : 1.0f;
+      for (int a = 0; a < 8; a++) A(a, a) = (ti + P * a) < K ? A(a, a) + reg : 1.0f;
     }
 #pragma unroll
     for (int b = 0; b < 8; b++) {
@@ -250,10 +252,12 @@ __global__ __launch_bounds__(P * P) void alsw_solve_kernel(const int32_t* __rest
         float* buf = colbuf + (k & 1) * KP;
         if (tj == kk) {
 #pragma unroll
-          for (int a = b; a < 8; a++) buf[ti + P * a] = A[a][b];
+          for (int a = b; a < 8; a++) buf[ti + P * a] = A(a, b);
         }
         __syncthreads();
-        const float rdk = 1.0f / buf[k];
+        const float dk = buf[k];
+        float rdk = __builtin_amdgcn_rcpf(dk);                           // reciprocal + one Newton step (as als.hip)
+        rdk = __builtin_fmaf(__builtin_fmaf(-dk, rdk, 1.0f), rdk, rdk);
         float li[8], cj[8];
 #pragma unroll
         for (int a = b; a < 8; a++) li[a] = buf[ti + P * a] * rdk;
@@ -262,20 +266,29 @@ __global__ __launch_bounds__(P * P) void alsw_solve_kernel(const int32_t* __rest
         // element (ti + P a, tj + P c) is below column k and inside the lower triangle: decided at compile time
         // except in the block column of k (c == b: tj > kk) and on the diagonal blocks (a == c: tj <= ti)
         const bool right_of_k = tj > kk, on_or_below = tj <= ti;
+        // in the block column of k only the threads right of k take part: they see the pivot column, the others a zero
+        // (A - l * 0 is A), so that column needs one select instead of one per element
+        const float cjb = right_of_k ? cj[b] : 0.0f;
 #pragma unroll
         for (int a = b; a < 8; a++)
 #pragma unroll
           for (int c = b; c <= a; c++) {
-            const float upd = __builtin_fmaf(-li[a], cj[c], A[a][c]);
-            if (c > b && a > c) A[a][c] = upd;
-            else if (c > b) A[a][c] = on_or_below ? upd : A[a][c];
-            else if (a > c) A[a][c] = right_of_k ? upd : A[a][c];
-            else A[a][c] = (right_of_k && on_or_below) ? upd : A[a][c];
+            // (all three conditions are compile-time constants once a, b, c are unrolled)
+            if ((c & 1) == 1 && c - 1 >= b && c < a) continue;            // went with its even neighbour
+            if ((c & 1) == 0 && c + 1 < a) {                              // two columns strictly below the diagonal blocks
+              const f32x2s nl = {-li[a], -li[a]};
+              const f32x2s v = {c == b ? cjb : cj[c], cj[c + 1 < 8 ? c + 1 : 0]};
+              A2[a][c >> 1] = __builtin_elementwise_fma(nl, v, A2[a][c >> 1]);
+              continue;
+            }
+            const float upd = __builtin_fmaf(-li[a], c == b ? cjb : cj[c], A(a, c));
+            if (a > c) A(a, c) = upd;                         // strictly below the diagonal blocks
+            else A(a, c) = on_or_below ? upd : A(a, c);       // diagonal block: lower triangle only
           }
         if (tj == kk) {
 #pragma unroll
           for (int a = b; a < 8; a++)
-            if (ti + P * a > k) A[a][b] = li[a];
+            if (ti + P * a > k) A(a, b) = li[a];
         }
       }
     }
@@ -285,8 +298,8 @@ __global__ __launch_bounds__(P * P) void alsw_solve_kernel(const int32_t* __rest
 #pragma unroll
       for (int b = 0; b <= a; b++) {
         const int gi = ti + P * a, gj = tj + P * b;
-        if (gj < gi) Lp[gi * (gi + 1) / 2 + gj] = A[a][b];
-        else if (gj == gi) dvec[gi] = A[a][b];
+        if (gj < gi) Lp[gi * (gi + 1) / 2 + gj] = A(a, b);
+        else if (gj == gi) dvec[gi] = A(a, b);
       }
     __syncthreads();
     // The substitutions run on ONE wavefront (lane l owns rows l, l+64, ...): the pivot value travels by a
@@ -338,6 +351,7 @@ __global__ __launch_bounds__(P * P) void alsw_solve_kernel(const int32_t* __rest
     __syncthreads();
   }
 }
+#undef A
 
 // ---------------------------------------------------------------------------
 // host
