@@ -314,10 +314,10 @@ __global__ __launch_bounds__(P * P) void alsw_solve_kernel(const int32_t* __rest
       // L y = b
 #pragma unroll
       for (int q = 0; q < Q; q++) {
-#pragma nounroll
-        for (int kk = 0; kk < 64; kk++) {
+#pragma unroll 8
+        for (int kk = 0; kk < 64; kk++) {   // unrolled so that the L reads of the next steps are in flight; the pivot is a v_readlane
           const int k = 64 * q + kk;
-          const float zk = __shfl(zz[q], kk, 64);
+          const float zk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zz[q]), kk));
 #pragma unroll
           for (int q2 = q; q2 < Q; q2++) {
             const int i = tid + 64 * q2;
@@ -330,10 +330,10 @@ __global__ __launch_bounds__(P * P) void alsw_solve_kernel(const int32_t* __rest
       // L^T x = y, one column of L^T (= row j of L) per step
 #pragma unroll
       for (int q = Q - 1; q >= 0; q--) {
-#pragma nounroll
+#pragma unroll 8
         for (int jj = 63; jj >= 0; jj--) {
           const int j = 64 * q + jj;
-          const float xj = __shfl(zz[q], jj, 64);
+          const float xj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zz[q]), jj));
           const float* Lj = Lp + j * (j + 1) / 2;
 #pragma unroll
           for (int q2 = 0; q2 <= q; q2++) {
