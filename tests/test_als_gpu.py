@@ -114,6 +114,38 @@ def test_nonpositive_ratings_are_skipped():
     assert rel.max() < 2e-4
 
 
+@pytest.mark.parametrize("K", [64, 128])
+def test_zero_row_behind_the_tables_survives_the_other_trainers(K):
+    """The ALS accumulation gathers an all-zero row stored behind each factor table for every rating it skips.  Nothing
+    else may ever write there: run the other device paths that write U and V, then repeat the skipped-ratings check."""
+    reg = 1.0
+    d, tr, _ = _data(300, 200, 8000, seed=34)
+    tr.rowval[::5] = 0.0
+    tr.rowval[2::9] = -2.0
+    nU, nI = d["nUsers"], d["nItems"]
+    rng = np.random.default_rng(3)
+    U0 = rng.normal(0, 0.3, (nU, K)).astype(np.float32)
+    V0 = rng.normal(0, 0.3, (nI, K)).astype(np.float32)
+    with Ctx(0) as ctx:
+        invU, invI = load_ctx(ctx, d, K, U0, V0)
+        for mode, order in ((mfx.SGD_TILED, mfx.ORDER_DEVICE), (mfx.SGD_HOGWILD, mfx.ORDER_DEVICE), (mfx.SGD_USERS, mfx.ORDER_NATURAL)):
+            ctx.sgd_epoch(0.002, 0.02, 0.02, mode=mode, order=order, seed=1, epoch=0)
+        ctx.snapshot_best()
+        ctx.ccdpp_begin()
+        ctx.ccdpp_rank1(0, reg, reg, add_back=False)
+        ctx.ccdpp_end()
+        ctx.svd_init(1, 8, 1)
+        ctx.restore_best()
+        ctx.als_half_sweep(mfx.SIDE_ITEMS, reg)
+        ctx.set_factors(U0, V0)                       # known input again; the padding row is not part of it
+        ctx.als_half_sweep(mfx.SIDE_USERS, reg)
+        U1, _ = ctx.get_factors()
+    Uo, Vo = U0.copy(), V0.copy()
+    orc.als_half(0, Uo, Vo, tr.nrows, tr.rowptr, tr.rowind, tr.rowval, invU, reg)
+    rel = np.linalg.norm(U1 - Uo, axis=1) / np.maximum(np.linalg.norm(Uo, axis=1), 1e-6)
+    assert rel.max() < 2e-4
+
+
 def test_wide_als_in_several_batches_equals_one_batch(monkeypatch):
     """als_wide.hip caps the segment partials (default 8 GB) and sweeps the rows in batches; a tiny cap forces many."""
     K, reg = 128, 1.5
