@@ -236,7 +236,11 @@ __device__ __forceinline__ float gram_solve(const GramAcc& g, int K, float reg, 
     const float dk = rdlane(a[k >> 1][k & 1], k);
     float rk = __builtin_amdgcn_rcpf(dk);
     rk = __builtin_fmaf(__builtin_fmaf(-dk, rk, 1.0f), rk, rk);
-    const float lik = lane > k ? a[k >> 1][k & 1] * rk : 0.0f;
+    // the lane number is re-materialised per step: with a loop-invariant one the compiler forms all 128 lane masks up
+    // front and spills them (two v_readlane per use instead of one v_cmp)
+    int lv = lane;
+    asm volatile("" : "+v"(lv));
+    const float lik = lv > k ? a[k >> 1][k & 1] * rk : 0.0f;
     if ((k & 1) == 0) a[k >> 1][1] = __builtin_fmaf(-lik, rdlane(a[k >> 1][1], k), a[k >> 1][1]);
     const f32x2 l2 = {lik, lik};
 #pragma unroll
@@ -245,8 +249,8 @@ __device__ __forceinline__ float gram_solve(const GramAcc& g, int K, float reg, 
       a[p] = __builtin_elementwise_fma(-l2, row, a[p]);   // v_pk_fma_f32 with the scalar pair as one source
     }
     z = __builtin_fmaf(-lik, rdlane(z, k), z);
-    a[k >> 1][k & 1] = lane > k ? lik : a[k >> 1][k & 1];
-    d = lane == k ? dk : d;
+    a[k >> 1][k & 1] = lv > k ? lik : a[k >> 1][k & 1];
+    d = lv == k ? dk : d;
     __builtin_amdgcn_sched_barrier(0);   // keep the steps apart: interleaved, each column becomes one dependent chain
   }
   // L^T x = D^-1 y from the last row up: x_j is final in lane j; lanes k < j subtract (d_k l_jk) x_j before their division
