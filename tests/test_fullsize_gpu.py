@@ -99,3 +99,43 @@ def test_ccdpp_views_in_lockstep_and_monotone_at_full_size(c2):
     assert np.abs(rr[sel] - (tr.rowval[sel] - est)).max() < 1e-3
     ctx.ccdpp_end()
     ctx.close()
+
+
+@pytest.mark.parametrize("K", [64, 128])
+def test_als_gathers_from_a_factor_table_beyond_4_gb(K):
+    """Maximum size: a gathered factor table of 4 GB or more switches the ALS accumulation to 64-bit row offsets
+    (als.hip / als_wide.hip, BIG).  17 M (8.5 M at rank 128) users of which 3000 have ratings, many of them in the rows
+    behind the 4 GB mark; the item half sweep must give bit for bit what it gives on the same ratings with the users
+    renumbered 0..2999 (same users per item in the same order, same segments)."""
+    row_bytes = 4 * (64 if K <= 64 else 128)
+    nU_big = (1 << 32) // row_bytes + 250_000           # table = 4 GB + 250 000 rows
+    nI, n_act, per_user = 500, 3000, 40
+    rng = np.random.default_rng(7)
+    first_far = (1 << 32) // row_bytes - 1000           # 1000 rows before the mark, the rest behind it
+    ids = np.sort(np.concatenate([rng.choice(first_far, n_act // 2, replace=False),
+                                  first_far + rng.choice(nU_big - first_far, n_act - n_act // 2, replace=False)])).astype(np.int64)
+    assert (ids * row_bytes >= (1 << 32)).sum() > 1000
+    cols = np.sort(np.stack([rng.choice(nI, per_user, replace=False) for _ in range(n_act)]), axis=1).astype(np.int32)
+    vals = rng.integers(1, 11, size=(n_act, per_user)).astype(np.float32) * 0.5
+    Us = rng.normal(0, 0.3, (n_act, K)).astype(np.float32)
+    V0 = rng.normal(0, 0.3, (nI, K)).astype(np.float32)
+
+    def sweep(nU, rows, U0):
+        counts = np.zeros(nU, np.int64)
+        counts[rows] = per_user
+        rowptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        with Ctx(0) as ctx:
+            ctx.set_csr(mfx.MAT_TRAIN, nU, nI, rowptr, cols.reshape(-1), vals.reshape(-1))
+            ctx.set_model(nU, nI, K)
+            ctx.set_factors(U0, V0)
+            ctx.compute_invalid()
+            ctx.als_half_sweep(mfx.SIDE_ITEMS, 2.0)
+            _, V = ctx.get_factors()
+        return V
+
+    V_small = sweep(n_act, np.arange(n_act), Us)
+    U_big = np.zeros((nU_big, K), np.float32)
+    U_big[ids] = Us
+    V_big = sweep(nU_big, ids, U_big)
+    assert np.array_equal(V_big, V_small)
+    assert np.abs(V_small - V0).max() > 1e-3            # the sweep did something
