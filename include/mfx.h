@@ -129,7 +129,18 @@ typedef struct {
                           lock-free updates collide), 1 = user rows, 2 = alternate by epoch --
                           1 and 2 are experiments: measured worse / unstable       */
   int64_t first, count; /* sub-range of the epoch list; count <= 0: everything  */
+  int32_t flags;       /* MFX_SGD_F_* (0 for production runs)                    */
+  int32_t reserved;    /* 0                                                      */
 } mfx_sgd_opts;
+/* Test hooks of MFX_SGD_TILED (tests/test_sgd_gpu.py, tests/test_fullsize_gpu.py):
+ *  ONE_GROUP     the slots are visited tile by tile and slot by slot by ONE lane group, one rating at a
+ *                time, with the production kernel's per-rating code: the list mfx_debug_epoch_list returns IS
+ *                the visiting order, so a sequential replay of that list (the reference's loop,
+ *                modelMF.cpp:83-105 / :1747-1763) must reproduce the factors.
+ *  COUNT_VISITS  every rating record the update loop consumes bumps a device counter; read them (and zero
+ *                them) with mfx_debug_visit_counts: "every rating exactly once per epoch" as observed by
+ *                the kernel itself.                                                                        */
+enum { MFX_SGD_F_ONE_GROUP = 1, MFX_SGD_F_COUNT_VISITS = 2 };
 /* Permutation of the train ratings (indices into the CSR-order rating list with
  * invalid users/items removed -- on a train matrix that is every rating), as
  * std::vector<size_t> uiRatingInds in modelMF.cpp:67-68; for MFX_SGD_USERS the
@@ -142,6 +153,10 @@ int mfx_debug_epoch_list(mfx_ctx* ctx, int32_t* u, int32_t* i, float* r, int64_t
 /* test hook: digest of the slot lists the last MFX_SGD_TILED epoch ran on.  counts = {slots, ratings, row
  * references, rows per slot}; sums = FNV-1a of {rating records, slot_beg, slot_ibeg, slot rows, tile_slot} */
 int mfx_debug_slots_digest(mfx_ctx* ctx, int64_t counts[4], uint64_t sums[5]);
+/* test hook: visits per rating record (slot-list order, as mfx_debug_epoch_list indexes its positions through the
+ * per-slot permutation) accumulated by epochs run with MFX_SGD_F_COUNT_VISITS; zeroes the counters.  n receives
+ * the number of records; counts may be NULL to query n.                                                         */
+int mfx_debug_visit_counts(mfx_ctx* ctx, uint32_t* counts, int64_t cap, int64_t* n);
 /* test hook: the column view of the train matrix as the device holds it (given or built by mfx_set_csr) */
 int mfx_debug_col_view(mfx_ctx* ctx, int64_t* colptr, int32_t* colind, float* colval);
 

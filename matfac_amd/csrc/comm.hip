@@ -42,7 +42,11 @@ bool load_rccl() {
     g_rccl.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
     if (g_rccl.h) break;
   }
-  if (!g_rccl.h) { g_rccl.err = dlerror() ? dlerror() : "dlopen(librccl) failed"; return false; }
+  if (!g_rccl.h) {
+    const char* e = dlerror();   // one call: dlerror() clears the message it returns
+    g_rccl.err = e ? e : "dlopen(librccl) failed";
+    return false;
+  }
   g_rccl.get_uid = (fn_get_uid)dlsym(g_rccl.h, "ncclGetUniqueId");
   g_rccl.init_rank = (fn_init_rank)dlsym(g_rccl.h, "ncclCommInitRank");
   g_rccl.destroy = (fn_destroy)dlsym(g_rccl.h, "ncclCommDestroy");
@@ -95,6 +99,7 @@ int mfx_comm_free_internal(mfx_ctx* ctx) {
   ctx->nranks = 1;
   ctx->rank = 0;
   dev_free(ctx->comm_tmp);
+  ctx->comm_tmp_cap = 0;
   if (ctx->ext_stage) (void)hipHostFree(ctx->ext_stage);
   ctx->ext_stage = nullptr;
   ctx->ext_stage_bytes = 0;
@@ -203,7 +208,12 @@ extern "C" int mfx_comm_destroy(mfx_ctx* ctx) {
 static int ensure_sync_buffers(mfx_ctx* ctx) {
   const size_t n = (size_t)ctx->nI * ctx->ld;
   int rc;
-  if (!ctx->comm_tmp && (rc = dev_alloc(ctx, &ctx->comm_tmp, n))) return rc;
+  if (!ctx->comm_tmp || ctx->comm_tmp_cap < n) {   // mfx_set_model may have grown the item table since the last exchange
+    dev_free(ctx->comm_tmp);
+    ctx->comm_tmp_cap = 0;
+    if ((rc = dev_alloc(ctx, &ctx->comm_tmp, n))) return rc;
+    ctx->comm_tmp_cap = n;
+  }
   if (!ctx->Vsync) {
     if ((rc = dev_alloc(ctx, &ctx->Vsync, n))) return rc;
     HIPCHK(hipMemcpyAsync(ctx->Vsync, ctx->V, n * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));

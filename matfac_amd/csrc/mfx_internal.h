@@ -107,6 +107,7 @@ struct mfx_ctx {
   void* comm = nullptr;      // ncclComm_t
   int nranks = 1, rank = 0;
   float* comm_tmp = nullptr;
+  size_t comm_tmp_cap = 0;              // floats
   mfx_reduce_fn ext_reduce = nullptr;   // caller-supplied all-reduce on a host copy (mfx_comm_init_external)
   void* ext_user = nullptr;
   void* ext_stage = nullptr;            // pinned staging buffer for it

@@ -23,6 +23,7 @@ struct SlotList {
   int32_t* slot_items = nullptr;   // global item ids of every slot
   int32_t* tile_slot = nullptr;    // [NTILE+1] slot range of a tile
   unsigned* ctr = nullptr;         // [NTILE] slot counters
+  unsigned* visit = nullptr;       // [nnz] visits per rating record (MFX_SGD_F_COUNT_VISITS), or NULL
   int32_t* attr = nullptr;         // sibling models: per rating (slot order) weight bits (var 1) or rank (var 2)
   int var = 0;                     // which of them attr holds (0: none)
   uint64_t attr_gen = 0;           // ctx->var_gen it was computed for

@@ -18,8 +18,9 @@
 // row -- no item update is lost and the 64 groups of the workgroup always read the freshest row.  The user
 // side stays a lock-free read-modify-write through the XCD's L2 (sc1 loads bypass the CU's L1).
 // An item with more than CAP_R/2 ratings in a tile gets ONE slot of its own, however long.
-// Slots are pulled from per-tile counters and a final sweep launch drains whatever is left, so
-// "every rating exactly once per epoch" holds for ANY workgroup->XCD placement.
+// Slots are pulled from per-tile counters and eight drain launches (the same diagonals, keyed on the workgroup
+// index instead of the XCD) take whatever is left, so "every rating exactly once per epoch" and "one owner per
+// item row" hold for ANY workgroup->XCD placement.
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -35,7 +36,7 @@ void mfx_slots_free_internal(mfx_ctx* ctx) {
   SlotState* st = state(ctx);
   if (!st) return;
   for (SlotList& s : st->side) {
-    dev_free(s.rec); dev_free(s.slot_beg); dev_free(s.slot_ibeg); dev_free(s.slot_items); dev_free(s.attr);
+    dev_free(s.rec); dev_free(s.slot_beg); dev_free(s.slot_ibeg); dev_free(s.slot_items); dev_free(s.attr); dev_free(s.visit);
     dev_free(s.tile_slot); dev_free(s.ctr);
   }
   delete st;
@@ -145,7 +146,7 @@ static int build_slots(mfx_ctx* ctx, SlotList* S, int rows, int side) {
     for (int32_t it : items) cnt[it] = 0;
   }
   tile_slot[NTILE] = nslots;
-  dev_free(S->rec); dev_free(S->slot_beg); dev_free(S->slot_ibeg); dev_free(S->slot_items);
+  dev_free(S->visit); dev_free(S->attr); dev_free(S->rec); dev_free(S->slot_beg); dev_free(S->slot_ibeg); dev_free(S->slot_items);
   dev_free(S->tile_slot);
   int rc;
   if ((rc = up(ctx, &S->rec, rec))) return rc;
@@ -243,6 +244,11 @@ int mfx_launch_sgd_tiled(mfx_ctx* ctx, const mfx_sgd_opts* o) {
     S->attr_gen = ctx->var_gen;
   }
   S->var = var;
+  if ((o->flags & MFX_SGD_F_COUNT_VISITS) && !S->visit) {
+    int rc;
+    if ((rc = dev_alloc(ctx, &S->visit, (size_t)S->nnz))) return rc;
+    HIPCHK(hipMemsetAsync(S->visit, 0, sizeof(unsigned) * (size_t)S->nnz, ctx->stream));
+  }
   const uint32_t k0 = mfx_mix32(o->seed ^ 0x3c6ef372U) + (uint32_t)o->epoch * 0x9e3779b9U;
   const uint32_t k1 = mfx_mix32(o->seed * 0x85ebca6bU + 0xdaa66d2bU) ^ mfx_mix32((uint32_t)o->epoch + 0x1b873593U);
   st->last_k0 = k0; st->last_k1 = k1; st->last_side = side;
@@ -277,6 +283,23 @@ int mfx_slots_materialise_order(mfx_ctx* ctx) {
                      S->slot_beg, S->nslots, st->last_side, st->last_k0, st->last_k1, ctx->eu, ctx->ei, ctx->er);
   HIPCHK(hipGetLastError());
   ctx->elist_n = S->nnz;
+  return MFX_OK;
+}
+
+extern "C" int mfx_debug_visit_counts(mfx_ctx* ctx, uint32_t* counts, int64_t cap, int64_t* n) {
+  if (!ctx) return MFX_E_ARG;
+  SlotState* st = state(ctx);
+  NEED(n, MFX_E_ARG, "mfx_debug_visit_counts: n NULL");
+  NEED(st && st->side[st->last_side].built && st->side[st->last_side].visit, MFX_E_STATE,
+       "mfx_debug_visit_counts: no tiled epoch has run with MFX_SGD_F_COUNT_VISITS");
+  SlotList& S = st->side[st->last_side];
+  *n = S.nnz;
+  if (!counts) return MFX_OK;
+  NEED(cap >= S.nnz, MFX_E_ARG, "mfx_debug_visit_counts: cap too small");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpy(counts, S.visit, sizeof(unsigned) * (size_t)S.nnz, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemset(S.visit, 0, sizeof(unsigned) * (size_t)S.nnz));
   return MFX_OK;
 }
 

@@ -42,7 +42,8 @@ __device__ __forceinline__ int slot_take(int v, int g) {
 // (regk = the ld values of mfx_sgd_set_dim_reg, svd.hip; no per-rating attribute).
 template <int L, int C, int ARITH, bool OWN_U, bool FIX, int VAR, int S>
 struct SlotSteps {
-  static __device__ __forceinline__ void run(const Rows<3>& Um, int* q_lds, int tx, int ty, int tz, int tw, const float* regk,
+  template <class RowsT>
+  static __device__ __forceinline__ void run(const RowsT& Um, int* q_lds, int tx, int ty, int tz, int tw, const float* regk,
                                              int g, int j, int nvalid, float lr, float uReg, float iReg,
                                              float4v (&pn)[C], int64_t& pen, float4v (&pnn)[C], int64_t& penn) {
     constexpr int G = 64 / L;
@@ -205,6 +206,15 @@ struct SlotSteps {
 };
 
 // C = 1 (K <= 64): 2 workgroups per CU (<= 64 VGPRs); wider ranks keep 1 workgroup per CU and get 128 VGPRs
+//
+// SWEEP = false: round `round` of the epoch; the workgroups on XCD x (HW_REG_XCC_ID) take tile
+// (x, (x + round) mod 8), user rows stay in that XCD's L2 (sc1 loads, plain stores).
+// SWEEP = true: the placement-independent drain of whatever the rounds left (normally nothing).  Same diagonal
+// schedule, but x comes from the workgroup index, so that an item row still has ONE owner at a time whatever the
+// XCC_ID values were (a partition mode that reports a constant id leaves 56 of the 64 tiles to this path); its user
+// rows go through memory (sc1 loads and write-through stores: the workgroups of one tile may sit on several XCDs).
+// It also carries the two test hooks of include/mfx.h: `tile_only` >= 0 restricts a launch to that tile and `one`
+// makes ONE lane group visit a slot's ratings one at a time (MFX_SGD_F_ONE_GROUP).
 template <int L, int C, int ARITH, bool SWEEP, bool OWN_U, int VAR>
 __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kernel(const int4* __restrict__ rec,
                                                            const int64_t* __restrict__ slot_beg,
@@ -213,7 +223,8 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
                                                            const int32_t* __restrict__ tile_slot, unsigned* ctr,
                                                            int round, float* Oth, float* Own, uint32_t obytes,
                                                            float lr, float uReg, float iReg, uint32_t k0,
-                                                           uint32_t k1, const int32_t* __restrict__ attr) {
+                                                           uint32_t k1, const int32_t* __restrict__ attr,
+                                                           unsigned* __restrict__ visit, int tile_only, int one) {
   constexpr int G = 64 / L;
   constexpr int LD = 4 * L * C;
   constexpr int LD4 = LD / 4;
@@ -221,22 +232,23 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
   __shared__ __attribute__((aligned(16))) int q_lds[ROWS * LD];
   __shared__ int s_slot, s_bad;
   // Oth: the lock-free side (user rows when item rows are owned, and vice versa); Own: staged in LDS
-  const Rows<3> Um(Oth, obytes);
+  const Rows<SWEEP ? 1 : 3> Um(Oth, obytes);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane / L, j = lane % L;
   const int xcc = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7);  // HW_REG_XCC_ID[3:0]
   // round r: XCD x takes user block x*SUB + r%SUB and item block (x + r/SUB) mod 8
-  const int t_first = SWEEP ? 0 : (xcc * SUB + round % SUB) * 8 + ((xcc + round / SUB) & 7);
-  const int t_last = SWEEP ? NTILE - 1 : t_first;
+  const int x = SWEEP ? (int)(blockIdx.x & 7) : xcc;
+  const int tile = (SWEEP && tile_only >= 0) ? tile_only : (x * SUB + round % SUB) * 8 + ((x + round / SUB) & 7);
+  const bool onegrp = SWEEP && one != 0;
   int4* q4 = (int4*)q_lds;
-  for (int tile = t_first; tile <= t_last; tile++) {
+  {
     const int s0 = tile_slot[tile], ns = tile_slot[tile + 1] - s0;
     if (SWEEP) {  // nothing left in this tile (the normal case): do not queue on its counter
       if (tid == 0) s_slot = (int)__hip_atomic_load(&ctr[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __syncthreads();
       const int seen = s_slot;
       __syncthreads();
-      if (seen >= ns) continue;
+      if (seen >= ns) return;
     }
     for (;;) {
       if (tid == 0) { s_slot = (int)atomicAdd(&ctr[tile], 1u); s_bad = 0; }
@@ -268,17 +280,22 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
       }
       __syncthreads();
       const uint32_t ks0 = k0 + (uint32_t)slot * 0x632be5abU, ks1 = k1 ^ mfx_mix32((uint32_t)slot + 77U);
-      for (int64_t cb = (int64_t)wave * 64; cb < R; cb += (WG / 64) * 64) {
-        const int64_t t = cb + lane;
-        const bool ok = t < R;
+      // one group (test hook): wave 0 alone, L ratings per chunk, rating cb+s in entry s*G (group 0's entry of step s)
+      const int64_t cb0 = onegrp ? (wave == 0 ? 0 : R) : (int64_t)wave * 64;
+      const int64_t cstep = onegrp ? L : (WG / 64) * 64;
+      for (int64_t cb = cb0; cb < R; cb += cstep) {
+        const int64_t t = onegrp ? cb + lane / G : cb + lane;
+        const bool ok = onegrp ? (lane % G == 0 && t < R) : t < R;
         int4 rc4 = make_int4(0, 0, 0, 0);
         int tw = 0;
         if (ok) {
           const int64_t src = rb + slot_perm(t, R, ks0, ks1);
           rc4 = rec[src];
           if (VAR == 1 || VAR == 2) tw = attr[src];
+          if (visit) atomicAdd(&visit[src], 1u);       // MFX_SGD_F_COUNT_VISITS
         }
-        const int nvalid = (int)(R - cb < 64 ? R - cb : 64);
+        int nvalid = (int)(R - cb < 64 ? R - cb : 64);
+        if (onegrp) nvalid = g == 0 ? (int)(R - cb < L ? R - cb : L) * G : 0;
         // L == 16: a group is one DPP row.  Transpose the chunk once (3 ds_bpermute) so that lane s of row g
         // holds entry s*G+g; every step then takes its entry with a row_share broadcast (no LDS traffic).
         int tx = rc4.x, ty = rc4.y, tz = rc4.z;
@@ -340,20 +357,30 @@ static int launch_slots(mfx_ctx* ctx, SlotList* S, const mfx_sgd_opts* o, int bl
   float* oth = OWN_U ? ctx->V : ctx->U;
   float* own = OWN_U ? ctx->U : ctx->V;
   const uint64_t ob = (uint64_t)(OWN_U ? ctx->nI : ctx->nU) * ctx->ld * 4;
+  const int32_t* at = VAR == 3 ? (const int32_t*)ctx->dimreg : (VAR ? S->attr : (const int32_t*)nullptr);
+  unsigned* visit = (o->flags & MFX_SGD_F_COUNT_VISITS) ? S->visit : nullptr;
   HIPCHK(hipMemsetAsync(S->ctr, 0, NTILE * sizeof(unsigned), ctx->stream));
+  if (o->flags & MFX_SGD_F_ONE_GROUP) {   // test hook: tiles in order, one workgroup, one lane group
+    for (int tile = 0; tile < NTILE; tile++)
+      hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, true, OWN_U, VAR>), dim3(1), dim3(WG), 0, ctx->stream,
+                         (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->tile_slot, S->ctr, 0,
+                         oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1, at, visit, tile, 1);
+    HIPCHK(hipGetLastError());
+    return MFX_OK;
+  }
   for (int round = 0; round < NUB; round++) {
     ProfScope ps(ctx, MFX_K_SGD);
     hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, false, OWN_U, VAR>), dim3(blocks), dim3(WG), 0, ctx->stream,
                        (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->tile_slot, S->ctr, round,
-                       oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1,
-                       VAR == 3 ? (const int32_t*)ctx->dimreg : (VAR ? S->attr : (const int32_t*)nullptr));
+                       oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1, at, visit, -1, 0);
   }
   {
+    // the drain: the same 8 diagonals keyed on the workgroup index (an item row keeps a single owner)
     ProfScope ps(ctx, MFX_K_SGD_SWEEP);
-    hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, true, OWN_U, VAR>), dim3(256), dim3(WG), 0, ctx->stream,
-                       (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->tile_slot, S->ctr, -1,
-                       oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1,
-                       VAR == 3 ? (const int32_t*)ctx->dimreg : (VAR ? S->attr : (const int32_t*)nullptr));
+    for (int round = 0; round < NUB; round++)
+      hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, true, OWN_U, VAR>), dim3(256), dim3(WG), 0, ctx->stream,
+                         (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->tile_slot, S->ctr, round,
+                         oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1, at, visit, -1, 0);
   }
   HIPCHK(hipGetLastError());
   return MFX_OK;

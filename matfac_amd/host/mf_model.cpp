@@ -546,7 +546,7 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
   std::vector<uint16_t> uOrder, iOrder;
   if (kind == K_CCD) dev->check(mfx_ccd_begin(dev->ctx), "mfx_ccd_begin");
 
-  mfx_sgd_opts o;
+  mfx_sgd_opts o = mfx_sgd_opts();
   o.uReg = uReg; o.iReg = iReg; o.seed = (uint32_t)trainSeed; o.blocks = 0; o.own = 0; o.first = 0; o.count = 0;
   // Arithmetic of the bracket: the reference's own per trainer when its order is replayed (MFX_EXACT), hogTrain's
   // float row expressions otherwise -- on the lock-free schedule the 1e-7 relative difference between the double

@@ -13,6 +13,7 @@ SIDE_USERS, SIDE_ITEMS = 0, 1
 SGD_HOGWILD, SGD_SERIAL, SGD_USERS, SGD_TILED = 0, 1, 2, 3
 ORDER_DEVICE, ORDER_HOST, ORDER_NATURAL = 0, 1, 2
 ARITH_REF64, ARITH_REF64F, ARITH_F32 = 0, 1, 2
+SGD_F_ONE_GROUP, SGD_F_COUNT_VISITS = 1, 2
 REDUCE_DELTA_SUM, REDUCE_AVERAGE = 0, 1
 K_SGD, K_PERMUTE, K_EVAL, K_ALS_GRAM, K_ALS_SOLVE, K_CCD_ROW, K_CCD_COL, K_CCD_RESID, K_SGD_SWEEP, K_CD = range(10)
 E_NODEVICE = -6
@@ -31,7 +32,7 @@ class SgdOpts(C.Structure):
     _fields_ = [("mode", C.c_int32), ("order", C.c_int32), ("arith", C.c_int32),
                 ("learnRate", C.c_float), ("uReg", C.c_float), ("iReg", C.c_float),
                 ("seed", C.c_uint32), ("epoch", C.c_int32), ("blocks", C.c_int32), ("own", C.c_int32),
-                ("first", C.c_int64), ("count", C.c_int64)]
+                ("first", C.c_int64), ("count", C.c_int64), ("flags", C.c_int32), ("reserved", C.c_int32)]
 
 
 class EvalOut(C.Structure):
@@ -138,8 +139,8 @@ class Ctx:
         self._chk(self.lib.mfx_sgd_set_order(self.h, k[1], C.c_int64(k[0].size)))
 
     def sgd_epoch(self, lr, uReg, iReg, mode=SGD_HOGWILD, order=ORDER_DEVICE, arith=ARITH_F32, seed=1,
-                  epoch=0, first=0, count=0, blocks=0, own=0):
-        o = SgdOpts(mode, order, arith, lr, uReg, iReg, seed, epoch, blocks, own, first, count)
+                  epoch=0, first=0, count=0, blocks=0, own=0, flags=0):
+        o = SgdOpts(mode, order, arith, lr, uReg, iReg, seed, epoch, blocks, own, first, count, flags, 0)
         self._chk(self.lib.mfx_sgd_epoch(self.h, C.byref(o)))
 
     def debug_epoch_list(self):
@@ -151,6 +152,13 @@ class Ctx:
         self._chk(self.lib.mfx_debug_epoch_list(self.h, u.ctypes.data_as(C.c_void_p), i.ctypes.data_as(C.c_void_p),
                                                 r.ctypes.data_as(C.c_void_p), C.c_int64(n.value), C.byref(n)))
         return u, i, r
+
+    def debug_visit_counts(self):
+        n = C.c_int64()
+        self._chk(self.lib.mfx_debug_visit_counts(self.h, None, C.c_int64(0), C.byref(n)))
+        c = np.empty(n.value, np.uint32)
+        self._chk(self.lib.mfx_debug_visit_counts(self.h, c.ctypes.data_as(C.c_void_p), C.c_int64(n.value), C.byref(n)))
+        return c
 
     def debug_slots_digest(self):
         counts = (C.c_int64 * 4)()

@@ -36,7 +36,11 @@ def test_tiled_sgd_visits_every_rating_once_and_learns(c2):
     key = tr.rowids().astype(np.int64) * c2["nItems"] + tr.rowind
     r0 = ctx.rmse(mfx.MAT_TRAIN)
     for ep in range(3):
-        ctx.sgd_epoch(0.0025, 0.01, 0.01, mode=mfx.SGD_TILED, seed=1, epoch=ep)
+        ctx.sgd_epoch(0.0025, 0.01, 0.01, mode=mfx.SGD_TILED, seed=1, epoch=ep, flags=mfx.SGD_F_COUNT_VISITS)
+        # counted by the update loop itself (one atomic per consumed rating record): the XCC-scheduled rounds plus
+        # the drain consumed every record of every slot exactly once
+        visits = ctx.debug_visit_counts()
+        assert visits.size == tr.nnz and visits.min() == 1 and visits.max() == 1
     u, i, r = ctx.debug_epoch_list()
     k = u.astype(np.int64) * c2["nItems"] + i
     assert k.size == tr.nnz

@@ -44,8 +44,12 @@ def test_hogwild_conflict_free_batch_bit_exact(K, arith):
     assert np.array_equal(V, Vo)
 
 
-@pytest.mark.parametrize("K", [10, 64, 256])
-def test_tiled_conflict_free_batch_bit_exact(K):
+@pytest.mark.parametrize("K", [10, 32, 64, 128, 192, 256])
+@pytest.mark.parametrize("arith", ARITHS)
+def test_tiled_conflict_free_batch_matches_oracle(K, arith):
+    """The kernel instantiations the host default and bench.py run (sgd_slots_kernel<.., ARITH_F32, item rows
+    owned, fixed point>: the delta branch for K <= 128, the LEAN re-read branch beyond) and the two double-bracket
+    ones, each against the oracle's pass with the SAME arithmetic (modelMF.cpp:1755-1762 / :91-103 / :288-299)."""
     n = 3000
     tr = _conflict_free_matrix(n, K, seed=K + 1)
     rng = np.random.default_rng(200 + K)
@@ -55,17 +59,117 @@ def test_tiled_conflict_free_batch_bit_exact(K):
         ctx.set_csr(mfx.MAT_TRAIN, n, n, tr.rowptr, tr.rowind, tr.rowval)
         ctx.set_model(n, n, K)
         ctx.set_factors(U0, V0)
-        ctx.sgd_epoch(0.01, 0.05, 0.02, mode=mfx.SGD_TILED, order=mfx.ORDER_DEVICE, arith=mfx.ARITH_REF64, seed=3, epoch=1)
+        ctx.sgd_epoch(0.01, 0.05, 0.02, mode=mfx.SGD_TILED, order=mfx.ORDER_DEVICE, arith=arith[0], seed=3, epoch=1,
+                      flags=mfx.SGD_F_COUNT_VISITS)
         U, V = ctx.get_factors()
         u, i, r = ctx.debug_epoch_list()
+        visits = ctx.debug_visit_counts()
     Uo, Vo = U0.copy(), V0.copy()
-    orc.sgd_pass(Uo, Vo, tr.rowids(), tr.rowind, tr.rowval, None, 0.01, 0.05, 0.02, orc.ARITH_REF64, orc.DOT_TREE)
-    # every rating visited exactly once.  The item rows are accumulated in LDS in 2^-24 fixed point
-    # (DESIGN.md 3.1): each differs from the oracle's fp32 row by at most ~2 * 2^-24; the user rows see the
-    # item row through that representation, hence the same bound scaled by lr * |diff|.
+    orc.sgd_pass(Uo, Vo, tr.rowids(), tr.rowind, tr.rowval, None, 0.01, 0.05, 0.02, arith[1], orc.DOT_TREE)
+    # The item rows are accumulated in LDS in 2^-24 fixed point: the row a visit reads is the fp32
+    # row rounded to that grid (<= 2^-25 off) and the row written back adds the rounded delta (<= 2^-25 off):
+    # <= 2 * 2^-25 + one fp32 rounding of the sum ~ 1.2e-7 on V; the user rows see the item row through that
+    # representation, the same bound scaled by lr * (|diff| + ...) << 1.
     assert np.abs(V - Vo).max() <= 2.0e-7
     assert np.abs(U - Uo).max() <= 2.0e-7
+    assert np.abs(V - V0).max() > 1e-3 and np.abs(U - U0).max() > 1e-3     # the epoch did something
     assert np.array_equal(np.sort(u), np.arange(n))
+    assert visits.size == n and np.all(visits == 1)                        # as counted by the update loop itself
+
+
+@pytest.mark.parametrize("K", [64, 256])
+def test_tiled_rows_outside_the_fixed_point_range(K):
+    """A slot whose staged item rows exceed +-127 runs on float rows (plain stores; on a conflict-free batch that is
+    bit-identical to the oracle), and a row that LEAVES the range while being updated is written back as NaN, so that
+    Model::isTerminateModel's guard (model.cpp:1486-1498) still sees the divergence."""
+    n = 2000
+    tr = _conflict_free_matrix(n, K, seed=K + 5)
+    rng = np.random.default_rng(300 + K)
+    U0 = rng.normal(0, 0.3, (n, K)).astype(np.float32)
+    V0 = rng.normal(0, 0.3, (n, K)).astype(np.float32)
+    big = rng.choice(n, 200, replace=False)
+    V0[big, 0] = 500.0                                    # these items' slots cannot use the fixed-point rows
+    with Ctx(0) as ctx:
+        ctx.set_csr(mfx.MAT_TRAIN, n, n, tr.rowptr, tr.rowind, tr.rowval)
+        ctx.set_model(n, n, K)
+        ctx.set_factors(U0, V0)
+        ctx.sgd_epoch(1e-4, 0.05, 0.02, mode=mfx.SGD_TILED, order=mfx.ORDER_DEVICE, arith=mfx.ARITH_F32, seed=3, epoch=1)
+        U, V = ctx.get_factors()
+    Uo, Vo = U0.copy(), V0.copy()
+    orc.sgd_pass(Uo, Vo, tr.rowids(), tr.rowind, tr.rowval, None, 1e-4, 0.05, 0.02, orc.ARITH_F32, orc.DOT_TREE)
+    assert np.isfinite(V).all()
+    # rows that shared a slot with an out-of-range row were handled as floats: exact; the others: fixed point
+    assert np.abs(V - Vo).max() <= 2.0e-7 * 500 and np.abs(U - Uo).max() <= 1e-6
+    exact_rows = np.all(V == Vo, axis=1)
+    assert exact_rows[big].all()
+    # leaving the range: rows at 126.99 pushed beyond 127 by one step
+    V1 = rng.normal(0, 0.3, (n, K)).astype(np.float32)
+    U1 = rng.normal(0, 0.01, (n, K)).astype(np.float32)
+    hot = rng.choice(n, 50, replace=False)
+    V1[hot, 1] = 126.99
+    users_of = np.empty(n, np.int64)
+    users_of[tr.rowind] = np.arange(n)                    # user of each item (conflict-free: one each)
+    U1[users_of[hot], 1] = 1.0                            # est ~ 127 -> diff ~ -122 -> p'[1] ~ -2.1 -> q[1] += ~0.05
+    with Ctx(0) as ctx:
+        ctx.set_csr(mfx.MAT_TRAIN, n, n, tr.rowptr, tr.rowind, tr.rowval)
+        ctx.set_model(n, n, K)
+        ctx.set_factors(U1, V1)
+        ctx.sgd_epoch(1e-4, 0.05, 0.02, mode=mfx.SGD_TILED, order=mfx.ORDER_DEVICE, arith=mfx.ARITH_F32, seed=3, epoch=1)
+        U, V = ctx.get_factors()
+    Uo, Vo = U1.copy(), V1.copy()
+    orc.sgd_pass(Uo, Vo, tr.rowids(), tr.rowind, tr.rowval, None, 1e-4, 0.05, 0.02, orc.ARITH_F32, orc.DOT_TREE)
+    assert (Vo[hot, 1] > 127.0).all()                     # the reference's float row does leave the range
+    assert np.isnan(V[hot, 1]).all()
+    cold = np.setdiff1d(np.arange(n), hot)
+    assert np.isfinite(V[cold]).all() and np.abs(V[cold] - Vo[cold]).max() <= 2e-7
+
+
+def _contended_matrix(n, nI, seed):
+    """n ratings, pairwise distinct users, items drawn from nI only: every item row is updated n/nI times."""
+    rng = np.random.default_rng(seed)
+    items = rng.integers(0, nI, n).astype(np.int32)
+    rowptr = np.arange(n + 1, dtype=np.int64)
+    vals = (rng.integers(1, 11, n) * 0.5).astype(np.float32)
+    return synth.CSR(n, nI, rowptr, items, vals)
+
+
+@pytest.mark.parametrize("K,nI", [(64, 6), (64, 60), (256, 6), (10, 60), (128, 60)])
+@pytest.mark.parametrize("arith", ARITHS)
+def test_tiled_owned_rows_under_repeated_updates_replay_the_sequential_loop(K, nI, arith):
+    """Hundreds to thousands of updates per item row, ONE lane group in flight (MFX_SGD_F_ONE_GROUP): the list
+    mfx_debug_epoch_list returns is then the visiting order, and the reference's sequential loop over that list
+    (oracle) must give the same factors.  nI = 6: every (tile, item) has > 512 ratings -> single-item slots;
+    nI = 60: slots of several items.  This is the owned fixed-point row read, updated by ds_add_u32 and read again,
+    which the conflict-free test cannot see."""
+    n = 48000
+    tr = _contended_matrix(n, nI, seed=K + nI)
+    rng = np.random.default_rng(400 + K)
+    U0 = rng.normal(0, 0.3, (n, K)).astype(np.float32)
+    V0 = rng.normal(0, 0.3, (nI, K)).astype(np.float32)
+    lr = 0.002
+    with Ctx(0) as ctx:
+        ctx.set_csr(mfx.MAT_TRAIN, n, nI, tr.rowptr, tr.rowind, tr.rowval)
+        ctx.set_model(n, nI, K)
+        ctx.set_factors(U0, V0)
+        ctx.sgd_epoch(lr, 0.05, 0.02, mode=mfx.SGD_TILED, order=mfx.ORDER_DEVICE, arith=arith[0], seed=11, epoch=2,
+                      flags=mfx.SGD_F_ONE_GROUP | mfx.SGD_F_COUNT_VISITS)
+        U, V = ctx.get_factors()
+        u, i, r = ctx.debug_epoch_list()
+        visits = ctx.debug_visit_counts()
+        counts, _ = ctx.debug_slots_digest()
+    assert np.all(visits == 1)
+    assert np.array_equal(np.sort(u), np.arange(n))
+    if nI == 6:
+        assert counts[2] == counts[0]                      # row references == slots: every slot has ONE item
+    Uo, Vo = U0.copy(), V0.copy()
+    orc.sgd_pass(Uo, Vo, u, i, r, None, lr, 0.05, 0.02, arith[1], orc.DOT_TREE)
+    per_row = n / nI
+    # every update leaves <= 2^-25 of rounding in the fixed-point row (uniform): a random walk of per_row steps
+    tol = 4.0 * 2.0 ** -25 * np.sqrt(per_row) + 2e-7
+    print("max |dV| %.3g  |dU| %.3g  tol %.3g" % (np.abs(V - Vo).max(), np.abs(U - Uo).max(), tol))
+    assert np.abs(Vo - V0).max() > 0.05                    # the rows moved far more than the tolerance
+    assert np.abs(V - Vo).max() <= tol
+    assert np.abs(U - Uo).max() <= tol
 
 
 def test_tiled_epoch_list_is_tile_grouped_permutation():
