@@ -97,13 +97,19 @@ enum {
   MFX_SGD_SERIAL = 1,   /* one rating at a time in list order: bit-exact a4 / a7 order  */
   MFX_SGD_USERS = 2,    /* one wave-group per user row, items in CSR order, users in
                            the (shuffled) user list: parallel trainUShuffle (a7)      */
-  MFX_SGD_TILED = 3     /* Hogwild scheduled in 8x8 (user-block x item-block) tiles: in
+  MFX_SGD_TILED = 3,    /* Hogwild scheduled in 8x8 (user-block x item-block) tiles: in
                            round r the workgroups running on XCD x visit tile
                            (x, (x+r) mod 8) only, so every factor row has ONE XCD (one
                            coherent L2) reading and writing it at a time; the order
                            inside a tile is the per-epoch device permutation.  This is
                            the stratification of trainSGDPar (modelMF.cpp:229-304) mapped
                            onto the chip's 8 L2 domains; MFX_ORDER_DEVICE only.        */
+  MFX_SGD_LEVELS = 4    /* the SEQUENTIAL loop in list order, bit for bit what MFX_SGD_SERIAL
+                           gives, run in parallel: ratings are cut into dependency levels
+                           (a rating waits for the previous rating of its user and of its
+                           item; everything else commutes exactly) and the levels run in
+                           order.  The exact replay of ModelMF::train / trainUShuffle /
+                           trainSGDPar orders (modelMF.cpp:83-105, 637-659, 273-304).     */
 };
 enum {
   MFX_ORDER_DEVICE = 0,  /* fresh device-side pseudo-random permutation per (seed, epoch) */
@@ -150,6 +156,9 @@ int mfx_sgd_epoch(mfx_ctx* ctx, const mfx_sgd_opts* opts);
 /* test hook: the (u,i,r) list the last epoch visited, in visiting order */
 int mfx_debug_epoch_list(mfx_ctx* ctx, int32_t* u, int32_t* i, float* r, int64_t cap,
                          int64_t* n);
+/* info = {levels, levels run with the grid barrier, tail threshold} of the last MFX_SGD_LEVELS epoch;
+ * prep_ms (may be NULL) = host time spent building its levels                                          */
+int mfx_debug_levels_info(mfx_ctx* ctx, int64_t info[3], double* prep_ms);
 /* test hook: digest of the slot lists the last MFX_SGD_TILED epoch ran on.  counts = {slots, ratings, row
  * references, rows per slot}; sums = FNV-1a of {rating records, slot_beg, slot_ibeg, slot rows, tile_slot} */
 int mfx_debug_slots_digest(mfx_ctx* ctx, int64_t counts[4], uint64_t sums[5]);

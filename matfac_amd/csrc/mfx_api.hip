@@ -111,6 +111,7 @@ void mfx_destroy(mfx_ctx* ctx) {
   free_model(ctx);
   dev_free(ctx->eu); dev_free(ctx->ei); dev_free(ctx->er); dev_free(ctx->order);
   mfx_slots_free_internal(ctx);
+  mfx_levels_free_internal(ctx);
   dev_free(ctx->ulist); dev_free(ctx->red_d); dev_free(ctx->red_i);
   if (ctx->red_out) (void)hipHostFree(ctx->red_out);
   for (auto& s : ctx->prof) {
@@ -465,7 +466,7 @@ extern "C" int mfx_sgd_epoch(mfx_ctx* ctx, const mfx_sgd_opts* o) {
   NEED(ctx->U, MFX_E_STATE, "mfx_sgd_epoch: no model");
   NEED(m.nrows <= ctx->nU && m.ncols <= ctx->nI, MFX_E_ARG,
        "mfx_sgd_epoch: train matrix %dx%d exceeds model %dx%d", m.nrows, m.ncols, ctx->nU, ctx->nI);
-  NEED(o->mode >= MFX_SGD_HOGWILD && o->mode <= MFX_SGD_TILED, MFX_E_ARG, "mfx_sgd_epoch: mode=%d", o->mode);
+  NEED(o->mode >= MFX_SGD_HOGWILD && o->mode <= MFX_SGD_LEVELS, MFX_E_ARG, "mfx_sgd_epoch: mode=%d", o->mode);
   NEED(!ctx->dimreg || o->mode == MFX_SGD_HOGWILD || o->mode == MFX_SGD_SERIAL || o->mode == MFX_SGD_TILED, MFX_E_ARG,
        "mfx_sgd_epoch: per-dimension regularisation (mfx_sgd_set_dim_reg) runs on MFX_SGD_HOGWILD / MFX_SGD_SERIAL / MFX_SGD_TILED");
   NEED(!ctx->ifw || o->mode == MFX_SGD_HOGWILD || o->mode == MFX_SGD_SERIAL || o->mode == MFX_SGD_TILED, MFX_E_ARG,

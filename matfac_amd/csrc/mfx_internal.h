@@ -72,6 +72,8 @@ struct mfx_ctx {
   int64_t ulist_cap = 0;
   // MFX_SGD_TILED: slot lists (sgd_slots.hip owns the type)
   void* slots = nullptr;
+  // MFX_SGD_LEVELS: level lists (sgd_levels.hip owns the type)
+  void* levels = nullptr;
 
   // reduction scratch
   double* red_d = nullptr;   // [blocks][4]
@@ -203,6 +205,8 @@ void mfx_ifw_tables(mfx_ctx* ctx, const float2** ua, const float2** ia, float* r
 int mfx_launch_sgd_tmf(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_t count);      // sgd_tmf.hip
 void mfx_tmf_free_internal(mfx_ctx* ctx);
 int mfx_launch_sgd_dimreg(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_t count);   // svd.hip
+int mfx_launch_sgd_levels(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_t count);   // sgd_levels.hip
+void mfx_levels_free_internal(mfx_ctx* ctx);
 int mfx_slots_materialise_order(mfx_ctx* ctx);
 void mfx_slots_free_internal(mfx_ctx* ctx);
 int mfx_launch_eval(mfx_ctx* ctx, const DevCSR& m, const float* U, const float* V,

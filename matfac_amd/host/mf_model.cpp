@@ -13,7 +13,9 @@
 #include <fstream>
 #include <iostream>
 #include <numeric>
+#include <omp.h>
 #include <random>
+#include <unordered_set>
 
 // ---------------------------------------------------------------------------
 // device session
@@ -458,6 +460,76 @@ bool Model::terminateImpl(bool sing, Model& bestModel, const Data& data, int ite
 // ---------------------------------------------------------------------------
 // ModelMF trainers
 // ---------------------------------------------------------------------------
+// ---- ModelMF::trainSGDPar's stratification (modelMF.cpp:229-265, 273-304; util.cpp:1077-1107) ------------------
+// The reference keeps every part as a std::unordered_set<int> and sweeps a block in that container's iteration order;
+// the sets are rebuilt here by the same insertion sequence (same libstdc++ => same order) and flattened once.
+namespace {
+struct Strata {
+  int T = 0;
+  std::vector<std::vector<int>> users;   // users of each part, in the iteration order of the reference's set
+  std::vector<int> itemPart;             // part of each item, -1: not in any
+
+  template <class Set>
+  void deal(std::mt19937& mt, const csr_t* trainMat, const Set& invalidUsers, const Set& invalidItems, int parts) {
+    T = parts;
+    std::vector<int> trainUsers, trainItems;
+    for (int u = 0; u < trainMat->nrows; u++)
+      if (!invalidUsers.count(u)) trainUsers.push_back(u);
+    for (int item = 0; item < trainMat->ncols; item++)
+      if (!invalidItems.count(item)) trainItems.push_back(item);
+    std::shuffle(trainUsers.begin(), trainUsers.end(), mt);
+    std::shuffle(trainItems.begin(), trainItems.end(), mt);
+    // the part index advances AFTER the insert whenever i % perPart == 0 (and i != 0): the first part gets one extra
+    auto partOf = [&](size_t n, std::vector<int>& out) {
+      const int per = (int)n / T;
+      out.resize(n);
+      int cur = 0;
+      for (size_t i = 0; i < n; i++) {
+        out[i] = cur;
+        if (i != 0 && per > 0 && (int)i % per == 0 && cur != T - 1) cur++;
+      }
+    };
+    std::vector<int> pu, pi;
+    partOf(trainUsers.size(), pu);
+    partOf(trainItems.size(), pi);
+    std::vector<std::unordered_set<int>> sets((size_t)T);
+    for (size_t i = 0; i < trainUsers.size(); i++) sets[(size_t)pu[i]].insert(trainUsers[i]);
+    users.assign((size_t)T, std::vector<int>());
+    for (int t = 0; t < T; t++) users[(size_t)t].assign(sets[(size_t)t].begin(), sets[(size_t)t].end());
+    itemPart.assign((size_t)trainMat->ncols, -1);
+    for (size_t i = 0; i < trainItems.size(); i++) itemPart[(size_t)trainItems[i]] = pi[i];
+  }
+
+  // sgdUpdateBlockSeq: user parts in shuffled order, each drawing one of the item parts still free
+  void matching(std::mt19937& mt, std::vector<std::pair<int, int>>& seq) const {
+    seq.clear();
+    std::vector<int> rows((size_t)T), left((size_t)T);
+    std::iota(rows.begin(), rows.end(), 0);
+    std::iota(left.begin(), left.end(), 0);
+    std::shuffle(rows.begin(), rows.end(), mt);
+    for (int r : rows) {
+      std::uniform_int_distribution<int> dis(0, (int)left.size() - 1);
+      const int at = dis(mt);
+      seq.emplace_back(r, left[(size_t)at]);
+      left.erase(left.begin() + at);          // the free parts stay in ascending order, as the reference re-collects them
+    }
+  }
+
+  // CSR positions of one epoch's visits: T rounds x T blocks, a block = its users' rows restricted to its item part
+  void epochList(std::mt19937& mt, const csr_t* trainMat, std::vector<size_t>& out) const {
+    out.clear();
+    std::vector<std::pair<int, int>> seq;
+    for (int k = 0; k < T; k++) {
+      matching(mt, seq);
+      for (const auto& blk : seq)
+        for (int u : users[(size_t)blk.first])
+          for (int64_t e = trainMat->rowptr[u]; e < trainMat->rowptr[u + 1]; e++)
+            if (itemPart[(size_t)trainMat->rowind[e]] == blk.second) out.push_back((size_t)e);
+    }
+  }
+};
+}  // namespace
+
 void ModelMF::train(const Data& d, Model& b, IntSet& iu, IntSet& ii) { run(K_SGD, "train", d, b, iu, ii); }
 void ModelMF::hogTrain(const Data& d, Model& b, IntSet& iu, IntSet& ii) { run(K_HOG, "hogTrain", d, b, iu, ii); }
 void ModelMF::trainSGDPar(const Data& d, Model& b, IntSet& iu, IntSet& ii) { run(K_SGDPAR, "trainSGDPar", d, b, iu, ii); }
@@ -473,7 +545,10 @@ void ModelMF::trainSGDParSVD(const Data& d, Model& b, IntSet& iu, IntSet& ii) { 
 void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestModel, IntSet& invalidUsers,
                   IntSet& invalidItems) {
   std::cout << "\nModelMF::" << name << " trainSeed: " << trainSeed;
-  const bool exact = getenv("MFX_EXACT") != nullptr;   // replay the reference's sequential order bit by bit
+  // MFX_EXACT: replay the reference's own visiting order bit by bit -- 1: level-scheduled (MFX_SGD_LEVELS, parallel),
+  // 2: one lane group in list order (MFX_SGD_SERIAL, the slow statement of the same thing)
+  const bool exact = getenv("MFX_EXACT") != nullptr;
+  const int replayMode = (exact && atoi(getenv("MFX_EXACT")) == 2) ? MFX_SGD_SERIAL : MFX_SGD_LEVELS;
   const csr_t* trainMat = data.trainMat;
 
   // bestModel starts as its own initialisation (main.cpp:1326-1327); it becomes the BEST snapshot
@@ -533,6 +608,12 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
     uiRatingInds.resize((size_t)nRatings);
     std::iota(uiRatingInds.begin(), uiRatingInds.end(), 0);
   }
+  Strata strata;
+  if (kind == K_SGDPAR && exact) {
+    // modelMF.cpp:191-265: valid users / items shuffled with mt and dealt into T = omp_get_max_threads() parts
+    const char* e = getenv("MFX_SGDPAR_PARTS");
+    strata.deal(mt, trainMat, invalidUsers, invalidItems, e ? std::max(1, atoi(e)) : omp_get_max_threads());
+  }
   if (kind == K_SGDU) {
     for (int u = 0; u < nUsers; u++)
       if (!invalidUsers.count(u)) validUsers.push_back(u);
@@ -569,15 +650,28 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
           // OpenMP thread is a plain std::shuffle; the reference is only reproducible that way)
           std::shuffle(uiRatingInds.begin(), uiRatingInds.end(), mt);
           dev->check(mfx_sgd_set_order(dev->ctx, (const uint64_t*)uiRatingInds.data(), nRatings), "set_order");
-          o.mode = MFX_SGD_SERIAL; o.order = MFX_ORDER_HOST;
+          o.mode = kind == K_IFW ? MFX_SGD_SERIAL : replayMode; o.order = MFX_ORDER_HOST;
         } else {
           o.mode = MFX_SGD_TILED; o.order = MFX_ORDER_DEVICE;   // (K_IFW: the tiled kernel's weighted variant)
         }
         dev->check(mfx_sgd_epoch(dev->ctx, &o), "mfx_sgd_epoch");
         break;
-      case K_SGDPAR:   // stratified: user-block x item-block tiles, one L2 domain per tile
-        o.mode = MFX_SGD_TILED; o.order = MFX_ORDER_DEVICE;
-        dev->check(mfx_sgd_epoch(dev->ctx, &o), "mfx_sgd_epoch");
+      case K_SGDPAR:
+        if (exact) {
+          // modelMF.cpp:273-304: T rounds, each a fresh random matching user part -> item part; the blocks of a round
+          // share no rows, so their sequential sweeps commute and ONE list (round by round, block by block) replayed in
+          // order is the reference's parallel-for.  float diff, double bracket (:289-299).
+          strata.epochList(mt, trainMat, uiRatingInds);
+          if (!uiRatingInds.empty()) {
+            dev->check(mfx_sgd_set_order(dev->ctx, (const uint64_t*)uiRatingInds.data(), (int64_t)uiRatingInds.size()), "set_order");
+            o.mode = replayMode; o.order = MFX_ORDER_HOST;
+            dev->check(mfx_sgd_epoch(dev->ctx, &o), "mfx_sgd_epoch");
+          }
+        } else {
+          // default: the stratification mapped onto the chip's own strata -- user-block x item-block tiles, one L2 domain per tile
+          o.mode = MFX_SGD_TILED; o.order = MFX_ORDER_DEVICE;
+          dev->check(mfx_sgd_epoch(dev->ctx, &o), "mfx_sgd_epoch");
+        }
         break;
       case K_TMFD:        // modelPoissonDropout.cpp:170-224: K_TMF with the draws mfx_set_tmf_dropout installed
       case K_TMF:         // modelDropoutSigmoid.cpp:140-192 with the rank table beforeLoop() installed; float diff
@@ -599,7 +693,7 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
             for (int64_t e = trainMat->rowptr[u]; e < trainMat->rowptr[u + 1]; e++) uiRatingInds.push_back((size_t)e);
           dev->check(mfx_sgd_set_order(dev->ctx, (const uint64_t*)uiRatingInds.data(), (int64_t)uiRatingInds.size()),
                      "set_order");
-          o.mode = MFX_SGD_SERIAL; o.order = MFX_ORDER_HOST;
+          o.mode = replayMode; o.order = MFX_ORDER_HOST;
         } else if (getenv("MFX_SGDU_USERS_KERNEL")) {
           // one group per user, the user row kept in registers over the user's ratings (closest to the reference's
           // order; 12x slower than the tiled schedule at the ML-20M shape)

@@ -10,7 +10,7 @@ MAT_TRAIN, MAT_VAL, MAT_TEST = 0, 1, 2
 ROWMAJOR, COLMAJOR = 0, 1
 SNAP_CURRENT, SNAP_BEST = 0, 1
 SIDE_USERS, SIDE_ITEMS = 0, 1
-SGD_HOGWILD, SGD_SERIAL, SGD_USERS, SGD_TILED = 0, 1, 2, 3
+SGD_HOGWILD, SGD_SERIAL, SGD_USERS, SGD_TILED, SGD_LEVELS = 0, 1, 2, 3, 4
 ORDER_DEVICE, ORDER_HOST, ORDER_NATURAL = 0, 1, 2
 ARITH_REF64, ARITH_REF64F, ARITH_F32 = 0, 1, 2
 SGD_F_ONE_GROUP, SGD_F_COUNT_VISITS = 1, 2
@@ -152,6 +152,12 @@ class Ctx:
         self._chk(self.lib.mfx_debug_epoch_list(self.h, u.ctypes.data_as(C.c_void_p), i.ctypes.data_as(C.c_void_p),
                                                 r.ctypes.data_as(C.c_void_p), C.c_int64(n.value), C.byref(n)))
         return u, i, r
+
+    def debug_levels_info(self):
+        info = (C.c_int64 * 3)()
+        ms = C.c_double()
+        self._chk(self.lib.mfx_debug_levels_info(self.h, info, C.byref(ms)))
+        return list(info), ms.value
 
     def debug_visit_counts(self):
         n = C.c_int64()

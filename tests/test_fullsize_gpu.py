@@ -54,6 +54,39 @@ def test_tiled_sgd_visits_every_rating_once_and_learns(c2):
     ctx.close()
 
 
+def test_level_schedule_at_full_size_is_the_sequential_loop_bit_for_bit(c2):
+    """ModelMF::train's loop (modelMF.cpp:83-105) over the whole C2 list in a std::shuffle order: the level-scheduled
+    replay (MFX_SGD_LEVELS) against the oracle's sequential pass, np.array_equal on both factor matrices.  This is the
+    path north_star's "SGD test RMSE within 1e-4 under a fixed seed" is stated for; its speed is printed."""
+    import time
+    from oracle import binding as orc
+    tr = c2["train"]
+    K = 64
+    ctx, U0, V0 = _ctx(c2, K)
+    order = np.arange(tr.nnz, dtype=np.uint64)
+    orc.MT(1).shuffle_u64(order)
+    ctx.sgd_set_order(order)
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    t0 = time.perf_counter()
+    ctx.sgd_epoch(0.0025, 0.01, 0.01, mode=mfx.SGD_LEVELS, order=mfx.ORDER_HOST, arith=mfx.ARITH_REF64)
+    ctx.synchronize()
+    wall = time.perf_counter() - t0
+    ms, _ = ctx.prof_get(mfx.K_SGD)
+    info, prep_ms = ctx.debug_levels_info()
+    U, V = ctx.get_factors()
+    ctx.close()
+    Uo, Vo = U0.copy(), V0.copy()
+    t0 = time.perf_counter()
+    orc.sgd_pass(Uo, Vo, tr.rowids(), tr.rowind, tr.rowval, order, 0.0025, 0.01, 0.01, orc.ARITH_REF64, orc.DOT_TREE)
+    cpu = time.perf_counter() - t0
+    print("C2 exact epoch: %d levels (%d with grid barrier), kernels %.1f ms = %.1f M updates/s, host level "
+          "construction %.0f ms, whole call %.0f ms; oracle sequential pass %.1f s"
+          % (info[0], info[1], ms, tr.nnz / ms / 1e3, prep_ms, wall * 1e3, cpu))
+    assert np.array_equal(U, Uo)
+    assert np.array_equal(V, Vo)
+
+
 def test_als_rows_solve_their_normal_equations_at_full_size(c2):
     tr = c2["train"]
     K, reg = 64, 5.0

@@ -46,14 +46,14 @@ def host_train(method, d, K, maxIter, seed, lr, ureg, ireg, prefix=None, env=Non
                 invU=invU, invI=invI, nItems=int(stats[5]), loop_s=stats[6], iters=int(stats[7]))
 
 
-def oracle_train(method, d, K, maxIter, seed, lr, ureg, ireg, dot_mode=orc.DOT_SEQ):
+def oracle_train(method, d, K, maxIter, seed, lr, ureg, ireg, dot_mode=orc.DOT_SEQ, nthreads=1):
     tr, va, te = d["train"], d["val"], d["test"]
     nU, nI = d["nUsers"], d["nItems"]
     cp, ci, cv = orc.create_col_index(tr.nrows, tr.ncols, tr.rowptr, tr.rowind, tr.rowval)
     U0, V0 = orc.init_factors(seed, nU, nI, K)
     r = orc.train(method, U0, V0, (tr.nrows, tr.ncols, tr.rowptr, tr.rowind, tr.rowval, cp, ci, cv),
                   (va.nrows, va.rowptr, va.rowind, va.rowval), nU, nI, K, maxIter, seed, lr, ureg, ireg,
-                  nthreads=1, dot_mode=dot_mode)
+                  nthreads=nthreads, dot_mode=dot_mode)
     r["test"], _, _ = orc.rmse(r["Ubest"], r["Vbest"], nU, nI, te.nrows, te.rowptr, te.rowind, te.rowval,
                                r["invU"], r["invI"], dot_mode)
     r["valbest"], _, _ = orc.rmse(r["Ubest"], r["Vbest"], nU, nI, va.nrows, va.rowptr, va.rowind, va.rowval,
@@ -78,6 +78,33 @@ def test_train_exact_mode_is_bit_identical_to_sequential_reference_loop():
     # and the reference's own dot order (sequential) lands on the same RMSE to round-off
     o2 = oracle_train(orc.M_SGD, d, K, 25, 1, 0.01, 0.02, 0.03, dot_mode=orc.DOT_SEQ)
     assert abs(h["test"] - o2["test"]) < 1e-4          # north_star: SGD test RMSE within 1e-4 under a fixed seed
+
+
+@pytest.mark.parametrize("exact", ["1", "2"])
+def test_train_exact_mode_level_schedule_and_serial_kernel_agree_on_a_contended_matrix(exact):
+    """MFX_EXACT=1 (level-scheduled replay, MFX_SGD_LEVELS) and MFX_EXACT=2 (one group in list order) are the same
+    function: both bit-identical to the oracle on a matrix with 500-rating item rows."""
+    d, K = data(1500, 120, 60000, seed=21), 32
+    h = host_train("sgd", d, K, 6, 4, 0.01, 0.02, 0.03, env={"MFX_EXACT": exact})
+    o = oracle_train(orc.M_SGD, d, K, 6, 4, 0.01, 0.02, 0.03, dot_mode=orc.DOT_TREE)
+    assert np.array_equal(h["U"], o["U"]) and np.array_equal(h["V"], o["V"])
+    assert np.array_equal(h["Ubest"], o["Ubest"]) and np.array_equal(h["Vbest"], o["Vbest"])
+
+
+@pytest.mark.parametrize("T", [1, 3, 8])
+def test_sgdpar_exact_mode_is_bit_identical_to_the_stratified_reference_loop(T):
+    """ModelMF::trainSGDPar (modelMF.cpp:229-304 + util.cpp:1077-1107) with MFX_EXACT: the host class deals users and
+    items into T parts and draws a random matching per round exactly as the reference does (same mt19937 stream,
+    same unordered_set iteration order); the blocks of a round share no rows, so the list replayed by the level
+    schedule is the reference's parallel-for.  float diff, double bracket.  T = the reference's OpenMP thread count."""
+    d, K = data(400, 300, 20000, seed=9), 16
+    h = host_train("sgdpar", d, K, 10, 2, 0.01, 0.02, 0.03, env={"MFX_EXACT": "1", "MFX_SGDPAR_PARTS": str(T)})
+    o = oracle_train(orc.M_SGDPAR, d, K, 10, 2, 0.01, 0.02, 0.03, dot_mode=orc.DOT_TREE, nthreads=T)
+    assert np.array_equal(h["U"], o["U"]) and np.array_equal(h["V"], o["V"])
+    assert np.array_equal(h["Ubest"], o["Ubest"]) and np.array_equal(h["Vbest"], o["Vbest"])
+    assert abs(h["test"] - o["test"]) < 1e-12
+    o2 = oracle_train(orc.M_SGDPAR, d, K, 10, 2, 0.01, 0.02, 0.03, dot_mode=orc.DOT_SEQ, nthreads=T)
+    assert abs(h["test"] - o2["test"]) < 1e-4          # the reference's own dot order: round-off only
 
 
 def test_ushuffle_exact_mode_is_bit_identical():

@@ -202,6 +202,56 @@ def test_tiled_epoch_list_is_tile_grouped_permutation():
     assert np.all(np.diff(tile) >= 0)
 
 
+@pytest.mark.parametrize("K", [5, 10, 32, 64, 128, 256, 320])
+@pytest.mark.parametrize("arith", ARITHS)
+def test_level_schedule_is_the_sequential_loop_bit_for_bit(K, arith):
+    """MFX_SGD_LEVELS on a contended list (items with ~1000 ratings, users with ~100; both phases of the schedule:
+    grid-barrier levels and the one-workgroup tail) == the oracle's sequential pass over the same list, every bit,
+    for every rank shape and arithmetic, over 3 epochs with fresh std::shuffle orders."""
+    d = small(nU=1200, nI=100, nnz=100_000, K=K, seed=6)
+    tr = d["train"]
+    nU, nI = d["nUsers"], d["nItems"]
+    U0, V0 = orc.init_factors(1, nU, nI, K)
+    U0 *= 30
+    V0 *= 30
+    ru = tr.rowids()
+    mt = orc.MT(2)
+    order = np.arange(tr.nnz, dtype=np.uint64)
+    Uo, Vo = U0.copy(), V0.copy()
+    with Ctx(0) as ctx:
+        load_ctx(ctx, d, K, U0, V0)
+        for ep in range(3):
+            mt.shuffle_u64(order)
+            ctx.sgd_set_order(order)
+            ctx.sgd_epoch(0.005, 0.01, 0.01, mode=mfx.SGD_LEVELS, order=mfx.ORDER_HOST, arith=arith[0])
+            orc.sgd_pass(Uo, Vo, ru, tr.rowind, tr.rowval, order, 0.005, 0.01, 0.01, arith[1], orc.DOT_TREE)
+            info, prep_ms = ctx.debug_levels_info()
+            assert 0 < info[1] < info[0]                  # both phases ran
+            assert info[0] >= np.bincount(tr.rowind).max()  # at least as many levels as the longest item chain
+        U, V = ctx.get_factors()
+    assert np.array_equal(U, Uo)
+    assert np.array_equal(V, Vo)
+
+
+def test_level_schedule_sub_range_and_natural_order():
+    d = small(nU=300, nI=80, nnz=20_000, K=64, seed=8)
+    tr, K = d["train"], 64
+    U0, V0 = orc.init_factors(3, d["nUsers"], d["nItems"], K)
+    U0 *= 20
+    V0 *= 20
+    ru = tr.rowids()
+    n = tr.nnz
+    Uo, Vo = U0.copy(), V0.copy()
+    with Ctx(0) as ctx:
+        load_ctx(ctx, d, K, U0, V0)
+        ctx.sgd_epoch(0.01, 0.02, 0.03, mode=mfx.SGD_LEVELS, order=mfx.ORDER_NATURAL, arith=mfx.ARITH_REF64,
+                      first=100, count=n - 300)
+        U, V = ctx.get_factors()
+    sel = np.arange(100, n - 200, dtype=np.uint64)
+    orc.sgd_pass(Uo, Vo, ru, tr.rowind, tr.rowval, sel, 0.01, 0.02, 0.03, orc.ARITH_REF64, orc.DOT_TREE)
+    assert np.array_equal(U, Uo) and np.array_equal(V, Vo)
+
+
 @pytest.mark.parametrize("K", [10, 64, 128])
 @pytest.mark.parametrize("arith", ARITHS)
 def test_serial_epochs_bit_exact(K, arith):
