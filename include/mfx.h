@@ -105,11 +105,13 @@ enum {
                            the stratification of trainSGDPar (modelMF.cpp:229-304) mapped
                            onto the chip's 8 L2 domains; MFX_ORDER_DEVICE only.        */
   MFX_SGD_LEVELS = 4    /* the SEQUENTIAL loop in list order, bit for bit what MFX_SGD_SERIAL
-                           gives, run in parallel: ratings are cut into dependency levels
-                           (a rating waits for the previous rating of its user and of its
-                           item; everything else commutes exactly) and the levels run in
-                           order.  The exact replay of ModelMF::train / trainUShuffle /
-                           trainSGDPar orders (modelMF.cpp:83-105, 637-659, 273-304).     */
+                           gives, run in parallel: a rating waits for the previous rating
+                           of its user and of its item in the list and for nothing else
+                           (visits that share no row commute exactly).  Dataflow schedule
+                           (owned rows + version counters, sgd_flow.hip) or dependency
+                           levels with a grid barrier (sgd_levels.hip).  The exact replay
+                           of ModelMF::train / trainUShuffle / trainSGDPar orders
+                           (modelMF.cpp:83-105, 637-659, 273-304).                        */
 };
 enum {
   MFX_ORDER_DEVICE = 0,  /* fresh device-side pseudo-random permutation per (seed, epoch) */
@@ -156,9 +158,10 @@ int mfx_sgd_epoch(mfx_ctx* ctx, const mfx_sgd_opts* opts);
 /* test hook: the (u,i,r) list the last epoch visited, in visiting order */
 int mfx_debug_epoch_list(mfx_ctx* ctx, int32_t* u, int32_t* i, float* r, int64_t cap,
                          int64_t* n);
-/* info = {levels, levels run with the grid barrier, tail threshold} of the last MFX_SGD_LEVELS epoch;
- * prep_ms (may be NULL) = host time spent building its levels                                          */
-int mfx_debug_levels_info(mfx_ctx* ctx, int64_t info[3], double* prep_ms);
+/* the schedule of the last MFX_SGD_LEVELS epoch: info = {1 (dataflow), longest queue, lane groups, owned side} or
+ * {0 (levels), levels, levels run with the grid barrier, tail threshold}; prep_ms (may be NULL) = host time spent
+ * building it                                                                                                  */
+int mfx_debug_levels_info(mfx_ctx* ctx, int64_t info[4], double* prep_ms);
 /* test hook: digest of the slot lists the last MFX_SGD_TILED epoch ran on.  counts = {slots, ratings, row
  * references, rows per slot}; sums = FNV-1a of {rating records, slot_beg, slot_ibeg, slot rows, tile_slot} */
 int mfx_debug_slots_digest(mfx_ctx* ctx, int64_t counts[4], uint64_t sums[5]);

@@ -112,6 +112,7 @@ void mfx_destroy(mfx_ctx* ctx) {
   dev_free(ctx->eu); dev_free(ctx->ei); dev_free(ctx->er); dev_free(ctx->order);
   mfx_slots_free_internal(ctx);
   mfx_levels_free_internal(ctx);
+  mfx_flow_free_internal(ctx);
   dev_free(ctx->ulist); dev_free(ctx->red_d); dev_free(ctx->red_i);
   if (ctx->red_out) (void)hipHostFree(ctx->red_out);
   for (auto& s : ctx->prof) {

@@ -74,6 +74,8 @@ struct mfx_ctx {
   void* slots = nullptr;
   // MFX_SGD_LEVELS: level lists (sgd_levels.hip owns the type)
   void* levels = nullptr;
+  bool last_exact_flow = false;   // which schedule the last MFX_SGD_LEVELS epoch ran on
+  void* flow = nullptr;       // its dataflow schedule (sgd_flow.hip owns the type)
 
   // reduction scratch
   double* red_d = nullptr;   // [blocks][4]
@@ -207,6 +209,10 @@ void mfx_tmf_free_internal(mfx_ctx* ctx);
 int mfx_launch_sgd_dimreg(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_t count);   // svd.hip
 int mfx_launch_sgd_levels(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_t count);   // sgd_levels.hip
 void mfx_levels_free_internal(mfx_ctx* ctx);
+int mfx_launch_sgd_flow(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_t count);     // sgd_flow.hip
+bool mfx_flow_usable(const mfx_ctx* ctx, int64_t count);
+bool mfx_flow_info(mfx_ctx* ctx, int64_t info[4], double* prep_ms);
+void mfx_flow_free_internal(mfx_ctx* ctx);
 int mfx_slots_materialise_order(mfx_ctx* ctx);
 void mfx_slots_free_internal(mfx_ctx* ctx);
 int mfx_launch_eval(mfx_ctx* ctx, const DevCSR& m, const float* U, const float* V,

@@ -46,30 +46,37 @@ struct LevelState {
 };
 LevelState* lv(mfx_ctx* ctx) { return (LevelState*)ctx->levels; }
 
-template <int L, int C, int ARITH>
-__device__ __forceinline__ void level_visit(float* U, float* V, int u, int it, float r, int j, float lr, float uReg, float iReg) {
+// POL 1: agent-scope (sc1) loads and write-through stores -- the rows never sit in a non-coherent cache, so the
+// grid barrier needs no cache maintenance; POL 0: plain accesses (tables of 4 GiB and more, which a buffer
+// descriptor cannot address), the barrier then writes back / invalidates the L2 (a full-cache walk per level).
+template <int L, int C, int ARITH, int POL>
+__device__ __forceinline__ void level_visit(const Rows<POL>& Um, const Rows<POL>& Vm, int u, int it, float r, int j, float lr,
+                                            float uReg, float iReg) {
   constexpr int LD = 4 * L * C;
-  float* pr = U + (int64_t)u * LD + 4 * j;
-  float* qr = V + (int64_t)it * LD + 4 * j;
+  const int64_t pe = (int64_t)u * LD + 4 * j, qe = (int64_t)it * LD + 4 * j;
   float4v p[C], q[C];
 #pragma unroll
   for (int c = 0; c < C; c++) {
-    p[c] = *(const float4v*)(pr + c * 4 * L);
-    q[c] = *(const float4v*)(qr + c * 4 * L);
+    p[c] = Um.ld(pe + c * 4 * L);
+    q[c] = Vm.ld(qe + c * 4 * L);
   }
   const float est = group_dot<L, C>(p, q);
   sgd_axpys<C, ARITH>(p, q, r, est, lr, uReg, iReg);
 #pragma unroll
   for (int c = 0; c < C; c++) {
-    *(float4v*)(pr + c * 4 * L) = p[c];
-    *(float4v*)(qr + c * 4 * L) = q[c];
+    Um.st(pe + c * 4 * L, p[c]);
+    Vm.st(qe + c * 4 * L, q[c]);
   }
 }
 
 // every workgroup arrives once per level; `target` = workgroups x levels completed.  A waiter that sees no progress for
 // ~2 s raises the abort flag and everybody leaves: a grid barrier must not be able to hang the device.
+template <int POL>
 __device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned target) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");     // this wave's row stores are visible device-wide ...
+  // this wave's row stores are visible device-wide (POL 1: acknowledged write-through stores, only the wait is
+  // needed; POL 0: L2 write-back) ...
+  if (POL == 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   __syncthreads();                                       // ... for every wave of the workgroup, before it arrives
   __shared__ int s_abort;
   if (threadIdx.x == 0) {
@@ -88,25 +95,26 @@ __device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned target) {
     s_abort = ab;
   }
   __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // drop stale lines before the next level's row loads
+  if (POL != 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // drop stale lines before the next level's row loads
   return s_abort != 0;
 }
 
-template <int L, int C, int ARITH>
+template <int L, int C, int ARITH, int POL>
 __global__ __launch_bounds__(LV_WG) void sgd_levels_grid_kernel(const int32_t* __restrict__ lu, const int32_t* __restrict__ li,
                                                                 const float* __restrict__ lr_, const int64_t* __restrict__ loff,
-                                                                int64_t lev0, int64_t lev1, float* U, float* V, float lr, float uReg,
-                                                                float iReg, unsigned* bar) {
+                                                                int64_t lev0, int64_t lev1, float* U, float* V, uint32_t ubytes,
+                                                                uint32_t vbytes, float lr, float uReg, float iReg, unsigned* bar) {
   constexpr int G = 64 / L;
+  const Rows<POL> Um(U, ubytes), Vm(V, vbytes);
   const int lane = threadIdx.x & 63, g = lane / L, j = lane % L;
   const int64_t grp = ((int64_t)blockIdx.x * (LV_WG / 64) + (threadIdx.x >> 6)) * G + g;
   const int64_t ngrp = (int64_t)gridDim.x * (LV_WG / 64) * G;
   unsigned done = 0;
   for (int64_t l = lev0; l < lev1; l++) {
     const int64_t b = loff[l], e = loff[l + 1];
-    for (int64_t x = b + grp; x < e; x += ngrp) level_visit<L, C, ARITH>(U, V, lu[x], li[x], lr_[x], j, lr, uReg, iReg);
+    for (int64_t x = b + grp; x < e; x += ngrp) level_visit<L, C, ARITH, POL>(Um, Vm, lu[x], li[x], lr_[x], j, lr, uReg, iReg);
     done += gridDim.x;
-    if (l + 1 < lev1 && grid_barrier(bar, done)) return;
+    if (l + 1 < lev1 && grid_barrier<POL>(bar, done)) return;
   }
 }
 
@@ -116,13 +124,14 @@ __global__ __launch_bounds__(LV_WG) void sgd_levels_tail_kernel(const int32_t* _
                                                                 int64_t lev0, int64_t lev1, float* U, float* V, float lr, float uReg,
                                                                 float iReg) {
   constexpr int G = 64 / L;
+  const Rows<0> Um(U, 0), Vm(V, 0);
   const int lane = threadIdx.x & 63, g = lane / L, j = lane % L;
   const int grp = (threadIdx.x >> 6) * G + g;
   constexpr int ngrp = (LV_WG / 64) * G;
   int64_t b = loff[lev0];
   for (int64_t l = lev0; l < lev1; l++) {
     const int64_t e = loff[l + 1];
-    for (int64_t x = b + grp; x < e; x += ngrp) level_visit<L, C, ARITH>(U, V, lu[x], li[x], lr_[x], j, lr, uReg, iReg);
+    for (int64_t x = b + grp; x < e; x += ngrp) level_visit<L, C, ARITH, 0>(Um, Vm, lu[x], li[x], lr_[x], j, lr, uReg, iReg);
     b = e;
     // one CU, one L1, one L2: workgroup scope is enough between the levels of the tail
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -220,8 +229,13 @@ int launch_levels_lca(mfx_ctx* ctx, const mfx_sgd_opts* o) {
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const int blocks = std::max(1, std::min(cus, 1024));      // one workgroup per CU: all resident, the barrier cannot starve
     HIPCHK(hipMemsetAsync(S->bar, 0, 2 * sizeof(unsigned), ctx->stream));
-    hipLaunchKernelGGL((sgd_levels_grid_kernel<L, C, ARITH>), dim3(blocks), dim3(LV_WG), 0, ctx->stream, S->lu, S->li, S->lr, S->loff,
-                       (int64_t)0, S->cut, ctx->U, ctx->V, o->learnRate, o->uReg, o->iReg, S->bar);
+    const uint64_t ub = (uint64_t)ctx->nU * ctx->ld * 4, vb = (uint64_t)ctx->nI * ctx->ld * 4;
+    if (ub < (1ull << 32) && vb < (1ull << 32) && !getenv("MFX_LEVELS_FENCE"))
+      hipLaunchKernelGGL((sgd_levels_grid_kernel<L, C, ARITH, 1>), dim3(blocks), dim3(LV_WG), 0, ctx->stream, S->lu, S->li, S->lr,
+                         S->loff, (int64_t)0, S->cut, ctx->U, ctx->V, (uint32_t)ub, (uint32_t)vb, o->learnRate, o->uReg, o->iReg, S->bar);
+    else
+      hipLaunchKernelGGL((sgd_levels_grid_kernel<L, C, ARITH, 0>), dim3(blocks), dim3(LV_WG), 0, ctx->stream, S->lu, S->li, S->lr,
+                         S->loff, (int64_t)0, S->cut, ctx->U, ctx->V, 0u, 0u, o->learnRate, o->uReg, o->iReg, S->bar);
   }
   if (S->cut < S->nlevels)
     hipLaunchKernelGGL((sgd_levels_tail_kernel<L, C, ARITH>), dim3(1), dim3(LV_WG), 0, ctx->stream, S->lu, S->li, S->lr, S->loff, S->cut,
@@ -252,6 +266,11 @@ void mfx_levels_free_internal(mfx_ctx* ctx) {
 int mfx_launch_sgd_levels(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_t count) {
   NEED(!ctx->dimreg && !ctx->ifw && !ctx->tmf_u, MFX_E_ARG,
        "MFX_SGD_LEVELS runs the plain update; the SGD variants replay their order with MFX_SGD_SERIAL");
+  // default: the barrier-free dataflow schedule (sgd_flow.hip); the level schedule below serves factor tables a buffer
+  // descriptor cannot address (4 GiB and more) and MFX_EXACT_SCHED=levels
+  const char* sched = getenv("MFX_EXACT_SCHED");
+  ctx->last_exact_flow = mfx_flow_usable(ctx, count) && !(sched && sched[0] == 'l');
+  if (ctx->last_exact_flow) return mfx_launch_sgd_flow(ctx, o, first, count);
   int rc = build_levels(ctx, first, count);
   if (rc) return rc;
   const int L = ctx->L, C = ctx->C;
@@ -280,11 +299,13 @@ int mfx_launch_sgd_levels(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, in
   return MFX_OK;
 }
 
-extern "C" int mfx_debug_levels_info(mfx_ctx* ctx, int64_t info[3], double* prep_ms) {
+extern "C" int mfx_debug_levels_info(mfx_ctx* ctx, int64_t info[4], double* prep_ms) {
   if (!ctx) return MFX_E_ARG;
+  NEED(info, MFX_E_ARG, "mfx_debug_levels_info: info NULL");
+  if (ctx->last_exact_flow && mfx_flow_info(ctx, info, prep_ms)) return MFX_OK;
   LevelState* S = lv(ctx);
-  NEED(S && info, MFX_E_STATE, "mfx_debug_levels_info: no MFX_SGD_LEVELS epoch has run");
-  info[0] = S->nlevels; info[1] = S->cut; info[2] = TAIL;
+  NEED(S, MFX_E_STATE, "mfx_debug_levels_info: no MFX_SGD_LEVELS epoch has run");
+  info[0] = 0; info[1] = S->nlevels; info[2] = S->cut; info[3] = TAIL;
   if (prep_ms) *prep_ms = S->prep_ms;
   return MFX_OK;
 }

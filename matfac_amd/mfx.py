@@ -154,7 +154,7 @@ class Ctx:
         return u, i, r
 
     def debug_levels_info(self):
-        info = (C.c_int64 * 3)()
+        info = (C.c_int64 * 4)()
         ms = C.c_double()
         self._chk(self.lib.mfx_debug_levels_info(self.h, info, C.byref(ms)))
         return list(info), ms.value

@@ -26,8 +26,8 @@ for name, K, serial_n in (("C1", 10, None), ("C2", 64, 400_000)):
             wall = time.perf_counter() - t0
             ms, _ = ctx.prof_get(mfx.K_SGD)
             info, prep = ctx.debug_levels_info()
-        print("%s levels: %d levels (%d grid), kernels %.2f ms = %.1f M upd/s; host prep %.0f ms; call %.0f ms = %.1f M upd/s"
-              % (name, info[0], info[1], ms, tr.nnz / ms / 1e3, prep, wall * 1e3, tr.nnz / wall / 1e6), flush=True)
+        print("%s exact replay [sched %d: %d / %d], kernels %.2f ms = %.1f M upd/s; host prep %.0f ms; call %.0f ms = %.1f M upd/s"
+              % (name, info[0], info[1], info[2], ms, tr.nnz / ms / 1e3, prep, wall * 1e3, tr.nnz / wall / 1e6), flush=True)
         n = serial_n or tr.nnz
         ctx.prof_reset()
         ctx.sgd_epoch(0.0025, 0.01, 0.01, mode=mfx.SGD_SERIAL, order=mfx.ORDER_HOST, arith=mfx.ARITH_REF64, first=0, count=n)

@@ -80,9 +80,9 @@ def test_level_schedule_at_full_size_is_the_sequential_loop_bit_for_bit(c2):
     t0 = time.perf_counter()
     orc.sgd_pass(Uo, Vo, tr.rowids(), tr.rowind, tr.rowval, order, 0.0025, 0.01, 0.01, orc.ARITH_REF64, orc.DOT_TREE)
     cpu = time.perf_counter() - t0
-    print("C2 exact epoch: %d levels (%d with grid barrier), kernels %.1f ms = %.1f M updates/s, host level "
+    print("C2 exact epoch (%s schedule, %d / %d): kernels %.1f ms = %.1f M updates/s, host schedule "
           "construction %.0f ms, whole call %.0f ms; oracle sequential pass %.1f s"
-          % (info[0], info[1], ms, tr.nnz / ms / 1e3, prep_ms, wall * 1e3, cpu))
+          % ("dataflow" if info[0] else "level", info[1], info[2], ms, tr.nnz / ms / 1e3, prep_ms, wall * 1e3, cpu))
     assert np.array_equal(U, Uo)
     assert np.array_equal(V, Vo)
 

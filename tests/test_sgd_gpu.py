@@ -202,12 +202,20 @@ def test_tiled_epoch_list_is_tile_grouped_permutation():
     assert np.all(np.diff(tile) >= 0)
 
 
+@pytest.fixture(params=["flow", "levels"])
+def exact_sched(request, monkeypatch):
+    """the two schedules behind MFX_SGD_LEVELS: dataflow (default) and dependency levels with a grid barrier"""
+    monkeypatch.setenv("MFX_EXACT_SCHED", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("K", [5, 10, 32, 64, 128, 256, 320])
 @pytest.mark.parametrize("arith", ARITHS)
-def test_level_schedule_is_the_sequential_loop_bit_for_bit(K, arith):
-    """MFX_SGD_LEVELS on a contended list (items with ~1000 ratings, users with ~100; both phases of the schedule:
-    grid-barrier levels and the one-workgroup tail) == the oracle's sequential pass over the same list, every bit,
-    for every rank shape and arithmetic, over 3 epochs with fresh std::shuffle orders."""
+def test_level_schedule_is_the_sequential_loop_bit_for_bit(K, arith, exact_sched):
+    """MFX_SGD_LEVELS on a contended list (items with ~1000 ratings, users with ~100) == the oracle's sequential pass
+    over the same list, every bit, for every rank shape and arithmetic, over 3 epochs with fresh std::shuffle orders;
+    both schedules (dataflow: owned item rows + user version counters; levels: grid-barrier levels and the
+    one-workgroup tail)."""
     d = small(nU=1200, nI=100, nnz=100_000, K=K, seed=6)
     tr = d["train"]
     nU, nI = d["nUsers"], d["nItems"]
@@ -226,14 +234,16 @@ def test_level_schedule_is_the_sequential_loop_bit_for_bit(K, arith):
             ctx.sgd_epoch(0.005, 0.01, 0.01, mode=mfx.SGD_LEVELS, order=mfx.ORDER_HOST, arith=arith[0])
             orc.sgd_pass(Uo, Vo, ru, tr.rowind, tr.rowval, order, 0.005, 0.01, 0.01, arith[1], orc.DOT_TREE)
             info, prep_ms = ctx.debug_levels_info()
-            assert 0 < info[1] < info[0]                  # both phases ran
-            assert info[0] >= np.bincount(tr.rowind).max()  # at least as many levels as the longest item chain
+            assert info[0] == (1 if exact_sched == "flow" else 0)
+            if exact_sched == "levels":
+                assert 0 < info[2] < info[1]                  # both phases ran
+            assert info[1] >= np.bincount(tr.rowind).max()    # levels / longest queue >= the longest item chain
         U, V = ctx.get_factors()
     assert np.array_equal(U, Uo)
     assert np.array_equal(V, Vo)
 
 
-def test_level_schedule_sub_range_and_natural_order():
+def test_level_schedule_sub_range_and_natural_order(exact_sched):
     d = small(nU=300, nI=80, nnz=20_000, K=64, seed=8)
     tr, K = d["train"], 64
     U0, V0 = orc.init_factors(3, d["nUsers"], d["nItems"], K)
