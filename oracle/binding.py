@@ -76,6 +76,7 @@ lib.orc_strat_create.restype = C.c_void_p
 lib.orc_objective.restype = C.c_double
 lib.orc_rmse.restype = C.c_double
 lib.orc_time_hogwild.restype = C.c_double
+lib.orc_time_strat.restype = C.c_double
 
 
 class TrainCfg(C.Structure):
@@ -364,6 +365,17 @@ def time_hogwild(U, V, u, i, r, nU, nI, K, lr, uReg, iReg, nthreads, colmajor, e
     return lib.orc_time_hogwild(K, nU, nI, F(U), F(V), I32(u), I32(i), F(r), C.c_int64(len(u)),
                                 C.c_float(lr), C.c_float(uReg), C.c_float(iReg), nthreads,
                                 int(colmajor), epochs)
+
+
+def time_strat(U, V, rowptr, rowind, rowval, nrows, ncols, invU, invI, T, lr, uReg, iReg, seed=1, epochs=1):
+    """seconds for `epochs` stratified epochs (trainSGDPar) with T parts / T OpenMP threads"""
+    mt = MT(seed)
+    h = C.c_void_p(lib.orc_strat_create(mt.h, nrows, ncols, U8(invU), U8(invI), T))
+    try:
+        return lib.orc_time_strat(h, mt.h, U.shape[1], F(U), F(V), I64(rowptr), I32(rowind), F(rowval),
+                                  C.c_float(lr), C.c_float(uReg), C.c_float(iReg), epochs)
+    finally:
+        lib.orc_strat_free(h)
 
 
 def max_threads():

@@ -1139,3 +1139,35 @@ double orc_time_hogwild(int K, int32_t nU, int32_t nI, float* U, float* V, const
   auto t1 = std::chrono::steady_clock::now();
   return std::chrono::duration<double>(t1 - t0).count();
 }
+
+// modelMF.cpp:271-309 bracket: trainSGDPar's epoch as the reference runs it -- T rounds, the T disjoint blocks of a
+// round in an OpenMP parallel for (one block per thread), each block scanning its users' rows and skipping the
+// items outside its item part through unordered_set::count (:279-285).  Returns seconds for `epochs` epochs.
+double orc_time_strat(void* h, void* mth, int K, float* U, float* V, const int64_t* rowptr,
+                      const int32_t* rowind, const float* rowval, float lr, float uReg, float iReg,
+                      int epochs) {
+  Strat* s = (Strat*)h;
+  std::mt19937& mt = *(std::mt19937*)mth;
+  const int T = s->T;
+  std::vector<std::pair<int, int>> updateSeq;
+  auto t0 = std::chrono::steady_clock::now();
+  for (int ep = 0; ep < epochs; ep++)
+    for (int k = 0; k < T; k++) {
+      block_seq(T, updateSeq, mt);
+#pragma omp parallel for num_threads(T) schedule(static, 1)
+      for (int t = 0; t < T; t++) {
+        const auto& users = s->usersPart[updateSeq[t].first];
+        const auto& items = s->itemsPart[updateSeq[t].second];
+        for (const auto& u : users)
+          for (int64_t ii = rowptr[u]; ii < rowptr[u + 1]; ii++) {
+            const int item = rowind[ii];
+            if (items.count(item) == 0) continue;
+            sgd_update(U + (int64_t)u * K, V + (int64_t)item * K, rowval[ii], K, lr, uReg, iReg,
+                       ORC_ARITH_REF64F, ORC_DOT_SEQ);
+          }
+      }
+    }
+  auto t1 = std::chrono::steady_clock::now();
+  return std::chrono::duration<double>(t1 - t0).count();
+}
+

@@ -223,6 +223,11 @@ double orc_time_hogwild(int K, int32_t nU, int32_t nI, float* U, float* V,
                         const int32_t* u, const int32_t* i, const float* r, int64_t n,
                         float lr, float uReg, float iReg, int nthreads, int colmajor,
                         int epochs);
+/* trainSGDPar's epoch (modelMF.cpp:271-309 bracket) with the T blocks of a round in an OpenMP parallel for;
+ * h from orc_strat_create.  Returns seconds for `epochs` epochs.                                          */
+double orc_time_strat(void* h, void* mt, int K, float* U, float* V, const int64_t* rowptr,
+                      const int32_t* rowind, const float* rowval, float lr, float uReg, float iReg,
+                      int epochs);
 int orc_max_threads(void);
 
 #ifdef __cplusplus
