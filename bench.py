@@ -1,24 +1,47 @@
 #!/usr/bin/env python3
-"""bench.py -- rating-updates/sec of the rank-64 SGD hot path on synthetic ML-20M-shape CSR.
+"""bench.py -- rating-updates/sec of the rank-64 SGD hot path on synthetic ML-20M-shape CSR (BASELINE.json C2).
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = one SGD epoch (device-side reshuffle + Hogwild update kernel, modelMF.cpp:1739-1767)
-over the rank's train ratings.  N > 1: one process per GPU (torch.distributed.run), the rating
-matrix is sharded by user-row blocks (every rank owns a full ML-20M-shape block of users over the
-SAME item catalogue: weak scaling) and the item-factor replicas are averaged with one RCCL all-reduce
-after every local epoch.  Rank 0 prints ONE JSON line (see the driver contract in the task statement).
+One "step" = one SGD epoch (device-side reshuffle + the tiled lock-free update kernel, the bracket of
+modelMF.cpp:1739-1767) over the rank's train ratings.  N > 1: one process per GPU (started by torch.distributed.run, or
+by this script itself when it finds no WORLD_SIZE), the rating matrix sharded by user-row blocks, the item-factor
+replicas averaged with one RCCL all-reduce after every local epoch.
+  --scaling weak    (default) every rank owns a full ML-20M-shape block of users over the SAME item catalogue
+  --scaling strong  ONE ML-20M-shape matrix cut into N nnz-balanced user blocks (matfac_amd.dist.user_blocks)
+Rank 0 prints ONE JSON line.  At N = 1 the line also carries `cpu_baseline` (the oracle's OpenMP loops on the host
+cores), `secondary` (ALS at C3, CCD++ at C4, SGD at the C5-shard shape, each with its own roofline and CPU baseline)
+and `rmse_parity` (the fast path against the reference's own seed-to-seed spread).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec); f32 MFMA 157.3 TFLOP/s; 256 CUs x 4 SIMD-32, a wave64 vector instruction
+# issues over 2 cycles, max clock 2.4 GHz
+HBM_PEAK_GBS = 8000.0
+MFMA_F32_PEAK_TF = 157.3
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0      # G wave-instructions/s
+PMC_SUMMARY = os.path.join("profiles", "r02_pmc_summary.json")
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (before anything
+    here has touched the GPU), forward rank 0's JSON line, return their exit code."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def main():
@@ -31,10 +54,18 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="scale nnz (debug only)")
     ap.add_argument("--arith", default="f32", choices=["f32", "ref64"])
     ap.add_argument("--mode", default="tiled", choices=["tiled", "hogwild"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--blocks", type=int, default=0, help="workgroups in flight (0 = library heuristic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the ALS / CCD++ / C5-shard records (N = 1 only)")
+    ap.add_argument("--secondary", default="als,ccd,c5", help="which secondary records to take")
+    ap.add_argument("--no-parity", action="store_true", help="skip the rmse_parity record")
     ap.add_argument("--cpu-sample", type=float, default=1.0, help="epochs of the CPU baseline sample")
     args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "0") or 0)
+    if world == 0 and args.gpus > 1:
+        sys.exit(self_launch(args))
 
     # everything but the final JSON line goes to stderr (RCCL prints its version banner on stdout)
     sys.stdout.flush()
@@ -42,13 +73,9 @@ def main():
     os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = max(world, 1)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    N = args.gpus
-    if N != world:
-        if world == 1 and N > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % N)
-        N = world
+    N = world
 
     import numpy as np
 
@@ -57,7 +84,8 @@ def main():
     # BENCH_COMM=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks -- the ranks share the
     # visible GPUs and the exchange goes through mfx_comm_init_external + gloo instead of RCCL (never the driver's mode)
     use_gloo = os.environ.get("BENCH_COMM") == "gloo"
-    if N > 1 or force_dist:
+    multi = N > 1 or force_dist
+    if multi:
         import torch
         import torch.distributed as dist
         if use_gloo:
@@ -68,20 +96,29 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from matfac_amd import Ctx, mfx, synth
+    from matfac_amd import dist as mdist
 
     K = args.K
     shape = dict(synth.SHAPES[args.workload])
     # the NAMED shape is the training matrix: generate train/val/test = 80/10/10 around it
     shape["nnz"] = int(shape["nnz"] * args.scale / 0.8)
     t0 = time.time()
-    d = synth.make(shape, seed=1, shard=rank)
-    tr, va = d["train"], d["val"]
-    nU, nI = d["nUsers"], shape["nI"]
+    if args.scaling == "strong" and N > 1:
+        full = synth.make(shape, seed=1, shard=0)                 # the same matrix on every rank ...
+        b = mdist.user_blocks(full["train"].rowptr, N)            # ... cut by train ratings
+        tr = mdist.take_rows(full["train"], b[rank], b[rank + 1])
+        va = mdist.take_rows(full["val"], b[rank], b[rank + 1])
+        nU = int(b[rank + 1] - b[rank])
+        del full
+    else:
+        d = synth.make(shape, seed=1, shard=rank)
+        tr, va = d["train"], d["val"]
+        nU = d["nUsers"]
+    nI = shape["nI"]
     gen_s = time.time() - t0
 
     ctx = Ctx(local_rank)
-    cp, ci, cv = tr.col_view() if False else (None, None, None)
-    ctx.set_csr(mfx.MAT_TRAIN, tr.nrows, nI, tr.rowptr, tr.rowind, tr.rowval, cp, ci, cv)
+    ctx.set_csr(mfx.MAT_TRAIN, tr.nrows, nI, tr.rowptr, tr.rowind, tr.rowval)
     ctx.set_csr(mfx.MAT_VAL, va.nrows, nI, va.rowptr, va.rowind, va.rowval)
     ctx.set_model(nU, nI, K)
     U0, _ = synth.init_factors(1 + rank, nU, nI, K, want_v=False)   # U shard: per-rank stream
@@ -89,7 +126,7 @@ def main():
     ctx.set_factors(U0, V0)
     ctx.compute_invalid()
     exchange = "RCCL item-factor all-reduce"
-    if N > 1 or force_dist:
+    if multi:
         import torch
         if use_gloo:
             exchange = "gloo all-reduce staged through the host (rehearsal)"
@@ -131,25 +168,33 @@ def main():
 
     # main.cpp:29-31 defaults are learnrate 0.005, ureg = ireg = 0.01.  On ML-20M-skewed data the
     # reference's sequential loop diverges at 0.005 in its first epoch (NaN) and its own guard
-    # (model.cpp:1486-1498) halves the rate: 0.0025 is where the CPU reference actually trains.
+    # (model.cpp:1486-1498) halves the rate: 0.0025 is where the CPU reference actually trains
+    # (tests/test_fullsize_gpu.py::test_reference_loop_needs_the_halved_rate_at_c2 replays that first epoch).
     lr, ureg, ireg = 0.0025, 0.01, 0.01
     arith = mfx.ARITH_F32 if args.arith == "f32" else mfx.ARITH_REF64
     nnz = tr.nnz
     mode = mfx.SGD_TILED if args.mode == "tiled" else mfx.SGD_HOGWILD
 
-    def step(ep):
+    def step(ep, exch=True):
         ctx.sgd_epoch(lr, ureg, ireg, mode=mode, order=mfx.ORDER_DEVICE, arith=arith, seed=1, epoch=ep,
                       blocks=args.blocks)
-        if N > 1 or force_dist:
+        if multi and exch:
             ctx.allreduce_item_factors(mfx.REDUCE_AVERAGE)   # replicas of V averaged (summed deltas overshoot: DESIGN.md 3.1)
 
     def barrier():
         ctx.synchronize()
-        if N > 1 or force_dist:
+        if multi:
             import torch
             dist.barrier()
             if not use_gloo:
                 torch.cuda.synchronize()
+
+    def global_rmse(which):
+        o = ctx.eval(which)
+        v = np.array([o.sse, float(o.n)])
+        if multi:
+            v = ctx.allreduce_f64(v)
+        return float(np.sqrt(v[0] / v[1])) if v[1] else float("nan")
 
     for ep in range(args.warmup):
         step(ep)
@@ -164,11 +209,20 @@ def main():
     ctx.prof_enable(False)
     sgd_ms, sgd_launches = ctx.prof_get(mfx.K_SGD)
     perm_ms, _ = ctx.prof_get(mfx.K_PERMUTE)
-    val_rmse = ctx.rmse(mfx.MAT_VAL)
-    tr_rmse = ctx.rmse(mfx.MAT_TRAIN)
+    val_rmse = global_rmse(mfx.MAT_VAL)
+    tr_rmse = global_rmse(mfx.MAT_TRAIN)
+    val_rmse_solo = None
+    if multi:
+        # the same epochs WITHOUT the exchange (every rank on its own replica of V): what averaging the replicas costs
+        # or buys in convergence is the difference between the two validation RMSEs
+        ctx.set_factors(U0, V0)
+        ctx.comm_mark_synced()
+        for ep in range(args.warmup + args.steps):
+            step(ep, exch=False)
+        val_rmse_solo = global_rmse(mfx.MAT_VAL)
 
     total_nnz = nnz
-    if N > 1 or force_dist:
+    if multi:
         import torch
         t = torch.tensor([elapsed, float(nnz)], dtype=torch.float64, device="cpu" if use_gloo else "cuda")
         tmax = t.clone()
@@ -182,62 +236,111 @@ def main():
         value = total_nnz * args.steps / elapsed
         avg_ms = sgd_ms / max(1, sgd_launches)
         launches_per_step = max(1, sgd_launches // args.steps)   # tiled: 8 round launches per epoch
-        # B_sgd(K) = 16K+12 bytes per update x updates one launch processes
-        alg_bytes = (16 * K + 12) * nnz / launches_per_step
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        kernel = "sgd_slots_kernel" if mode == mfx.SGD_TILED else "sgd_hogwild_kernel"
         out = {
             "metric": "rating-updates/sec @ rank=%d" % K, "value": value, "unit": "updates/s",
             "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %s synthetic CSR %dx%d per GPU, train nnz=%d per GPU, rank=%d, "
-                                   "%s Hogwild SGD epoch (device reshuffle + update kernel%s)"
+            "config": {"workload": "%s: %s synthetic CSR, %s, train nnz=%d %s, rank=%d, %s Hogwild SGD epoch (device reshuffle "
+                                   "+ update kernel%s)"
                                    % (args.workload, {"C1": "ML-100K-shape", "C2": "ML-20M-shape", "C4": "Netflix-shape"}.get(args.workload, ""),
-                                      nU, nI, nnz, K, "XCD-tiled" if mode == mfx.SGD_TILED else "flat",
-                                      ", " + exchange if N > 1 or force_dist else ""),
+                                      ("%dx%d per GPU (weak scaling: one such user block per GPU over the same items)" % (nU, nI)) if args.scaling == "weak" or N == 1
+                                      else ("ONE %dx%d matrix cut into %d nnz-balanced user blocks (strong scaling)" % (shape["nU"], nI, N)),
+                                      nnz if N == 1 or args.scaling == "weak" else total_nnz, "per GPU" if args.scaling == "weak" or N == 1 else "in total",
+                                      K, "XCD-tiled" if mode == mfx.SGD_TILED else "flat", ", " + exchange if multi else ""),
                        "learnrate": lr, "ureg": ureg, "ireg": ireg, "arith": args.arith,
                        "parallelism": "user-block x%d" % N},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(mode),
-                         "kernel": "sgd_slots_kernel" if mode == mfx.SGD_TILED else "sgd_hogwild_kernel",
-                         "avg_launch_ms": avg_ms, "launches": sgd_launches, "launches_per_step": launches_per_step,
-                         "algorithmic_bytes_per_launch": alg_bytes},
+            "roofline": sgd_roofline(K, nnz, launches_per_step, avg_ms, sgd_launches, kernel),
             "permute_ms_per_step": perm_ms / max(1, args.steps),
             "val_rmse_after": val_rmse, "train_rmse_after": tr_rmse,
             "datagen_s": gen_s,
         }
-        if N == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(np, tr, nU, nI, K, lr, ureg, ireg, args.cpu_sample)
-    if N > 1 or force_dist:
+        if multi:
+            out["val_rmse_after_same_epochs_without_exchange"] = val_rmse_solo
+    solo = N == 1 and not force_dist
+    if multi:
         ctx.comm_destroy()
         dist.barrier()
-        dist.destroy_process_group()
     ctx.close()
+    if rank == 0 and solo:
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(np, tr, nU, nI, K, lr, ureg, ireg, args.cpu_sample)
+        if not args.no_secondary and args.workload == "C2" and args.scale == 1.0:
+            out["secondary"] = secondary(np, args, d, K, with_cpu=not args.no_cpu_baseline)
+        if not args.no_parity:
+            out["rmse_parity"] = rmse_parity(np)
+    if multi:
+        dist.barrier()
+        dist.destroy_process_group()
     sys.stdout.flush()
     os.dup2(saved_stdout, 1)
     if rank == 0:
         print(json.dumps(out), flush=True)
 
 
-def pmc_traffic(mode):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
-    command (profiles/r01_pmc_summary.json: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, KB -> bytes).
-    rocprofv3 cannot run inside this process; None when no summary is committed for the kernel."""
-    from matfac_amd import mfx
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-    if not os.path.exists(path):
-        return None
+def pmc(kernel):
+    """Counters of `kernel` from the committed rocprofv3 PMC passes of this same command (scripts/profile_round.sh ->
+    profiles/r02_pmc_summary.json).  rocprofv3 cannot run inside this process: these are per-launch means of THAT run,
+    named as such in the record; None when the summary has no entry for the kernel."""
+    path = os.path.join(ROOT, PMC_SUMMARY)
     try:
-        d = json.load(open(path))
-        key = "sgd_slots_kernel" if mode == mfx.SGD_TILED else "sgd_hogwild_kernel"
-        return d[key]["hbm_bytes_per_launch"]
+        return json.load(open(path))[kernel]
     except Exception:
         return None
 
 
+def sgd_roofline(K, nnz, launches_per_step, avg_ms, launches, kernel):
+    """What bounds the dominant kernel, with fractions that cannot exceed 1.
+
+    SURVEY 8(d)'s algorithmic figure (16K+12 bytes per update) assumes both rows of every update come from and go
+    back to HBM.  At C2 they do not: the item rows of a slot live in LDS and the 42 MB of factors stay in L2 /
+    Infinity Cache, so that figure exceeds the HBM peak and bounds nothing (kept as `algorithmic`).  The counters show
+    two candidates: bytes that really cross the L2's memory side (FETCH_SIZE x2 + WRITE_SIZE), and vector
+    instructions issued.  `bound` names the larger fraction."""
+    avg_s = avg_ms * 1e-3
+    per_launch = nnz / launches_per_step
+    alg_bytes = (16 * K + 12) * per_launch
+    r = {"kernel": kernel, "avg_launch_ms": avg_ms, "launches": launches, "launches_per_step": launches_per_step,
+         "updates_per_launch": per_launch,
+         "algorithmic": {"bytes_per_launch": alg_bytes, "achieved": alg_bytes / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg_bytes / avg_s / 1e9 / HBM_PEAK_GBS,
+                         "note": "SURVEY 8(d) model: every row read and written in HBM; exceeds 1 when the rows are "
+                                 "served from LDS / L2 / Infinity Cache (C2: 42 MB of factors) -- not a bound there"}}
+    c = pmc(kernel)
+    cands = []
+    if c and "hbm_bytes_per_launch" in c:
+        traffic = c["hbm_bytes_per_launch"] * (per_launch / c.get("updates_per_launch", per_launch))
+        fr = traffic / avg_s / 1e9 / HBM_PEAK_GBS
+        cands.append(("hbm", traffic / avg_s / 1e9, HBM_PEAK_GBS, "GB/s", fr))
+        r["traffic"] = traffic
+        r["traffic_source"] = ("%s: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per launch, separate --pmc passes of "
+                               "this command; time from this run's HIP events" % PMC_SUMMARY)
+        r["l2_hit_rate"] = c.get("l2_hit_rate")
+    else:
+        r["traffic"] = None
+    if c and "SQ_INSTS_VALU" in c.get("counters_mean_per_launch", {}):
+        valu = c["counters_mean_per_launch"]["SQ_INSTS_VALU"]
+        per_update = valu / c.get("updates_per_launch", per_launch)
+        ach = per_update * per_launch / avg_s / 1e9
+        cands.append(("valu-issue", ach, VALU_PEAK_GINST, "G wave-instr/s", ach / VALU_PEAK_GINST))
+        r["valu_issue"] = {"wave_instructions_per_update": per_update, "achieved": ach, "peak": VALU_PEAK_GINST,
+                           "unit": "G wave-instr/s", "frac": ach / VALU_PEAK_GINST,
+                           "note": "SQ_INSTS_VALU per launch from %s / updates of that launch; peak = 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 "
+                                   "cycles per wave64 instruction" % PMC_SUMMARY}
+    if cands:
+        b = max(cands, key=lambda x: x[4])
+        r.update({"bound": b[0], "achieved": b[1], "peak": b[2], "unit": b[3], "frac": b[4]})
+    else:   # no committed counters for this kernel: only the model line exists
+        a = r["algorithmic"]
+        r.update({"bound": "hbm", "achieved": a["achieved"], "peak": a["peak"], "unit": a["unit"], "frac": a["frac"]})
+    return r
+
+
 def cpu_baseline(np, tr, nU, nI, K, lr, ureg, ireg, epochs):
-    """The oracle's OpenMP Hogwild loop (restatement of modelMF.cpp:1746-1767) on the host cores:
-    reported baseline only.  Sample = `epochs` epoch(s) over the first part of the same train list."""
+    """The oracle's OpenMP loops on the host cores: Hogwild (restatement of the modelMF.cpp:1746-1767 bracket) and the
+    stratified epoch of trainSGDPar (:271-309).  Reported baseline only.  Sample = `epochs` epoch(s) over the first part
+    of the same train list (Hogwild) / the first users of the same matrix (stratified)."""
     from oracle import binding as orc
     from matfac_amd import synth
     threads = orc.max_threads()
@@ -255,10 +358,271 @@ def cpu_baseline(np, tr, nU, nI, K, lr, ureg, ireg, epochs):
         orc.time_hogwild(Uc, Vc, u[: n // 20], i[: n // 20], r[: n // 20], nU, nI, K, lr, ureg, ireg, threads, colmajor)
         s = orc.time_hogwild(Uc, Vc, u, i, r, nU, nI, K, lr, ureg, ireg, threads, colmajor)
         res[name] = n / s
-    return {"value": res["rowmajor"], "unit": "updates/s", "cores": threads, "kind": "port",
-            "sample": "%d shuffled train ratings (%.2f epoch) of the same workload, OpenMP Hogwild "
-                      "(modelMF.cpp:1746-1767 restated), row-major factors" % (n, n / tr.nnz),
-            "value_colmajor_reference_layout": res["colmajor"]}
+    out = {"value": res["rowmajor"], "unit": "updates/s", "cores": threads, "kind": "port",
+           "sample": "%d shuffled train ratings (%.2f epoch) of the same workload, OpenMP Hogwild "
+                     "(modelMF.cpp:1746-1767 restated), row-major factors" % (n, n / tr.nnz),
+           "value_colmajor_reference_layout": res["colmajor"]}
+    # trainSGDPar: T = threads parts; every rating is scanned T times per epoch and updated about once, so the sample is
+    # the first users holding ~1/8 of the ratings (bounded CPU time), timed for one epoch
+    try:
+        m = int(np.searchsorted(tr.rowptr, tr.nnz // 8))
+        sub_ptr = tr.rowptr[: m + 1]
+        sub_n = int(sub_ptr[-1])
+        invU = np.zeros(m, np.uint8)
+        invI = np.zeros(nI, np.uint8)
+        Us, Vs = U[:m].copy(), V.copy()
+        s = orc.time_strat(Us, Vs, sub_ptr, tr.rowind[:sub_n], tr.rowval[:sub_n], m, nI, invU, invI, threads, lr, ureg, ireg)
+        out["stratified"] = {"value": sub_n / s, "unit": "updates/s (ratings of the matrix per epoch time)", "cores": threads,
+                             "sample": "first %d users, %d ratings, one epoch of trainSGDPar (modelMF.cpp:271-309 restated), "
+                                       "T = %d parts" % (m, sub_n, threads)}
+    except Exception as e:                      # noqa: BLE001 -- the baseline is optional, the bench line is not
+        out["stratified"] = {"error": str(e)}
+    return out
+
+
+def secondary(np, args, d2, K, with_cpu=True):
+    """BASELINE.json configs 3 and 4 and one GPU's share of config 5, each one short timed run with its own roofline
+    and (unless --no-cpu-baseline) a sampled CPU baseline from the oracle."""
+    from matfac_amd import Ctx, mfx, synth
+    want = set(args.secondary.split(","))
+    recs = []
+    if "als" in want:
+        try:
+            recs.append(bench_als(np, d2, 64, with_cpu))
+        except Exception as e:                  # noqa: BLE001
+            recs.append({"config": "C3 ALS", "error": str(e)})
+    if "ccd" in want:
+        try:
+            recs.append(bench_ccd(np, with_cpu))
+        except Exception as e:                  # noqa: BLE001
+            recs.append({"config": "C4 CCD++", "error": str(e)})
+    if "c5" in want:
+        try:
+            recs.append(bench_c5_shard(np))
+        except Exception as e:                  # noqa: BLE001
+            recs.append({"config": "C5 shard SGD", "error": str(e)})
+    return recs
+
+
+def bench_als(np, d, K, with_cpu):
+    """C3: MovieLens-20M shape, rank 64, ALS (modelMF.cpp:792-886 bracket: one users + items sweep = one step)."""
+    from matfac_amd import Ctx, mfx, synth
+    tr, va = d["train"], d["val"]
+    nU, nI = d["nUsers"], synth.SHAPES["C2"]["nI"]
+    reg, iters = 5.0, 5
+    U0, V0 = synth.init_factors(1, nU, nI, K)
+    with Ctx(0) as ctx:
+        ctx.set_csr(mfx.MAT_TRAIN, tr.nrows, nI, tr.rowptr, tr.rowind, tr.rowval)
+        ctx.set_csr(mfx.MAT_VAL, va.nrows, nI, va.rowptr, va.rowind, va.rowval)
+        ctx.set_model(nU, nI, K)
+        ctx.set_factors(U0, V0)
+        ctx.compute_invalid()
+        ctx.als_half_sweep(mfx.SIDE_USERS, reg)
+        ctx.als_half_sweep(mfx.SIDE_ITEMS, reg)
+        ctx.synchronize()
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            ctx.als_half_sweep(mfx.SIDE_USERS, reg)
+            ctx.als_half_sweep(mfx.SIDE_ITEMS, reg)
+        ctx.synchronize()
+        wall = (time.perf_counter() - t0) / iters
+        g_ms, g_n = ctx.prof_get(mfx.K_ALS_GRAM)
+        s_ms, s_n = ctx.prof_get(mfx.K_ALS_SOLVE)
+        val = ctx.rmse(mfx.MAT_VAL)
+    # SURVEY 8(d): 2*(2K^2+2K) flops per rating per iteration (both triangles, as the reference forms them) + K^3/3+2K^2 per row
+    flops = 2 * tr.nnz * (2 * K * K + 2 * K) + (nU + nI) * (K ** 3 / 3 + 2 * K * K)
+    ev = (g_ms + s_ms) / iters * 1e-3
+    rec = {"config": "C3: ML-20M-shape, train nnz=%d, rank=%d, ALS (MFMA Gramian + in-register LDL^T), reg=%.1f" % (tr.nnz, K, reg),
+           "metric": "rating-iterations/sec", "value": tr.nnz / wall, "ms_per_iteration": wall * 1e3, "steps": iters,
+           "kernel_ms_per_iteration": ev * 1e3, "val_rmse_after": val,
+           "roofline": {"bound": "mfma", "achieved": flops / ev / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                        "frac": flops / ev / 1e12 / MFMA_F32_PEAK_TF, "flops_per_iteration": flops, "traffic": None,
+                        "kernel": "als_segment_kernel + als_reduce_kernel (HIP events)",
+                        "note": "flop count of the reference (both triangles); the kernels form 3 of the 4 32x32 tiles"}}
+    if with_cpu:
+        from oracle import binding as orc
+        threads = orc.max_threads()
+        m = int(np.searchsorted(tr.rowptr, 1_000_000))           # users holding the first ~1 M ratings
+        X = U0[:m].copy()
+        t0 = time.perf_counter()
+        orc.als_half(0, X, V0, m, tr.rowptr[: m + 1], tr.rowind, tr.rowval, np.zeros(m, np.uint8), reg, nthreads=threads)
+        s = time.perf_counter() - t0
+        n = int(tr.rowptr[m])
+        rec["cpu_baseline"] = {"value": n / s / 2, "unit": "rating-iterations/sec", "cores": threads, "kind": "port",
+                               "sample": "user half-sweep over the first %d users (%d ratings), modelMF.cpp:805-841 restated; "
+                                         "an iteration is two half-sweeps, so ratings / seconds / 2" % (m, n)}
+    return rec
+
+
+def bench_ccd(np, with_cpu):
+    """C4: Netflix shape (480 189 x 17 770, 100 M train ratings), rank 128, CCD++ (modelMF.cpp:1025-1126 bracket)."""
+    from matfac_amd import Ctx, mfx, synth
+    K, reg, nk = 128, 2.0, 16
+    shape = dict(synth.SHAPES["C4"])
+    shape["nnz"] = int(shape["nnz"] / 0.8)
+    t0 = time.time()
+    d = synth.make(shape, seed=1)
+    gen = time.time() - t0
+    tr, va = d["train"], d["val"]
+    nU, nI = d["nUsers"], shape["nI"]
+    U0, V0 = synth.init_factors(1, nU, nI, K)
+    with Ctx(0) as ctx:
+        ctx.set_csr(mfx.MAT_TRAIN, tr.nrows, nI, tr.rowptr, tr.rowind, tr.rowval)
+        ctx.set_csr(mfx.MAT_VAL, va.nrows, nI, va.rowptr, va.rowind, va.rowval)
+        ctx.set_model(nU, nI, K)
+        ctx.set_factors(U0, V0)
+        ctx.compute_invalid()
+        ctx.ccdpp_begin()
+        for k in range(2):
+            ctx.ccdpp_rank1(k, reg, reg, add_back=False)
+        ctx.synchronize()
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        t0 = time.perf_counter()
+        for k in range(nk):
+            ctx.ccdpp_rank1(k, reg, reg, add_back=True)
+        ctx.synchronize()
+        per_k = (time.perf_counter() - t0) / nk
+        r_ms, r_n = ctx.prof_get(mfx.K_CCD_ROW)
+        c_ms, c_n = ctx.prof_get(mfx.K_CCD_COL)
+        x_ms, x_n = ctx.prof_get(mfx.K_CCD_RESID)
+        ctx.ccdpp_end()
+    bytes_per_k = 128 * tr.nnz                    # SURVEY 8(d): 128 B per (rating, factor) per outer iteration, T = 5
+    rec = {"config": "C4: Netflix-shape %dx%d, train nnz=%d, rank=%d, CCD++ (5 inner sweeps per factor), reg=%.1f" % (nU, nI, tr.nnz, K, reg),
+           "metric": "rating-factor updates/sec", "value": tr.nnz / per_k, "ms_per_factor": per_k * 1e3,
+           "s_per_outer_iteration": per_k * K, "steps": nk, "datagen_s": gen,
+           "row_pass_ms": r_ms / max(r_n, 1), "col_pass_ms": c_ms / max(c_n, 1), "resid_update_ms": x_ms / max(x_n, 1),
+           "roofline": {"bound": "hbm", "achieved": bytes_per_k / per_k / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": bytes_per_k / per_k / 1e9 / HBM_PEAK_GBS, "bytes_per_factor": bytes_per_k, "traffic": None,
+                        "kernel": "ccd_pass_kernel / ccd_cols pass / resid_update_kernel (whole rank-one step, wall clock)"}}
+    if with_cpu:
+        from oracle import binding as orc
+        threads = orc.max_threads()
+        m = int(np.searchsorted(tr.rowptr, 4_000_000))           # first users holding ~4 M ratings
+        n = int(tr.rowptr[m])
+        rp, ri, rv = tr.rowptr[: m + 1], tr.rowind[:n], tr.rowval[:n]
+        cp, ci, cv = orc.create_col_index(m, nI, rp, ri, rv)
+        Us, Vs = np.zeros((m, K), np.float32), V0.copy()
+        rr, rc = rv.copy(), cv.copy()
+        invU = np.zeros(m, np.uint8)
+        invI = (np.diff(cp) == 0).astype(np.uint8)
+        orc.ccdpp_rank1(0, Us, Vs, m, nI, nI, rp, ri, rr, cp, ci, rc, invU, invI, reg, reg, False, nthreads=threads)
+        t0 = time.perf_counter()
+        for k in (1, 2):
+            orc.ccdpp_rank1(k, Us, Vs, m, nI, nI, rp, ri, rr, cp, ci, rc, invU, invI, reg, reg, True, nthreads=threads)
+        s = (time.perf_counter() - t0) / 2
+        rec["cpu_baseline"] = {"value": n / s, "unit": "rating-factor updates/sec", "cores": threads, "kind": "port",
+                               "sample": "first %d users (%d ratings), two rank-one steps with add-back, modelMF.cpp:1027-1121 restated" % (m, n)}
+    return rec
+
+
+def bench_c5_shard(np):
+    """One GPU's share of C5 (10 M x 1 M, 1 B ratings, rank 256 over 8 GPUs): 1.25 M users x 1 M items, 125 M train
+    ratings, U 1.28 GB + V 1.02 GB -- a working set beyond every cache, where HBM does bind the SGD update."""
+    from matfac_amd import Ctx, mfx, synth
+    K, n = 256, 4
+    shape = dict(nU=1_250_000, nI=1_000_000, nnz=int(125_000_000 / 0.8), K=K)
+    t0 = time.time()
+    d = synth.make(shape, seed=1, r0_i=0.002)
+    gen = time.time() - t0
+    tr, va = d["train"], d["val"]
+    nU, nI = d["nUsers"], shape["nI"]
+    U0, V0 = synth.init_factors(1, nU, nI, K)
+    with Ctx(0) as ctx:
+        ctx.set_csr(mfx.MAT_TRAIN, tr.nrows, nI, tr.rowptr, tr.rowind, tr.rowval)
+        ctx.set_csr(mfx.MAT_VAL, va.nrows, nI, va.rowptr, va.rowind, va.rowval)
+        ctx.set_model(nU, nI, K)
+        ctx.set_factors(U0, V0)
+        ctx.compute_invalid()
+        v0 = ctx.rmse(mfx.MAT_VAL)
+        ctx.sgd_epoch(0.0025, 0.01, 0.01, mode=mfx.SGD_TILED, seed=1, epoch=0)
+        ctx.synchronize()
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        t0 = time.perf_counter()
+        for ep in range(1, 1 + n):
+            ctx.sgd_epoch(0.0025, 0.01, 0.01, mode=mfx.SGD_TILED, seed=1, epoch=ep)
+        ctx.synchronize()
+        wall = (time.perf_counter() - t0) / n
+        ms, cnt = ctx.prof_get(mfx.K_SGD)
+        v1 = ctx.rmse(mfx.MAT_VAL)
+    alg = (16 * K + 12) * tr.nnz
+    # compulsory HBM traffic of one epoch: every rating record once (16 B) + both factor tables read and written once
+    compulsory = 16 * tr.nnz + 2 * 4 * K * (nU + nI)
+    return {"config": "C5 shard: %dx%d, train nnz=%d, rank=%d, XCD-tiled Hogwild SGD epoch on ONE GPU (1/8 of config 5)" % (nU, nI, tr.nnz, K),
+            "metric": "rating-updates/sec @ rank=%d" % K, "value": tr.nnz / wall, "ms_per_step": wall * 1e3, "steps": n,
+            "datagen_s": gen, "val_rmse_before": v0, "val_rmse_after": v1,
+            "roofline": {"bound": "hbm", "achieved": alg / wall / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / wall / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": alg,
+                         "compulsory_bytes_per_step": compulsory, "avg_launch_ms": ms / max(cnt, 1), "traffic": None,
+                         "kernel": "sgd_slots_kernel<16,4,F32>",
+                         "note": "algorithmic = SURVEY 8(d)'s 16K+12 bytes per update; above 1 means rows were reused from LDS / L2 "
+                                 "instead of re-read (item rows are owned in LDS for a slot, a user row serves its ratings of a tile)"}}
+
+
+def rmse_parity(np):
+    """The fast path against the reference's OWN run-to-run spread (tests/golden/sgd_spread_*.json, produced by
+    tests/golden/make_sgd_spread.py from the CPU oracle's full training loops; nothing of the oracle runs here): the
+    same seeded synthetic matrix trained by the host classes, default path and forced lock-free schedule."""
+    import ctypes as C
+    from matfac_amd import synth
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    recs = {}
+    for name in ("c1", "mid"):
+        path = os.path.join(ROOT, "tests", "golden", "sgd_spread_%s.json" % name)
+        if not os.path.exists(path):
+            continue
+        f = json.load(open(path))
+        cfg = f["config"]
+        shape = dict(synth.SHAPES[cfg["shape"]]) if isinstance(cfg["shape"], str) else dict(cfg["shape"])
+        shape["nnz"] = int(shape["nnz"] / 0.8)
+        d = synth.make(shape, seed=cfg["data_seed"])
+        seq = np.array([x["test_rmse"] for x in f["sequential"]])
+        hog = np.array([x["test_rmse"] for x in f["hogwild"]])
+        rec = {"data": "%s synthetic, train nnz=%d, rank=%d, lr=%g, maxiter=%d" % (cfg["shape"], f["train_nnz"], cfg["K"], cfg["lr"], cfg["maxIter"]),
+               "reference_sequential_test_rmse_mean": float(seq.mean()), "reference_sequential_test_rmse_std": float(seq.std(ddof=1)),
+               "reference_sequential_seeds": int(seq.size), "reference_hogwild_test_rmse": [float(x) for x in hog],
+               "source": "tests/golden/sgd_spread_%s.json" % name}
+        for label, env in (("gpu_default_path", {}), ("gpu_lock_free_tiled", {"MFX_EXACT": "0"})):
+            try:
+                t = host_train_rmse(C, np, synth, d, cfg, env)
+                rec[label + "_test_rmse"] = t
+                rec[label + "_sigmas_from_mean"] = (t - float(seq.mean())) / float(seq.std(ddof=1))
+            except Exception as e:              # noqa: BLE001
+                rec[label + "_error"] = str(e)
+        recs[name] = rec
+    return recs
+
+
+def host_train_rmse(C, np, synth, d, cfg, env):
+    """ModelMF::train through libmfhost.so (mfh_train): best-validation model's test RMSE."""
+    lib = synth._host()
+    tr, va, te = d["train"], d["val"], d["test"]
+    nU, nI, K = d["nUsers"], d["nItems"], cfg["K"]
+    bufs = [np.empty((nU, K), np.float32), np.empty((nI, K), np.float32), np.empty((nU, K), np.float32), np.empty((nI, K), np.float32)]
+    stats = np.zeros(8)
+    invU, invI = np.empty(nU, np.uint8), np.empty(nI, np.uint8)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    os.environ["MFX_NO_SAVE"] = "1"
+    try:
+        rc = lib.mfh_train(b"sgd", C.c_int32(tr.nrows), P(tr.rowptr), P(tr.rowind), P(tr.rowval), C.c_int32(tr.ncols),
+                           P(va.rowptr), P(va.rowind), P(va.rowval), C.c_int32(va.ncols), P(te.rowptr), P(te.rowind), P(te.rowval),
+                           C.c_int32(te.ncols), C.c_int32(K), C.c_int32(cfg["maxIter"]), C.c_int32(1), C.c_float(cfg["lr"]),
+                           C.c_float(cfg["ureg"]), C.c_float(cfg["ireg"]), None, P(bufs[0]), P(bufs[1]), P(bufs[2]), P(bufs[3]),
+                           P(stats), P(invU), P(invI))
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    if rc != 0:
+        raise RuntimeError("mfh_train returned %d" % rc)
+    return float(stats[1])
 
 
 if __name__ == "__main__":

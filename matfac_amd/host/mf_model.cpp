@@ -547,8 +547,18 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
   std::cout << "\nModelMF::" << name << " trainSeed: " << trainSeed;
   // MFX_EXACT: replay the reference's own visiting order bit by bit -- 1: level-scheduled (MFX_SGD_LEVELS, parallel),
   // 2: one lane group in list order (MFX_SGD_SERIAL, the slow statement of the same thing)
-  const bool exact = getenv("MFX_EXACT") != nullptr;
-  const int replayMode = (exact && atoi(getenv("MFX_EXACT")) == 2) ? MFX_SGD_SERIAL : MFX_SGD_LEVELS;
+  //            0: never -- the lock-free tiled schedule (a different, valid visiting order; its result moves inside the
+  //               reference's own seed-to-seed spread only once the matrix is large, tests/test_parity_spread_gpu.py)
+  // unset: the plain SGD trainers replay the reference's order when the train matrix has at most MFX_EXACT_BELOW ratings
+  // (default 2 M: there the replay costs milliseconds per epoch and the lock-free schedule, which keeps >= 64 ratings of
+  // a workgroup in flight, collides on the few hundred rows of a tile); larger matrices take the tiled schedule.
+  const char* exactEnv = getenv("MFX_EXACT");
+  const bool plainSgd = kind == K_SGD || kind == K_HOG || kind == K_SGDU || kind == K_SGDPAR;
+  const char* belowEnv = getenv("MFX_EXACT_BELOW");
+  const int64_t exactBelow = belowEnv ? atoll(belowEnv) : 2000000;
+  const bool exact = exactEnv ? atoi(exactEnv) != 0 : (plainSgd && data.trainMat->nnz() <= exactBelow);
+  const int replayMode = (exactEnv && atoi(exactEnv) == 2) ? MFX_SGD_SERIAL : MFX_SGD_LEVELS;
+  if (plainSgd) std::cout << " [" << (exact ? (replayMode == MFX_SGD_SERIAL ? "order replay, serial" : "order replay, dataflow schedule") : "lock-free tiled schedule") << "]";
   const csr_t* trainMat = data.trainMat;
 
   // bestModel starts as its own initialisation (main.cpp:1326-1327); it becomes the BEST snapshot

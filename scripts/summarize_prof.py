@@ -36,5 +36,14 @@ for k, cs in vals.items():
     if "TCC_HIT_sum" in m and "TCC_MISS_sum" in m and m["TCC_HIT_sum"] + m["TCC_MISS_sum"] > 0:
         e["l2_hit_rate"] = m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"])
     summary[k] = e
+# updates one launch of the round kernel processed in the profiled command (its JSON line is the last line of trace.log)
+try:
+    line = [l for l in open(os.path.join(out, "trace.log")) if l.startswith("{")][-1]
+    upl = json.loads(line)["roofline"]["updates_per_launch"]
+    for k in ("sgd_slots_kernel", "sgd_hogwild_kernel"):
+        if k in summary:
+            summary[k]["updates_per_launch"] = upl
+except Exception as e:
+    print("no updates_per_launch:", e)
 json.dump(summary, open(os.path.join(dst, "%s_pmc_summary.json" % rnd), "w"), indent=1)
 print(json.dumps({k: {x: v.get(x) for x in ("hbm_bytes_per_launch", "l2_hit_rate")} for k, v in summary.items()}))

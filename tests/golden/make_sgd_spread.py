@@ -19,15 +19,19 @@ from matfac_amd import synth             # noqa: E402
 from oracle import binding as orc        # noqa: E402
 
 CFG = dict(shape="C1", K=10, lr=0.005, ureg=0.01, ireg=0.01, maxIter=2000, init_seed=1, data_seed=1)
+# a matrix beyond MFX_EXACT_BELOW, where the host classes take the lock-free tiled schedule: 30 000 x 8 000, 2.4 M train
+# ratings, rank 32 (python tests/golden/make_sgd_spread.py mid -> sgd_spread_mid.json, about 5 minutes on 8 cores)
+CFG_MID = dict(shape=dict(nU=30000, nI=8000, nnz=2_400_000, K=32), K=32, lr=0.005, ureg=0.01, ireg=0.01, maxIter=150,
+               init_seed=1, data_seed=1)
 
 
-def problem():
-    shape = dict(synth.SHAPES[CFG["shape"]])
+def problem(CFG=CFG):
+    shape = dict(synth.SHAPES[CFG["shape"]]) if isinstance(CFG["shape"], str) else dict(CFG["shape"])
     shape["nnz"] = int(shape["nnz"] / 0.8)
     return synth.make(shape, seed=CFG["data_seed"])
 
 
-def run(d, method, train_seed, nthreads):
+def run(d, method, train_seed, nthreads, CFG=CFG):
     tr, va, te = d["train"], d["val"], d["test"]
     nU, nI, K = d["nUsers"], d["nItems"], CFG["K"]
     cp, ci, cv = orc.create_col_index(tr.nrows, tr.ncols, tr.rowptr, tr.rowind, tr.rowval)
@@ -44,14 +48,16 @@ def run(d, method, train_seed, nthreads):
 
 
 if __name__ == "__main__":
-    d = problem()
-    out = dict(config=CFG, train_nnz=d["train"].nnz, sequential=[], hogwild=[])
-    for seed in range(1, 9):
-        out["sequential"].append(run(d, orc.M_SGD, seed, 1))
+    mid = len(sys.argv) > 1 and sys.argv[1] == "mid"
+    cfg = CFG_MID if mid else CFG
+    d = problem(cfg)
+    out = dict(config=cfg, train_nnz=d["train"].nnz, sequential=[], hogwild=[])
+    for seed in range(1, 6 if mid else 9):
+        out["sequential"].append(run(d, orc.M_SGD, seed, 1, cfg))
         print(out["sequential"][-1], flush=True)
-    for threads in (8, 64):
-        for seed in (1, 2, 3):
-            out["hogwild"].append(run(d, orc.M_HOGSGD, seed, threads))
+    for threads in ((8,) if mid else (8, 64)):
+        for seed in ((1, 2) if mid else (1, 2, 3)):
+            out["hogwild"].append(run(d, orc.M_HOGSGD, seed, threads, cfg))
             print(out["hogwild"][-1], flush=True)
     t = np.array([x["test_rmse"] for x in out["sequential"]])
     out["sequential_test_rmse_mean"] = float(t.mean())
@@ -59,5 +65,6 @@ if __name__ == "__main__":
     h = np.array([x["test_rmse"] for x in out["hogwild"]])
     out["hogwild_test_rmse_mean"] = float(h.mean())
     out["hogwild_test_rmse_std"] = float(h.std(ddof=1))
-    json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "sgd_spread_c1.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "sgd_spread_%s.json" % ("mid" if mid else "c1")), "w"),
+              indent=1)
     print("sequential %.5f +- %.5f   hogwild %.5f +- %.5f" % (t.mean(), t.std(ddof=1), h.mean(), h.std(ddof=1)))
