@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmfx.so")
+LIB_PATH = os.environ.get("MFX_LIBRARY") or os.path.join(_HERE, "libmfx.so")   # MFX_LIBRARY: a diagnostic build (scripts/exp_bound.sh)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mfx.h")
 
 _lib = None

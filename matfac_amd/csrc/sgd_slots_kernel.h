@@ -9,6 +9,13 @@
 #include "sgd_common.h"
 #include "sgd_slots.h"
 
+// Diagnostic builds (scripts/exp_bound.sh; results are WRONG on purpose): what the round time does when one resource is
+// taken out.  1: no user-row stores  2: no LDS atomic adds  3: 16 extra vector multiplies per step  4: user rows are
+// never loaded  5: 32 extra multiplies.  0 (the product): nothing of this is compiled.
+#ifndef MFX_EXP
+#define MFX_EXP 0
+#endif
+
 // ---------------------------------------------------------------------------
 // kernel
 // ---------------------------------------------------------------------------
@@ -72,7 +79,7 @@ struct SlotSteps {
         if (e + 2 * G < nvalid) {
           penn = (int64_t)un * LD + 4 * j;
 #pragma unroll
-          for (int c = 0; c < C; c++) pnn[c] = Um.ld(penn + c * 4 * L);
+          for (int c = 0; c < C; c++) pnn[c] = MFX_EXP == 4 ? float4v{0.01f, 0.02f, 0.03f, 0.01f} : Um.ld(penn + c * 4 * L);
         }
       }
     } else if constexpr (S + 1 < L) {
@@ -174,11 +181,23 @@ struct SlotSteps {
         for (int c = 0; c < C; c++) {
 #pragma unroll
           for (int x = 0; x < 4; x++) p[c][x] = upd_f32(p[c][x], q[c][x], c1, cu, lr);
+#if MFX_EXP == 3 || MFX_EXP == 5
+#pragma unroll
+          for (int y = 0; y < (MFX_EXP == 3 ? 4 : 8); y++)
+#pragma unroll
+            for (int x = 0; x < 4; x++) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(q[c][x]) : "v"(1.0f));
+#endif
+#if MFX_EXP != 1
           Um.st(pe + c * 4 * L, p[c]);
+#endif
 #pragma unroll
           for (int x = 0; x < 4; x++) {
             const float t = lr * (c1 * p[c][x] + ci * q[c][x]);
+#if MFX_EXP != 2
             atomicAdd(qrow + c * 4 * L + x, __float2int_rn(t * -FIX_SCALE));   // ds_add_u32
+#else
+            asm volatile("" ::"v"(__float2int_rn(t * -FIX_SCALE)));
+#endif
           }
         }
       } else {
@@ -263,7 +282,11 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
       bool mybad = false;
       for (int x = tid; x < ni * LD4; x += WG) {
         const int row = x / LD4, c4 = x % LD4;
+#if MFX_EXP == 7
+        const float4v v = __builtin_nontemporal_load((const float4v*)(Own + (int64_t)slot_items[ib + row] * LD + 4 * c4));
+#else
         const float4v v = *(const float4v*)(Own + (int64_t)slot_items[ib + row] * LD + 4 * c4);
+#endif
 #pragma unroll
         for (int e = 0; e < 4; e++) mybad |= !(__builtin_fabsf(v[e]) <= FIX_MAX);   // also true for NaN
         q4[row * LD4 + c4] = __builtin_bit_cast(int4, v);
@@ -290,7 +313,15 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
         int tw = 0;
         if (ok) {
           const int64_t src = rb + slot_perm(t, R, ks0, ks1);
+#if MFX_EXP == 6 || MFX_EXP == 7
+          {
+            typedef int int4v __attribute__((ext_vector_type(4)));
+            const int4v t4 = __builtin_nontemporal_load((const int4v*)&rec[src]);
+            rc4 = make_int4(t4.x, t4.y, t4.z, t4.w);
+          }
+#else
           rc4 = rec[src];
+#endif
           if (VAR == 1 || VAR == 2) tw = attr[src];
           if (visit) atomicAdd(&visit[src], 1u);       // MFX_SGD_F_COUNT_VISITS
         }
@@ -310,11 +341,11 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
         int64_t penn = (int64_t)slot_take<L, 1>(tx, g) * LD + 4 * j;
         if (g < nvalid) {
 #pragma unroll
-          for (int c = 0; c < C; c++) pn[c] = Um.ld(pen + c * 4 * L);
+          for (int c = 0; c < C; c++) pn[c] = MFX_EXP == 4 ? float4v{0.01f, 0.02f, 0.03f, 0.01f} : Um.ld(pen + c * 4 * L);
         }
         if ((C <= 2 || (!OWN_U && ARITH == MFX_ARITH_F32 && VAR == 0)) && G + g < nvalid) {   // two-steps-ahead pipelines only
 #pragma unroll
-          for (int c = 0; c < C; c++) pnn[c] = Um.ld(penn + c * 4 * L);
+          for (int c = 0; c < C; c++) pnn[c] = MFX_EXP == 4 ? float4v{0.01f, 0.02f, 0.03f, 0.01f} : Um.ld(penn + c * 4 * L);
         }
         const float* regk = VAR == 3 ? (const float*)attr : nullptr;
         if (fix) SlotSteps<L, C, ARITH, OWN_U, true, VAR, 0>::run(Um, q_lds, tx, ty, tz, tw, regk, g, j, nvalid, lr, uReg, iReg, pn, pen, pnn, penn);
