@@ -42,8 +42,18 @@ def test_header_is_plain_c():
 
 
 def test_struct_layouts_match_ctypes():
-    assert C.sizeof(mfx.SgdOpts) == 56
-    assert C.sizeof(mfx.EvalOut) == 32
+    """sizeof / offsetof of the two structs of include/mfx.h as gcc lays them out == the ctypes mirrors of matfac_amd/mfx.py"""
+    import subprocess, tempfile
+    fields = [f for f, _ in mfx.SgdOpts._fields_]
+    prog = '#include <stdio.h>\n#include <stddef.h>\n#include "mfx.h"\nint main(void){printf("%zu %zu", sizeof(mfx_sgd_opts), sizeof(mfx_eval_out));\n'
+    prog += "".join('printf(" %%zu", offsetof(mfx_sgd_opts, %s));\n' % f for f in fields) + "return 0;}\n"
+    with tempfile.TemporaryDirectory() as td:
+        open(os.path.join(td, "t.c"), "w").write(prog)
+        subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), os.path.join(td, "t.c"), "-o", os.path.join(td, "t")])
+        got = [int(x) for x in subprocess.check_output([os.path.join(td, "t")]).split()]
+    assert got[0] == C.sizeof(mfx.SgdOpts) == 64
+    assert got[1] == C.sizeof(mfx.EvalOut) == 32
+    assert got[2:] == [getattr(mfx.SgdOpts, f).offset for f in fields]
 
 
 def test_no_cpu_fallback_without_a_device():
