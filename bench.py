@@ -551,15 +551,27 @@ def bench_c5_shard(np):
     alg = (16 * K + 12) * tr.nnz
     # compulsory HBM traffic of one epoch: every rating record once (16 B) + both factor tables read and written once
     compulsory = 16 * tr.nnz + 2 * 4 * K * (nU + nI)
+    launch_ms = ms / max(cnt, 1)
+    roof = {"kernel": "sgd_slots_kernel<16,4,F32>", "avg_launch_ms": launch_ms, "launches": cnt,
+            "algorithmic": {"bytes_per_step": alg, "achieved": alg / wall / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": alg / wall / 1e9 / HBM_PEAK_GBS,
+                            "note": "SURVEY 8(d)'s 16K+12 bytes per update; above 1 because item rows are owned in LDS for a slot and a "
+                                    "user row serves several ratings of a tile from L2: fewer bytes cross the memory side than the model counts"},
+            "compulsory_bytes_per_step": compulsory}
+    try:   # bytes that really crossed the L2's memory side, from the committed PMC passes of scripts/c5_shard.py (scripts/pmc_c5.sh)
+        c = json.load(open(os.path.join(ROOT, "profiles", "r02_c5_pmc.json")))
+        traffic = c["hbm_bytes_per_launch"] * (tr.nnz / 8.0) / c["updates_per_launch"]
+        ach = traffic / (launch_ms * 1e-3) / 1e9
+        roof.update({"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_source": "profiles/r02_c5_pmc.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per round launch, separate "
+                                       "--pmc passes of the same workload; launch time from this run's HIP events",
+                     "l2_hit_rate": c.get("l2_hit_rate")})
+    except Exception:                             # noqa: BLE001 -- no committed counters: only the model line
+        a = roof["algorithmic"]
+        roof.update({"bound": "hbm", "achieved": a["achieved"], "peak": a["peak"], "unit": "GB/s", "frac": a["frac"], "traffic": None})
     return {"config": "C5 shard: %dx%d, train nnz=%d, rank=%d, XCD-tiled Hogwild SGD epoch on ONE GPU (1/8 of config 5)" % (nU, nI, tr.nnz, K),
             "metric": "rating-updates/sec @ rank=%d" % K, "value": tr.nnz / wall, "ms_per_step": wall * 1e3, "steps": n,
-            "datagen_s": gen, "val_rmse_before": v0, "val_rmse_after": v1,
-            "roofline": {"bound": "hbm", "achieved": alg / wall / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg / wall / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": alg,
-                         "compulsory_bytes_per_step": compulsory, "avg_launch_ms": ms / max(cnt, 1), "traffic": None,
-                         "kernel": "sgd_slots_kernel<16,4,F32>",
-                         "note": "algorithmic = SURVEY 8(d)'s 16K+12 bytes per update; above 1 means rows were reused from LDS / L2 "
-                                 "instead of re-read (item rows are owned in LDS for a slot, a user row serves its ratings of a tile)"}}
+            "datagen_s": gen, "val_rmse_before": v0, "val_rmse_after": v1, "roofline": roof}
 
 
 def rmse_parity(np):

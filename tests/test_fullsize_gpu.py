@@ -138,6 +138,62 @@ def test_ccdpp_views_in_lockstep_and_monotone_at_full_size(c2):
     ctx.close()
 
 
+def test_ccdpp_at_the_c4_shape_rank_128():
+    """BASELINE.json config 4: Netflix shape (480 189 x 17 770, 100 M train ratings), rank 128, CCD++ -- the strip-major
+    column view with 59 user strips.  Size-independent properties of modelMF.cpp:1025-1126: the two residual views stay
+    bit-identical entry for entry, the objective never increases from one rank-one step to the next, and the residual
+    IS r - p.q for the factors learnt so far."""
+    shape = dict(synth.SHAPES["C4"])
+    shape["nnz"] = int(shape["nnz"] / 0.8)
+    d = synth.make(shape, seed=1)
+    d["nItems"] = shape["nI"]
+    tr = d["train"]
+    assert tr.nrows == 480189 and d["nItems"] == 17770 and abs(tr.nnz - 100_000_000) < 1_000_000
+    K, reg = 128, 2.0
+    ctx, U0, V0 = _ctx(d, K)
+    ctx.ccdpp_begin()
+    objs = []
+    for k in range(3):
+        ctx.ccdpp_rank1(k, reg, reg, add_back=False)
+        objs.append(ctx.objective(reg, reg))
+    for k in range(2):                                   # second outer iteration: add-back + deferred subtract
+        ctx.ccdpp_rank1(k, reg, reg, add_back=True)
+        objs.append(ctx.objective(reg, reg))
+    rr, rc = ctx.debug_residuals(tr.nnz)
+    order = np.argsort(tr.rowind, kind="stable")
+    assert np.array_equal(rr[order], rc)
+    del order
+    assert all(b <= a * (1 + 1e-6) for a, b in zip(objs, objs[1:])), objs
+    U, V = ctx.get_factors()
+    sel = np.random.default_rng(1).integers(0, tr.nnz, 200000)
+    ru = np.searchsorted(tr.rowptr, sel, side="right") - 1
+    est = np.einsum("ij,ij->i", U[ru].astype(np.float64), V[tr.rowind[sel]].astype(np.float64))
+    assert np.abs(rr[sel] - (tr.rowval[sel] - est)).max() < 1e-3
+    assert np.abs(U[:, 3:]).max() == 0.0                 # uFac.fill(0) (:1020): untouched factors of U stay zero
+    ctx.ccdpp_end()
+    ctx.close()
+
+
+def test_reference_loop_needs_the_halved_rate_at_c2(c2):
+    """bench.py runs the C2 epoch at learnrate 0.0025, half the reference's default (main.cpp:29): at 0.005 the
+    reference's OWN sequential loop (oracle, modelMF.cpp:83-105, std::shuffle order) leaves its first epoch on this
+    matrix with non-finite factors, which Model::isTerminateModel answers by halving the rate (model.cpp:1486-1510)."""
+    from oracle import binding as orc
+    tr = c2["train"]
+    K = 64
+    U0, V0 = synth.init_factors(1, c2["nUsers"], c2["nItems"], K)
+    order = np.arange(tr.nnz, dtype=np.uint64)
+    orc.MT(1).shuffle_u64(order)
+    ru = tr.rowids()
+    res = {}
+    for lr in (0.005, 0.0025):
+        U, V = U0.copy(), V0.copy()
+        orc.sgd_pass(U, V, ru, tr.rowind, tr.rowval, order, lr, 0.01, 0.01, orc.ARITH_REF64, orc.DOT_SEQ)
+        res[lr] = bool(np.isfinite(U).all() and np.isfinite(V).all())
+    print("reference first epoch at C2 finite: lr 0.005 -> %s, lr 0.0025 -> %s" % (res[0.005], res[0.0025]))
+    assert not res[0.005] and res[0.0025]
+
+
 @pytest.mark.parametrize("K", [64, 128])
 def test_als_gathers_from_a_factor_table_beyond_4_gb(K):
     """Maximum size: a gathered factor table of 4 GB or more switches the ALS accumulation to 64-bit row offsets
