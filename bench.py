@@ -198,7 +198,10 @@ def main():
 
     for ep in range(args.warmup):
         step(ep)
-    ctx.prof_enable(True)
+    # HIP events inside the timed region, on the library's stream, around the launches of every 8th epoch: an event pair
+    # around each of an epoch's 9 launches costs 6 % of its millisecond (scripts/event_overhead.py)
+    prof_every = 8 if args.steps >= 16 else 1
+    ctx.prof_enable(prof_every)
     ctx.prof_reset()
     barrier()
     t0 = time.perf_counter()
@@ -235,7 +238,8 @@ def main():
     if rank == 0:
         value = total_nnz * args.steps / elapsed
         avg_ms = sgd_ms / max(1, sgd_launches)
-        launches_per_step = max(1, sgd_launches // args.steps)   # tiled: 8 round launches per epoch
+        profiled_steps = (args.steps + prof_every - 1) // prof_every
+        launches_per_step = max(1, sgd_launches // profiled_steps)   # tiled: 8 round launches per epoch
         kernel = "sgd_slots_kernel" if mode == mfx.SGD_TILED else "sgd_hogwild_kernel"
         out = {
             "metric": "rating-updates/sec @ rank=%d" % K, "value": value, "unit": "updates/s",
@@ -252,7 +256,7 @@ def main():
                        "learnrate": lr, "ureg": ureg, "ireg": ireg, "arith": args.arith,
                        "parallelism": "user-block x%d" % N},
             "roofline": sgd_roofline(K, nnz, launches_per_step, avg_ms, sgd_launches, kernel),
-            "permute_ms_per_step": perm_ms / max(1, args.steps),
+            "permute_ms_per_step": perm_ms / max(1, profiled_steps),
             "val_rmse_after": val_rmse, "train_rmse_after": tr_rmse,
             "datagen_s": gen_s,
         }

@@ -147,8 +147,11 @@ typedef struct {
  *                modelMF.cpp:83-105 / :1747-1763) must reproduce the factors.
  *  COUNT_VISITS  every rating record the update loop consumes bumps a device counter; read them (and zero
  *                them) with mfx_debug_visit_counts: "every rating exactly once per epoch" as observed by
- *                the kernel itself.                                                                        */
-enum { MFX_SGD_F_ONE_GROUP = 1, MFX_SGD_F_COUNT_VISITS = 2 };
+ *                the kernel itself.
+ *  DRAIN_ONLY    the eight XCD-scheduled round launches are skipped and the placement-independent drain launch does
+ *                the whole epoch: what a partition mode with one reported XCC_ID would run (and the only way to
+ *                make the drain's barrier-separated diagonals do real work on a healthy device).                */
+enum { MFX_SGD_F_ONE_GROUP = 1, MFX_SGD_F_COUNT_VISITS = 2, MFX_SGD_F_DRAIN_ONLY = 4 };
 /* Permutation of the train ratings (indices into the CSR-order rating list with
  * invalid users/items removed -- on a train matrix that is every rating), as
  * std::vector<size_t> uiRatingInds in modelMF.cpp:67-68; for MFX_SGD_USERS the
@@ -297,6 +300,8 @@ enum {
   MFX_K_CD = 9,        /* one mfx_ccd_sweep (transpose + row kernels + view copy) */
   MFX_K_COUNT = 10
 };
+/* on = 0: off; 1: an event pair around every launch; N > 1: around the launches of every N-th mfx_sgd_epoch only
+ * (an event pair per launch costs ~6 % of a 1 ms epoch; sampling keeps the timed region honest)                  */
 int mfx_prof_enable(mfx_ctx* ctx, int on);
 int mfx_prof_reset(mfx_ctx* ctx);
 int mfx_prof_get(mfx_ctx* ctx, int kernel, double* total_ms, int64_t* launches);

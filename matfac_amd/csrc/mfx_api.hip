@@ -479,6 +479,13 @@ extern "C" int mfx_sgd_epoch(mfx_ctx* ctx, const mfx_sgd_opts* o) {
   NEED(o->order >= MFX_ORDER_DEVICE && o->order <= MFX_ORDER_NATURAL, MFX_E_ARG, "mfx_sgd_epoch: order=%d", o->order);
   NEED(o->arith >= MFX_ARITH_REF64 && o->arith <= MFX_ARITH_F32, MFX_E_ARG, "mfx_sgd_epoch: arith=%d", o->arith);
   HIPCHK(hipSetDevice(ctx->device));
+  // sampled timing (mfx_prof_enable(ctx, N > 1)): events around the launches of every N-th epoch only -- an event pair per
+  // launch costs 6 % of a 1 ms epoch (scripts/event_overhead.py)
+  struct ProfGate {
+    mfx_ctx* c; bool saved;
+    ProfGate(mfx_ctx* c_) : c(c_), saved(c_->prof_on) { if (saved && c->prof_period > 1) c->prof_on = (c->prof_tick++ % c->prof_period) == 0; }
+    ~ProfGate() { c->prof_on = saved; }
+  } gate(ctx);
 
   if (o->mode == MFX_SGD_USERS) {
     // user list: host order (shuffled valid users) or 0..nrows-1
@@ -642,6 +649,8 @@ extern "C" int mfx_eval_filtered(mfx_ctx* ctx, int which, int snapshot, const ui
 extern "C" int mfx_prof_enable(mfx_ctx* ctx, int on) {
   if (!ctx) return MFX_E_ARG;
   ctx->prof_on = on != 0;
+  ctx->prof_period = on > 1 ? on : 1;
+  ctx->prof_tick = 0;
   return MFX_OK;
 }
 static int prof_resolve(mfx_ctx* ctx) {

@@ -120,6 +120,8 @@ struct mfx_ctx {
   float* als_global = nullptr;          // sharded ALS: per-item (A, b) summed over ranks
 
   bool prof_on = false;
+  int prof_period = 1;       // > 1: only every prof_period-th SGD epoch records events
+  int64_t prof_tick = 0;
   ProfSlot prof[MFX_K_COUNT];
 };
 

@@ -317,7 +317,7 @@ int mfx_slots_build_device(mfx_ctx* ctx, SlotList* S, int rows, int side) {
   if ((rc = dev_alloc(ctx, &S->rec, (size_t)nnz * 4)) || (rc = dev_alloc(ctx, &S->slot_beg, (size_t)nslots + 1)) ||
       (rc = dev_alloc(ctx, &S->slot_ibeg, (size_t)nslots + 1)) || (rc = dev_alloc(ctx, &S->tile_slot, (size_t)NTILE + 1)))
     return rc;
-  if (!S->ctr && (rc = dev_alloc(ctx, &S->ctr, (size_t)NTILE))) return rc;
+  if (!S->ctr && (rc = dev_alloc(ctx, &S->ctr, (size_t)NTILE + 2))) return rc;
   static_assert(NTILE + 1 <= TB, "tile_slot is written by the first workgroup");
   hipLaunchKernelGGL(slot_heads_kernel, dim3(grid_for(R)), dim3(TB), 0, st, head, hs, dst, R, nslots, nnz, trun, NTILE,
                      S->slot_beg, S->slot_ibeg, S->tile_slot);

@@ -107,6 +107,38 @@ __device__ __forceinline__ void sgd_axpys(float4v (&p)[C], float4v (&q)[C], floa
   }
 }
 
+// Grid barrier of a persistent launch whose workgroups are ALL resident: every workgroup arrives once per phase;
+// `target` = workgroups x phases completed.  A waiter that sees no progress for
+// ~2 s raises the abort flag and everybody leaves: a grid barrier must not be able to hang the device.
+template <int POL>
+__device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned target) {
+  // this wave's row stores are visible device-wide (POL 1: acknowledged write-through stores, only the wait is
+  // needed; POL 0: L2 write-back) ...
+  if (POL == 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();                                       // ... for every wave of the workgroup, before it arrives
+  __shared__ int s_abort;
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int ab = 0;
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(&bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ab = 1; break; }
+      if (wall_clock64() - t0 > 200000000LL) {           // 100 MHz constant clock: 2 s
+        __hip_atomic_store(&bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ab = 1;
+        break;
+      }
+    }
+    s_abort = ab;
+  }
+  __syncthreads();
+  if (POL != 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // drop stale lines before the next level's row loads
+  return s_abort != 0;
+}
+
+
 // ---- per-rating attributes of the sibling models, derived from one pair per user and one per item ----
 // ModelInvPopMF (modelInvPopMF.cpp:161-166): (freq, score) pairs -> float wt = 1/(1 + rhoRMS*score of the rarer side)
 __device__ __forceinline__ float mfx_ifw_weight(float2 ua, float2 ia, float rho) {

@@ -69,36 +69,6 @@ __device__ __forceinline__ void level_visit(const Rows<POL>& Um, const Rows<POL>
   }
 }
 
-// every workgroup arrives once per level; `target` = workgroups x levels completed.  A waiter that sees no progress for
-// ~2 s raises the abort flag and everybody leaves: a grid barrier must not be able to hang the device.
-template <int POL>
-__device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned target) {
-  // this wave's row stores are visible device-wide (POL 1: acknowledged write-through stores, only the wait is
-  // needed; POL 0: L2 write-back) ...
-  if (POL == 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  __syncthreads();                                       // ... for every wave of the workgroup, before it arrives
-  __shared__ int s_abort;
-  if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int ab = 0;
-    const long long t0 = wall_clock64();
-    while (__hip_atomic_load(&bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(1);
-      if (__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ab = 1; break; }
-      if (wall_clock64() - t0 > 200000000LL) {           // 100 MHz constant clock: 2 s
-        __hip_atomic_store(&bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ab = 1;
-        break;
-      }
-    }
-    s_abort = ab;
-  }
-  __syncthreads();
-  if (POL != 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // drop stale lines before the next level's row loads
-  return s_abort != 0;
-}
-
 template <int L, int C, int ARITH, int POL>
 __global__ __launch_bounds__(LV_WG) void sgd_levels_grid_kernel(const int32_t* __restrict__ lu, const int32_t* __restrict__ li,
                                                                 const float* __restrict__ lr_, const int64_t* __restrict__ loff,

@@ -22,7 +22,8 @@ struct SlotList {
   int32_t* slot_ibeg = nullptr;    // [nslots+1] range into slot_items
   int32_t* slot_items = nullptr;   // global item ids of every slot
   int32_t* tile_slot = nullptr;    // [NTILE+1] slot range of a tile
-  unsigned* ctr = nullptr;         // [NTILE] slot counters
+  unsigned* ctr = nullptr;         // [NTILE] slot counters + [2] barrier counter and abort flag of the drain
+  unsigned* abort_host = nullptr;  // pinned copy of the abort flag of the previous epoch's drain
   unsigned* visit = nullptr;       // [nnz] visits per rating record (MFX_SGD_F_COUNT_VISITS), or NULL
   int32_t* attr = nullptr;         // sibling models: per rating (slot order) weight bits (var 1) or rank (var 2)
   int var = 0;                     // which of them attr holds (0: none)

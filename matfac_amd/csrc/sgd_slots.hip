@@ -38,6 +38,7 @@ void mfx_slots_free_internal(mfx_ctx* ctx) {
   for (SlotList& s : st->side) {
     dev_free(s.rec); dev_free(s.slot_beg); dev_free(s.slot_ibeg); dev_free(s.slot_items); dev_free(s.attr); dev_free(s.visit);
     dev_free(s.tile_slot); dev_free(s.ctr);
+    if (s.abort_host) (void)hipHostFree(s.abort_host);
   }
   delete st;
   ctx->slots = nullptr;
@@ -154,7 +155,7 @@ static int build_slots(mfx_ctx* ctx, SlotList* S, int rows, int side) {
   if ((rc = up(ctx, &S->slot_ibeg, slot_ibeg))) return rc;
   if ((rc = up(ctx, &S->slot_items, slot_items))) return rc;
   if ((rc = up(ctx, &S->tile_slot, tile_slot))) return rc;
-  if (!S->ctr && (rc = dev_alloc(ctx, &S->ctr, (size_t)NTILE))) return rc;
+  if (!S->ctr && (rc = dev_alloc(ctx, &S->ctr, (size_t)NTILE + 2))) return rc;
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (getenv("MFX_DEBUG")) {
     int64_t mx = 0, small = 0;
@@ -244,6 +245,15 @@ int mfx_launch_sgd_tiled(mfx_ctx* ctx, const mfx_sgd_opts* o) {
     S->attr_gen = ctx->var_gen;
   }
   S->var = var;
+  if (!S->abort_host) {
+    HIPCHK(hipHostMalloc((void**)&S->abort_host, sizeof(unsigned), hipHostMallocDefault));
+    *S->abort_host = 0;
+  }
+  if (*(volatile unsigned*)S->abort_host) {
+    *S->abort_host = 0;
+    return mfx_fail(ctx, MFX_E_HIP, "MFX_SGD_TILED: the drain of the previous epoch gave up at its grid barrier (no progress for 2 s; "
+                    "is the device shared with another resident kernel?) -- that epoch may have left ratings unvisited");
+  }
   if ((o->flags & MFX_SGD_F_COUNT_VISITS) && !S->visit) {
     int rc;
     if ((rc = dev_alloc(ctx, &S->visit, (size_t)S->nnz))) return rc;

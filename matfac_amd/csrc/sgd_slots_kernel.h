@@ -32,6 +32,14 @@ struct SlotRows { static constexpr int value = 4096 / LD > 64 ? 64 : (4096 / LD 
 // row that leaves the range while being updated is written back as NaN, so Model::isTerminateModel's NaN
 // guard (model.cpp:1486-1498) still sees a diverged model.
 constexpr float FIX_SCALE = 16777216.0f, FIX_INV = 1.0f / 16777216.0f, FIX_MAX = 127.0f;
+// round(x) for the fixed-point deltas: v_cvt_rpi_i32_f32 = floor(x + 0.5), ONE conversion instead of v_rndne_f32 +
+// v_cvt_i32_f32 (conversions issue at half rate; scripts/valu_probe.hip).  Ties go up instead of to even: both are
+// within half a unit (2^-25), which is all the representation promises.
+__device__ __forceinline__ int fix_round(float x) {
+  int r;
+  asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
 
 // entry S*G+g of the chunk: row_share broadcast of the transposed chunk (L == 16) or a cross-lane read
 template <int L, int S>
@@ -95,36 +103,39 @@ struct SlotSteps {
         int* qrow = q_lds + li * LD + 4 * j;
         float a = 0.0f;
 #pragma unroll
-        for (int c = 0; c < C; c++) {          // pass 1: the dot, same per-lane chain as group_dot
+        for (int c = 0; c < C; c++) {          // pass 1: the dot, same per-lane chain as group_dot (on the unscaled float(Q))
           const int4 qi = *(const int4*)(qrow + c * 4 * L);
-          a = __builtin_fmaf(p[c].x, (float)qi.x * FIX_INV, a);
-          a = __builtin_fmaf(p[c].y, (float)qi.y * FIX_INV, a);
-          a = __builtin_fmaf(p[c].z, (float)qi.z * FIX_INV, a);
-          a = __builtin_fmaf(p[c].w, (float)qi.w * FIX_INV, a);
+          a = __builtin_fmaf(p[c].x, (float)qi.x, a);
+          a = __builtin_fmaf(p[c].y, (float)qi.y, a);
+          a = __builtin_fmaf(p[c].z, (float)qi.z, a);
+          a = __builtin_fmaf(p[c].w, (float)qi.w, a);
         }
-        const float est = group_sum<L>(a);
-        const float c1 = -2.0f * (r - est), cu = 2.0f * uReg, ci = 2.0f * iReg;
+        const float est = group_sum<L>(a) * FIX_INV;
+        const float c1 = -2.0f * (r - est), cu = 2.0f * uReg;
+        const float c1s = c1 * FIX_INV, cis = (2.0f * iReg) * FIX_INV;
 #pragma unroll
         for (int c = 0; c < C; c++) {          // pass 2: both steps of this chunk
           const int4 qi = *(const int4*)(qrow + c * 4 * L);
-          const float4v q = float4v{(float)qi.x * FIX_INV, (float)qi.y * FIX_INV, (float)qi.z * FIX_INV, (float)qi.w * FIX_INV};
+          const float4v q = float4v{(float)qi.x, (float)qi.y, (float)qi.z, (float)qi.w};
 #pragma unroll
-          for (int x = 0; x < 4; x++) p[c][x] = upd_f32(p[c][x], q[x], c1, cu, lr);
+          for (int x = 0; x < 4; x++) p[c][x] = upd_f32(p[c][x], q[x], c1s, cu, lr);
           Um.st(pe + c * 4 * L, p[c]);
 #pragma unroll
           for (int x = 0; x < 4; x++) {
-            const float t = lr * (c1 * p[c][x] + ci * q[x]);
-            atomicAdd(qrow + c * 4 * L + x, __float2int_rn(t * -FIX_SCALE));   // ds_add_u32
+            const float t = lr * (c1 * p[c][x] + cis * q[x]);
+            atomicAdd(qrow + c * 4 * L + x, fix_round(t * -FIX_SCALE));   // ds_add_u32
           }
         }
       }
     } else if (e < nvalid) {
       int* qrow = q_lds + li * LD + 4 * j;
       float4v q[C];
+      constexpr bool UNSCALED = FIX && !OWN_U && ARITH == MFX_ARITH_F32 && VAR == 0;   // the hogTrain branch folds 2^-24 into its scalars
 #pragma unroll
       for (int c = 0; c < C; c++) {
         const int4 qi = *(const int4*)(qrow + c * 4 * L);
-        if (FIX) q[c] = float4v{(float)qi.x * FIX_INV, (float)qi.y * FIX_INV, (float)qi.z * FIX_INV, (float)qi.w * FIX_INV};
+        if (UNSCALED) q[c] = float4v{(float)qi.x, (float)qi.y, (float)qi.z, (float)qi.w};
+        else if (FIX) q[c] = float4v{(float)qi.x * FIX_INV, (float)qi.y * FIX_INV, (float)qi.z * FIX_INV, (float)qi.w * FIX_INV};
         else q[c] = __builtin_bit_cast(float4v, qi);
       }
       // p = the row from global memory, q = the owned row; the reference updates the USER row first
@@ -175,12 +186,15 @@ struct SlotSteps {
         }
       } else if constexpr (FIX && !OWN_U && ARITH == MFX_ARITH_F32) {
         // hogTrain's arithmetic (modelMF.cpp:1755-1762) with the item step taken as a delta: the new item
-        // row would be q - t, t = lr*(c1*p' + ci*q); the owner copy receives round(-t * 2^24) directly
-        const float c1 = -2.0f * (r - est), cu = 2.0f * uReg, ci = 2.0f * iReg;
+        // row would be q - t, t = lr*(c1*p' + ci*q); the owner copy receives round(-t * 2^24) directly.
+        // q here is the UNSCALED float(Q) (see the load above): q_true = q * 2^-24 exactly, so est_true = est * 2^-24,
+        // c1*q_true = (c1 * 2^-24)*q and ci*q_true = (ci * 2^-24)*q bit for bit (powers of two commute with every rounding)
+        const float c1 = -2.0f * (r - est * FIX_INV), cu = 2.0f * uReg;
+        const float c1s = c1 * FIX_INV, cis = (2.0f * iReg) * FIX_INV;
 #pragma unroll
         for (int c = 0; c < C; c++) {
 #pragma unroll
-          for (int x = 0; x < 4; x++) p[c][x] = upd_f32(p[c][x], q[c][x], c1, cu, lr);
+          for (int x = 0; x < 4; x++) p[c][x] = upd_f32(p[c][x], q[c][x], c1s, cu, lr);
 #if MFX_EXP == 3 || MFX_EXP == 5
 #pragma unroll
           for (int y = 0; y < (MFX_EXP == 3 ? 4 : 8); y++)
@@ -192,11 +206,11 @@ struct SlotSteps {
 #endif
 #pragma unroll
           for (int x = 0; x < 4; x++) {
-            const float t = lr * (c1 * p[c][x] + ci * q[c][x]);
+            const float t = lr * (c1 * p[c][x] + cis * q[c][x]);
 #if MFX_EXP != 2
-            atomicAdd(qrow + c * 4 * L + x, __float2int_rn(t * -FIX_SCALE));   // ds_add_u32
+            atomicAdd(qrow + c * 4 * L + x, fix_round(t * -FIX_SCALE));   // ds_add_u32
 #else
-            asm volatile("" ::"v"(__float2int_rn(t * -FIX_SCALE)));
+            asm volatile("" ::"v"(fix_round(t * -FIX_SCALE)));
 #endif
           }
         }
@@ -228,12 +242,16 @@ struct SlotSteps {
 //
 // SWEEP = false: round `round` of the epoch; the workgroups on XCD x (HW_REG_XCC_ID) take tile
 // (x, (x + round) mod 8), user rows stay in that XCD's L2 (sc1 loads, plain stores).
-// SWEEP = true: the placement-independent drain of whatever the rounds left (normally nothing).  Same diagonal
-// schedule, but x comes from the workgroup index, so that an item row still has ONE owner at a time whatever the
-// XCC_ID values were (a partition mode that reports a constant id leaves 56 of the 64 tiles to this path); its user
-// rows go through memory (sc1 loads and write-through stores: the workgroups of one tile may sit on several XCDs).
+// SWEEP = true: the placement-independent drain of whatever the rounds left (normally nothing), ONE launch of
+// DRAIN_WGS resident workgroups.  Every workgroup reads the tile counters, all meet at a grid barrier (nobody has
+// pulled a slot yet, so all of them see the same counters) and leave when nothing is left: the normal case costs one
+// launch and one barrier.  Otherwise they walk the same diagonals as the rounds, x taken from the workgroup index and a
+// grid barrier between diagonals, so that an item row still has ONE owner at a time whatever the XCC_ID values were
+// (a partition mode that reports a constant id leaves 56 of the 64 tiles to this path); the user rows go through
+// memory (sc1 loads and write-through stores: the workgroups of one tile may sit on several XCDs).
 // It also carries the two test hooks of include/mfx.h: `tile_only` >= 0 restricts a launch to that tile and `one`
 // makes ONE lane group visit a slot's ratings one at a time (MFX_SGD_F_ONE_GROUP).
+constexpr int DRAIN_WGS = 128;
 template <int L, int C, int ARITH, bool SWEEP, bool OWN_U, int VAR>
 __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kernel(const int4* __restrict__ rec,
                                                            const int64_t* __restrict__ slot_beg,
@@ -257,19 +275,32 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
   const int xcc = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7);  // HW_REG_XCC_ID[3:0]
   // round r: XCD x takes user block x*SUB + r%SUB and item block (x + r/SUB) mod 8
   const int x = SWEEP ? (int)(blockIdx.x & 7) : xcc;
-  const int tile = (SWEEP && tile_only >= 0) ? tile_only : (x * SUB + round % SUB) * 8 + ((x + round / SUB) & 7);
   const bool onegrp = SWEEP && one != 0;
+  const bool drain = SWEEP && tile_only < 0;          // the whole-epoch drain: all diagonals, grid barriers in between
   int4* q4 = (int4*)q_lds;
-  {
+  if (drain) {
+    // anything left anywhere?  (ctr[NTILE], ctr[NTILE + 1]: barrier counter and abort flag, zeroed with the counters)
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
+    if (tid < NTILE && __hip_atomic_load(&ctr[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(tile_slot[tid + 1] - tile_slot[tid]))
+      s_bad = 1;
+    __syncthreads();
+    const bool left = s_bad != 0;
+    if (grid_barrier<0>(ctr + NTILE, gridDim.x)) return;
+    if (!left) return;
+  }
+  const int r_end = drain ? NUB : round + 1;
+  for (int rr = drain ? 0 : round; rr < r_end; rr++) {
+    const int tile = (SWEEP && tile_only >= 0) ? tile_only : (x * SUB + rr % SUB) * 8 + ((x + rr / SUB) & 7);
     const int s0 = tile_slot[tile], ns = tile_slot[tile + 1] - s0;
-    if (SWEEP) {  // nothing left in this tile (the normal case): do not queue on its counter
+    bool skip = false;
+    if (SWEEP) {  // nothing left in this tile: do not queue on its counter
       if (tid == 0) s_slot = (int)__hip_atomic_load(&ctr[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __syncthreads();
-      const int seen = s_slot;
+      skip = s_slot >= ns;
       __syncthreads();
-      if (seen >= ns) return;
     }
-    for (;;) {
+    while (!skip) {
       if (tid == 0) { s_slot = (int)atomicAdd(&ctr[tile], 1u); s_bad = 0; }
       __syncthreads();
       const int sl = s_slot;
@@ -377,6 +408,8 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
       }
       __syncthreads();
     }
+    // the next diagonal re-owns these item rows from other workgroups (other XCDs): L2 write-back, barrier, invalidate
+    if (drain && rr + 1 < r_end && grid_barrier<0>(ctr + NTILE, (unsigned)(rr + 2) * gridDim.x)) return;
   }
 }
 
@@ -390,7 +423,7 @@ static int launch_slots(mfx_ctx* ctx, SlotList* S, const mfx_sgd_opts* o, int bl
   const uint64_t ob = (uint64_t)(OWN_U ? ctx->nI : ctx->nU) * ctx->ld * 4;
   const int32_t* at = VAR == 3 ? (const int32_t*)ctx->dimreg : (VAR ? S->attr : (const int32_t*)nullptr);
   unsigned* visit = (o->flags & MFX_SGD_F_COUNT_VISITS) ? S->visit : nullptr;
-  HIPCHK(hipMemsetAsync(S->ctr, 0, NTILE * sizeof(unsigned), ctx->stream));
+  HIPCHK(hipMemsetAsync(S->ctr, 0, (NTILE + 2) * sizeof(unsigned), ctx->stream));
   if (o->flags & MFX_SGD_F_ONE_GROUP) {   // test hook: tiles in order, one workgroup, one lane group
     for (int tile = 0; tile < NTILE; tile++)
       hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, true, OWN_U, VAR>), dim3(1), dim3(WG), 0, ctx->stream,
@@ -399,21 +432,23 @@ static int launch_slots(mfx_ctx* ctx, SlotList* S, const mfx_sgd_opts* o, int bl
     HIPCHK(hipGetLastError());
     return MFX_OK;
   }
-  for (int round = 0; round < NUB; round++) {
+  for (int round = 0; round < NUB && !(o->flags & MFX_SGD_F_DRAIN_ONLY); round++) {
     ProfScope ps(ctx, MFX_K_SGD);
     hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, false, OWN_U, VAR>), dim3(blocks), dim3(WG), 0, ctx->stream,
                        (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->tile_slot, S->ctr, round,
                        oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1, at, visit, -1, 0);
   }
   {
-    // the drain: the same 8 diagonals keyed on the workgroup index (an item row keeps a single owner)
+    // the drain: one launch; the same diagonals keyed on the workgroup index (an item row keeps a single owner)
     ProfScope ps(ctx, MFX_K_SGD_SWEEP);
-    for (int round = 0; round < NUB; round++)
-      hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, true, OWN_U, VAR>), dim3(256), dim3(WG), 0, ctx->stream,
-                         (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->tile_slot, S->ctr, round,
-                         oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1, at, visit, -1, 0);
+    hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, true, OWN_U, VAR>), dim3(DRAIN_WGS), dim3(WG), 0, ctx->stream,
+                       (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->tile_slot, S->ctr, 0,
+                       oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1, at, visit, -1, 0);
   }
   HIPCHK(hipGetLastError());
+  // a drain whose barrier gave up (2 s without progress: the device is shared with another resident kernel) leaves its
+  // flag in ctr[NTILE + 1]; it is copied back without waiting and looked at by the NEXT call on this context
+  if (S->abort_host) HIPCHK(hipMemcpyAsync(S->abort_host, S->ctr + NTILE + 1, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
   return MFX_OK;
 }
 

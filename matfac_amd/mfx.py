@@ -13,7 +13,7 @@ SIDE_USERS, SIDE_ITEMS = 0, 1
 SGD_HOGWILD, SGD_SERIAL, SGD_USERS, SGD_TILED, SGD_LEVELS = 0, 1, 2, 3, 4
 ORDER_DEVICE, ORDER_HOST, ORDER_NATURAL = 0, 1, 2
 ARITH_REF64, ARITH_REF64F, ARITH_F32 = 0, 1, 2
-SGD_F_ONE_GROUP, SGD_F_COUNT_VISITS = 1, 2
+SGD_F_ONE_GROUP, SGD_F_COUNT_VISITS, SGD_F_DRAIN_ONLY = 1, 2, 4
 REDUCE_DELTA_SUM, REDUCE_AVERAGE = 0, 1
 K_SGD, K_PERMUTE, K_EVAL, K_ALS_GRAM, K_ALS_SOLVE, K_CCD_ROW, K_CCD_COL, K_CCD_RESID, K_SGD_SWEEP, K_CD = range(10)
 E_NODEVICE = -6
@@ -325,6 +325,7 @@ class Ctx:
 
     # ---- measurement ----------------------------------------------------------
     def prof_enable(self, on=True):
+        """on: False / True / N > 1 = events around the launches of every N-th sgd_epoch only"""
         self._chk(self.lib.mfx_prof_enable(self.h, int(on)))
 
     def prof_reset(self):

@@ -41,6 +41,13 @@ def test_tiled_sgd_visits_every_rating_once_and_learns(c2):
         # the drain consumed every record of every slot exactly once
         visits = ctx.debug_visit_counts()
         assert visits.size == tr.nnz and visits.min() == 1 and visits.max() == 1
+    # and the drain launch alone (what a device that reports ONE XCC_ID would run): item rows shared by tiles of different
+    # diagonals, grid barriers in between -- every record once again, and the model keeps improving
+    rb = ctx.rmse(mfx.MAT_TRAIN)
+    ctx.sgd_epoch(0.0025, 0.01, 0.01, mode=mfx.SGD_TILED, seed=1, epoch=3, flags=mfx.SGD_F_COUNT_VISITS | mfx.SGD_F_DRAIN_ONLY)
+    visits = ctx.debug_visit_counts()
+    assert visits.min() == 1 and visits.max() == 1
+    assert ctx.rmse(mfx.MAT_TRAIN) < rb
     u, i, r = ctx.debug_epoch_list()
     k = u.astype(np.int64) * c2["nItems"] + i
     assert k.size == tr.nnz

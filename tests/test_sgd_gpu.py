@@ -77,6 +77,30 @@ def test_tiled_conflict_free_batch_matches_oracle(K, arith):
     assert visits.size == n and np.all(visits == 1)                        # as counted by the update loop itself
 
 
+@pytest.mark.parametrize("K", [10, 64, 256])
+def test_tiled_drain_launch_alone_runs_a_whole_epoch(K):
+    """MFX_SGD_F_DRAIN_ONLY: no XCD-scheduled rounds, the drain launch (diagonals keyed on the workgroup index, grid
+    barriers in between) visits everything -- every rating once, same factors as the oracle's pass."""
+    n = 6000
+    tr = _conflict_free_matrix(n, K, seed=K + 9)
+    rng = np.random.default_rng(250 + K)
+    U0 = rng.normal(0, 0.3, (n, K)).astype(np.float32)
+    V0 = rng.normal(0, 0.3, (n, K)).astype(np.float32)
+    with Ctx(0) as ctx:
+        ctx.set_csr(mfx.MAT_TRAIN, n, n, tr.rowptr, tr.rowind, tr.rowval)
+        ctx.set_model(n, n, K)
+        ctx.set_factors(U0, V0)
+        ctx.sgd_epoch(0.01, 0.05, 0.02, mode=mfx.SGD_TILED, order=mfx.ORDER_DEVICE, arith=mfx.ARITH_F32, seed=3, epoch=1,
+                      flags=mfx.SGD_F_COUNT_VISITS | mfx.SGD_F_DRAIN_ONLY)
+        ctx.sgd_epoch(0.0, 0.0, 0.0, mode=mfx.SGD_TILED, order=mfx.ORDER_DEVICE, seed=3, epoch=2)   # (reports a drain that gave up)
+        U, V = ctx.get_factors()
+        visits = ctx.debug_visit_counts()
+    Uo, Vo = U0.copy(), V0.copy()
+    orc.sgd_pass(Uo, Vo, tr.rowids(), tr.rowind, tr.rowval, None, 0.01, 0.05, 0.02, orc.ARITH_F32, orc.DOT_TREE)
+    assert np.all(visits == 1)
+    assert np.abs(V - Vo).max() <= 2.0e-7 and np.abs(U - Uo).max() <= 2.0e-7
+
+
 @pytest.mark.parametrize("K", [64, 256])
 def test_tiled_rows_outside_the_fixed_point_range(K):
     """A slot whose staged item rows exceed +-127 runs on float rows (plain stores; on a conflict-free batch that is
