@@ -9,6 +9,7 @@
 #include "model_invpop.h"
 #include "model_tmf.h"
 #include "mfhost.h"
+#include "dataprep.h"
 
 extern "C" int mfh_train(const char* method, int32_t nrows, const int64_t* tr_ptr, const int32_t* tr_ind,
                          const float* tr_val, int32_t tr_ncols, const int64_t* va_ptr, const int32_t* va_ind,
@@ -138,3 +139,23 @@ extern "C" int mfh_mat_read(const char* path, float* data, int32_t n, int32_t k)
   memcpy(data, m.data(), sizeof(float) * (size_t)n * k);
   return 0;
 }
+
+// the file-level data preparation (dataprep.cpp) for the tests: split an in-memory CSR into three files / write a
+// synthetic matrix from given factors (row-major doubles)
+extern "C" int mfh_write_train_test_val(int32_t nrows, int32_t ncols, const int64_t* rowptr, const int32_t* rowind, const float* rowval,
+                                        const char* trainFile, const char* testFile, const char* valFile, float testPc, float valPc,
+                                        int32_t seed) {
+  csr_t* m = csr_from_arrays(nrows, ncols, rowptr, rowind, rowval);
+  writeTrainTestValMat(m, trainFile, testFile, valFile, testPc, valPc, seed);
+  csr_free(&m);
+  return 0;
+}
+extern "C" int mfh_write_rand_mat_csr(const char* file, const double* U, const double* V, int32_t nUsers, int32_t nItems, int32_t facDim,
+                                      int32_t seed, int32_t nnz) {
+  std::vector<std::vector<double>> uFac((size_t)nUsers), iFac((size_t)nItems);
+  for (int u = 0; u < nUsers; u++) uFac[(size_t)u].assign(U + (size_t)u * facDim, U + (size_t)(u + 1) * facDim);
+  for (int i = 0; i < nItems; i++) iFac[(size_t)i].assign(V + (size_t)i * facDim, V + (size_t)(i + 1) * facDim);
+  writeRandMatCSR(file, uFac, iFac, facDim, seed, nnz);
+  return 0;
+}
+

@@ -77,6 +77,7 @@ lib.orc_objective.restype = C.c_double
 lib.orc_rmse.restype = C.c_double
 lib.orc_time_hogwild.restype = C.c_double
 lib.orc_time_strat.restype = C.c_double
+lib.orc_rand_pairs.restype = C.c_int64
 
 
 class TrainCfg(C.Structure):
@@ -376,6 +377,19 @@ def time_strat(U, V, rowptr, rowind, rowval, nrows, ncols, invU, invI, T, lr, uR
                                   C.c_float(lr), C.c_float(uReg), C.c_float(iReg), epochs)
     finally:
         lib.orc_strat_free(h)
+
+
+def split_colors(nnz, testPc, valPc, seed):
+    color = np.empty(nnz, np.int32)
+    lib.orc_split_colors(C.c_int64(nnz), C.c_float(testPc), C.c_float(valPc), int(seed), I32(color))
+    return color
+
+
+def rand_pairs(nUsers, nItems, seed, nnz):
+    n = lib.orc_rand_pairs(nUsers, nItems, int(seed), nnz, None)
+    pairs = np.empty((n, 2), np.int32)
+    lib.orc_rand_pairs(nUsers, nItems, int(seed), nnz, I32(pairs))
+    return pairs
 
 
 def max_threads():

@@ -1171,3 +1171,63 @@ double orc_time_strat(void* h, void* mth, int K, float* U, float* V, const int64
   return std::chrono::duration<double>(t1 - t0).count();
 }
 
+// ---------------------------------------------------------------------------
+// data preparation in front of the path (io.cpp:410-459, 726-787): the RNG-driven parts
+// ---------------------------------------------------------------------------
+// io.cpp:413-437: colour 1 = test (nTest draws with replacement), 2 = val (nVal uncoloured ratings), 0 = train
+void orc_split_colors(int64_t nnz, float testPc, float valPc, int seed, int32_t* color) {
+  int n = (int)nnz;
+  int nTest = testPc * n;
+  int nVal = valPc * n;
+  memset(color, 0, sizeof(int32_t) * (size_t)n);
+  std::mt19937 mt(seed);
+  std::uniform_int_distribution<int> nnzDist(0, n - 1);
+  for (int i = 0; i < nTest; i++) {
+    int k = nnzDist(mt);
+    color[k] = 1;
+  }
+  int i = 0;
+  while (i < nVal) {
+    int k = nnzDist(mt);
+    if (!color[k]) {
+      color[k] = 2;
+      i++;
+    }
+  }
+}
+// io.cpp:730-767: the sampled (user, item) pairs of writeRandMatCSR.  Two-call protocol: pairs == NULL returns the count;
+// otherwise fills pairs[2*t] = user, pairs[2*t+1] = item, users ascending and items ascending inside a user.
+int64_t orc_rand_pairs(int32_t nUsers, int32_t nItems, int seed, int32_t nnz, int32_t* pairs) {
+  std::vector<std::unordered_set<int>> uItemSet(nUsers);
+  std::mt19937 mt(seed);
+  std::uniform_int_distribution<int> uDist(0, nUsers - 1);
+  std::uniform_int_distribution<int> iDist(0, nItems - 1);
+  for (int u = 0; u < nUsers; u++) {
+    int item = iDist(mt);
+    uItemSet[u].insert(item);
+  }
+  for (int item = 0; item < nItems; item++) {
+    int user = uDist(mt);
+    uItemSet[user].insert(item);
+  }
+  auto nTuples = [&]() { int64_t c = 0; for (auto& s : uItemSet) c += (int64_t)s.size(); return c; };
+  int64_t nPairs = nTuples();
+  while (nPairs < nnz) {
+    for (int64_t i = 0; i < nnz - nPairs; i++) {
+      int user = uDist(mt);
+      int item = iDist(mt);
+      uItemSet[user].insert(item);
+    }
+    nPairs = nTuples();
+  }
+  if (pairs) {
+    int64_t t = 0;
+    for (int u = 0; u < nUsers; u++) {
+      std::vector<int> items(uItemSet[u].begin(), uItemSet[u].end());
+      std::sort(items.begin(), items.end());
+      for (int item : items) { pairs[2 * t] = u; pairs[2 * t + 1] = item; t++; }
+    }
+  }
+  return nPairs;
+}
+

@@ -215,6 +215,10 @@ int orc_train(const orc_train_cfg* cfg, float* U, float* V, float* Ubest, float*
               double* objTraj, double* valTraj, int32_t* bestIter, float* finalLearnRate,
               uint8_t* invU, uint8_t* invI);
 
+/* ---- data preparation in front of the path (io.cpp:410-459, 726-787) ---------- */
+void orc_split_colors(int64_t nnz, float testPc, float valPc, int seed, int32_t* color);
+int64_t orc_rand_pairs(int32_t nUsers, int32_t nItems, int seed, int32_t nnz, int32_t* pairs);
+
 /* ---- cpu_baseline timing (bench.py only) -------------------------------- */
 /* OpenMP Hogwild epoch (modelMF.cpp:1746-1767 bracket), colmajor=1 reproduces the
  * reference's Eigen column-major factor storage. Returns seconds for `epochs`

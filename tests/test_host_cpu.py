@@ -170,3 +170,49 @@ def test_dropin_example_compiles_and_links_against_the_class_surface(tmp_path):
             files.append(p)
         run = subprocess.run([exe] + files + [str(tmp_path / "run"), "sgd", "2", "1"], capture_output=True, text=True, timeout=120)
         assert run.returncode != 0 and "mfx_create failed" in run.stderr            # no CPU fallback
+
+
+def test_train_test_val_splitter_files(tmp_path):
+    """writeTrainTestValMat (io.cpp:410-459): the three files are the colour classes of the oracle's restatement of the
+    mt19937 colouring (test drawn WITH replacement, val exactly valPc*nnz), each with the full shape and the row order."""
+    d = synth.make(dict(nU=120, nI=70, nnz=2500, K=0), seed=4)
+    m = d["full"]
+    lib = synth._host()
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    files = [str(tmp_path / n) for n in ("train.csr", "test.csr", "val.csr")]
+    assert lib.mfh_write_train_test_val(C.c_int32(m.nrows), C.c_int32(m.ncols), P(m.rowptr), P(m.rowind), P(m.rowval),
+                                        files[0].encode(), files[1].encode(), files[2].encode(), C.c_float(0.1), C.c_float(0.2),
+                                        C.c_int32(7)) == 0
+    color = orc.split_colors(m.nnz, 0.1, 0.2, 7)
+    assert (color == 2).sum() == int(np.float32(0.2) * m.nnz) and 0 < (color == 1).sum() <= int(np.float32(0.1) * m.nnz)
+    rows = m.rowids()
+    for c, f in enumerate(files):
+        assert sum(1 for _ in open(f)) == m.nrows                  # one line per user, empty rows included
+        nr, nc, rp, ri, rv, *_ = host_read(f, want_cols=False)
+        sel = color == c
+        assert nr == m.nrows
+        assert np.array_equal(ri, m.rowind[sel]) and np.array_equal(rv, m.rowval[sel])      # ratings are multiples of 0.5: "%f" is exact
+        assert np.array_equal(np.diff(rp), np.bincount(rows[sel], minlength=m.nrows))
+    txt = open(files[0]).readline()
+    assert txt.startswith(" ") and "." in txt                      # GKlib's " %d %f" entries
+
+
+def test_rand_mat_csr_writer(tmp_path):
+    """writeRandMatCSR (io.cpp:726-787): the sampled pairs are the oracle's restatement of the mt19937 sequence; every user
+    and every item occurs; the rating is the double dot product of the given factors printed with ostream precision."""
+    nU, nI, K, nnz = 60, 40, 5, 900
+    rng = np.random.default_rng(3)
+    U = rng.normal(0, 1, (nU, K)); V = rng.normal(0, 1, (nI, K))
+    lib = synth._host()
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    f = str(tmp_path / "rand.csr")
+    assert lib.mfh_write_rand_mat_csr(f.encode(), P(U), P(V), nU, nI, K, 11, nnz) == 0
+    pairs = orc.rand_pairs(nU, nI, 11, nnz)
+    assert len(pairs) >= nnz
+    nr, nc, rp, ri, rv, *_ = host_read(f, want_cols=False)
+    assert nr == nU and rp[-1] == len(pairs)
+    assert np.array_equal(np.repeat(np.arange(nU), np.diff(rp)), pairs[:, 0]) and np.array_equal(ri, pairs[:, 1])
+    assert np.all(np.diff(rp) >= 1) and np.unique(ri).size == nI
+    exact = np.einsum("ij,ij->i", U[pairs[:, 0]], V[pairs[:, 1]])
+    assert np.allclose(rv, exact, rtol=2e-5, atol=1e-6)            # 6 significant digits in the file
+
