@@ -269,6 +269,22 @@ int mfx_set_tmf(mfx_ctx* ctx, const float* userFreq, const int32_t* userRank, co
  * (seed, opts->epoch, u, item) -- the reference's per-thread mt19937 streams depend on the thread count.  NULLs: off.  */
 int mfx_set_tmf_dropout(mfx_ctx* ctx, const int32_t* userLambda, const int32_t* itemLambda, uint32_t seed);
 
+/* ---- ModelMFBias: the bias-only sibling (modelMFBias.cpp) ------------------------------- */
+/* estRating = uBias[u] + iBias[item] (:94-99, a float sum); one visit (:178-197), diff taken ONCE before both steps:
+ *   uBias[u]    -= learnRate*(-2.0*diff + 2.0*uReg*uBias[u]);   iBias[item] -= learnRate*(-2.0*diff + 2.0*iReg*iBias[item])
+ * in double, narrowed to float on the store.  The vectors live next to the factor matrices of mfx_set_model (nUsers
+ * resp. nItems floats); mfx_snapshot_best / mfx_restore_best carry them once they are set.                               */
+int mfx_bias_set(mfx_ctx* ctx, const float* uBias, const float* iBias);
+int mfx_bias_get(mfx_ctx* ctx, int snapshot, float* uBias, float* iBias);
+/* one epoch of ModelMFBias::train's loop over the epoch list (opts->order as mfx_sgd_epoch; the reference shuffles the
+ * rating tuples with std::shuffle every epoch, :166).  opts->mode: MFX_SGD_SERIAL (one lane in list order) or
+ * MFX_SGD_LEVELS (the same result from the dataflow schedule of sgd_flow.hip); opts->arith is ignored.                    */
+int mfx_bias_epoch(mfx_ctx* ctx, const mfx_sgd_opts* opts);
+/* ModelMFBias::objective (:40-91) and Model::RMSE through the class's estRating: out->sse, out->n as mfx_eval,
+ * out->unorm2 = sum over valid users of uBias[u]^2, out->inorm2 = sum over valid items of iBias[item]^2
+ * (objective = sse + uReg*unorm2 + iReg*inorm2: the factor norms are computed and dropped by the reference).            */
+int mfx_bias_eval(mfx_ctx* ctx, int which, int snapshot, mfx_eval_out* out);
+
 /* ---- multi-GPU: user-row-block sharding, item-factor exchange over RCCL ------ */
 /* The reference is single-process; this is new.  Each rank owns a
  * user block (its CSR rows + U shard) and a replica of V.  After local work,

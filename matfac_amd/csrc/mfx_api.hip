@@ -89,6 +89,7 @@ static void free_csr(DevCSR& m) {
 }
 
 static void free_model(mfx_ctx* ctx) {
+  mfx_bias_free_internal(ctx);
   dev_free(ctx->U); dev_free(ctx->V); dev_free(ctx->Ubest); dev_free(ctx->Vbest);
   dev_free(ctx->Vsync); dev_free(ctx->invU); dev_free(ctx->invI);
   ctx->have_invalid = false;
@@ -394,6 +395,10 @@ extern "C" int mfx_snapshot_best(mfx_ctx* ctx) {
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipMemcpyAsync(ctx->Ubest, ctx->U, sizeof(float) * (size_t)ctx->nU * ctx->ld, hipMemcpyDeviceToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(ctx->Vbest, ctx->V, sizeof(float) * (size_t)ctx->nI * ctx->ld, hipMemcpyDeviceToDevice, ctx->stream));
+  if (ctx->ub) {
+    HIPCHK(hipMemcpyAsync(ctx->ub_best, ctx->ub, sizeof(float) * (size_t)ctx->nU, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->ib_best, ctx->ib, sizeof(float) * (size_t)ctx->nI, hipMemcpyDeviceToDevice, ctx->stream));
+  }
   return MFX_OK;
 }
 extern "C" int mfx_restore_best(mfx_ctx* ctx) {
@@ -402,6 +407,10 @@ extern "C" int mfx_restore_best(mfx_ctx* ctx) {
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipMemcpyAsync(ctx->U, ctx->Ubest, sizeof(float) * (size_t)ctx->nU * ctx->ld, hipMemcpyDeviceToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(ctx->V, ctx->Vbest, sizeof(float) * (size_t)ctx->nI * ctx->ld, hipMemcpyDeviceToDevice, ctx->stream));
+  if (ctx->ub) {
+    HIPCHK(hipMemcpyAsync(ctx->ub, ctx->ub_best, sizeof(float) * (size_t)ctx->nU, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->ib, ctx->ib_best, sizeof(float) * (size_t)ctx->nI, hipMemcpyDeviceToDevice, ctx->stream));
+  }
   return MFX_OK;
 }
 

@@ -99,6 +99,8 @@ struct mfx_ctx {
   void* ccd_cols = nullptr;   // strip-major column view (ccd_cols.hip owns the type)
   void* cd = nullptr;         // trainCCD state (cd.hip owns the type)
   void* als_wide = nullptr;   // ALS for K > 64 (als_wide.hip owns the type)
+  float *ub = nullptr, *ib = nullptr, *ub_best = nullptr, *ib_best = nullptr;   // ModelMFBias vectors (sgd_bias.hip), or NULL
+  bool bias_epoch = false;    // mfx_bias_epoch is driving the epoch-list machinery of mfx_sgd_epoch
   float* dimreg = nullptr;    // per-dimension regulariser [ld] of trainSGDParSVD (svd.hip), or NULL
   void* ifw = nullptr;        // rating weights of ModelInvPopMF (sgd_ifw.hip owns the type), or NULL
   uint64_t var_gen = 0;       // bumped whenever the rating weights / rank tables change
@@ -213,6 +215,9 @@ int mfx_launch_sgd_levels(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, in
 void mfx_levels_free_internal(mfx_ctx* ctx);
 int mfx_launch_sgd_flow(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_t count);     // sgd_flow.hip
 bool mfx_flow_usable(const mfx_ctx* ctx, int64_t count);
+int mfx_launch_bias_flow(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_t count);   // sgd_flow.hip
+int mfx_launch_sgd_bias(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_t count);    // sgd_bias.hip
+void mfx_bias_free_internal(mfx_ctx* ctx);
 bool mfx_flow_info(mfx_ctx* ctx, int64_t info[4], double* prep_ms);
 void mfx_flow_free_internal(mfx_ctx* ctx);
 int mfx_slots_materialise_order(mfx_ctx* ctx);

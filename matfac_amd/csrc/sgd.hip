@@ -214,6 +214,7 @@ static int launch_any(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_
 }
 
 int mfx_launch_sgd(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_t count) {
+  if (ctx->bias_epoch) return mfx_launch_sgd_bias(ctx, o, first, count);                              // sgd_bias.hip
   if (o->mode == MFX_SGD_LEVELS) return mfx_launch_sgd_levels(ctx, o, first, count);                  // sgd_levels.hip
   if (ctx->dimreg) return mfx_launch_sgd_dimreg(ctx, o, first, count);   // trainSGDParSVD's regulariser (svd.hip)
   if (ctx->ifw) return mfx_launch_sgd_ifw(ctx, o, first, count);         // ModelInvPopMF's rating weights (sgd_ifw.hip)

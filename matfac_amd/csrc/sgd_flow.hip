@@ -112,6 +112,56 @@ __global__ __launch_bounds__(FL_WG, FL_WG_PER_CU) void sgd_flow_kernel(const int
   }
 }
 
+// ModelMFBias (modelMFBias.cpp:178-197) on the same schedule with ONE lane per rating: the owned side's bias stays with
+// its lane's queue, the other side's bias carries the version counter.  The visit is sgd_bias.hip's, statement by statement.
+__global__ __launch_bounds__(FL_WG, FL_WG_PER_CU) void bias_flow_kernel(const int4* __restrict__ q, const int64_t* __restrict__ qoff,
+                                                                        unsigned* ver, float* ub, float* ib, int own_user, float lr,
+                                                                        float uReg, float iReg, unsigned* flag) {
+  const int64_t grp = (int64_t)blockIdx.x * FL_WG + threadIdx.x;
+  int64_t pos = qoff[grp];
+  const int64_t end = qoff[grp + 1];
+  long long t_last = wall_clock64();
+  int idle = 0;
+  while (__builtin_amdgcn_ballot_w64(pos < end) != 0) {
+    bool ready = false;
+    int4 rec = make_int4(0, 0, 0, 0);
+    if (pos < end) {
+      rec = q[pos];
+      ready = __hip_atomic_load(ver + rec.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)rec.w;
+    }
+    asm volatile("" ::: "memory");
+    if (ready) {
+      const int u = own_user ? rec.y : rec.x, it = own_user ? rec.x : rec.y;
+      float bu = __hip_atomic_load(ub + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      float bi = __hip_atomic_load(ib + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      {
+        const float est = bu + bi;
+        const double diff = (double)__int_as_float(rec.z) - (double)est;
+        bu = (float)((double)bu - (double)lr * (-2.0 * diff + (2.0 * (double)uReg) * (double)bu));
+        bi = (float)((double)bi - (double)lr * (-2.0 * diff + (2.0 * (double)iReg) * (double)bi));
+      }
+      __hip_atomic_store(ub + u, bu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(ib + it, bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the two stores are acknowledged, then the version moves
+      __hip_atomic_store(ver + rec.x, (unsigned)rec.w + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      pos++;
+    }
+    if (__builtin_amdgcn_ballot_w64(ready) != 0) {
+      t_last = wall_clock64();
+      idle = 0;
+    } else {
+      __builtin_amdgcn_s_sleep(2);
+      if ((++idle & 63) == 0) {
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+        if (wall_clock64() - t_last > 200000000LL) {
+          __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          return;
+        }
+      }
+    }
+  }
+}
+
 int build_flow(mfx_ctx* ctx, int64_t first, int64_t count, int64_t groups) {
   FlowState* S = fl(ctx);
   const auto t0 = std::chrono::steady_clock::now();
@@ -264,6 +314,29 @@ int mfx_launch_sgd_flow(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int6
   HIPCHK(hipMemcpyAsync(&flag, fl(ctx)->flag, sizeof flag, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   NEED(flag == 0, MFX_E_HIP, "MFX_SGD_LEVELS (dataflow): no progress for 2 s, launch abandoned (device shared with another resident kernel?)");
+  return MFX_OK;
+}
+
+int mfx_launch_bias_flow(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_t count) {
+  if (!fl(ctx)) ctx->flow = new FlowState;
+  int dev = 0, cus = 0;
+  HIPCHK(hipGetDevice(&dev));
+  HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const int blocks = std::max(1, cus) * FL_WG_PER_CU;
+  int rc = build_flow(ctx, first, count, (int64_t)blocks * FL_WG);     // one lane = one queue
+  if (rc) return rc;
+  FlowState* S = fl(ctx);
+  {
+    ProfScope ps(ctx, MFX_K_SGD);
+    hipLaunchKernelGGL(bias_flow_kernel, dim3(blocks), dim3(FL_WG), 0, ctx->stream, (const int4*)S->q, S->qoff, S->ver, ctx->ub, ctx->ib,
+                       S->own_user, o->learnRate, o->uReg, o->iReg, S->flag);
+    HIPCHK(hipGetLastError());
+  }
+  unsigned flag = 0;
+  HIPCHK(hipMemcpyAsync(&flag, S->flag, sizeof flag, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  NEED(flag == 0, MFX_E_HIP, "mfx_bias_epoch (dataflow): no progress for 2 s, launch abandoned");
+  ctx->last_exact_flow = true;
   return MFX_OK;
 }
 

@@ -10,6 +10,7 @@
 #include "model_tmf.h"
 #include "mfhost.h"
 #include "dataprep.h"
+#include "model_bias.h"
 
 extern "C" int mfh_train(const char* method, int32_t nrows, const int64_t* tr_ptr, const int32_t* tr_ind,
                          const float* tr_val, int32_t tr_ncols, const int64_t* va_ptr, const int32_t* va_ind,
@@ -156,6 +157,37 @@ extern "C" int mfh_write_rand_mat_csr(const char* file, const double* U, const d
   for (int u = 0; u < nUsers; u++) uFac[(size_t)u].assign(U + (size_t)u * facDim, U + (size_t)(u + 1) * facDim);
   for (int i = 0; i < nItems; i++) iFac[(size_t)i].assign(V + (size_t)i * facDim, V + (size_t)(i + 1) * facDim);
   writeRandMatCSR(file, uFac, iFac, facDim, seed, nnz);
+  return 0;
+}
+
+// ModelMFBias::train on in-memory matrices (the bias-only sibling): last and best bias vectors, stats as mfh_train
+extern "C" int mfh_train_bias(int32_t nrows, const int64_t* tr_ptr, const int32_t* tr_ind, const float* tr_val, int32_t tr_ncols,
+                              const int64_t* va_ptr, const int32_t* va_ind, const float* va_val, int32_t va_ncols, const int64_t* te_ptr,
+                              const int32_t* te_ind, const float* te_val, int32_t te_ncols, int32_t K, int32_t maxIter, int32_t seed,
+                              float learnRate, float uReg, float iReg, float* ubLast, float* ibLast, float* ubBest, float* ibBest,
+                              double* stats) {
+  std::string e, pfx = "";
+  setenv("MFX_NO_SAVE", "1", 1);
+  Params params(K, maxIter, K, seed, uReg, iReg, learnRate, 0.0f, 0.0f, e, e, e, e, e, e, e, e, pfx);
+  Data data(csr_from_arrays(nrows, tr_ncols, tr_ptr, tr_ind, tr_val), csr_from_arrays(nrows, te_ncols, te_ptr, te_ind, te_val),
+            csr_from_arrays(nrows, va_ncols, va_ptr, va_ind, va_val), pfx.c_str());
+  params.nUsers = data.nUsers;
+  params.nItems = data.nItems;
+  ModelMFBias model(params, params.seed), best(params, params.seed);
+  std::unordered_set<int> iu, ii;
+  model.train(data, best, iu, ii);
+  if (ubLast) memcpy(ubLast, model.uBias.data(), sizeof(float) * (size_t)data.nUsers);
+  if (ibLast) memcpy(ibLast, model.iBias.data(), sizeof(float) * (size_t)data.nItems);
+  if (ubBest) memcpy(ubBest, best.uBias.data(), sizeof(float) * (size_t)data.nUsers);
+  if (ibBest) memcpy(ibBest, best.iBias.data(), sizeof(float) * (size_t)data.nItems);
+  if (stats) {
+    stats[0] = best.RMSE(data.trainMat, iu, ii);
+    stats[1] = best.RMSE(data.testMat, iu, ii);
+    stats[2] = best.RMSE(data.valMat, iu, ii);
+    stats[3] = model.learnRate;
+    stats[4] = model.lastIters;
+  }
+  unsetenv("MFX_NO_SAVE");
   return 0;
 }
 

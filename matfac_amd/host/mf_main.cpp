@@ -11,6 +11,7 @@
 #include "mf_model.h"
 #include "model_invpop.h"
 #include "model_tmf.h"
+#include "model_bias.h"
 
 #include <algorithm>
 #include <fstream>
@@ -152,8 +153,8 @@ int main(int argc, char** argv) {
   params.nItems = data.nItems;
   params.display();
 
-  if (flags["algo"] != "mf" && flags["algo"] != "IFWMF" && flags["algo"] != "TMF" && flags["algo"] != "TMFDropout") {
-    std::cerr << "Invalid algo input: " << flags["algo"] << " (this build implements --algo=mf, IFWMF, TMF and TMFDropout)" << std::endl;
+  if (flags["algo"] != "mf" && flags["algo"] != "IFWMF" && flags["algo"] != "TMF" && flags["algo"] != "TMFDropout" && flags["algo"] != "mfbias") {
+    std::cerr << "Invalid algo input: " << flags["algo"] << " (this build implements --algo=mf, IFWMF, TMF, TMFDropout and mfbias)" << std::endl;
     exit(0);
   }
   Partition partItems, partUsers;
@@ -170,7 +171,11 @@ int main(int argc, char** argv) {
     bestModel.reset(new ModelMF(params, params.seed));
   }
   const std::string m = flags["mf_method"];
-  if (flags["algo"] == "IFWMF") {       // main.cpp:1361-1366
+  if (flags["algo"] == "mfbias") {      // ModelMFBias: built by the reference (CMakeLists.txt) but left out of its --algo dispatch (main.cpp:912, commented)
+    mfModel.reset(new ModelMFBias(params, params.seed));
+    bestModel.reset(new ModelMFBias(params, params.seed));
+    mfModel->train(data, *bestModel, invalidUsers, invalidItems);
+  } else if (flags["algo"] == "IFWMF") {       // main.cpp:1361-1366
     auto rowColFreq = getRowColFreq(data.trainMat);
     mfModel.reset(new ModelInvPopMF(params, params.seed, rowColFreq.first, rowColFreq.second));
     bestModel.reset(new ModelInvPopMF(params, params.seed, rowColFreq.first, rowColFreq.second));

@@ -110,8 +110,8 @@ class Model {
   bool hostStale = false;            // device copy is newer than uFac/iFac
   double lastLoopSeconds = 0;        // wall time of the last trainer's iteration loop (updates + termination checks)
   int lastIters = 0;
-  void syncHost();                   // download uFac/iFac if hostStale
-  void pushToDevice();               // upload uFac/iFac to the CURRENT snapshot
+  virtual void syncHost();           // download uFac/iFac if hostStale
+  virtual void pushToDevice();       // upload uFac/iFac to the CURRENT snapshot
   // scalar fields of `*this = other` without touching the factor storage
   void copyScalarsFrom(const Model& o);
 
@@ -120,7 +120,7 @@ class Model {
   void attach(const Data& data);     // open a session for data (if none) and upload the factors
   // getInvalidUsersItems + modelMF.cpp:40-45 on the device, returned as sets
   void deviceInvalid(const Data& data, IntSet& invalidUsers, IntSet& invalidItems);
-  void evalDevice(const csr_t* mat, int withNorms, mfx_eval_out* out);
+  virtual void evalDevice(const csr_t* mat, int withNorms, mfx_eval_out* out);
   // true while objective() is the base formula, so that isTerminateModel may take the objective and the
   // validation RMSE from one mfx_eval2 call; a class that overrides objective() returns false
   virtual bool baseObjective() const { return true; }

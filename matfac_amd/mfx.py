@@ -262,6 +262,26 @@ class Ctx:
         ks = [_p(userLambda, np.int32), _p(itemLambda, np.int32)]
         self._chk(self.lib.mfx_set_tmf_dropout(self.h, *[k[1] if k else None for k in ks], C.c_uint32(seed)))
 
+    # ---- ModelMFBias -----------------------------------------------------------------------
+    def bias_set(self, uBias, iBias):
+        a, b = _p(uBias, np.float32), _p(iBias, np.float32)
+        assert a[0].size == self.nU and b[0].size == self.nI
+        self._chk(self.lib.mfx_bias_set(self.h, a[1], b[1]))
+
+    def bias_get(self, snapshot=SNAP_CURRENT):
+        ub, ib = np.empty(self.nU, np.float32), np.empty(self.nI, np.float32)
+        self._chk(self.lib.mfx_bias_get(self.h, snapshot, ub.ctypes.data_as(C.c_void_p), ib.ctypes.data_as(C.c_void_p)))
+        return ub, ib
+
+    def bias_epoch(self, lr, uReg, iReg, mode=SGD_LEVELS, order=ORDER_HOST, seed=1, epoch=0, first=0, count=0):
+        o = SgdOpts(mode, order, ARITH_REF64, lr, uReg, iReg, seed, epoch, 0, 0, first, count, 0, 0)
+        self._chk(self.lib.mfx_bias_epoch(self.h, C.byref(o)))
+
+    def bias_eval(self, which, snapshot=SNAP_CURRENT):
+        out = EvalOut()
+        self._chk(self.lib.mfx_bias_eval(self.h, which, snapshot, C.byref(out)))
+        return out
+
     # ---- cyclic coordinate descent (trainCCD) ---------------------------------------
     def ccd_begin(self):
         self._chk(self.lib.mfx_ccd_begin(self.h))

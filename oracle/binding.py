@@ -78,6 +78,7 @@ lib.orc_rmse.restype = C.c_double
 lib.orc_time_hogwild.restype = C.c_double
 lib.orc_time_strat.restype = C.c_double
 lib.orc_rand_pairs.restype = C.c_int64
+lib.orc_bias_eval.restype = C.c_double
 
 
 class TrainCfg(C.Structure):
@@ -377,6 +378,25 @@ def time_strat(U, V, rowptr, rowind, rowval, nrows, ncols, invU, invI, T, lr, uR
                                   C.c_float(lr), C.c_float(uReg), C.c_float(iReg), epochs)
     finally:
         lib.orc_strat_free(h)
+
+
+def init_bias(seed, nU, nI, K):
+    ub, ib = np.empty(nU, np.float32), np.empty(nI, np.float32)
+    lib.orc_init_bias(int(seed), nU, nI, K, F(ub), F(ib))
+    return ub, ib
+
+
+def bias_pass(ub, ib, u, i, r, order, lr, uReg, iReg):
+    n = len(order) if order is not None else len(u)
+    lib.orc_bias_pass(F(ub), F(ib), I32(u), I32(i), F(r), p(order, _u64) if order is not None else None, C.c_int64(n),
+                      C.c_float(lr), C.c_float(uReg), C.c_float(iReg))
+
+
+def bias_eval(ub, ib, nUsers, nItems, nrows, rowptr, rowind, rowval, invU, invI, uReg=0.0, iReg=0.0):
+    sse, cnt, a, b = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+    obj = lib.orc_bias_eval(F(ub), F(ib), nUsers, nItems, nrows, I64(rowptr), I32(rowind), F(rowval), U8(invU), U8(invI),
+                            C.c_float(uReg), C.c_float(iReg), C.byref(sse), C.byref(cnt), C.byref(a), C.byref(b))
+    return obj, sse.value, cnt.value, a.value, b.value
 
 
 def split_colors(nnz, testPc, valPc, seed):

@@ -1231,3 +1231,54 @@ int64_t orc_rand_pairs(int32_t nUsers, int32_t nItems, int seed, int32_t nnz, in
   return nPairs;
 }
 
+// ---------------------------------------------------------------------------
+// ModelMFBias (modelMFBias.cpp)
+// ---------------------------------------------------------------------------
+// :163-197: the sequential loop over the rating tuples in order[] (NULL: 0..n-1)
+void orc_bias_pass(float* uBias, float* iBias, const int32_t* u, const int32_t* i, const float* r, const uint64_t* order,
+                   int64_t n, float learnRate, float uReg, float iReg) {
+  for (int64_t t = 0; t < n; t++) {
+    const int64_t ind = order ? (int64_t)order[t] : t;
+    const int user = u[ind], item = i[ind];
+    const float itemRat = r[ind];
+    double r_ui_est = uBias[user] + iBias[item];                  // estRating (:94-99): float sum widened
+    double diff = itemRat - r_ui_est;
+    uBias[user] -= learnRate * (-2.0 * diff + 2.0 * uReg * uBias[user]);
+    iBias[item] -= learnRate * (-2.0 * diff + 2.0 * iReg * iBias[item]);
+  }
+}
+// :40-91 and Model::RMSE (model.cpp:214-251) through the class's estRating.  Returns the objective; *sse, *cnt,
+// *ubReg = sum uBias^2, *ibReg = sum iBias^2 over the valid users / items.
+double orc_bias_eval(const float* uBias, const float* iBias, int32_t nUsers, int32_t nItems, int32_t nrows, const int64_t* rowptr,
+                     const int32_t* rowind, const float* rowval, const uint8_t* invU, const uint8_t* invI, float uReg, float iReg,
+                     double* sse_out, int64_t* cnt_out, double* ub_out, double* ib_out) {
+  double rmse = 0, uBiasReg = 0, iBiasReg = 0;
+  int64_t cnt = 0;
+  for (int u = 0; u < nUsers && u < nrows; u++) {
+    if (invU[u]) continue;
+    for (int64_t ii = rowptr[u]; ii < rowptr[u + 1]; ii++) {
+      const int item = rowind[ii];
+      if (item >= nItems || invI[item]) continue;
+      double diff = rowval[ii] - (double)(uBias[u] + iBias[item]);
+      rmse += diff * diff;
+      cnt++;
+    }
+  }
+  for (int u = 0; u < nUsers; u++) if (!invU[u]) uBiasReg += uBias[u] * uBias[u];
+  for (int item = 0; item < nItems; item++) if (!invI[item]) iBiasReg += iBias[item] * iBias[item];
+  if (sse_out) *sse_out = rmse;
+  if (cnt_out) *cnt_out = cnt;
+  if (ub_out) *ub_out = uBiasReg;
+  if (ib_out) *ib_out = iBiasReg;
+  return rmse + uBiasReg * uReg + iBiasReg * iReg;
+}
+// model.cpp:2331-2362: the bias vectors are drawn from the SAME generator behind uFac and iFac
+void orc_init_bias(int seed, int nU, int nI, int K, float* uBias, float* iBias) {
+  std::default_random_engine generator(seed);
+  float lb = -0.01, ub = 0.01;
+  std::uniform_real_distribution<double> dist(lb, ub);
+  for (int64_t t = 0; t < (int64_t)nU * K + (int64_t)nI * K; t++) (void)dist(generator);
+  for (int u = 0; u < nU; u++) uBias[u] = dist(generator);
+  for (int i = 0; i < nI; i++) iBias[i] = dist(generator);
+}
+

@@ -215,6 +215,14 @@ int orc_train(const orc_train_cfg* cfg, float* U, float* V, float* Ubest, float*
               double* objTraj, double* valTraj, int32_t* bestIter, float* finalLearnRate,
               uint8_t* invU, uint8_t* invI);
 
+/* ---- ModelMFBias (modelMFBias.cpp:40-99, 163-197) ------------------------------ */
+void orc_init_bias(int seed, int nU, int nI, int K, float* uBias, float* iBias);   /* model.cpp:2331-2362 */
+void orc_bias_pass(float* uBias, float* iBias, const int32_t* u, const int32_t* i, const float* r, const uint64_t* order,
+                   int64_t n, float learnRate, float uReg, float iReg);
+double orc_bias_eval(const float* uBias, const float* iBias, int32_t nUsers, int32_t nItems, int32_t nrows, const int64_t* rowptr,
+                     const int32_t* rowind, const float* rowval, const uint8_t* invU, const uint8_t* invI, float uReg, float iReg,
+                     double* sse_out, int64_t* cnt_out, double* ub_out, double* ib_out);
+
 /* ---- data preparation in front of the path (io.cpp:410-459, 726-787) ---------- */
 void orc_split_colors(int64_t nnz, float testPc, float valPc, int seed, int32_t* color);
 int64_t orc_rand_pairs(int32_t nUsers, int32_t nItems, int seed, int32_t nnz, int32_t* pairs);
