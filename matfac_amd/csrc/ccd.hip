@@ -144,28 +144,14 @@ __global__ __launch_bounds__(1024) void ccd_pass_kernel(const int32_t* __restric
                                                        const int32_t* __restrict__ ind,
                                                        const float* __restrict__ otherg, int nother, float reg,
                                                        float* __restrict__ mine, double* __restrict__ part,
-                                                       const int64_t* __restrict__ ptr, float freq_thresh, int k) {
+                                                       const int64_t* __restrict__ ptr, float freq_thresh, int k, int64_t nmax) {
   if (LDSO) stage_vector(otherg, nother);
   const float* other = LDSO ? ccd_lds : otherg;
   const int lane = threadIdx.x & 63;
   const int j = lane & 15;
   const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
   const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
-  for (int64_t s = grp; s < nseg; s += ngrp) {
-    const int64_t b = seg_beg[s], e = seg_end[s];
-    double num = 0.0, den = 0.0;
-    // 4 independent 16-rating strides per trip, the trailing ones masked: the loads of one trip are all in flight
-    // together (a separate tail loop serialised up to three dependent loads per short row); a masked entry adds +0.0
-    for (int64_t t = b + j; t < e; t += 64) {
-      const bool v1 = t + 16 < e, v2 = t + 32 < e, v3 = t + 48 < e;
-      const int i0 = ind[t], i1 = v1 ? ind[t + 16] : 0, i2 = v2 ? ind[t + 32] : 0, i3 = v3 ? ind[t + 48] : 0;
-      const float r0 = res[t], r1 = v1 ? res[t + 16] : 0.0f, r2 = v2 ? res[t + 32] : 0.0f, r3 = v3 ? res[t + 48] : 0.0f;
-      const float o0 = other[i0], o1 = v1 ? other[i1] : 0.0f, o2 = v2 ? other[i2] : 0.0f, o3 = v3 ? other[i3] : 0.0f;
-      num += (double)(r0 * o0); den += (double)(o0 * o0);   // float products (modelMF.cpp:1069-1070)
-      num += (double)(r1 * o1); den += (double)(o1 * o1);
-      num += (double)(r2 * o2); den += (double)(o2 * o2);
-      num += (double)(r3 * o3); den += (double)(o3 * o3);
-    }
+  mfx_ccd_pass_loop(seg_beg, seg_end, grp, nseg, ngrp, res, ind, other, j, nmax, [&](int64_t s, double num, double den) {
     num = group16_sum(num);
     den = group16_sum(den);
     if (j == 0) {
@@ -183,7 +169,7 @@ __global__ __launch_bounds__(1024) void ccd_pass_kernel(const int32_t* __restric
         part[2 * (int64_t)slab + 1] = den;
       }
     }
-  }
+  });
 }
 
 // rows with several segments: partials summed by a 16-lane group, lane-strided in segment order then a fixed
@@ -276,12 +262,12 @@ static int run_pass(mfx_ctx* ctx, int side, float reg, float freq_thresh, int k)
       HIPCHK(set_lds(ctx, (const void*)ccd_pass_kernel<true>, lds));
       hipLaunchKernelGGL(ccd_pass_kernel<true>, dim3(blocks), dim3(1024), lds, ctx->stream, sg->seg_row, sg->seg_beg,
                          sg->seg_end, sg->seg_slab, sg->nseg, res, ind, other, nother, reg, mine, ctx->ccd_part, ptr,
-                         freq_thresh, k);
+                         freq_thresh, k, m.nnz);
     } else {
       const int blocks = (int)std::min<int64_t>((sg->nseg + 63) / 64, 256 * 2);
       hipLaunchKernelGGL(ccd_pass_kernel<false>, dim3(blocks), dim3(1024), 0, ctx->stream, sg->seg_row, sg->seg_beg,
                          sg->seg_end, sg->seg_slab, sg->nseg, res, ind, other, nother, reg, mine, ctx->ccd_part, ptr,
-                         freq_thresh, k);
+                         freq_thresh, k, m.nnz);
     }
     HIPCHK(hipGetLastError());
   }

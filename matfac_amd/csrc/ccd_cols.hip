@@ -9,7 +9,13 @@
 // colind/colval (gk_csr_CreateIndex order) cut into UB-user strips.  A workgroup stages u_k[b*UB ...] (32 KB)
 // in LDS and works on entries of that strip only.  Column sums are formed per (strip, column) segment of <= 1024
 // entries and finished per column in a fixed order (strip-major), so every sum has a fixed association.
+//
+// LIGHT columns (at most LIGHT entries in the whole column: at the Netflix shape two thirds of the items, 4 % of the
+// entries, and two thirds of the 1 M (strip, column) segments, each 1..16 entries long -- the pass spent its time on
+// per-segment latency, not on bytes) stay OUT of the strip scheme: their entries are kept contiguous behind the strips,
+// users ascending (the reference's CSC order), one segment per column, and u_k is gathered from L2 for them.
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "mfx_internal.h"
@@ -17,6 +23,7 @@
 namespace {
 constexpr int UB = 8192;          // users per strip: 32 KB of u_k (two vectors fit for the fused update)
 constexpr int CSEG = 1024;        // entries per segment
+constexpr int LIGHT = 1024;       // columns with at most this many entries are handled whole, outside the strips
 constexpr int SEGS_PER_WG = 256;  // segments a 1024-thread workgroup (64 groups) works through
 constexpr int64_t ENT_PER_WG = 128 * 1024;
 
@@ -38,6 +45,8 @@ struct ColState {
   // workgroup tables
   int32_t* pw_blk = nullptr; int32_t* pw_s0 = nullptr; int32_t* pw_s1 = nullptr; int npw = 0;       // pass
   int32_t* rw_blk = nullptr; int64_t* rw_e0 = nullptr; int64_t* rw_e1 = nullptr; int nrw = 0;       // residual
+  int64_t light0 = 0;               // blocked position where the light columns start (== nnz: none)
+  int32_t lseg0 = 0, nlseg = 0;     // their segments (one per column) in the segment tables
 };
 ColState* st(mfx_ctx* ctx) { return (ColState*)ctx->ccd_cols; }
 
@@ -84,8 +93,8 @@ __global__ __launch_bounds__(256) void strip_scatter_kernel(const int64_t* __res
                                                             const float* __restrict__ colval,
                                                             const int32_t* __restrict__ off,
                                                             const int64_t* __restrict__ dst, int32_t ncols, int nb,
-                                                            int32_t* __restrict__ buser, int32_t* __restrict__ bcol,
-                                                            float* __restrict__ res) {
+                                                            int64_t light0, int32_t* __restrict__ buser,
+                                                            int32_t* __restrict__ bcol, float* __restrict__ res) {
   const int j = threadIdx.x & 15;
   const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
   const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
@@ -94,8 +103,9 @@ __global__ __launch_bounds__(256) void strip_scatter_kernel(const int64_t* __res
     const int64_t src = colptr[i] + off[(int64_t)i * (nb + 1) + b];
     const int64_t n = off[(int64_t)i * (nb + 1) + b + 1] - off[(int64_t)i * (nb + 1) + b];
     const int64_t d = dst[(int64_t)b * ncols + i];
+    const int base = d >= light0 ? 0 : b * UB;      // light columns keep the absolute user id (u_k comes from L2)
     for (int64_t t = j; t < n; t += 16) {
-      buser[d + t] = colind[src + t] - b * UB;
+      buser[d + t] = colind[src + t] - base;
       bcol[d + t] = i;
       res[d + t] = colval[src + t];
     }
@@ -143,11 +153,16 @@ int mfx_ccd_cols_build(mfx_ctx* ctx) {
   std::vector<int64_t> dst((size_t)nb * nI), seg_beg, seg_end, rw_e0, rw_e1;
   std::vector<int32_t> seg_col, pw_blk, pw_s0, pw_s1, rw_blk;
   std::vector<int32_t> col_cnt((size_t)nI, 0);
+  std::vector<uint8_t> light((size_t)nI, 0);
+  const char* le = getenv("MFX_CCD_LIGHT");        // experiment / test knob: the threshold (0: every column goes through the strips)
+  const int light_max = le ? atoi(le) : LIGHT;
+  for (int32_t i = 0; i < nI; i++) light[(size_t)i] = off[(size_t)i * (nb + 1) + nb] <= light_max;
   int64_t pos = 0;
   for (int b = 0; b < nb; b++) {
     const int64_t ent0 = pos;
     const int32_t sg0 = (int32_t)seg_col.size();
     for (int32_t i = 0; i < nI; i++) {
+      if (light[(size_t)i]) continue;
       const int64_t n = off[(size_t)i * (nb + 1) + b + 1] - off[(size_t)i * (nb + 1) + b];
       dst[(size_t)b * nI + i] = pos;
       for (int64_t c = 0; c < n; c += CSEG) {
@@ -162,6 +177,22 @@ int mfx_ccd_cols_build(mfx_ctx* ctx) {
     for (int32_t a = sg0; a < sg1; a += SEGS_PER_WG) { pw_blk.push_back(b); pw_s0.push_back(a); pw_s1.push_back(std::min(sg1, a + SEGS_PER_WG)); }
     for (int64_t a = ent0; a < pos; a += ENT_PER_WG) { rw_blk.push_back(b); rw_e0.push_back(a); rw_e1.push_back(std::min(pos, a + ENT_PER_WG)); }
   }
+  // the light columns behind the strips: whole columns, one segment each; piece (b, i) sits at its CSC offset
+  s->light0 = pos;
+  s->lseg0 = (int32_t)seg_col.size();
+  for (int32_t i = 0; i < nI; i++) {
+    if (!light[(size_t)i]) continue;
+    const int64_t n = off[(size_t)i * (nb + 1) + nb];
+    for (int b = 0; b < nb; b++) dst[(size_t)b * nI + i] = pos + off[(size_t)i * (nb + 1) + b];
+    if (n > 0) {
+      seg_beg.push_back(pos);
+      seg_end.push_back(pos + n);
+      seg_col.push_back(i);
+      col_cnt[i]++;
+    }
+    pos += n;
+  }
+  s->nlseg = (int32_t)seg_col.size() - s->lseg0;
   std::vector<int32_t> col_ptr((size_t)nI + 1, 0), col_seg(seg_col.size());
   for (int32_t i = 0; i < nI; i++) col_ptr[i + 1] = col_ptr[i] + col_cnt[i];
   {
@@ -189,7 +220,7 @@ int mfx_ccd_cols_build(mfx_ctx* ctx) {
   if ((rc = dev_alloc(ctx, &s->res, (size_t)m.nnz))) return rc;
   if (m.nnz > 0) {
     hipLaunchKernelGGL(strip_scatter_kernel, dim3(2048), dim3(256), 0, ctx->stream, m.colptr, m.colind, m.colval,
-                       s->off, s->dst, nI, nb, s->buser, s->bcol, s->res);
+                       s->off, s->dst, nI, nb, s->light0, s->buser, s->bcol, s->res);
     HIPCHK(hipGetLastError());
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -219,30 +250,51 @@ __global__ __launch_bounds__(1024) void colpass_kernel(const int32_t* __restrict
                                                        const float* __restrict__ res,
                                                        const int32_t* __restrict__ buser,
                                                        const float* __restrict__ uk, int nU,
-                                                       double* __restrict__ part) {
+                                                       double* __restrict__ part, int64_t nmax) {
   __shared__ __attribute__((aligned(16))) float su[UB];
   const int b = pw_blk[blockIdx.x];
   stage_strip(su, uk, b * UB, min(UB, nU - b * UB));
   __syncthreads();
   const int j = threadIdx.x & 15, grp = threadIdx.x >> 4;
-  for (int s = pw_s0[blockIdx.x] + grp; s < pw_s1[blockIdx.x]; s += 64) {
-    const int64_t beg = seg_beg[s], end = seg_end[s];
-    double num = 0.0, den = 0.0;
-    // 4 strides of 16 entries per trip, the trailing ones masked: all loads of a trip are in flight together (a
-    // separate tail loop made a 95-entry segment wait for three dependent loads in a row); a masked entry adds +0.0
-    for (int64_t t = beg + j; t < end; t += 64) {
-      const bool v1 = t + 16 < end, v2 = t + 32 < end, v3 = t + 48 < end;
-      const int i0 = buser[t], i1 = v1 ? buser[t + 16] : 0, i2 = v2 ? buser[t + 32] : 0, i3 = v3 ? buser[t + 48] : 0;
-      const float r0 = res[t], r1 = v1 ? res[t + 16] : 0.0f, r2 = v2 ? res[t + 32] : 0.0f, r3 = v3 ? res[t + 48] : 0.0f;
-      const float o0 = su[i0], o1 = v1 ? su[i1] : 0.0f, o2 = v2 ? su[i2] : 0.0f, o3 = v3 ? su[i3] : 0.0f;
-      num += (double)(r0 * o0); den += (double)(o0 * o0);   // float products (modelMF.cpp:1085-1086)
-      num += (double)(r1 * o1); den += (double)(o1 * o1);
-      num += (double)(r2 * o2); den += (double)(o2 * o2);
-      num += (double)(r3 * o3); den += (double)(o3 * o3);
-    }
-    num = g16_sum(num);
-    den = g16_sum(den);
-    if (j == 0) { part[2 * (int64_t)s] = num; part[2 * (int64_t)s + 1] = den; }
+  mfx_ccd_pass_loop(seg_beg, seg_end, (int64_t)pw_s0[blockIdx.x] + grp, (int64_t)pw_s1[blockIdx.x], 64, res, buser, su, j, nmax,
+                    [&](int64_t s, double num, double den) {
+                      num = g16_sum(num);
+                      den = g16_sum(den);
+                      if (j == 0) { part[2 * s] = num; part[2 * s + 1] = den; }
+                    });
+}
+
+// light columns: one 16-lane group per column (one segment), u_k gathered from L2 by the absolute user id
+__global__ __launch_bounds__(256) void colpass_light_kernel(const int64_t* __restrict__ seg_beg, const int64_t* __restrict__ seg_end,
+                                                            int32_t lseg0, int32_t nlseg, const float* __restrict__ res,
+                                                            const int32_t* __restrict__ buser, const float* __restrict__ uk,
+                                                            double* __restrict__ part, int64_t nmax) {
+  const int j = threadIdx.x & 15;
+  const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  if (grp >= nlseg) return;
+  mfx_ccd_pass_loop(seg_beg, seg_end, (int64_t)lseg0 + grp, (int64_t)lseg0 + grp + 1, 1, res, buser, uk, j, nmax,
+                    [&](int64_t s, double num, double den) {
+                      num = g16_sum(num);
+                      den = g16_sum(den);
+                      if (j == 0) { part[2 * s] = num; part[2 * s + 1] = den; }
+                    });
+}
+
+// residual update of the light region (MODE as colresid_kernel): u_k from L2
+template <int MODE>
+__global__ __launch_bounds__(256) void colresid_light_kernel(int64_t e0, int64_t e1, float* __restrict__ res, const int32_t* __restrict__ buser,
+                                                             const int32_t* __restrict__ bcol, const float* __restrict__ uk0,
+                                                             const float* __restrict__ vk0, const float* __restrict__ uk1,
+                                                             const float* __restrict__ vk1) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = e0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < e1; t += stride) {
+    const int u = buser[t], c = bcol[t];
+    const float p0 = uk0[u] * vk0[c];
+    float r = res[t];
+    if (MODE == 1) r = r + p0;
+    else r = r - p0;
+    if (MODE == 2) r = r + uk1[u] * vk1[c];
+    res[t] = r;
   }
 }
 
@@ -306,24 +358,49 @@ __global__ __launch_bounds__(1024) void colresid_kernel(const int32_t* __restric
   stage_strip(su, uk0, b * UB, n);
   if (MODE == 2) stage_strip(su + UB, uk1, b * UB, n);
   __syncthreads();
-  for (int64_t t = rw_e0[blockIdx.x] + threadIdx.x; t < rw_e1[blockIdx.x]; t += blockDim.x) {
-    const int lu = buser[t], c = bcol[t];
-    const float p0 = su[lu] * vk0[c];   // u_k(u)*v_k(item): float product (modelMF.cpp:1053, :1114)
-    float r = res[t];
-    if (MODE == 1) r = r + p0;
-    else r = r - p0;
-    if (MODE == 2) r = r + su[UB + lu] * vk1[c];
-    res[t] = r;
+  // 16 aligned bytes per lane and array (4 entries); the entries of a neighbouring workgroup's range are left alone
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef int i4 __attribute__((ext_vector_type(4)));
+  const int64_t e0 = rw_e0[blockIdx.x], e1 = rw_e1[blockIdx.x];
+  for (int64_t t = (e0 & ~(int64_t)3) + 4 * (int64_t)threadIdx.x; t < e1; t += 4 * (int64_t)blockDim.x) {
+    if (t >= e0 && t + 4 <= e1) {
+      const i4 lu = *(const i4*)(buser + t), c = *(const i4*)(bcol + t);
+      f4 r = *(const f4*)(res + t);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const float p0 = su[lu[q]] * vk0[c[q]];   // u_k(u)*v_k(item): float product (modelMF.cpp:1053, :1114)
+        if (MODE == 1) r[q] = r[q] + p0;
+        else r[q] = r[q] - p0;
+        if (MODE == 2) r[q] = r[q] + su[UB + lu[q]] * vk1[c[q]];
+      }
+      *(f4*)(res + t) = r;
+    } else {
+      for (int q = 0; q < 4; q++) {
+        const int64_t tt = t + q;
+        if (tt < e0 || tt >= e1) continue;
+        const int lu = buser[tt], c = bcol[tt];
+        const float p0 = su[lu] * vk0[c];
+        float r = res[tt];
+        if (MODE == 1) r = r + p0;
+        else r = r - p0;
+        if (MODE == 2) r = r + su[UB + lu] * vk1[c];
+        res[tt] = r;
+      }
+    }
   }
 }
 
 int mfx_ccd_cols_pass(mfx_ctx* ctx, const float* uk, float* vk, float reg, float freq_thresh, int k) {
   ColState* s = st(ctx);
   const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
-  if (s->npw > 0) {
+  if (s->npw > 0 || s->nlseg > 0) {
     ProfScope ps(ctx, MFX_K_CCD_COL);
-    hipLaunchKernelGGL(colpass_kernel, dim3(s->npw), dim3(1024), 0, ctx->stream, s->pw_blk, s->pw_s0, s->pw_s1,
-                       s->seg_beg, s->seg_end, s->res, s->buser, uk, m.nrows, s->part);
+    if (s->npw > 0)
+      hipLaunchKernelGGL(colpass_kernel, dim3(s->npw), dim3(1024), 0, ctx->stream, s->pw_blk, s->pw_s0, s->pw_s1,
+                         s->seg_beg, s->seg_end, s->res, s->buser, uk, m.nrows, s->part, s->nnz);
+    if (s->nlseg > 0)
+      hipLaunchKernelGGL(colpass_light_kernel, dim3((unsigned)(((int64_t)s->nlseg * 16 + 255) / 256)), dim3(256), 0, ctx->stream, s->seg_beg,
+                         s->seg_end, s->lseg0, s->nlseg, s->res, s->buser, uk, s->part, s->nnz);
     const unsigned fb = (unsigned)(((int64_t)m.ncols * 16 + 255) / 256);
     if (!mfx_sharded(ctx)) {
       hipLaunchKernelGGL(colfinish_kernel<false>, dim3(fb), dim3(256), 0, ctx->stream, s->col_ptr, s->col_seg, s->part,
@@ -338,7 +415,7 @@ int mfx_ccd_cols_pass(mfx_ctx* ctx, const float* uk, float* vk, float reg, float
     if (!s->sums && (rc = dev_alloc(ctx, &s->sums, (size_t)m.ncols * 2))) return rc;
     const double* gcol;
     if ((rc = mfx_comm_global_col_counts(ctx, &gcol))) return rc;
-    if (s->npw > 0) {
+    if (s->npw > 0 || s->nlseg > 0) {
       hipLaunchKernelGGL(colfinish_kernel<true>, dim3((unsigned)(((int64_t)m.ncols * 16 + 255) / 256)), dim3(256), 0, ctx->stream,
                          s->col_ptr, s->col_seg, s->part, m.ncols, reg, vk, m.colptr, freq_thresh, k, s->sums);
       HIPCHK(hipGetLastError());
@@ -357,12 +434,20 @@ int mfx_ccd_cols_resid(mfx_ctx* ctx, int mode, const float* uk0, const float* vk
                        const float* vk1) {
   ColState* s = st(ctx);
   const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
-  if (s->nrw == 0) return MFX_OK;
+  if (s->nrw > 0) {
 #define MFX_CR(MD)                                                                                             \
   hipLaunchKernelGGL(colresid_kernel<MD>, dim3(s->nrw), dim3(1024), 0, ctx->stream, s->rw_blk, s->rw_e0, s->rw_e1, \
                      s->res, s->buser, s->bcol, uk0, vk0, uk1, vk1, m.nrows)
-  if (mode == 1) MFX_CR(1); else if (mode == 2) MFX_CR(2); else MFX_CR(-1);
+    if (mode == 1) MFX_CR(1); else if (mode == 2) MFX_CR(2); else MFX_CR(-1);
 #undef MFX_CR
+  }
+  if (s->light0 < s->nnz) {
+    const unsigned lb = (unsigned)std::min<int64_t>((s->nnz - s->light0 + 255) / 256, 4096);
+#define MFX_CL(MD) \
+  hipLaunchKernelGGL(colresid_light_kernel<MD>, dim3(lb), dim3(256), 0, ctx->stream, s->light0, s->nnz, s->res, s->buser, s->bcol, uk0, vk0, uk1, vk1)
+    if (mode == 1) MFX_CL(1); else if (mode == 2) MFX_CL(2); else MFX_CL(-1);
+#undef MFX_CL
+  }
   HIPCHK(hipGetLastError());
   return MFX_OK;
 }

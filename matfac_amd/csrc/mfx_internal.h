@@ -194,6 +194,77 @@ __host__ __device__ static inline int64_t mfx_perm_index(int64_t t, int64_t n, i
 }
 
 
+// The CCD++ pass loop of one 16-lane group (lane j): for the segments s = s_first, s_first + s_step, ... < s_last,
+// (num, den) = (sum res*o, sum o*o) over the entries [seg_beg[s], seg_end[s]), o = other[ind[t]] -- float products, double
+// accumulation (modelMF.cpp:1069-1070, 1085-1086) -- handed lane-wise to fin(s, num, den), which finishes with its
+// butterfly over the group: a fixed association.
+// Every lane loads 16 ALIGNED bytes of indices and of residuals per trip (64 entries per group per trip; entries in front of
+// the segment or behind it are masked to +0.0).  Segments are short (C4: 200 entries per row, 270 per (strip, column)
+// piece), so the loop is software-pipelined ACROSS segments: while segment s is summed, the first trip of the next one and
+// the bounds of the one after are already in flight -- a group never sits idle on a dependent bounds -> data round trip.
+struct MfxCcdTrip {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef int i4 __attribute__((ext_vector_type(4)));
+  i4 x;
+  f4 r;
+  __device__ __forceinline__ void load(const float* __restrict__ res, const int32_t* __restrict__ ind, int64_t t, int64_t e, int64_t nmax) {
+    x = i4{0, 0, 0, 0};
+    r = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (t >= e) return;
+    if (t + 4 <= nmax) {
+      x = *(const i4*)(ind + t);
+      r = *(const f4*)(res + t);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        if (t + q < nmax) { x[q] = ind[t + q]; r[q] = res[t + q]; }
+    }
+  }
+  __device__ __forceinline__ void consume(const float* other, int64_t t, int64_t b, int64_t e, double& num, double& den) const {
+    float o[4], rr[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const bool ok = t + q >= b && t + q < e;
+      o[q] = other[ok ? x[q] : 0];
+      o[q] = ok ? o[q] : 0.0f;
+      rr[q] = ok ? r[q] : 0.0f;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) { num += (double)(rr[q] * o[q]); den += (double)(o[q] * o[q]); }
+  }
+};
+template <class Fin>
+__device__ __forceinline__ void mfx_ccd_pass_loop(const int64_t* __restrict__ seg_beg, const int64_t* __restrict__ seg_end, int64_t s_first,
+                                                  int64_t s_last, int64_t s_step, const float* __restrict__ res,
+                                                  const int32_t* __restrict__ ind, const float* other, int j, int64_t nmax, Fin&& fin) {
+  int64_t s = s_first;
+  if (s >= s_last) return;
+  int64_t b = seg_beg[s], e = seg_end[s];
+  int64_t sn = s + s_step, bn = 0, en = 0;
+  if (sn < s_last) { bn = seg_beg[sn]; en = seg_end[sn]; }
+  MfxCcdTrip cur, nxt, more;
+  cur.load(res, ind, (b & ~(int64_t)3) + 4 * j, e, nmax);
+  for (;;) {
+    const int64_t snn = sn + s_step;
+    int64_t bnn = 0, enn = 0;
+    if (snn < s_last) { bnn = seg_beg[snn]; enn = seg_end[snn]; }                        // bounds two segments ahead
+    nxt.load(res, ind, (bn & ~(int64_t)3) + 4 * j, sn < s_last ? en : bn, nmax);      // first trip of the next segment
+    double num = 0.0, den = 0.0;
+    int64_t t = (b & ~(int64_t)3) + 4 * j;
+    cur.consume(other, t, b, e, num, den);
+    for (t += 64; t < e; t += 128) {          // long segments: two trips in flight
+      cur.load(res, ind, t, e, nmax);
+      more.load(res, ind, t + 64, e, nmax);
+      cur.consume(other, t, b, e, num, den);
+      more.consume(other, t + 64, b, e, num, den);
+    }
+    fin(s, num, den);
+    if (sn >= s_last) break;
+    s = sn; b = bn; e = en; cur = nxt;
+    sn = snn; bn = bnn; en = enn;
+  }
+}
+
 static inline void mfx_tree_shape(int K, int* L, int* C) {
   if (K <= 16) { *L = 4; *C = 1; }
   else if (K <= 32) { *L = 8; *C = 1; }

@@ -92,3 +92,36 @@ def test_ccdpp_outer_iterations_track_oracle_and_objective_decreases():
             objs.append(g_obj)
         ctx.ccdpp_end()
     assert all(b <= a * (1 + 1e-6) for a, b in zip(objs, objs[1:]))   # CCD++ never increases the objective
+
+
+@pytest.mark.parametrize("light", ["1024", "0", "1000000"])
+def test_column_view_strips_and_light_columns_agree(light, monkeypatch):
+    """The column view keeps columns of at most MFX_CCD_LIGHT (default 1024) entries whole behind the user strips and
+    cuts the others into 8192-user strips: 20 000 users = 3 strips, 300 items of which about half are light.  All three
+    layouts (mixed, strips only, whole columns only) give the oracle's columns within 2 ulp and bit-identical views."""
+    monkeypatch.setenv("MFX_CCD_LIGHT", light)
+    K = 8
+    d, tr, (cp, ci, cv), U0, V0 = _setup(20000, 300, 500000, K, seed=31)
+    nU, nI = d["nUsers"], d["nItems"]
+    deg = np.bincount(tr.rowind, minlength=tr.ncols)
+    assert (deg > 1024).sum() > 20 and ((deg > 0) & (deg <= 1024)).sum() > 20
+    uReg, iReg = 0.3, 0.2
+    Uo, Vo = U0.copy(), V0.copy()
+    Uo[:] = 0
+    rr, rc = tr.rowval.copy(), cv.copy()
+    with Ctx(0) as ctx:
+        invU, invI = load_ctx(ctx, d, K, U0, V0)
+        ctx.ccdpp_begin()
+        for it in range(2):
+            for k in range(3):
+                ctx.ccdpp_rank1(k, uReg, iReg, add_back=it > 0, inner=5)
+                orc.ccdpp_rank1(k, Uo, Vo, nU, nI, tr.ncols, tr.rowptr, tr.rowind, rr, cp, ci, rc, invU, invI, uReg, iReg, it > 0, 5,
+                                -1.0, nthreads=4)
+                U, V = ctx.get_factors()
+                assert ulp_diff(U[:, k], Uo[:, k]).max() <= 2 and ulp_diff(V[:, k], Vo[:, k]).max() <= 2, (it, k)
+        grr, grc = ctx.debug_residuals(tr.nnz)
+        ctx.ccdpp_end()
+    assert np.abs(grr - rr).max() < 1e-5 and np.abs(grc - rc).max() < 1e-5
+    order = np.argsort(tr.rowind, kind="stable")
+    assert np.array_equal(grr[order], grc)
+
