@@ -165,6 +165,9 @@ int mfx_debug_epoch_list(mfx_ctx* ctx, int32_t* u, int32_t* i, float* r, int64_t
  * {0 (levels), levels, levels run with the grid barrier, tail threshold}; prep_ms (may be NULL) = host time spent
  * building it                                                                                                  */
 int mfx_debug_levels_info(mfx_ctx* ctx, int64_t info[4], double* prep_ms);
+/* test hook: the queues of the last dataflow epoch: records = int32[4] per rating {other-side row, owned row, rating bits,
+ * expected version}, queue g = records [qoff[g], qoff[g+1]); records == NULL queries the two counts                     */
+int mfx_debug_flow_queues(mfx_ctx* ctx, int32_t* records, int64_t cap, int64_t* qoff, int64_t* n_records, int64_t* n_groups);
 /* test hook: digest of the slot lists the last MFX_SGD_TILED epoch ran on.  counts = {slots, ratings, row
  * references, rows per slot}; sums = FNV-1a of {rating records, slot_beg, slot_ibeg, slot rows, tile_slot} */
 int mfx_debug_slots_digest(mfx_ctx* ctx, int64_t counts[4], uint64_t sums[5]);

@@ -114,7 +114,9 @@ template <int POL>
 __device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned target) {
   // this wave's row stores are visible device-wide (POL 1: acknowledged write-through stores, only the wait is
   // needed; POL 0: L2 write-back) ...
-  if (POL == 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  // (POL 1: an explicit wait -- a workgroup-scope release fence emits no s_waitcnt for global stores, and the arrival below
+  // must not overtake them)
+  if (POL == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   __syncthreads();                                       // ... for every wave of the workgroup, before it arrives
   __shared__ int s_abort;

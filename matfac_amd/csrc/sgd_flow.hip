@@ -16,8 +16,11 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
+#include <cstring>
 #include <queue>
 #include <vector>
+
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include "mfx_internal.h"
 
@@ -41,6 +44,16 @@ struct FlowState {
   std::vector<int32_t> hu, hi, cnt, owner;
   std::vector<uint32_t> hpos, hver;
   std::vector<int64_t> hoff;
+  // device-side construction (build_flow_device): sort buffers, per-row tables
+  uint32_t *k0 = nullptr, *k1 = nullptr, *v0 = nullptr, *v1 = nullptr, *vert = nullptr;
+  char* sort_tmp = nullptr;
+  size_t sort_tmp_bytes = 0;
+  int64_t dcap = 0;
+  int32_t *degU = nullptr, *degI = nullptr, *downer = nullptr;
+  int64_t* dstart = nullptr;
+  int64_t rows_cap = 0;
+  std::vector<int32_t> hdeg;
+  std::vector<int64_t> hstart;
 };
 FlowState* fl(mfx_ctx* ctx) { return (FlowState*)ctx->flow; }
 
@@ -92,7 +105,9 @@ __global__ __launch_bounds__(FL_WG, FL_WG_PER_CU) void sgd_flow_kernel(const int
         Um.st(pe + c * 4 * L, p[c]);
         Vm.st(qe + c * 4 * L, qv[c]);
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // s_waitcnt: the write-through row stores are acknowledged ...
+      // the write-through row stores must be ACKNOWLEDGED before the version moves.  (A workgroup-scope release fence emits
+      // nothing here -- the version store overtook the row stores on another channel and a C2 epoch came out wrong.)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (j == 0) __hip_atomic_store(ver + rec.x, (unsigned)rec.w + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... then publish
       pos++;
     }
@@ -142,7 +157,7 @@ __global__ __launch_bounds__(FL_WG, FL_WG_PER_CU) void bias_flow_kernel(const in
       }
       __hip_atomic_store(ub + u, bu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(ib + it, bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the two stores are acknowledged, then the version moves
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the two stores are acknowledged, then the version moves
       __hip_atomic_store(ver + rec.x, (unsigned)rec.w + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       pos++;
     }
@@ -253,6 +268,172 @@ int build_flow(mfx_ctx* ctx, int64_t first, int64_t count, int64_t groups) {
   return MFX_OK;
 }
 
+// ---- the same construction on the device (default): the host keeps only the assignment of owned rows to queues -----
+__global__ void flow_degrees_kernel(const int32_t* __restrict__ eu, const int32_t* __restrict__ ei, int64_t n, int32_t* __restrict__ degU,
+                                    int32_t* __restrict__ degI) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
+    atomicAdd(degU + eu[t], 1);
+    atomicAdd(degI + ei[t], 1);
+  }
+}
+// key = row of `side` for every list position (or the queue of its owned row), value = the position
+__global__ void flow_keys_kernel(const int32_t* __restrict__ rows, const int32_t* __restrict__ owner, int64_t n, uint32_t* __restrict__ key,
+                                 uint32_t* __restrict__ val) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
+    key[t] = owner ? (uint32_t)owner[rows[t]] : (uint32_t)rows[t];
+    val[t] = (uint32_t)t;
+  }
+}
+// sorted by other-side row (stable: list order inside a row): rank of position v1[k] in its row's chain = k - start[row]
+__global__ void flow_rank_kernel(const uint32_t* __restrict__ k1, const uint32_t* __restrict__ v1, const int64_t* __restrict__ start, int64_t n,
+                                 uint32_t* __restrict__ vert) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) vert[v1[k]] = (uint32_t)(k - start[k1[k]]);
+}
+__global__ void flow_gather2_kernel(const uint32_t* __restrict__ lpos, const uint32_t* __restrict__ vert, int64_t n, const int32_t* __restrict__ eu,
+                                    const int32_t* __restrict__ ei, const float* __restrict__ er, int own_user, int4* __restrict__ q) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
+    const uint32_t s = lpos[t];
+    const int u = eu[s], i = ei[s];
+    q[t] = make_int4(own_user ? i : u, own_user ? u : i, __float_as_int(er[s]), (int)vert[s]);
+  }
+}
+// qoff[g] = number of sorted queue keys < g
+__global__ void flow_bounds_kernel(const uint32_t* __restrict__ keys, int64_t n, int64_t ng1, int64_t* __restrict__ qoff) {
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ng1; g += (int64_t)gridDim.x * blockDim.x) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if ((int64_t)keys[mid] < g) lo = mid + 1; else hi = mid;
+    }
+    qoff[g] = lo;
+  }
+}
+static int bits_for(uint64_t n) {
+  int b = 1;
+  while (b < 32 && ((uint64_t)1 << b) < n) b++;
+  return b;
+}
+
+int build_flow_device(mfx_ctx* ctx, int64_t first, int64_t count, int64_t groups) {
+  FlowState* S = fl(ctx);
+  const auto t0 = std::chrono::steady_clock::now();
+  int rc;
+  const int64_t nU = ctx->nU, nI = ctx->nI;
+  if (S->cap < count) {
+    dev_free(S->q); dev_free(S->lpos); dev_free(S->vexp);
+    S->cap = 0;
+    if ((rc = dev_alloc(ctx, &S->q, (size_t)count)) || (rc = dev_alloc(ctx, &S->lpos, (size_t)count)) ||
+        (rc = dev_alloc(ctx, &S->vexp, (size_t)count)))
+      return rc;
+    S->cap = count;
+  }
+  if (S->dcap < count) {
+    dev_free(S->k0); dev_free(S->k1); dev_free(S->v0); dev_free(S->v1); dev_free(S->vert); dev_free(S->sort_tmp);
+    S->dcap = 0;
+    if ((rc = dev_alloc(ctx, &S->k0, (size_t)count)) || (rc = dev_alloc(ctx, &S->k1, (size_t)count)) || (rc = dev_alloc(ctx, &S->v0, (size_t)count)) ||
+        (rc = dev_alloc(ctx, &S->v1, (size_t)count)) || (rc = dev_alloc(ctx, &S->vert, (size_t)count)))
+      return rc;
+    size_t bytes = 0;
+    HIPCHK(rocprim::radix_sort_pairs(nullptr, bytes, S->k0, S->k1, S->v0, S->v1, (size_t)count, 0, 32, ctx->stream));
+    if ((rc = dev_alloc(ctx, &S->sort_tmp, bytes))) return rc;
+    S->sort_tmp_bytes = bytes;
+    S->dcap = count;
+  }
+  if (S->rows_cap < nU + nI) {
+    dev_free(S->degU); dev_free(S->downer); dev_free(S->dstart);
+    S->rows_cap = 0;
+    if ((rc = dev_alloc(ctx, &S->degU, (size_t)(nU + nI))) || (rc = dev_alloc(ctx, &S->downer, (size_t)std::max(nU, nI))) ||
+        (rc = dev_alloc(ctx, &S->dstart, (size_t)std::max(nU, nI) + 1)))
+      return rc;
+    S->rows_cap = nU + nI;
+  }
+  S->degI = S->degU + nU;
+  if (S->goff_cap < groups + 1) {
+    dev_free(S->qoff);
+    S->goff_cap = 0;
+    if ((rc = dev_alloc(ctx, &S->qoff, (size_t)groups + 1))) return rc;
+    S->goff_cap = groups + 1;
+  }
+  if (!S->flag && (rc = dev_alloc(ctx, &S->flag, (size_t)1))) return rc;
+  const int32_t *eu = ctx->eu + first, *ei = ctx->ei + first;
+  const float* er = ctx->er + first;
+  const int grid = (int)std::min<int64_t>((count + 255) / 256, 8192);
+  // chain lengths of both sides; the side with the longest chain is owned
+  HIPCHK(hipMemsetAsync(S->degU, 0, sizeof(int32_t) * (size_t)(nU + nI), ctx->stream));
+  hipLaunchKernelGGL(flow_degrees_kernel, dim3(grid), dim3(256), 0, ctx->stream, eu, ei, count, S->degU, S->degI);
+  S->hdeg.resize((size_t)(nU + nI));
+  HIPCHK(hipMemcpyAsync(S->hdeg.data(), S->degU, sizeof(int32_t) * (size_t)(nU + nI), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const int32_t *hdU = S->hdeg.data(), *hdI = S->hdeg.data() + nU;
+  const int32_t maxU = *std::max_element(hdU, hdU + nU), maxI = *std::max_element(hdI, hdI + nI);
+  const int own_user = maxU > maxI ? 1 : 0;
+  const int32_t* degOwn = own_user ? hdU : hdI;
+  const int32_t* degOth = own_user ? hdI : hdU;
+  const int64_t nOwn = own_user ? nU : nI, nOth = own_user ? nI : nU;
+  // owned rows -> queues: longest chain first onto the least loaded queue (host: a few 10^4..10^6 rows)
+  S->owner.assign((size_t)nOwn, 0);
+  {
+    std::vector<int32_t> rows;
+    for (int64_t r = 0; r < nOwn; r++)
+      if (degOwn[r] > 0) rows.push_back((int32_t)r);
+    std::sort(rows.begin(), rows.end(), [&](int32_t a, int32_t b) { return degOwn[a] != degOwn[b] ? degOwn[a] > degOwn[b] : a < b; });
+    typedef std::pair<int64_t, int32_t> Load;
+    std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap;
+    for (int64_t gI = 0; gI < groups; gI++) heap.push(Load(0, (int32_t)gI));
+    for (int32_t r : rows) {
+      Load l = heap.top();
+      heap.pop();
+      S->owner[(size_t)r] = l.second;
+      l.first += degOwn[r];
+      heap.push(l);
+    }
+  }
+  S->hstart.resize((size_t)nOth + 1);
+  S->hstart[0] = 0;
+  for (int64_t r = 0; r < nOth; r++) S->hstart[(size_t)r + 1] = S->hstart[(size_t)r] + degOth[r];
+  HIPCHK(hipMemcpyAsync(S->downer, S->owner.data(), sizeof(int32_t) * (size_t)nOwn, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(S->dstart, S->hstart.data(), sizeof(int64_t) * ((size_t)nOth + 1), hipMemcpyHostToDevice, ctx->stream));
+  if (S->ver_cap < nOth) {
+    dev_free(S->ver);
+    S->ver_cap = 0;
+    if ((rc = dev_alloc(ctx, &S->ver, (size_t)nOth))) return rc;
+    S->ver_cap = nOth;
+  }
+  HIPCHK(hipMemsetAsync(S->ver, 0, sizeof(unsigned) * (size_t)nOth, ctx->stream));
+  HIPCHK(hipMemsetAsync(S->flag, 0, sizeof(unsigned), ctx->stream));
+  const int32_t* own_rows = own_user ? eu : ei;
+  const int32_t* oth_rows = own_user ? ei : eu;
+  // expected version of every list position: its rank in the other side's chain (stable sort by that row)
+  hipLaunchKernelGGL(flow_keys_kernel, dim3(grid), dim3(256), 0, ctx->stream, oth_rows, (const int32_t*)nullptr, count, S->k0, S->v0);
+  size_t bytes = S->sort_tmp_bytes;
+  HIPCHK(rocprim::radix_sort_pairs(S->sort_tmp, bytes, S->k0, S->k1, S->v0, S->v1, (size_t)count, 0, bits_for((uint64_t)nOth), ctx->stream));
+  hipLaunchKernelGGL(flow_rank_kernel, dim3(grid), dim3(256), 0, ctx->stream, S->k1, S->v1, S->dstart, count, S->vert);
+  // queue order: stable sort of the list positions by the queue of their owned row
+  hipLaunchKernelGGL(flow_keys_kernel, dim3(grid), dim3(256), 0, ctx->stream, own_rows, (const int32_t*)S->downer, count, S->k0, S->v0);
+  bytes = S->sort_tmp_bytes;
+  HIPCHK(rocprim::radix_sort_pairs(S->sort_tmp, bytes, S->k0, S->k1, S->v0, S->lpos, (size_t)count, 0, bits_for((uint64_t)groups), ctx->stream));
+  hipLaunchKernelGGL(flow_bounds_kernel, dim3((unsigned)std::min<int64_t>((groups + 256) / 256, 4096)), dim3(256), 0, ctx->stream, S->k1, count,
+                     groups + 1, S->qoff);
+  hipLaunchKernelGGL(flow_gather2_kernel, dim3(grid), dim3(256), 0, ctx->stream, S->lpos, S->vert, count, eu, ei, er, own_user, S->q);
+  HIPCHK(hipGetLastError());
+  S->hoff.resize((size_t)groups + 1);
+  HIPCHK(hipMemcpyAsync(S->hoff.data(), S->qoff, sizeof(int64_t) * ((size_t)groups + 1), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  int64_t longest = 0;
+  for (int64_t gI = 0; gI < groups; gI++) longest = std::max(longest, S->hoff[(size_t)gI + 1] - S->hoff[(size_t)gI]);
+  S->groups = groups; S->longest = longest; S->own_user = own_user;
+  S->prep_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (getenv("MFX_DEBUG"))
+    fprintf(stderr, "[mfx] dataflow replay (device construction): %lld ratings on %lld queues (%s rows owned), longest queue %lld, longest chains "
+            "%d users / %d items, preparation %.1f ms\n", (long long)count, (long long)groups, own_user ? "user" : "item", (long long)longest, maxU,
+            maxI, S->prep_ms);
+  return MFX_OK;
+}
+
 template <int L, int C>
 int launch_flow_lc(mfx_ctx* ctx, const mfx_sgd_opts* o, int blocks) {
   FlowState* S = fl(ctx);
@@ -277,6 +458,8 @@ void mfx_flow_free_internal(mfx_ctx* ctx) {
   FlowState* S = fl(ctx);
   if (!S) return;
   dev_free(S->q); dev_free(S->qoff); dev_free(S->lpos); dev_free(S->vexp); dev_free(S->ver); dev_free(S->flag);
+  dev_free(S->k0); dev_free(S->k1); dev_free(S->v0); dev_free(S->v1); dev_free(S->vert); dev_free(S->sort_tmp);
+  dev_free(S->degU); dev_free(S->downer); dev_free(S->dstart);
   delete S;
   ctx->flow = nullptr;
 }
@@ -291,10 +474,13 @@ int mfx_launch_sgd_flow(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int6
   int dev = 0, cus = 0;
   HIPCHK(hipGetDevice(&dev));
   HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  const int blocks = std::max(1, cus) * FL_WG_PER_CU;          // every workgroup resident: the queues cannot starve each other
   const int L = ctx->L, C = ctx->C;
-  const int64_t groups = (int64_t)blocks * (FL_WG / 64) * (64 / L);
-  int rc = build_flow(ctx, first, count, groups);
+  // every workgroup resident: the queues cannot starve each other; no more queues than there are rows to own
+  const int64_t per_block = (int64_t)(FL_WG / 64) * (64 / L);
+  const int blocks = (int)std::min<int64_t>((int64_t)std::max(1, cus) * FL_WG_PER_CU, (std::max(ctx->nU, ctx->nI) + per_block - 1) / per_block);
+  const int64_t groups = (int64_t)blocks * per_block;
+  // queues and versions are built on the device; MFX_FLOW_HOST=1 keeps the host statement of the same lists (the cross-check)
+  int rc = getenv("MFX_FLOW_HOST") ? build_flow(ctx, first, count, groups) : build_flow_device(ctx, first, count, groups);
   if (rc) return rc;
   if (L == 4) rc = launch_flow_lc<4, 1>(ctx, o, blocks);
   else if (L == 8) rc = launch_flow_lc<8, 1>(ctx, o, blocks);
@@ -322,8 +508,9 @@ int mfx_launch_bias_flow(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int
   int dev = 0, cus = 0;
   HIPCHK(hipGetDevice(&dev));
   HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  const int blocks = std::max(1, cus) * FL_WG_PER_CU;
-  int rc = build_flow(ctx, first, count, (int64_t)blocks * FL_WG);     // one lane = one queue
+  const int blocks = (int)std::min<int64_t>((int64_t)std::max(1, cus) * FL_WG_PER_CU, (std::max(ctx->nU, ctx->nI) + FL_WG - 1) / FL_WG);
+  int rc = getenv("MFX_FLOW_HOST") ? build_flow(ctx, first, count, (int64_t)blocks * FL_WG)     // one lane = one queue
+                                   : build_flow_device(ctx, first, count, (int64_t)blocks * FL_WG);
   if (rc) return rc;
   FlowState* S = fl(ctx);
   {
@@ -348,3 +535,22 @@ bool mfx_flow_info(mfx_ctx* ctx, int64_t info[4], double* prep_ms) {
   if (prep_ms) *prep_ms = S->prep_ms;
   return true;
 }
+
+// test hook: the queues of the last dataflow epoch (records {other-side row, owned row, rating bits, expected version})
+extern "C" int mfx_debug_flow_queues(mfx_ctx* ctx, int32_t* records, int64_t cap, int64_t* qoff, int64_t* n_records, int64_t* n_groups) {
+  if (!ctx) return MFX_E_ARG;
+  FlowState* S = fl(ctx);
+  NEED(S && S->q && n_records && n_groups, MFX_E_STATE, "mfx_debug_flow_queues: no dataflow epoch has run");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  std::vector<int64_t> off((size_t)S->groups + 1);
+  HIPCHK(hipMemcpy(off.data(), S->qoff, sizeof(int64_t) * off.size(), hipMemcpyDeviceToHost));
+  *n_records = off.back();
+  *n_groups = S->groups;
+  if (!records) return MFX_OK;
+  NEED(cap >= off.back(), MFX_E_ARG, "mfx_debug_flow_queues: cap too small");
+  HIPCHK(hipMemcpy(records, S->q, sizeof(int4) * (size_t)off.back(), hipMemcpyDeviceToHost));
+  if (qoff) memcpy(qoff, off.data(), sizeof(int64_t) * off.size());
+  return MFX_OK;
+}
+

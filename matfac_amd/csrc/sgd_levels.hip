@@ -104,9 +104,8 @@ __global__ __launch_bounds__(LV_WG) void sgd_levels_tail_kernel(const int32_t* _
     for (int64_t x = b + grp; x < e; x += ngrp) level_visit<L, C, ARITH, 0>(Um, Vm, lu[x], li[x], lr_[x], j, lr, uReg, iReg);
     b = e;
     // one CU, one L1, one L2: workgroup scope is enough between the levels of the tail
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's row stores have landed before anybody moves on
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   }
 }
 

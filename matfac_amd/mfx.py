@@ -159,6 +159,15 @@ class Ctx:
         self._chk(self.lib.mfx_debug_levels_info(self.h, info, C.byref(ms)))
         return list(info), ms.value
 
+    def debug_flow_queues(self):
+        n, g = C.c_int64(), C.c_int64()
+        self._chk(self.lib.mfx_debug_flow_queues(self.h, None, C.c_int64(0), None, C.byref(n), C.byref(g)))
+        rec = np.empty((n.value, 4), np.int32)
+        off = np.empty(g.value + 1, np.int64)
+        self._chk(self.lib.mfx_debug_flow_queues(self.h, rec.ctypes.data_as(C.c_void_p), C.c_int64(n.value), off.ctypes.data_as(C.c_void_p),
+                                                 C.byref(n), C.byref(g)))
+        return rec, off
+
     def debug_visit_counts(self):
         n = C.c_int64()
         self._chk(self.lib.mfx_debug_visit_counts(self.h, None, C.c_int64(0), C.byref(n)))

@@ -226,11 +226,14 @@ def test_tiled_epoch_list_is_tile_grouped_permutation():
     assert np.all(np.diff(tile) >= 0)
 
 
-@pytest.fixture(params=["flow", "levels"])
+@pytest.fixture(params=["flow", "flow-host", "levels"])
 def exact_sched(request, monkeypatch):
-    """the two schedules behind MFX_SGD_LEVELS: dataflow (default) and dependency levels with a grid barrier"""
-    monkeypatch.setenv("MFX_EXACT_SCHED", request.param)
-    return request.param
+    """the schedules behind MFX_SGD_LEVELS: dataflow (default; queues and versions built on the device, or by the host
+    statement of the same lists) and dependency levels with a grid barrier"""
+    monkeypatch.setenv("MFX_EXACT_SCHED", "levels" if request.param == "levels" else "flow")
+    if request.param == "flow-host":
+        monkeypatch.setenv("MFX_FLOW_HOST", "1")
+    return "levels" if request.param == "levels" else "flow"
 
 
 @pytest.mark.parametrize("K", [5, 10, 32, 64, 128, 256, 320])
