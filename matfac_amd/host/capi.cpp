@@ -1,5 +1,6 @@
 // capi.cpp -- C entry point that drives the host classes on in-memory matrices, so that the
 // parity tests (Python) can run ModelMF::train* exactly as main() would, without text files.
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -12,7 +13,7 @@
 #include "dataprep.h"
 #include "model_bias.h"
 
-extern "C" int mfh_train(const char* method, int32_t nrows, const int64_t* tr_ptr, const int32_t* tr_ind,
+static int mfh_train_impl(const char* method, int32_t nrows, const int64_t* tr_ptr, const int32_t* tr_ind,
                          const float* tr_val, int32_t tr_ncols, const int64_t* va_ptr, const int32_t* va_ind,
                          const float* va_val, int32_t va_ncols, const int64_t* te_ptr, const int32_t* te_ind,
                          const float* te_val, int32_t te_ncols, int32_t K, int32_t maxIter, int32_t seed,
@@ -89,6 +90,22 @@ extern "C" int mfh_train(const char* method, int32_t nrows, const int64_t* tr_pt
   if (invI) for (int i = 0; i < data.nItems; i++) invI[i] = ii.count(i) ? 1 : 0;
   if (!prefix) unsetenv("MFX_NO_SAVE");
   return 0;
+}
+
+// no exception leaves the C entry points: an MfxError becomes its (negative) code with the message on stderr
+extern "C" int mfh_train(const char* method, int32_t nrows, const int64_t* tr_ptr, const int32_t* tr_ind,
+                         const float* tr_val, int32_t tr_ncols, const int64_t* va_ptr, const int32_t* va_ind,
+                         const float* va_val, int32_t va_ncols, const int64_t* te_ptr, const int32_t* te_ind,
+                         const float* te_val, int32_t te_ncols, int32_t K, int32_t maxIter, int32_t seed,
+                         float learnRate, float uReg, float iReg, const char* prefix, float* Ulast, float* Vlast,
+                         float* Ubest, float* Vbest, double* stats, uint8_t* invU, uint8_t* invI) {
+  try {
+    return mfh_train_impl(method, nrows, tr_ptr, tr_ind, tr_val, tr_ncols, va_ptr, va_ind, va_val, va_ncols, te_ptr, te_ind, te_val,
+                          te_ncols, K, maxIter, seed, learnRate, uReg, iReg, prefix, Ulast, Vlast, Ubest, Vbest, stats, invU, invI);
+  } catch (const MfxError& e) {
+    fprintf(stderr, "\n%s\n", e.what());
+    return e.code < 0 ? e.code : -2;
+  }
 }
 
 // Text-CSR loader / writer of the host library (csr.cpp) for the CPU-side tests: two-call protocol like
@@ -175,7 +192,12 @@ extern "C" int mfh_train_bias(int32_t nrows, const int64_t* tr_ptr, const int32_
   params.nItems = data.nItems;
   ModelMFBias model(params, params.seed), best(params, params.seed);
   std::unordered_set<int> iu, ii;
-  model.train(data, best, iu, ii);
+  try {
+    model.train(data, best, iu, ii);
+  } catch (const MfxError& e) {
+    fprintf(stderr, "\n%s\n", e.what());
+    return e.code < 0 ? e.code : -2;
+  }
   if (ubLast) memcpy(ubLast, model.uBias.data(), sizeof(float) * (size_t)data.nUsers);
   if (ibLast) memcpy(ibLast, model.iBias.data(), sizeof(float) * (size_t)data.nItems);
   if (ubBest) memcpy(ubBest, best.uBias.data(), sizeof(float) * (size_t)data.nUsers);

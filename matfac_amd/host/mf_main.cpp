@@ -130,7 +130,16 @@ static void parse(int argc, char** argv) {
   }
 }
 
+static int run_main(int argc, char** argv);
 int main(int argc, char** argv) {
+  try {
+    return run_main(argc, argv);
+  } catch (const MfxError& e) {          // the library classes throw; the driver ends like the reference's does
+    std::cerr << "\n" << e.what() << std::endl;
+    return 254;                          // exit(-2)
+  }
+}
+static int run_main(int argc, char** argv) {
   parse(argc, argv);
   bool isexit = false;
   if (flags["trainmat"].empty() || flags["testmat"].empty() || flags["valmat"].empty()) {

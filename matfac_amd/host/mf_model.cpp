@@ -26,8 +26,7 @@ MfxSession::~MfxSession() {
 
 void MfxSession::check(int rc, const char* what) const {
   if (rc == MFX_OK) return;
-  std::cerr << "\nmfx error " << rc << " in " << what << ": " << mfx_last_error(ctx) << std::endl;
-  exit(-2);
+  throw MfxError(rc, std::string("mfx error ") + std::to_string(rc) + " in " + what + ": " + mfx_last_error(ctx));
 }
 
 static void upload(MfxSession& s, int which, const csr_t* m, int nItems) {
@@ -45,10 +44,7 @@ std::shared_ptr<MfxSession> MfxSession::open(const Data& data, int nUsers, int n
   auto s = std::make_shared<MfxSession>();
   const char* dv = getenv("MFX_DEVICE");
   int rc = mfx_create(dv ? atoi(dv) : 0, &s->ctx);
-  if (rc != MFX_OK) {
-    std::cerr << "\nmfx_create failed (" << rc << "): " << mfx_last_error(nullptr) << std::endl;
-    exit(-2);
-  }
+  if (rc != MFX_OK) throw MfxError(rc, std::string("mfx_create failed (") + std::to_string(rc) + "): " + mfx_last_error(nullptr));
   s->nUsers = nUsers; s->nItems = nItems; s->K = K;
   upload(*s, MFX_MAT_TRAIN, data.trainMat, nItems);
   upload(*s, MFX_MAT_VAL, data.valMat, nItems);
@@ -307,8 +303,7 @@ void Model::deviceInvalid(const Data& data, IntSet& invalidUsers, IntSet& invali
 void Model::evalDevice(const csr_t* mat, int withNorms, mfx_eval_out* out) {
   const int w = dev ? dev->which(mat) : -1;
   if (w < 0) {
-    std::cerr << "\nModel: matrix is not part of the device session" << std::endl;
-    exit(-2);
+    throw MfxError(-100, "Model: matrix is not part of the device session");
   }
   dev->check(mfx_eval(dev->ctx, w, devSnap, withNorms, out), "mfx_eval");
 }
@@ -319,8 +314,7 @@ double Model::RMSE(csr_t* mat, IntSet& invalidUsers, IntSet& invalidItems) {
   (void)invalidUsers; (void)invalidItems;
   if (!mat) return NAN;
   if (!dev || dev->which(mat) < 0) {
-    std::cerr << "\nModel::RMSE: no device session for this matrix (call a trainer first)" << std::endl;
-    exit(-2);
+    throw MfxError(-100, "Model::RMSE: no device session for this matrix (call a trainer first)");
   }
   mfx_eval_out o;
   evalDevice(mat, 0, &o);
@@ -330,8 +324,7 @@ double Model::RMSE(csr_t* mat, IntSet& invalidUsers, IntSet& invalidItems) {
 // model.cpp:348-394 / :446-486: RMSE over the ratings of the given items / users only; (count, rmse)
 static std::pair<int, double> filteredRMSE(Model& md, csr_t* mat, const Model::IntSet* users, const Model::IntSet* items) {
   if (!mat || !md.dev || md.dev->which(mat) < 0) {
-    std::cerr << "\nModel::RMSE(filtered): no device session for this matrix (call a trainer first)" << std::endl;
-    exit(-2);
+    throw MfxError(-100, "Model::RMSE(filtered): no device session for this matrix (call a trainer first)");
   }
   std::vector<uint8_t> ku, ki;
   if (users) { ku.assign((size_t)md.nUsers, 0); for (int u : *users) if (u >= 0 && u < md.nUsers) ku[u] = 1; }
@@ -390,8 +383,7 @@ double Model::objectiveSing(const Data& data, IntSet& invalidUsers, IntSet& inva
   (void)invalidUsers; (void)invalidItems;
   const int w = dev ? dev->which(data.trainMat) : -1;
   if (w < 0 || (int)singularVals.size() != facDim) {
-    std::cerr << "\nModel::objectiveSing: needs a device session and facDim singular values" << std::endl;
-    exit(-2);
+    throw MfxError(-100, "Model::objectiveSing: needs a device session and facDim singular values");
   }
   mfx_eval_out o;
   dev->check(mfx_eval_weighted(dev->ctx, w, devSnap, singularVals.data(), &o), "mfx_eval_weighted");

@@ -5,6 +5,7 @@
 #define MFHOST_MF_MODEL_H_
 #include <cmath>
 #include <memory>
+#include <stdexcept>
 #include <string>
 #include <unordered_set>
 #include <vector>
@@ -38,6 +39,15 @@ struct DenseF32 {
   }
 };
 
+// What the library classes throw instead of calling exit(): a failed device call (code = mfx_status, what() = the text of
+// mfx_last_error) or a misuse of the class surface (code -100).  The `mf` driver catches it, prints it and exits like the
+// reference does; a program that embeds libmfhost.so decides for itself.
+class MfxError : public std::runtime_error {
+ public:
+  int code;
+  MfxError(int c, const std::string& msg) : std::runtime_error(msg), code(c) {}
+};
+
 // One mfx_ctx with the three rating matrices of a Data uploaded.  Shared by a trainer's
 // model (snapshot CURRENT) and its bestModel (snapshot BEST).
 class MfxSession {
@@ -48,7 +58,7 @@ class MfxSession {
   ~MfxSession();
   static std::shared_ptr<MfxSession> open(const Data& data, int nUsers, int nItems, int K);
   int which(const csr_t* m) const;
-  void check(int rc, const char* what) const;   // prints mfx_last_error and exits on failure
+  void check(int rc, const char* what) const;   // throws MfxError(rc, what + mfx_last_error) on failure
 };
 
 class Model {

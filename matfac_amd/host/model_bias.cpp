@@ -37,8 +37,7 @@ void ModelMFBias::evalDevice(const csr_t* mat, int withNorms, mfx_eval_out* out)
   (void)withNorms;
   const int w = dev ? dev->which(mat) : -1;
   if (w < 0) {
-    std::cerr << "\nModelMFBias: matrix is not part of the device session" << std::endl;
-    exit(-2);
+    throw MfxError(-100, "ModelMFBias: matrix is not part of the device session");
   }
   dev->check(mfx_bias_eval(dev->ctx, w, devSnap, out), "mfx_bias_eval");
 }

@@ -18,8 +18,7 @@ void ModelInvPopMF::beforeLoop(Kind kind, const Data& data, IntSet& invalidUsers
     if (invalidItems.count(item) == 0) trainItems.push_back(item);
   nTrainItems = (int)trainItems.size();
   if ((int)userFreq.size() < trainMat->nrows || (int)itemFreq.size() < trainMat->ncols) {
-    std::cerr << "\nModelInvPopMF: userFreq/itemFreq do not cover the train matrix" << std::endl;
-    exit(-2);
+    throw MfxError(-100, "ModelInvPopMF: userFreq/itemFreq do not cover the train matrix");
   }
   double sumPopScore = 0;
   for (auto& u : trainUsers) {

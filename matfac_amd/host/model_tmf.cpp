@@ -40,8 +40,7 @@ void ModelDropoutSigmoid::train(const Data& data, Model& bestModel, IntSet& inva
 void ModelDropoutSigmoid::beforeLoop(Kind kind, const Data& data, IntSet&, IntSet&) {
   if (kind != K_TMF) return;
   if ((int)userFreq.size() < data.trainMat->nrows || (int)itemFreq.size() < data.trainMat->ncols) {
-    std::cerr << "\nModelDropoutSigmoid: userFreq/itemFreq do not cover the train matrix" << std::endl;
-    exit(-2);
+    throw MfxError(-100, "ModelDropoutSigmoid: userFreq/itemFreq do not cover the train matrix");
   }
   std::vector<float> uf((size_t)nUsers, 0.0f), itf((size_t)nItems, 0.0f);
   std::vector<int32_t> ru((size_t)nUsers, 1), ri((size_t)nItems, 1);
@@ -105,8 +104,7 @@ void ModelPoissonDropout::train(const Data& data, Model& bestModel, IntSet& inva
 void ModelPoissonDropout::beforeLoop(Kind kind, const Data& data, IntSet&, IntSet&) {
   if (kind != K_TMFD) return;
   if ((int)userFreq.size() < data.trainMat->nrows || (int)itemFreq.size() < data.trainMat->ncols) {
-    std::cerr << "\nModelPoissonDropout: userFreq/itemFreq do not cover the train matrix" << std::endl;
-    exit(-2);
+    throw MfxError(-100, "ModelPoissonDropout: userFreq/itemFreq do not cover the train matrix");
   }
   std::vector<float> uf((size_t)nUsers, 0.0f), itf((size_t)nItems, 0.0f);
   std::vector<int32_t> lu((size_t)nUsers, 1), li((size_t)nItems, 1), eu((size_t)nUsers, 1), ei((size_t)nItems, 1);

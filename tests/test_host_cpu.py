@@ -216,3 +216,21 @@ def test_rand_mat_csr_writer(tmp_path):
     exact = np.einsum("ij,ij->i", U[pairs[:, 0]], V[pairs[:, 1]])
     assert np.allclose(rv, exact, rtol=2e-5, atol=1e-6)            # 6 significant digits in the file
 
+
+def test_host_classes_report_a_missing_device_instead_of_exiting():
+    """The library classes throw MfxError (caught at the C entry points) where round 1 called exit(-2): without a GPU
+    ModelMF::train must come back with MFX_E_NODEVICE and leave the embedding process alive."""
+    from tests.conftest import has_gpu
+    if has_gpu():
+        pytest.skip("a GPU is present")
+    d = synth.make(dict(nU=40, nI=30, nnz=400, K=0), seed=1)
+    tr, va, te = d["train"], d["val"], d["test"]
+    lib = synth._host()
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    K = 4
+    bufs = [np.zeros((d["nUsers"], K), np.float32), np.zeros((d["nItems"], K), np.float32)]
+    rc = lib.mfh_train(b"sgd", C.c_int32(tr.nrows), P(tr.rowptr), P(tr.rowind), P(tr.rowval), C.c_int32(tr.ncols), P(va.rowptr), P(va.rowind),
+                       P(va.rowval), C.c_int32(va.ncols), P(te.rowptr), P(te.rowind), P(te.rowval), C.c_int32(te.ncols), C.c_int32(K), C.c_int32(2),
+                       C.c_int32(1), C.c_float(0.01), C.c_float(0.01), C.c_float(0.01), None, P(bufs[0]), P(bufs[1]), None, None, None, None, None)
+    assert rc == -6                      # MFX_E_NODEVICE
+
