@@ -30,6 +30,7 @@ struct SlotList {
   uint64_t attr_gen = 0;           // ctx->var_gen it was computed for
   int64_t nslots = 0, nnz = 0;
   int rows = 0;                    // owned rows per slot the lists were built for
+  int active_waves = WG / 64;      // waves of a workgroup that work on a slot (fewer when a tile has few lock-free rows)
   bool built = false;
 };
 // side 0: item rows owned (slots item-major), side 1: user rows owned (slots user-major)

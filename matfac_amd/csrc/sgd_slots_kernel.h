@@ -261,7 +261,7 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
                                                            int round, float* Oth, float* Own, uint32_t obytes,
                                                            float lr, float uReg, float iReg, uint32_t k0,
                                                            uint32_t k1, const int32_t* __restrict__ attr,
-                                                           unsigned* __restrict__ visit, int tile_only, int one) {
+                                                           unsigned* __restrict__ visit, int tile_only, int one, int aw) {
   constexpr int G = 64 / L;
   constexpr int LD = 4 * L * C;
   constexpr int LD4 = LD / 4;
@@ -335,8 +335,9 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
       __syncthreads();
       const uint32_t ks0 = k0 + (uint32_t)slot * 0x632be5abU, ks1 = k1 ^ mfx_mix32((uint32_t)slot + 77U);
       // one group (test hook): wave 0 alone, L ratings per chunk, rating cb+s in entry s*G (group 0's entry of step s)
-      const int64_t cb0 = onegrp ? (wave == 0 ? 0 : R) : (int64_t)wave * 64;
-      const int64_t cstep = onegrp ? L : (WG / 64) * 64;
+      // aw = waves of the workgroup that take part (16 unless the tile has few lock-free rows: mfx_launch_sgd_tiled)
+      const int64_t cb0 = onegrp ? (wave == 0 ? 0 : R) : (wave < aw ? (int64_t)wave * 64 : R);
+      const int64_t cstep = onegrp ? L : (int64_t)aw * 64;
       for (int64_t cb = cb0; cb < R; cb += cstep) {
         const int64_t t = onegrp ? cb + lane / G : cb + lane;
         const bool ok = onegrp ? (lane % G == 0 && t < R) : t < R;
@@ -428,7 +429,7 @@ static int launch_slots(mfx_ctx* ctx, SlotList* S, const mfx_sgd_opts* o, int bl
     for (int tile = 0; tile < NTILE; tile++)
       hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, true, OWN_U, VAR>), dim3(1), dim3(WG), 0, ctx->stream,
                          (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->tile_slot, S->ctr, 0,
-                         oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1, at, visit, tile, 1);
+                         oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1, at, visit, tile, 1, 1);
     HIPCHK(hipGetLastError());
     return MFX_OK;
   }
@@ -436,14 +437,14 @@ static int launch_slots(mfx_ctx* ctx, SlotList* S, const mfx_sgd_opts* o, int bl
     ProfScope ps(ctx, MFX_K_SGD);
     hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, false, OWN_U, VAR>), dim3(blocks), dim3(WG), 0, ctx->stream,
                        (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->tile_slot, S->ctr, round,
-                       oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1, at, visit, -1, 0);
+                       oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1, at, visit, -1, 0, S->active_waves);
   }
   {
     // the drain: one launch; the same diagonals keyed on the workgroup index (an item row keeps a single owner)
     ProfScope ps(ctx, MFX_K_SGD_SWEEP);
     hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, true, OWN_U, VAR>), dim3(DRAIN_WGS), dim3(WG), 0, ctx->stream,
                        (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->tile_slot, S->ctr, 0,
-                       oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1, at, visit, -1, 0);
+                       oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1, at, visit, -1, 0, S->active_waves);
   }
   HIPCHK(hipGetLastError());
   // a drain whose barrier gave up (2 s without progress: the device is shared with another resident kernel) leaves its
