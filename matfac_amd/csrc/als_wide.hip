@@ -19,6 +19,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2s __attribute__((ext_vector_type(2)));
+typedef float f32x4w __attribute__((ext_vector_type(4)));
 
 namespace {
 constexpr int BLK = 64 * 64;
@@ -32,6 +33,8 @@ struct WideState {
   WideSide side[2];
   float* slabs = nullptr;
   size_t slab_floats = 0;
+  float* bws = nullptr;          // blocked solver: per-wave workspace
+  size_t bws_floats = 0;
 };
 WideState* wst(mfx_ctx* ctx) { return (WideState*)ctx->als_wide; }
 }  // namespace
@@ -41,6 +44,7 @@ void mfx_als_wide_free_internal(mfx_ctx* ctx) {
   if (!s) return;
   for (WideSide& w : s->side) { dev_free(w.wrow); dev_free(w.wfirst); dev_free(w.wn); }
   dev_free(s->slabs);
+  dev_free(s->bws);
   delete s;
   ctx->als_wide = nullptr;
 }
@@ -353,6 +357,253 @@ __global__ __launch_bounds__(P * P) void alsw_solve_kernel(const int32_t* __rest
 }
 #undef A
 
+
+// ---------------------------------------------------------------------------
+// phase B, blocked: ONE WAVEFRONT PER ROW, 64 x 64 blocks, the block products on the f32 MFMA
+// ---------------------------------------------------------------------------
+// Left-looking block LDL^T of the K x K system (K = 64 C).  For block column J:
+//   * every block (I, J), I >= J, is loaded in the accumulator layout phase A wrote it in and receives
+//         A(I,J) -= sum_{k<J} (L(I,k) D_k) L(J,k)^T                      -- 32 steps of v_mfma_f32_32x32x2_f32 per tile and k;
+//     both operands come from the wave's workspace in HBM/L2, where finished blocks are kept "k-major"
+//     (Lt[kk][i] = L(I,k)[i][kk]): for one MFMA step the 64 lanes read two contiguous 128-byte rows;
+//   * the block goes through a padded LDS image (64 x 65 floats per wave) to change layout: the diagonal block to
+//     "lane i owns row i" (its missing upper-right tile is read transposed: the block is symmetric), an off-diagonal block
+//     to "lane j owns COLUMN j";
+//   * diagonal block: unpivoted right-looking LDL^T in registers, the block's right-hand side riding along (as als.hip);
+//     afterwards lane k holds L(k, m<k), d_k and the pivot row d_k L(j>k, k) -- kept in registers for the panel below and
+//     written to the workspace for the back substitution;
+//   * off-diagonal block (the panel): with B^T in "lane j owns row j", L_JJ Z = B^T is a forward substitution ACROSS lanes --
+//     step m broadcasts row m (64 v_readlane) and every lane j > m subtracts L(j,m) times it; Y = D^-1 Z is L(I,J)^T, so
+//     lane j writes its 64 registers as row j of the k-major block (and -Z as the pre-scaled copy the MFMA's first operand reads).
+// Forward substitution happens on the way (block right-hand sides are corrected with k-major matrix-vector products), the
+// back substitution walks the block columns from the last: w = L(I,J)^T x_I is lane-local in the k-major rows.
+namespace {
+constexpr int IMG_LD = 65;                 // row stride of the LDS image (floats): row- and column-wise reads are conflict-free
+struct BlkAcc { f32x16 t00, t01, t10, t11; };
+
+// acc (4 tiles; t01 not valid when sym) -> LDS image, then lane l takes row l (by_col = false) or column l (by_col = true)
+__device__ __forceinline__ void alsb_relayout(const BlkAcc& g, float* img, int lane, bool sym, bool by_col, float (&v)[64]) {
+  const int h = lane >> 5, c = lane & 31;
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
+    img[rr * IMG_LD + c] = g.t00[r];
+    if (!sym) img[rr * IMG_LD + 32 + c] = g.t01[r];
+    img[(32 + rr) * IMG_LD + c] = g.t10[r];
+    img[(32 + rr) * IMG_LD + 32 + c] = g.t11[r];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  if (by_col) {
+#pragma unroll
+    for (int q = 0; q < 64; q++) v[q] = img[q * IMG_LD + lane];
+  } else {
+#pragma unroll
+    for (int q = 0; q < 64; q++) {
+      // symmetric block: A(l, q) for l < 32 <= q was not accumulated; it equals A(q, l)
+      const bool mirror = sym && lane < 32 && q >= 32;
+      v[q] = mirror ? img[q * IMG_LD + lane] : img[lane * IMG_LD + q];
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ float alsb_bcast(float x, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));
+}
+}  // namespace
+
+namespace {
+// One buffer descriptor per wave-uniform base pointer: the lane offset sits in ONE vector register and everything else in the
+// scalar / immediate offset of the instruction.  (Plain pointer arithmetic made the compiler keep ~64 64-bit addresses per
+// block alive and spill them: 1.2 KB of scratch per lane and a third of the kernel's time.)
+struct BufF {
+  __amdgpu_buffer_rsrc_t rs;
+  __device__ __forceinline__ BufF(const float* base) { rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7ffffffc, 0x00020000); }
+  __device__ __forceinline__ float ld(int voff_bytes, int soff_bytes) const {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff_bytes, soff_bytes, 0));
+  }
+  __device__ __forceinline__ f32x4w ld4(int voff_bytes, int soff_bytes) const {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    return __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128(rs, voff_bytes, soff_bytes, 0));
+  }
+  __device__ __forceinline__ void st(float v, int voff_bytes, int soff_bytes) const {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff_bytes, soff_bytes, 0);
+  }
+  __device__ __forceinline__ void st4(f32x4w v, int voff_bytes, int soff_bytes) const {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), rs, voff_bytes, soff_bytes, 0);
+  }
+};
+}  // namespace
+
+template <int C>
+__global__ __launch_bounds__(256, 2) void alsw_bsolve_kernel(const int32_t* __restrict__ wrow, const int32_t* __restrict__ wfirst,
+                                                             const int32_t* __restrict__ wn, int64_t row0, int64_t nrows, int64_t seg0,
+                                                             const float* __restrict__ slabs, int64_t stride, int K, int ld, float reg,
+                                                             float* __restrict__ X, float* __restrict__ wsp, int64_t ws_stride, int dbg) {
+  constexpr int NPAIRS = C * (C + 1) / 2;
+  __shared__ float img_all[4][64 * IMG_LD];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, half = lane >> 5, idx = lane & 31;
+  float* img = img_all[wv];
+  const int64_t wave = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
+  // workspace of this wave: off-diagonal blocks k-major (Lt) and pre-scaled (-D L)^T, diagonal blocks as factored rows
+  const BufF W(wsp + wave * ws_stride);
+  // byte offsets inside the workspace
+  auto LT = [&](int I, int J) { return (I * (I - 1) / 2 + J) * (2 * BLK) * 4; };          // I > J
+  auto LTD = [&](int I, int J) { return ((I * (I - 1) / 2 + J) * (2 * BLK) + BLK) * 4; };
+  constexpr int DG = (C * (C - 1) / 2) * (2 * BLK) * 4;                                   // [C][64 lanes][64]
+  constexpr int VEC = DG + C * BLK * 4;                                                   // z, d, x per block column: [3][C][64]
+  const int l4 = lane * 4, l256 = lane * 256;
+  // The block loops are REAL loops (the 64-step factorisation and panel bodies are unrolled once each, not once per block: the
+  // first version, unrolled over the blocks too, was 77 k instructions at C = 4 and ran out of the instruction cache).
+  for (int64_t m = wave; m < nrows; m += nwaves) {
+    const int row = wrow[row0 + m], nsg = wn[row0 + m];
+    const float* sl0 = slabs + ((int64_t)wfirst[row0 + m] - seg0) * stride;
+    const int sbytes = (int)(stride * 4);
+#pragma unroll 1
+    for (int J = 0; J < C; J++) {
+      // ---- right-hand side of block J, corrected by the finished block columns: r = b_J - sum_k L(J,k) z_k
+      float rJ = 0.0f;
+      for (int sg = 0; sg < nsg; sg++) rJ += BufF(sl0 + sg * stride).ld(l4, (NPAIRS * BLK + 64 * J) * 4);
+#pragma unroll 1
+      for (int k = 0; k < J; k++) {
+        const int lt = LT(J, k);
+        const float zk = W.ld(l4, VEC + (0 * C + k) * 256);
+#pragma unroll 8
+        for (int kk = 0; kk < 64; kk++) rJ = __builtin_fmaf(-W.ld(l4, lt + kk * 256), alsb_bcast(zk, kk), rJ);
+      }
+      float a[64];     // the factored diagonal block of this column: lane l = row l (see above)
+      float dJ = 1.0f;
+#pragma unroll 1
+      for (int I = J; I < C; I++) {
+        // ---- A(I,J): sum of the segment partials (segment order: reproducible)
+        BlkAcc g;
+        {
+          const int p = I * (I + 1) / 2 + J;
+#pragma unroll
+          for (int r = 0; r < 16; r++) { g.t00[r] = 0.0f; g.t01[r] = 0.0f; g.t10[r] = 0.0f; g.t11[r] = 0.0f; }
+          for (int sg = 0; sg < nsg; sg++) {
+            const BufF S(sl0 + sg * stride);
+            const int po = p * BLK * 4;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+              g.t00[r] += S.ld(l4, po + (0 * 16 + r) * 256);
+              g.t01[r] += I != J ? S.ld(l4, po + (1 * 16 + r) * 256) : 0.0f;
+              g.t10[r] += S.ld(l4, po + (2 * 16 + r) * 256);
+              g.t11[r] += S.ld(l4, po + (3 * 16 + r) * 256);
+            }
+          }
+        }
+        // ---- minus the contributions of the finished block columns (the diagonal block computes its unused tile too: one code path)
+#pragma unroll 1
+        for (int k = 0; k < ((dbg & 4) ? 0 : J); k++) {
+          const int pa = LTD(I, k);         // (-D_k L(I,k))^T, k-major
+          const int pb = LT(J, k);          // L(J,k)^T
+          const int vo = (half * 64 + idx) * 4;
+#pragma unroll 4
+          for (int s2 = 0; s2 < 32; s2++) {
+            const int o = 2 * s2 * 256;
+            const float a0 = W.ld(vo, pa + o), a1 = W.ld(vo, pa + o + 128), y0 = W.ld(vo, pb + o), y1 = W.ld(vo, pb + o + 128);
+            g.t00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, y0, g.t00, 0, 0, 0);
+            g.t01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, y1, g.t01, 0, 0, 0);
+            g.t10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, y0, g.t10, 0, 0, 0);
+            g.t11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, y1, g.t11, 0, 0, 0);
+          }
+        }
+        if (I == J) {
+          alsb_relayout(g, img, lane, true, false, a);
+          // YTY(j,j) += reg for j < K (modelMF.cpp:831-833); padded dimensions (all zero) become identity rows
+          const float regv = (64 * J + lane) < K ? reg : 1.0f;
+#pragma unroll
+          for (int q = 0; q < 64; q++) a[q] += lane == q ? regv : 0.0f;
+          float z = rJ, d = 1.0f;
+          if (!(dbg & 1))
+#pragma unroll
+          for (int k = 0; k < 64; k++) {
+            const float dk = alsb_bcast(a[k], k);
+            float rk = __builtin_amdgcn_rcpf(dk);
+            rk = __builtin_fmaf(__builtin_fmaf(-dk, rk, 1.0f), rk, rk);
+            int lv = lane;
+            asm volatile("" : "+v"(lv));
+            const float lik = lv > k ? a[k] * rk : 0.0f;
+#pragma unroll
+            for (int q = k + 1; q < 64; q++) a[q] = __builtin_fmaf(-lik, alsb_bcast(a[q], k), a[q]);
+            z = __builtin_fmaf(-lik, alsb_bcast(z, k), z);
+            a[k] = lv > k ? lik : a[k];
+            d = lv == k ? dk : d;
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          dJ = d;
+          W.st(z, l4, VEC + (0 * C + J) * 256);
+          W.st(d, l4, VEC + (1 * C + J) * 256);
+#pragma unroll
+          for (int q = 0; q < 64; q += 4) W.st4(f32x4w{a[q], a[q + 1], a[q + 2], a[q + 3]}, l256, DG + J * BLK * 4 + q * 4);
+        } else {
+          // ---- panel block, lane i owns row i of B: X (D L^T) = B row by row.  Step j: x_j = b_j / d_j; the later columns lose
+          // x_j (d_j L(c,j)), and d_j L(c,j) is entry c of lane j's pivot row: one v_readlane per (step, column)
+          float y[64];
+          alsb_relayout(g, img, lane, false, false, y);
+          float rdv = __builtin_amdgcn_rcpf(dJ);
+          rdv = __builtin_fmaf(__builtin_fmaf(-dJ, rdv, 1.0f), rdv, rdv);
+          const int lt = LT(I, J), ltd = LTD(I, J);
+          if (!(dbg & 2))
+#pragma unroll
+          for (int j = 0; j < 64; j++) {
+            const float zj = y[j];                                  // x_j d_j
+            const float xj = zj * alsb_bcast(rdv, j);
+            W.st(-zj, l4, ltd + j * 256);                           // k-major: row j, element `lane`
+            W.st(xj, l4, lt + j * 256);
+#pragma unroll
+            for (int c = j + 1; c < 64; c++) y[c] = __builtin_fmaf(-xj, alsb_bcast(a[c], j), y[c]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      // the blocks this wave wrote are read back by other lanes in the next block column
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+    }
+    // ---- back substitution, block columns from the last: D L^T x = z - D w,  w = sum_{I>J} L(I,J)^T x_I
+#pragma unroll 1
+    for (int J = C - 1; J >= 0; J--) {
+      float w = 0.0f;
+#pragma unroll 1
+      for (int I = J + 1; I < C; I++) {
+        const int lt = LT(I, J);                      // row `lane` of the k-major block = column `lane` of L(I,J)
+        const float xI = W.ld(l4, VEC + (2 * C + I) * 256);
+#pragma unroll 4
+        for (int q = 0; q < 64; q += 4) {
+          const f32x4w v = W.ld4(l256, lt + q * 4);
+          w = __builtin_fmaf(v[0], alsb_bcast(xI, q), w);
+          w = __builtin_fmaf(v[1], alsb_bcast(xI, q + 1), w);
+          w = __builtin_fmaf(v[2], alsb_bcast(xI, q + 2), w);
+          w = __builtin_fmaf(v[3], alsb_bcast(xI, q + 3), w);
+        }
+      }
+      float a[64];
+#pragma unroll
+      for (int q = 0; q < 64; q += 4) {
+        const f32x4w v = W.ld4(l256, DG + J * BLK * 4 + q * 4);
+        a[q] = v[0]; a[q + 1] = v[1]; a[q + 2] = v[2]; a[q + 3] = v[3];
+      }
+      const float d = W.ld(l4, VEC + (1 * C + J) * 256);
+      float rd = __builtin_amdgcn_rcpf(d);
+      rd = __builtin_fmaf(__builtin_fmaf(-d, rd, 1.0f), rd, rd);
+      float acc = __builtin_fmaf(-d, w, W.ld(l4, VEC + (0 * C + J) * 256)), x = 0.0f;
+#pragma unroll
+      for (int j = 63; j >= 0; j--) {
+        const float xv = acc * rd;
+        x = lane == j ? xv : x;
+        acc = __builtin_fmaf(-a[j], alsb_bcast(xv, j), acc);      // lanes k < j hold d_k L(j,k) in a[j]
+      }
+      W.st(x, l4, VEC + (2 * C + J) * 256);
+      if (64 * J + lane < K) X[(int64_t)row * ld + 64 * J + lane] = x;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // host
 // ---------------------------------------------------------------------------
@@ -437,7 +688,34 @@ int mfx_als_wide_half_sweep(mfx_ctx* ctx, int side, float reg) {
                            val, Y, ctx->ld, st->slabs, stride, (int)yrows);
       HIPCHK(hipGetLastError());
     }
-    {
+    // blocked LDL^T (one wavefront per row, block products on the MFMA) from three blocks on: K = 192: 36 vs 60 ms, K = 256: 72 vs
+    // 94 ms per iteration at the C2 matrix; at two blocks (K <= 128) the register-resident workgroup kernel below is still ahead
+    // (10.9 vs 14.5 ms).  MFX_ALS_SOLVER=blocked / unblocked overrides.
+    const char* sv = getenv("MFX_ALS_SOLVER");
+    const bool blocked = sv ? sv[0] == 'b' : C >= 3;
+    if (blocked) {
+      ProfScope ps(ctx, MFX_K_ALS_SOLVE);
+      int dev = 0, cus = 0;
+      HIPCHK(hipGetDevice(&dev));
+      HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+      const int blocksb = (int)std::min<int64_t>((nr + 3) / 4, (int64_t)std::max(cus, 1) * 2);
+      const char* dbe = getenv("MFX_ALS_DBG");       // timing probes: 1 no factorisation, 2 no panel solve, 4 no block products (results wrong)
+      const int dbgb = dbe ? atoi(dbe) : 0;
+      const int64_t ws_stride = ((int64_t)C * (C - 1) / 2 * 2 + C) * BLK + 3 * C * 64;
+      const size_t needw = (size_t)blocksb * 4 * (size_t)ws_stride;
+      if (needw > st->bws_floats) {
+        dev_free(st->bws);
+        st->bws_floats = 0;
+        if ((rc = dev_alloc(ctx, &st->bws, needw))) return rc;
+        st->bws_floats = needw;
+      }
+#define MFX_BSOLVE(CC)                                                                                                         \
+  hipLaunchKernelGGL(alsw_bsolve_kernel<CC>, dim3(blocksb), dim3(256), 0, ctx->stream, w.wrow, w.wfirst, w.wn, r0, nr, s0, st->slabs, \
+                     stride, K, ctx->ld, reg, X, st->bws, ws_stride, dbgb)
+      if (C == 2) MFX_BSOLVE(2); else if (C == 3) MFX_BSOLVE(3); else MFX_BSOLVE(4);
+#undef MFX_BSOLVE
+      HIPCHK(hipGetLastError());
+    } else {
       ProfScope ps(ctx, MFX_K_ALS_SOLVE);
       const int blocks = (int)std::min<int64_t>(nr, 256 * 8);
 #define MFX_SOLVE(PP)                                                                                                        \

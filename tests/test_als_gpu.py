@@ -146,6 +146,35 @@ def test_zero_row_behind_the_tables_survives_the_other_trainers(K):
     assert rel.max() < 2e-4
 
 
+@pytest.mark.parametrize("K", [100, 128, 192, 256])
+@pytest.mark.parametrize("solver", ["blocked", "unblocked"])
+def test_wide_als_both_solvers_match_oracle(K, solver, monkeypatch):
+    """K > 64 has two phase-B kernels (als_wide.hip): the workgroup-per-row LDL^T in registers and the blocked one-wave-per-row
+    LDL^T with its block products on the MFMA.  The library picks by block count; both are held to the oracle at every K here."""
+    monkeypatch.setenv("MFX_ALS_SOLVER", solver)
+    reg = 2.0
+    d, tr, (cp, ci, cv) = _data(1500, 300, 70000, seed=K + 3)
+    nU, nI = d["nUsers"], d["nItems"]
+    rng = np.random.default_rng(K)
+    U0 = rng.normal(0, 0.3, (nU, K)).astype(np.float32)
+    V0 = rng.normal(0, 0.3, (nI, K)).astype(np.float32)
+    assert np.bincount(tr.rowind).max() > 1024            # several segment partials per row
+    with Ctx(0) as ctx:
+        invU, invI = load_ctx(ctx, d, K, U0, V0)
+        ctx.als_half_sweep(mfx.SIDE_USERS, reg)
+        U1, _ = ctx.get_factors()
+        ctx.als_half_sweep(mfx.SIDE_ITEMS, reg)
+        _, V2 = ctx.get_factors()
+    Uo, Vo = U0.copy(), V0.copy()
+    orc.als_half(0, Uo, Vo, tr.nrows, tr.rowptr, tr.rowind, tr.rowval, invU, reg, nthreads=4)
+    orc.als_half(1, Vo, U1, tr.ncols, cp, ci, cv, invI, reg, nthreads=4)
+    relu = np.linalg.norm(U1 - Uo, axis=1) / np.maximum(np.linalg.norm(Uo, axis=1), 1e-6)
+    reli = np.linalg.norm(V2[:tr.ncols] - Vo[:tr.ncols], axis=1) / np.maximum(np.linalg.norm(Vo[:tr.ncols], axis=1), 1e-6)
+    # unpivoted LDL^T vs Eigen's pivoted one: both backward stable, they agree to eps * cond(A); the item systems here sum up to
+    # 2000 outer products against reg = 2 (cond ~ 1e3..1e4): 5e-4 relative per row
+    assert relu.max() < 5e-4 and reli.max() < 5e-4, (relu.max(), reli.max())
+
+
 def test_wide_als_in_several_batches_equals_one_batch(monkeypatch):
     """als_wide.hip caps the segment partials (default 8 GB) and sweeps the rows in batches; a tiny cap forces many."""
     K, reg = 128, 1.5
