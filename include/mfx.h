@@ -111,7 +111,9 @@ enum {
                            (owned rows + version counters, sgd_flow.hip) or dependency
                            levels with a grid barrier (sgd_levels.hip).  The exact replay
                            of ModelMF::train / trainUShuffle / trainSGDPar orders
-                           (modelMF.cpp:83-105, 637-659, 273-304).                        */
+                           (modelMF.cpp:83-105, 637-659, 273-304); with rating weights,
+                           truncated ranks or a per-dimension regulariser installed, of
+                           the sibling models' loops (dataflow schedule only).             */
 };
 enum {
   MFX_ORDER_DEVICE = 0,  /* fresh device-side pseudo-random permutation per (seed, epoch) */

@@ -477,12 +477,12 @@ extern "C" int mfx_sgd_epoch(mfx_ctx* ctx, const mfx_sgd_opts* o) {
   NEED(m.nrows <= ctx->nU && m.ncols <= ctx->nI, MFX_E_ARG,
        "mfx_sgd_epoch: train matrix %dx%d exceeds model %dx%d", m.nrows, m.ncols, ctx->nU, ctx->nI);
   NEED(o->mode >= MFX_SGD_HOGWILD && o->mode <= MFX_SGD_LEVELS, MFX_E_ARG, "mfx_sgd_epoch: mode=%d", o->mode);
-  NEED(!ctx->dimreg || o->mode == MFX_SGD_HOGWILD || o->mode == MFX_SGD_SERIAL || o->mode == MFX_SGD_TILED, MFX_E_ARG,
+  NEED(!ctx->dimreg || o->mode == MFX_SGD_HOGWILD || o->mode == MFX_SGD_SERIAL || o->mode == MFX_SGD_TILED || o->mode == MFX_SGD_LEVELS, MFX_E_ARG,
        "mfx_sgd_epoch: per-dimension regularisation (mfx_sgd_set_dim_reg) runs on MFX_SGD_HOGWILD / MFX_SGD_SERIAL / MFX_SGD_TILED");
-  NEED(!ctx->ifw || o->mode == MFX_SGD_HOGWILD || o->mode == MFX_SGD_SERIAL || o->mode == MFX_SGD_TILED, MFX_E_ARG,
+  NEED(!ctx->ifw || o->mode == MFX_SGD_HOGWILD || o->mode == MFX_SGD_SERIAL || o->mode == MFX_SGD_TILED || o->mode == MFX_SGD_LEVELS, MFX_E_ARG,
        "mfx_sgd_epoch: rating weights (mfx_sgd_set_ifw) run on MFX_SGD_HOGWILD / MFX_SGD_SERIAL / MFX_SGD_TILED");
   NEED(!(ctx->ifw && ctx->dimreg), MFX_E_STATE, "mfx_sgd_epoch: rating weights and per-dimension regularisation are exclusive");
-  NEED(!ctx->tmf_u || o->mode == MFX_SGD_HOGWILD || o->mode == MFX_SGD_SERIAL || o->mode == MFX_SGD_TILED, MFX_E_ARG,
+  NEED(!ctx->tmf_u || o->mode == MFX_SGD_HOGWILD || o->mode == MFX_SGD_SERIAL || o->mode == MFX_SGD_TILED || o->mode == MFX_SGD_LEVELS, MFX_E_ARG,
        "mfx_sgd_epoch: truncated ranks (mfx_set_tmf) run on MFX_SGD_HOGWILD / MFX_SGD_SERIAL / MFX_SGD_TILED");
   NEED(!(ctx->tmf_u && (ctx->ifw || ctx->dimreg)), MFX_E_STATE, "mfx_sgd_epoch: truncated ranks exclude the other SGD variants");
   NEED(o->order >= MFX_ORDER_DEVICE && o->order <= MFX_ORDER_NATURAL, MFX_E_ARG, "mfx_sgd_epoch: order=%d", o->order);

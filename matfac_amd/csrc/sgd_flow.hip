@@ -25,6 +25,7 @@
 #include "mfx_internal.h"
 
 #include "sgd_common.h"
+#include "sgd_variants.h"
 
 namespace {
 
@@ -119,6 +120,77 @@ __global__ __launch_bounds__(FL_WG, FL_WG_PER_CU) void sgd_flow_kernel(const int
       if ((++idle & 63) == 0) {
         if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
         if (wall_clock64() - t_last > 200000000LL) {              // 100 MHz constant clock: 2 s without progress
+          __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          return;
+        }
+      }
+    }
+  }
+}
+
+// The three SGD variants on the same schedule (VAR 1: ModelInvPopMF's rating weight, 2: ModelDropoutSigmoid's / ModelPoissonDropout's
+// truncated rank, 3: trainSGDParSVD's per-dimension regulariser): the visit is the variant's own (sgd_variants.h), the weight / rank of a
+// rating is derived from the user's and the item's attribute pair as in the variants' serial kernels.
+template <int L, int C, int VAR>
+__global__ __launch_bounds__(FL_WG, FL_WG_PER_CU) void sgd_flow_var_kernel(const int4* __restrict__ q, const int64_t* __restrict__ qoff,
+                                                                           unsigned* ver, float* U, float* V, uint32_t ubytes, uint32_t vbytes,
+                                                                           int own_user, float lr, float uReg, float iReg, unsigned* flag,
+                                                                           const float2* __restrict__ ua, const float2* __restrict__ ia, float rho,
+                                                                           const int2* __restrict__ tu, const int2* __restrict__ ti,
+                                                                           const int32_t* __restrict__ du, const int32_t* __restrict__ di,
+                                                                           const double* __restrict__ dexp, uint32_t seed, uint32_t epoch, int K,
+                                                                           const float* __restrict__ regk) {
+  constexpr int G = 64 / L;
+  constexpr int LD = 4 * L * C;
+  const Rows<1> Um(U, ubytes), Vm(V, vbytes);
+  const int lane = threadIdx.x & 63, g = lane / L, j = lane % L;
+  const int64_t grp = ((int64_t)blockIdx.x * (FL_WG / 64) + (threadIdx.x >> 6)) * G + g;
+  int64_t pos = qoff[grp];
+  const int64_t end = qoff[grp + 1];
+  float4v rk[C];
+  if (VAR == 3) {
+#pragma unroll
+    for (int c = 0; c < C; c++) rk[c] = *(const float4v*)(regk + c * 4 * L + 4 * j);
+  }
+  long long t_last = wall_clock64();
+  int idle = 0;
+  while (__builtin_amdgcn_ballot_w64(pos < end) != 0) {
+    bool ready = false;
+    int4 rec = make_int4(0, 0, 0, 0);
+    if (pos < end) {
+      rec = q[pos];
+      ready = __hip_atomic_load(ver + rec.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)rec.w;
+    }
+    asm volatile("" ::: "memory");
+    if (ready) {
+      const int u = own_user ? rec.y : rec.x, it = own_user ? rec.x : rec.y;
+      const int64_t pe = (int64_t)u * LD + 4 * j, qe = (int64_t)it * LD + 4 * j;
+      const float r = __int_as_float(rec.z);
+      if (VAR == 1) {
+        visit_ifw<L, C, 1>(Um, Vm, pe, qe, r, mfx_ifw_weight(ua[u], ia[it], rho), lr, uReg, iReg);
+      } else if (VAR == 2) {
+        const int2 a = tu[u], b = ti[it];
+        int rank = mfx_tmf_rank(a, b);
+        if (du) {
+          const int lam = __int_as_float(a.x) < __int_as_float(b.x) ? du[u] : di[it];
+          rank = mfx_poisson_rank(lam, dexp[lam], mfx_draw_hash(seed, epoch, (uint32_t)u, (uint32_t)it), K);
+        }
+        visit_tmf<L, C, 1>(Um, Vm, pe, qe, r, rank, j, lr, uReg, iReg);
+      } else {
+        visit_dimreg<L, C, 1>(Um, Vm, pe, qe, r, lr, rk);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // row stores acknowledged, then the version moves
+      if (j == 0) __hip_atomic_store(ver + rec.x, (unsigned)rec.w + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      pos++;
+    }
+    if (__builtin_amdgcn_ballot_w64(ready) != 0) {
+      t_last = wall_clock64();
+      idle = 0;
+    } else {
+      __builtin_amdgcn_s_sleep(2);
+      if ((++idle & 63) == 0) {
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+        if (wall_clock64() - t_last > 200000000LL) {
           __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           return;
         }
@@ -439,6 +511,24 @@ int launch_flow_lc(mfx_ctx* ctx, const mfx_sgd_opts* o, int blocks) {
   FlowState* S = fl(ctx);
   const uint32_t ub = (uint32_t)((uint64_t)ctx->nU * ctx->ld * 4), vb = (uint32_t)((uint64_t)ctx->nI * ctx->ld * 4);
   ProfScope ps(ctx, MFX_K_SGD);
+  const int var = ctx->ifw ? 1 : (ctx->tmf_u ? 2 : (ctx->dimreg ? 3 : 0));
+  if (var != 0) {
+    if constexpr (C <= 4) {      // K <= 256, as the variants' own kernels
+      const float2 *ua = nullptr, *ia = nullptr;
+      float rho = 0.0f;
+      mfx_ifw_tables(ctx, &ua, &ia, &rho);
+#define MFX_FLOWV(VV)                                                                                                          \
+  hipLaunchKernelGGL((sgd_flow_var_kernel<L, C, VV>), dim3(blocks), dim3(FL_WG), 0, ctx->stream, (const int4*)S->q, S->qoff, S->ver, \
+                     ctx->U, ctx->V, ub, vb, S->own_user, o->learnRate, o->uReg, o->iReg, S->flag, ua, ia, rho, ctx->tmf_u, ctx->tmf_i,  \
+                     ctx->tmfd_u, ctx->tmfd_i, ctx->tmfd_exp, ctx->tmfd_seed, (uint32_t)o->epoch, ctx->K, ctx->dimreg)
+      if (var == 1) MFX_FLOWV(1); else if (var == 2) MFX_FLOWV(2); else MFX_FLOWV(3);
+#undef MFX_FLOWV
+      HIPCHK(hipGetLastError());
+      return MFX_OK;
+    } else {
+      return mfx_fail(ctx, MFX_E_ARG, "MFX_SGD_LEVELS: the SGD variants are built for K <= 256");
+    }
+  }
 #define MFX_FLOW(A)                                                                                                        \
   hipLaunchKernelGGL((sgd_flow_kernel<L, C, A>), dim3(blocks), dim3(FL_WG), 0, ctx->stream, (const int4*)S->q, S->qoff, S->ver, \
                      ctx->U, ctx->V, ub, vb, S->own_user, o->learnRate, o->uReg, o->iReg, S->flag)

@@ -15,6 +15,7 @@
 #include "mfx_internal.h"
 
 #include "sgd_common.h"
+#include "sgd_variants.h"
 
 namespace {
 struct IfwState {
@@ -42,32 +43,6 @@ void mfx_ifw_free_internal(mfx_ctx* ctx) {
   dev_free(s->ua); dev_free(s->ia);
   delete s;
   ctx->ifw = nullptr;
-}
-
-template <int L, int C, int POL>
-__device__ __forceinline__ void visit_ifw(const Rows<POL>& Um, const Rows<POL>& Vm, int64_t pe, int64_t qe, float r, float wt,
-                                          float lr, float uReg, float iReg) {
-  float4v p[C], q[C];
-#pragma unroll
-  for (int c = 0; c < C; c++) {
-    p[c] = Um.ld(pe + c * 4 * L);
-    q[c] = Vm.ld(qe + c * 4 * L);
-  }
-  const float est = group_dot<L, C>(p, q);
-  const double diff = (double)r - (double)est;
-  const double m2 = (-2.0 * (double)wt) * diff, ru = 2.0 * (double)uReg, ri = 2.0 * (double)iReg, lrd = (double)lr;
-#pragma unroll
-  for (int c = 0; c < C; c++) {
-#pragma unroll
-    for (int e = 0; e < 4; e++) p[c][e] = upd_ref64(p[c][e], q[c][e], m2, ru, lrd);
-#pragma unroll
-    for (int e = 0; e < 4; e++) q[c][e] = upd_ref64(q[c][e], p[c][e], m2, ri, lrd);
-  }
-#pragma unroll
-  for (int c = 0; c < C; c++) {
-    Um.st(pe + c * 4 * L, p[c]);
-    Vm.st(qe + c * 4 * L, q[c]);
-  }
 }
 
 template <int L, int C, bool SERIAL>

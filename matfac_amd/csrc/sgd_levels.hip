@@ -233,13 +233,13 @@ void mfx_levels_free_internal(mfx_ctx* ctx) {
 }
 
 int mfx_launch_sgd_levels(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int64_t count) {
-  NEED(!ctx->dimreg && !ctx->ifw && !ctx->tmf_u, MFX_E_ARG,
-       "MFX_SGD_LEVELS runs the plain update; the SGD variants replay their order with MFX_SGD_SERIAL");
   // default: the barrier-free dataflow schedule (sgd_flow.hip); the level schedule below serves factor tables a buffer
-  // descriptor cannot address (4 GiB and more) and MFX_EXACT_SCHED=levels
+  // descriptor cannot address (4 GiB and more) and MFX_EXACT_SCHED=levels -- the plain update only
   const char* sched = getenv("MFX_EXACT_SCHED");
-  ctx->last_exact_flow = mfx_flow_usable(ctx, count) && !(sched && sched[0] == 'l');
+  const bool variant = ctx->dimreg || ctx->ifw || ctx->tmf_u;
+  ctx->last_exact_flow = mfx_flow_usable(ctx, count) && (variant || !(sched && sched[0] == 'l'));
   if (ctx->last_exact_flow) return mfx_launch_sgd_flow(ctx, o, first, count);
+  NEED(!variant, MFX_E_ARG, "MFX_SGD_LEVELS: the SGD variants run on the dataflow schedule only (factor tables < 4 GiB)");
   int rc = build_levels(ctx, first, count);
   if (rc) return rc;
   const int L = ctx->L, C = ctx->C;

@@ -16,41 +16,7 @@
 #include "mfx_internal.h"
 
 #include "sgd_common.h"
-
-template <int L, int C, int POL>
-__device__ __forceinline__ void visit_tmf(const Rows<POL>& Um, const Rows<POL>& Vm, int64_t pe, int64_t qe, float r, int rank, int j,
-                                          float lr, float uReg, float iReg) {
-  float4v p[C], q[C];
-#pragma unroll
-  for (int c = 0; c < C; c++) {
-    p[c] = Um.ld(pe + c * 4 * L);
-    q[c] = Vm.ld(qe + c * 4 * L);
-  }
-  float a = 0.0f;
-#pragma unroll
-  for (int c = 0; c < C; c++)
-#pragma unroll
-    for (int x = 0; x < 4; x++)
-      if (c * 4 * L + 4 * j + x < rank) a = __builtin_fmaf(p[c][x], q[c][x], a);
-  const float est = group_sum<L>(a);
-  const float d = r - est;                                        // float diff (:176)
-  const double m2 = -2.0 * (double)d, ru = 2.0 * (double)uReg, ri = 2.0 * (double)iReg, lrd = (double)lr;
-#pragma unroll
-  for (int c = 0; c < C; c++) {
-#pragma unroll
-    for (int x = 0; x < 4; x++)
-      if (c * 4 * L + 4 * j + x < rank) p[c][x] = upd_ref64(p[c][x], q[c][x], m2, ru, lrd);
-#pragma unroll
-    for (int x = 0; x < 4; x++)
-      if (c * 4 * L + 4 * j + x < rank) q[c][x] = upd_ref64(q[c][x], p[c][x], m2, ri, lrd);
-  }
-#pragma unroll
-  for (int c = 0; c < C; c++)
-    if (c * 4 * L + 4 * j < rank) {        // pieces entirely beyond the rank are not written back
-      Um.st(pe + c * 4 * L, p[c]);
-      Vm.st(qe + c * 4 * L, q[c]);
-    }
-}
+#include "sgd_variants.h"
 
 template <int L, int C, bool SERIAL>
 __global__ __launch_bounds__(256) void sgd_tmf_kernel(const int32_t* __restrict__ eu, const int32_t* __restrict__ ei,

@@ -16,36 +16,11 @@
 #include "mfx_internal.h"
 
 #include "sgd_common.h"
+#include "sgd_variants.h"
 
 // ---------------------------------------------------------------------------
 // SGD with per-dimension regularisation
 // ---------------------------------------------------------------------------
-template <int L, int C, int POL>
-__device__ __forceinline__ void visit_dimreg(const Rows<POL>& Um, const Rows<POL>& Vm, int64_t pe, int64_t qe, float r,
-                                             float lr, const float4v (&rk)[C]) {
-  float4v p[C], q[C];
-#pragma unroll
-  for (int c = 0; c < C; c++) {
-    p[c] = Um.ld(pe + c * 4 * L);
-    q[c] = Vm.ld(qe + c * 4 * L);
-  }
-  const float est = group_dot<L, C>(p, q);
-  const float d = r - est;                       // float diff (modelMF.cpp:494)
-  const double m2 = -2.0 * (double)d, lrd = (double)lr;
-#pragma unroll
-  for (int c = 0; c < C; c++) {
-#pragma unroll
-    for (int e = 0; e < 4; e++) p[c][e] = upd_ref64(p[c][e], q[c][e], m2, 2.0 * (double)rk[c][e], lrd);
-#pragma unroll
-    for (int e = 0; e < 4; e++) q[c][e] = upd_ref64(q[c][e], p[c][e], m2, 2.0 * (double)rk[c][e], lrd);
-  }
-#pragma unroll
-  for (int c = 0; c < C; c++) {
-    Um.st(pe + c * 4 * L, p[c]);
-    Vm.st(qe + c * 4 * L, q[c]);
-  }
-}
-
 template <int L, int C, bool SERIAL>
 __global__ __launch_bounds__(256) void sgd_dimreg_kernel(const int32_t* __restrict__ eu, const int32_t* __restrict__ ei,
                                                          const float* __restrict__ er, int64_t first, int64_t count, float* U,

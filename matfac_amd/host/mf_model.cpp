@@ -545,7 +545,8 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
   // (default 2 M: there the replay costs milliseconds per epoch and the lock-free schedule, which keeps >= 64 ratings of
   // a workgroup in flight, collides on the few hundred rows of a tile); larger matrices take the tiled schedule.
   const char* exactEnv = getenv("MFX_EXACT");
-  const bool plainSgd = kind == K_SGD || kind == K_HOG || kind == K_SGDU || kind == K_SGDPAR;
+  const bool plainSgd = kind == K_SGD || kind == K_HOG || kind == K_SGDU || kind == K_SGDPAR || kind == K_IFW || kind == K_TMF ||
+                        kind == K_TMFD || kind == K_SGDPARSVD;       // every SGD trainer, the sibling models included
   const char* belowEnv = getenv("MFX_EXACT_BELOW");
   const int64_t exactBelow = belowEnv ? atoll(belowEnv) : 2000000;
   const bool exact = exactEnv ? atoi(exactEnv) != 0 : (plainSgd && data.trainMat->nnz() <= exactBelow);
@@ -652,7 +653,7 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
           // OpenMP thread is a plain std::shuffle; the reference is only reproducible that way)
           std::shuffle(uiRatingInds.begin(), uiRatingInds.end(), mt);
           dev->check(mfx_sgd_set_order(dev->ctx, (const uint64_t*)uiRatingInds.data(), nRatings), "set_order");
-          o.mode = kind == K_IFW ? MFX_SGD_SERIAL : replayMode; o.order = MFX_ORDER_HOST;
+          o.mode = replayMode; o.order = MFX_ORDER_HOST;
         } else {
           o.mode = MFX_SGD_TILED; o.order = MFX_ORDER_DEVICE;   // (K_IFW: the tiled kernel's weighted variant)
         }
@@ -678,12 +679,12 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
       case K_TMFD:        // modelPoissonDropout.cpp:170-224: K_TMF with the draws mfx_set_tmf_dropout installed
       case K_TMF:         // modelDropoutSigmoid.cpp:140-192 with the rank table beforeLoop() installed; float diff
         o.arith = MFX_ARITH_REF64F;
-        o.mode = exact ? MFX_SGD_SERIAL : MFX_SGD_TILED;       // the tiled kernel's truncated-rank variant
+        o.mode = exact ? replayMode : MFX_SGD_TILED;           // the tiled kernel's truncated-rank variant
         o.order = exact ? MFX_ORDER_NATURAL : MFX_ORDER_DEVICE;
         dev->check(mfx_sgd_epoch(dev->ctx, &o), "mfx_sgd_epoch");
         break;
       case K_SGDPARSVD:   // modelMF.cpp:474-512 with the per-dimension regulariser set above; lock-free, coherent rows
-        o.mode = exact ? MFX_SGD_SERIAL : MFX_SGD_TILED;       // the tiled kernel's per-dimension-regulariser variant
+        o.mode = exact ? replayMode : MFX_SGD_TILED;           // the tiled kernel's per-dimension-regulariser variant
         o.order = exact ? MFX_ORDER_NATURAL : MFX_ORDER_DEVICE;
         dev->check(mfx_sgd_epoch(dev->ctx, &o), "mfx_sgd_epoch");
         break;

@@ -37,6 +37,10 @@ def test_weighted_visit_and_objective(K, rho):
         ctx.sgd_epoch(0.004, 0.05, 0.03, mode=mfx.SGD_SERIAL, order=mfx.ORDER_HOST)
         U, V = ctx.get_factors()
         e1 = ctx.eval_ifw()
+        ctx.set_factors(U0, V0)                                      # the same epoch on the dataflow schedule: the same bits
+        ctx.sgd_epoch(0.004, 0.05, 0.03, mode=mfx.SGD_LEVELS, order=mfx.ORDER_HOST)
+        Ul, Vl = ctx.get_factors()
+        assert np.array_equal(Ul, U) and np.array_equal(Vl, V)
         with pytest.raises(mfx.MfxError):
             ctx.sgd_epoch(0.004, 0.05, 0.03, mode=mfx.SGD_USERS, order=mfx.ORDER_NATURAL)
         # parallel kernel on a conflict-free batch

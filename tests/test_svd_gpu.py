@@ -81,7 +81,12 @@ def test_dimreg_sgd_serial_is_bit_exact_and_objective_sing_matches(K):
         ctx.set_factors(U0, V0)
         ctx.compute_invalid()
         ctx.sgd_set_dim_reg(regk)
-        ctx.sgd_epoch(0.01, 9.0, 9.0, mode=mfx.SGD_SERIAL, order=mfx.ORDER_NATURAL)       # uReg/iReg are ignored
+        ctx.sgd_epoch(0.01, 9.0, 9.0, mode=mfx.SGD_LEVELS, order=mfx.ORDER_NATURAL)       # dataflow replay ...
+        Ul, Vl = ctx.get_factors()
+        ctx.set_factors(U0, V0)
+        ctx.sgd_epoch(0.01, 9.0, 9.0, mode=mfx.SGD_SERIAL, order=mfx.ORDER_NATURAL)       # ... == one group in list order; uReg/iReg are ignored
+        Us, Vs = ctx.get_factors()
+        assert np.array_equal(Ul, Us) and np.array_equal(Vl, Vs)
         U, V = ctx.get_factors()
         e = ctx.eval_weighted(mfx.MAT_TRAIN, sing)
         with pytest.raises(mfx.MfxError):

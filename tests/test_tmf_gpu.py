@@ -36,7 +36,12 @@ def test_truncated_rank_visit_and_evaluation(K, rho, alpha):
         ctx.set_tmf(uf.astype(np.float32), ru, itf.astype(np.float32), ri)
         e0 = ctx.eval(mfx.MAT_TEST)
         ctx.sgd_set_order(order)
-        ctx.sgd_epoch(0.004, 0.05, 0.03, mode=mfx.SGD_SERIAL, order=mfx.ORDER_HOST)
+        ctx.sgd_epoch(0.004, 0.05, 0.03, mode=mfx.SGD_LEVELS, order=mfx.ORDER_HOST)     # dataflow replay of the list ...
+        Ul, Vl = ctx.get_factors()
+        ctx.set_factors(U0, V0)
+        ctx.sgd_epoch(0.004, 0.05, 0.03, mode=mfx.SGD_SERIAL, order=mfx.ORDER_HOST)     # ... and one group in list order: the same bits
+        Us, Vs = ctx.get_factors()
+        assert np.array_equal(Ul, Us) and np.array_equal(Vl, Vs)
         U, V = ctx.get_factors()
         e1 = ctx.eval(mfx.MAT_TRAIN)
         keep_i = (np.arange(nI) % 2).astype(np.uint8)
