@@ -19,7 +19,9 @@ void mfx_ccd_free_internal(mfx_ctx* ctx) {
   dev_free(ctx->res_row); dev_free(ctx->res_col); dev_free(ctx->uk); dev_free(ctx->vk);
   dev_free(ctx->uk_pend); dev_free(ctx->vk_pend);
   ctx->ccd_pending = false;
-  dev_free(ctx->ccd_part); dev_free(ctx->colid);
+  dev_free(ctx->ccd_part); dev_free(ctx->colid); dev_free(ctx->ccd_ind16); mfx_trips_free(ctx->ccd_trips); dev_free(ctx->ccd_gptr); dev_free(ctx->ccd_single);
+  ctx->ccd_nsingle = 0;
+  ctx->ccd_ngroups = 0;
   mfx_ccd_cols_free(ctx);
   ctx->ccd_part_cap = 0;
   ctx->ccd_active = false;
@@ -52,17 +54,28 @@ __global__ void store_col_kernel(float* __restrict__ X, int32_t n, int ld, int k
 // 128-byte line, which made these kernels L2-bandwidth-bound; from LDS the gather is free.
 extern __shared__ __attribute__((aligned(16))) float ccd_lds[];
 
+// (slot n holds +0.0: the pass loop's masked entries gather it)
 __device__ __forceinline__ void stage_vector(const float* __restrict__ v, int n) {
   typedef float f4 __attribute__((ext_vector_type(4)));
   const int n4 = n >> 2;
   for (int q = threadIdx.x; q < n4; q += blockDim.x) ((f4*)ccd_lds)[q] = ((const f4*)v)[q];
   for (int q = (n4 << 2) + threadIdx.x; q < n; q += blockDim.x) ccd_lds[q] = v[q];
+  if (threadIdx.x == 0) ccd_lds[n] = 0.0f;
   __syncthreads();
+}
+
+// The item ids of the row view: 16-bit wherever the gathered item vector is staged in LDS (it fits for at most 38 400 items), so
+// the streaming kernels move 2 instead of 4 bytes per entry for them (ctx->ccd_ind16, made once by mfx_ccdpp_begin).
+template <bool LDS> struct ItemIdx { typedef int32_t type; };
+template <> struct ItemIdx<true> { typedef uint16_t type; };
+__global__ void narrow_ids_kernel(const int32_t* __restrict__ src, int64_t n, uint16_t* __restrict__ dst) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) dst[t] = (uint16_t)src[t];
 }
 
 template <int SIGN, bool LDSB>
 __global__ __launch_bounds__(1024) void resid_update_kernel(float* __restrict__ res, const int32_t* __restrict__ ia,
-                                                            const int32_t* __restrict__ ib,
+                                                            const typename ItemIdx<LDSB>::type* __restrict__ ib,
                                                             const float* __restrict__ a, const float* __restrict__ bg,
                                                             int nb, int64_t n) {
   typedef float f4 __attribute__((ext_vector_type(4)));
@@ -72,7 +85,7 @@ __global__ __launch_bounds__(1024) void resid_update_kernel(float* __restrict__ 
   const int64_t n4 = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride) {
-    const i4 x = ((const i4*)ia)[q], y = ((const i4*)ib)[q];
+    const i4 x = ((const i4*)ia)[q], y = MfxCcdTrip::load4(ib + 4 * q);
     f4 r = ((const f4*)res)[q];
 #pragma unroll
     for (int e = 0; e < 4; e++) {
@@ -91,7 +104,7 @@ __global__ __launch_bounds__(1024) void resid_update_kernel(float* __restrict__ 
 // of the next factor (:1032-1056) touch the same residual entries back to back; the two roundings are kept.
 template <bool LDSB>
 __global__ __launch_bounds__(1024) void resid_fused_kernel(float* __restrict__ res, const int32_t* __restrict__ ia,
-                                                           const int32_t* __restrict__ ib,
+                                                           const typename ItemIdx<LDSB>::type* __restrict__ ib,
                                                            const float* __restrict__ a0, const float* __restrict__ b0g,
                                                            const float* __restrict__ a1, const float* __restrict__ b1g,
                                                            int nb, int64_t n) {
@@ -114,7 +127,7 @@ __global__ __launch_bounds__(1024) void resid_fused_kernel(float* __restrict__ r
   const int64_t n4 = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride) {
-    const i4 x = ((const i4*)ia)[q], y = ((const i4*)ib)[q];
+    const i4 x = ((const i4*)ia)[q], y = MfxCcdTrip::load4(ib + 4 * q);
     f4 r = ((const f4*)res)[q];
 #pragma unroll
     for (int e = 0; e < 4; e++) {
@@ -128,48 +141,37 @@ __global__ __launch_bounds__(1024) void resid_fused_kernel(float* __restrict__ r
     res[e] = (res[e] - a0[ia[e]] * b0[ib[e]]) + a1[ia[e]] * b1[ib[e]];
 }
 
-__device__ __forceinline__ double group16_sum(double v) {
-#pragma unroll
-  for (int m = 8; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  return v;
-}
+__device__ __forceinline__ double group16_sum(double v) { return mfx_row16_sum(v); }
 
-// One 16-lane group per row segment.
+// Row pass: one 16-lane group per range of the trip list (mfx_ccd_trip_loop).  meta of a trip = the slot of the segment's
+// (num, den) pair: rows with several segments first (RowSegs::seg_slab), then one slot per single-segment row.  The quotient
+// is taken by the finishing kernels: a double division is ~35 instructions, and with four groups per wavefront three steps out
+// of four end a segment somewhere in the wave -- it was a quarter of the pass.  (trainCCDPPFreqAdap's rule applies to items
+// only: modelMF.cpp:1336-1342 -- the row pass never sees a threshold.)
 template <bool LDSO>
-__global__ __launch_bounds__(1024) void ccd_pass_kernel(const int32_t* __restrict__ seg_row,
-                                                       const int64_t* __restrict__ seg_beg,
-                                                       const int64_t* __restrict__ seg_end,
-                                                       const int32_t* __restrict__ seg_slab, int64_t nseg,
+__global__ __launch_bounds__(1024) void ccd_pass_kernel(const MfxTrips trips, const int32_t* __restrict__ gptr, int ngroups,
                                                        const float* __restrict__ res,
-                                                       const int32_t* __restrict__ ind,
-                                                       const float* __restrict__ otherg, int nother, float reg,
-                                                       float* __restrict__ mine, double* __restrict__ part,
-                                                       const int64_t* __restrict__ ptr, float freq_thresh, int k, int64_t nmax) {
+                                                       const typename ItemIdx<LDSO>::type* __restrict__ ind,
+                                                       const float* __restrict__ otherg, int nother, double* __restrict__ part) {
   if (LDSO) stage_vector(otherg, nother);
   const float* other = LDSO ? ccd_lds : otherg;
-  const int lane = threadIdx.x & 63;
-  const int j = lane & 15;
-  const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-  const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
-  mfx_ccd_pass_loop(seg_beg, seg_end, grp, nseg, ngrp, res, ind, other, j, nmax, [&](int64_t s, double num, double den) {
+  const int j = threadIdx.x & 15;
+  const int grp = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
+  if (grp >= ngroups) return;
+  // (the global vectors of a CCD++ session carry one more element, +0.0: mfx_ccdpp_begin)
+  mfx_ccd_trip_loop(trips, gptr[grp], gptr[grp + 1], res, ind, other, nother, j, [&](int, int slot, double num, double den) {
     num = group16_sum(num);
     den = group16_sum(den);
-    if (j == 0) {
-      const int slab = seg_slab[s];
-      if (slab < 0) {
-        const int row = seg_row[s];
-        float v = (float)(num / ((double)reg + den));
-        if (freq_thresh >= 0.0f) {  // modelMF.cpp:1336-1342: itemFreq = ratings of the item in train
-          const double freq = (double)(ptr[row + 1] - ptr[row]);
-          if (freq < (double)freq_thresh && k > 0) v = 0.0f;
-        }
-        mine[row] = v;
-      } else {
-        part[2 * (int64_t)slab] = num;
-        part[2 * (int64_t)slab + 1] = den;
-      }
-    }
+    if (j == 0) mfx_store_unseen(part + 2 * (int64_t)slot, num, den);
   });
+}
+
+// single-segment rows: u_k[row] = num / (reg + den) from the row's slot
+__global__ __launch_bounds__(256) void ccd_divide_kernel(const int32_t* __restrict__ single, int64_t nsingle, const double* __restrict__ part,
+                                                         float reg, float* __restrict__ mine) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nsingle) return;
+  mine[single[i]] = (float)(part[2 * i] / ((double)reg + part[2 * i + 1]));
 }
 
 // rows with several segments: partials summed by a 16-lane group, lane-strided in segment order then a fixed
@@ -201,6 +203,12 @@ __global__ __launch_bounds__(256) void ccd_finish_kernel(const int32_t* __restri
   mine[row] = v;
 }
 
+constexpr size_t LDS_BUDGET = 160 * 1024;
+static bool lds_fits(size_t bytes) { return bytes > 0 && bytes <= 150 * 1024; }
+static hipError_t set_lds(mfx_ctx*, const void* fn, size_t bytes) {
+  return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
 extern "C" int mfx_ccdpp_begin(mfx_ctx* ctx) {
   if (!ctx) return MFX_E_ARG;
   const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
@@ -212,13 +220,24 @@ extern "C" int mfx_ccdpp_begin(mfx_ctx* ctx) {
   int rc;
   const size_t nnz = (size_t)m.nnz;
   if ((rc = dev_alloc(ctx, &ctx->res_row, nnz))) return rc;
-  if ((rc = dev_alloc(ctx, &ctx->uk, (size_t)ctx->nU))) return rc;
-  if ((rc = dev_alloc(ctx, &ctx->vk, (size_t)ctx->nI))) return rc;
-  if ((rc = dev_alloc(ctx, &ctx->uk_pend, (size_t)ctx->nU))) return rc;
-  if ((rc = dev_alloc(ctx, &ctx->vk_pend, (size_t)ctx->nI))) return rc;
+  // u_k, v_k and the pending pair: one more element each, +0.0, which masked entries of the pass loop gather
+  if ((rc = dev_alloc(ctx, &ctx->uk, (size_t)ctx->nU + 1))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->vk, (size_t)ctx->nI + 1))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->uk_pend, (size_t)ctx->nU + 1))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->vk_pend, (size_t)ctx->nI + 1))) return rc;
+  HIPCHK(hipMemsetAsync(ctx->uk + ctx->nU, 0, sizeof(float), ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->vk + ctx->nI, 0, sizeof(float), ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->uk_pend + ctx->nU, 0, sizeof(float), ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->vk_pend + ctx->nI, 0, sizeof(float), ctx->stream));
   // res = gk_csr_Dup(trainMat) (modelMF.cpp:1013): both value arrays
   if (nnz) {
     HIPCHK(hipMemcpyAsync(ctx->res_row, m.rowval, sizeof(float) * nnz, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  HIPCHK(hipMemsetAsync(ctx->res_row + nnz, 0, 16, ctx->stream));   // the pad behind the residuals is read (masked) by the pass loop: finite
+  if (nnz && lds_fits(((size_t)ctx->nI + 1) * sizeof(float))) {
+    if ((rc = dev_alloc(ctx, &ctx->ccd_ind16, nnz))) return rc;
+    hipLaunchKernelGGL(narrow_ids_kernel, dim3(2048), dim3(256), 0, ctx->stream, m.rowind, (int64_t)nnz, ctx->ccd_ind16);
+    HIPCHK(hipGetLastError());
   }
   // the column view (res->colval) lives in user-strip-major order: ccd_cols.hip
   if ((rc = mfx_ccd_cols_build(ctx))) return rc;
@@ -226,20 +245,57 @@ extern "C" int mfx_ccdpp_begin(mfx_ctx* ctx) {
   HIPCHK(hipMemsetAsync(ctx->U, 0, sizeof(float) * (size_t)ctx->nU * ctx->ld, ctx->stream));
   RowSegs* sg;
   if ((rc = mfx_get_segments(ctx, 0, &sg))) return rc;
-  if (sg->nslab > ctx->ccd_part_cap) {
-    dev_free(ctx->ccd_part);
-    if ((rc = dev_alloc(ctx, &ctx->ccd_part, (size_t)sg->nslab * 2))) return rc;
-    ctx->ccd_part_cap = sg->nslab;
+  // the row view's trip list: segments in memory order (a trip's aligned 64 entries overlap its neighbours' -- adjacent in
+  // time they hit in L2), cut into one range per group of the launch
+  if (sg->nseg > 0) {
+    std::vector<int64_t> sb((size_t)sg->nseg), se((size_t)sg->nseg);
+    std::vector<int32_t> srow((size_t)sg->nseg), sslab((size_t)sg->nseg);
+    HIPCHK(hipMemcpyAsync(sb.data(), sg->seg_beg, sizeof(int64_t) * sb.size(), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(se.data(), sg->seg_end, sizeof(int64_t) * se.size(), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(srow.data(), sg->seg_row, sizeof(int32_t) * srow.size(), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(sslab.data(), sg->seg_slab, sizeof(int32_t) * sslab.size(), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    std::vector<int32_t> order((size_t)sg->nseg);
+    for (size_t q = 0; q < order.size(); q++) order[q] = (int32_t)q;
+    std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return sb[x] < sb[y]; });
+    std::vector<int4> trips;
+    std::vector<int32_t> gptr, single;
+    std::vector<MfxSeg> segs;
+    segs.reserve(order.size());
+    int64_t ntrips = 0;
+    for (int32_t q : order) {
+      NEED(se[q] - sb[q] <= MFX_SEG, MFX_E_STATE, "mfx_ccdpp_begin: a segment longer than %d", MFX_SEG);
+      int32_t slot = sslab[q];
+      if (slot < 0) { slot = (int32_t)(sg->nslab + (int64_t)single.size()); single.push_back(srow[q]); }
+      segs.push_back(MfxSeg{sb[q], se[q], slot});
+      ntrips += mfx_seg_trips(segs.back());
+    }
+    NEED(sg->nslab + (int64_t)single.size() < ((int64_t)1 << 31), MFX_E_ARG, "mfx_ccdpp_begin: too many segments");
+    if ((rc = dev_alloc(ctx, &ctx->ccd_single, single.size()))) return rc;
+    if (!single.empty()) HIPCHK(hipMemcpy(ctx->ccd_single, single.data(), sizeof(int32_t) * single.size(), hipMemcpyHostToDevice));
+    ctx->ccd_nsingle = (int64_t)single.size();
+    if (sg->nslab + ctx->ccd_nsingle > ctx->ccd_part_cap) {
+      dev_free(ctx->ccd_part);
+      if ((rc = dev_alloc(ctx, &ctx->ccd_part, (size_t)(sg->nslab + ctx->ccd_nsingle) * 2))) return rc;
+      ctx->ccd_part_cap = sg->nslab + ctx->ccd_nsingle;
+    }
+    NEED(ntrips < ((int64_t)1 << 31), MFX_E_ARG, "mfx_ccdpp_begin: too many trips");
+    const char* we = getenv("MFX_CCD_ROW_WGS");
+    const int max_wg = we && atoi(we) > 0 ? atoi(we) : 512;
+    const int nwg = (int)std::max<int64_t>(1, std::min<int64_t>((ntrips + 8 * 64 - 1) / (8 * 64), max_wg));   // at least eight trips per group
+    const int ng = nwg * 64;
+    trips.reserve((size_t)ntrips);
+    mfx_trips_layout(segs, 0, segs.size(), nwg, 64, trips, gptr);
+    gptr.push_back((int32_t)trips.size());
+    if ((rc = mfx_trips_upload(ctx, trips, &ctx->ccd_trips))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->ccd_gptr, gptr.size()))) return rc;
+    HIPCHK(hipMemcpy(ctx->ccd_gptr, gptr.data(), sizeof(int32_t) * gptr.size(), hipMemcpyHostToDevice));
+    ctx->ccd_ngroups = ng;
   }
   ctx->ccd_active = true;
   return MFX_OK;
 }
 
-constexpr size_t LDS_BUDGET = 160 * 1024;
-static bool lds_fits(size_t bytes) { return bytes > 0 && bytes <= 150 * 1024; }
-static hipError_t set_lds(mfx_ctx*, const void* fn, size_t bytes) {
-  return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-}
 
 static int run_pass(mfx_ctx* ctx, int side, float reg, float freq_thresh, int k) {
   if (side == 1) return mfx_ccd_cols_pass(ctx, ctx->uk, ctx->vk, reg, freq_thresh, k);
@@ -254,21 +310,25 @@ static int run_pass(mfx_ctx* ctx, int side, float reg, float freq_thresh, int k)
   const int64_t* ptr = side == 0 ? m.rowptr : m.colptr;
   const int nother = side == 0 ? ctx->nI : ctx->nU;
   if (sg->nseg > 0) {
-    ProfScope ps(ctx, side == 0 ? MFX_K_CCD_ROW : MFX_K_CCD_COL);
-    const size_t lds = (size_t)nother * sizeof(float);
+    ProfScope ps(ctx, MFX_K_CCD_ROW);
+    const size_t lds = ((size_t)nother + 1) * sizeof(float);
+    const int blocks = (ctx->ccd_ngroups + 63) / 64;
     if (lds_fits(lds)) {   // the gathered vector fits in LDS (items: C2 107 KB, C4 71 KB)
-      const int per_cu = (int)std::min<size_t>(2, LDS_BUDGET / lds);
-      const int blocks = (int)std::min<int64_t>((sg->nseg + 63) / 64, 256 * per_cu);
       HIPCHK(set_lds(ctx, (const void*)ccd_pass_kernel<true>, lds));
-      hipLaunchKernelGGL(ccd_pass_kernel<true>, dim3(blocks), dim3(1024), lds, ctx->stream, sg->seg_row, sg->seg_beg,
-                         sg->seg_end, sg->seg_slab, sg->nseg, res, ind, other, nother, reg, mine, ctx->ccd_part, ptr,
-                         freq_thresh, k, m.nnz);
+      if (getenv("MFX_DEBUG") && k == 0) {
+        int occ = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)ccd_pass_kernel<true>, 1024, lds);
+        fprintf(stderr, "[mfx] row pass: %d workgroups of 1024 threads, %zu bytes of LDS each, %d resident per CU\n", blocks, lds, occ);
+      }
+      hipLaunchKernelGGL(ccd_pass_kernel<true>, dim3(blocks), dim3(1024), lds, ctx->stream, ctx->ccd_trips, ctx->ccd_gptr, ctx->ccd_ngroups,
+                         res, (const uint16_t*)ctx->ccd_ind16, other, nother, ctx->ccd_part);
     } else {
-      const int blocks = (int)std::min<int64_t>((sg->nseg + 63) / 64, 256 * 2);
-      hipLaunchKernelGGL(ccd_pass_kernel<false>, dim3(blocks), dim3(1024), 0, ctx->stream, sg->seg_row, sg->seg_beg,
-                         sg->seg_end, sg->seg_slab, sg->nseg, res, ind, other, nother, reg, mine, ctx->ccd_part, ptr,
-                         freq_thresh, k, m.nnz);
+      hipLaunchKernelGGL(ccd_pass_kernel<false>, dim3(blocks), dim3(1024), 0, ctx->stream, ctx->ccd_trips, ctx->ccd_gptr, ctx->ccd_ngroups,
+                         res, ind, other, nother, ctx->ccd_part);
     }
+    if (ctx->ccd_nsingle > 0)
+      hipLaunchKernelGGL(ccd_divide_kernel, dim3((unsigned)((ctx->ccd_nsingle + 255) / 256)), dim3(256), 0, ctx->stream, ctx->ccd_single,
+                         ctx->ccd_nsingle, ctx->ccd_part + 2 * sg->nslab, reg, mine);
     HIPCHK(hipGetLastError());
   }
   if (sg->nmrow > 0) {
@@ -288,12 +348,12 @@ static int run_resid(mfx_ctx* ctx, const float* uk, const float* vk) {
   const int blocks = (int)std::min<int64_t>((m.nnz / 4 + 1023) / 1024 + 1, 256 * 2);
   // row view: res_row[e] +-= u_k[rowid[e]] * v_k[rowind[e]] (v_k gathered: staged in LDS when it fits);
   // column view: res_col[e] +-= u_k[colind[e]] * v_k[colid[e]] (u_k gathered from L2)
-  const size_t lds = (size_t)ctx->nI * sizeof(float);
+  const size_t lds = ((size_t)ctx->nI + 1) * sizeof(float);
   if (lds_fits(lds)) {
     const int per_cu = (int)std::min<size_t>(2, LDS_BUDGET / lds);
     HIPCHK(set_lds(ctx, (const void*)resid_update_kernel<SIGN, true>, lds));
     hipLaunchKernelGGL((resid_update_kernel<SIGN, true>), dim3(std::min(blocks, 256 * per_cu)), dim3(1024), lds,
-                       ctx->stream, ctx->res_row, m.rowid, m.rowind, uk, vk, ctx->nI, m.nnz);
+                       ctx->stream, ctx->res_row, m.rowid, (const uint16_t*)ctx->ccd_ind16, uk, vk, ctx->nI, m.nnz);
   } else {
     hipLaunchKernelGGL((resid_update_kernel<SIGN, false>), dim3(blocks), dim3(1024), 0, ctx->stream, ctx->res_row,
                        m.rowid, m.rowind, uk, vk, ctx->nI, m.nnz);
@@ -312,7 +372,7 @@ static int run_resid_fused(mfx_ctx* ctx, const float* uk0, const float* vk0, con
   if (lds_fits(lds)) {
     HIPCHK(set_lds(ctx, (const void*)resid_fused_kernel<true>, lds));
     hipLaunchKernelGGL(resid_fused_kernel<true>, dim3(std::min(blocks, 256)), dim3(1024), lds, ctx->stream,
-                       ctx->res_row, m.rowid, m.rowind, uk0, vk0, uk1, vk1, ctx->nI, m.nnz);
+                       ctx->res_row, m.rowid, (const uint16_t*)ctx->ccd_ind16, uk0, vk0, uk1, vk1, ctx->nI, m.nnz);
   } else {
     hipLaunchKernelGGL(resid_fused_kernel<false>, dim3(blocks), dim3(1024), 0, ctx->stream, ctx->res_row, m.rowid,
                        m.rowind, uk0, vk0, uk1, vk1, ctx->nI, m.nnz);

@@ -24,7 +24,8 @@ namespace {
 constexpr int UB = 8192;          // users per strip: 32 KB of u_k (two vectors fit for the fused update)
 constexpr int CSEG = 1024;        // entries per segment
 constexpr int LIGHT = 1024;       // columns with at most this many entries are handled whole, outside the strips
-constexpr int SEGS_PER_WG = 256;  // segments a 1024-thread workgroup (64 groups) works through
+constexpr int GPW = 64;            // 16-lane groups per pass workgroup (1024 threads)
+constexpr int PASS_WGS = 1024;    // pass workgroups over all strips (two rounds of the 512 resident ones; MFX_CCD_PASS_WGS)
 constexpr int64_t ENT_PER_WG = 128 * 1024;
 
 struct ColState {
@@ -32,8 +33,13 @@ struct ColState {
   int64_t nnz = 0;
   int32_t* off = nullptr;           // [nI][nb+1] CSC position where strip b starts inside column i (relative to colptr[i])
   int64_t* dst = nullptr;           // [nb][nI] blocked position of segment (b,i)
-  int32_t* buser = nullptr;         // blocked: user - b*UB
-  int32_t* bcol = nullptr;          // blocked: column id
+  // Index widths (the kernels stream these arrays, so their width is a share of the time): a strip-local user id is below
+  // UB = 8192 -> 16 bits, always; the column id is 16 bits when there are at most 65 536 columns; the light region keeps absolute
+  // 32-bit user ids in its own array (entry t of the blocked order sits at luser[t - (light0 & ~3)]: 16-byte loads stay aligned).
+  uint16_t* buser = nullptr;        // blocked, strips only: user - b*UB
+  int32_t* luser = nullptr;         // light region: absolute user id
+  uint16_t* bcol16 = nullptr;       // blocked: column id (ncols <= 65536) ...
+  int32_t* bcol32 = nullptr;        // ... or 32-bit
   float* res = nullptr;             // blocked residual (the reference's res->colval in strip-major order)
   // pass segments
   int64_t* seg_beg = nullptr; int64_t* seg_end = nullptr; int32_t* seg_col = nullptr;
@@ -42,8 +48,11 @@ struct ColState {
   double* sums = nullptr;           // sharded runs: [ncols][2] (num, den) for the all-reduce
   int32_t* col_ptr = nullptr;       // [nI+1] column -> its segments (strip-major order)
   int32_t* col_seg = nullptr;
-  // workgroup tables
-  int32_t* pw_blk = nullptr; int32_t* pw_s0 = nullptr; int32_t* pw_s1 = nullptr; int npw = 0;       // pass
+  // pass: trip list (mfx_ccd_trip_loop), one range per group; the groups of the light region first, then the strips'
+  // workgroups (GPW groups each, one strip each)
+  MfxTrips trips; int32_t* gptr = nullptr;
+  int32_t* pw_blk = nullptr; int npw = 0;      // strip of each pass workgroup
+  int ngl = 0;                                 // groups of the light region (they come first, then the npw * GPW strip groups)
   int32_t* rw_blk = nullptr; int64_t* rw_e0 = nullptr; int64_t* rw_e1 = nullptr; int nrw = 0;       // residual
   int64_t light0 = 0;               // blocked position where the light columns start (== nnz: none)
   int32_t lseg0 = 0, nlseg = 0;     // their segments (one per column) in the segment tables
@@ -62,10 +71,10 @@ int up(mfx_ctx* ctx, T** dst, const std::vector<T>& v) {
 void mfx_ccd_cols_free(mfx_ctx* ctx) {
   ColState* s = st(ctx);
   if (!s) return;
-  dev_free(s->off); dev_free(s->dst); dev_free(s->buser); dev_free(s->bcol); dev_free(s->res);
+  dev_free(s->off); dev_free(s->dst); dev_free(s->buser); dev_free(s->luser); dev_free(s->bcol16); dev_free(s->bcol32); dev_free(s->res);
   dev_free(s->seg_beg); dev_free(s->seg_end); dev_free(s->seg_col); dev_free(s->part); dev_free(s->sums);
   dev_free(s->col_ptr); dev_free(s->col_seg);
-  dev_free(s->pw_blk); dev_free(s->pw_s0); dev_free(s->pw_s1);
+  dev_free(s->pw_blk); mfx_trips_free(s->trips); dev_free(s->gptr);
   dev_free(s->rw_blk); dev_free(s->rw_e0); dev_free(s->rw_e1);
   delete s;
   ctx->ccd_cols = nullptr;
@@ -88,13 +97,15 @@ __global__ void strip_offsets_kernel(const int64_t* __restrict__ colptr, const i
 }
 
 // copy the (strip, column) pieces into strip-major order
+template <typename ColT>
 __global__ __launch_bounds__(256) void strip_scatter_kernel(const int64_t* __restrict__ colptr,
                                                             const int32_t* __restrict__ colind,
                                                             const float* __restrict__ colval,
                                                             const int32_t* __restrict__ off,
                                                             const int64_t* __restrict__ dst, int32_t ncols, int nb,
-                                                            int64_t light0, int32_t* __restrict__ buser,
-                                                            int32_t* __restrict__ bcol, float* __restrict__ res) {
+                                                            int64_t light0, uint16_t* __restrict__ buser,
+                                                            int32_t* __restrict__ luser, ColT* __restrict__ bcol,
+                                                            float* __restrict__ res) {
   const int j = threadIdx.x & 15;
   const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
   const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
@@ -103,10 +114,11 @@ __global__ __launch_bounds__(256) void strip_scatter_kernel(const int64_t* __res
     const int64_t src = colptr[i] + off[(int64_t)i * (nb + 1) + b];
     const int64_t n = off[(int64_t)i * (nb + 1) + b + 1] - off[(int64_t)i * (nb + 1) + b];
     const int64_t d = dst[(int64_t)b * ncols + i];
-    const int base = d >= light0 ? 0 : b * UB;      // light columns keep the absolute user id (u_k comes from L2)
+    const bool is_light = d >= light0;                // light columns keep the absolute user id (u_k comes from L2)
     for (int64_t t = j; t < n; t += 16) {
-      buser[d + t] = colind[src + t] - base;
-      bcol[d + t] = i;
+      if (is_light) luser[d + t - (light0 & ~(int64_t)3)] = colind[src + t];
+      else buser[d + t] = (uint16_t)(colind[src + t] - b * UB);
+      bcol[d + t] = (ColT)i;
       res[d + t] = colval[src + t];
     }
   }
@@ -151,7 +163,7 @@ int mfx_ccd_cols_build(mfx_ctx* ctx) {
   HIPCHK(hipStreamSynchronize(ctx->stream));
   // strip-major positions, segments, per-column segment lists, workgroup tables
   std::vector<int64_t> dst((size_t)nb * nI), seg_beg, seg_end, rw_e0, rw_e1;
-  std::vector<int32_t> seg_col, pw_blk, pw_s0, pw_s1, rw_blk;
+  std::vector<int32_t> seg_col, pw_blk, rw_blk, strip_seg0;
   std::vector<int32_t> col_cnt((size_t)nI, 0);
   std::vector<uint8_t> light((size_t)nI, 0);
   const char* le = getenv("MFX_CCD_LIGHT");        // experiment / test knob: the threshold (0: every column goes through the strips)
@@ -174,7 +186,8 @@ int mfx_ccd_cols_build(mfx_ctx* ctx) {
       pos += n;
     }
     const int32_t sg1 = (int32_t)seg_col.size();
-    for (int32_t a = sg0; a < sg1; a += SEGS_PER_WG) { pw_blk.push_back(b); pw_s0.push_back(a); pw_s1.push_back(std::min(sg1, a + SEGS_PER_WG)); }
+    strip_seg0.push_back(sg0);
+    (void)sg1;
     for (int64_t a = ent0; a < pos; a += ENT_PER_WG) { rw_blk.push_back(b); rw_e0.push_back(a); rw_e1.push_back(std::min(pos, a + ENT_PER_WG)); }
   }
   // the light columns behind the strips: whole columns, one segment each; piece (b, i) sits at its CSC offset
@@ -184,15 +197,46 @@ int mfx_ccd_cols_build(mfx_ctx* ctx) {
     if (!light[(size_t)i]) continue;
     const int64_t n = off[(size_t)i * (nb + 1) + nb];
     for (int b = 0; b < nb; b++) dst[(size_t)b * nI + i] = pos + off[(size_t)i * (nb + 1) + b];
-    if (n > 0) {
-      seg_beg.push_back(pos);
-      seg_end.push_back(pos + n);
+    for (int64_t c = 0; c < n; c += CSEG) {        // (longer than CSEG only under MFX_CCD_LIGHT: a trip record holds 11 bits of length)
+      seg_beg.push_back(pos + c);
+      seg_end.push_back(pos + std::min<int64_t>(n, c + CSEG));
       seg_col.push_back(i);
       col_cnt[i]++;
     }
     pos += n;
   }
   s->nlseg = (int32_t)seg_col.size() - s->lseg0;
+  strip_seg0.push_back(s->lseg0);
+  // trips: strip by strip (workgroups of one strip each), then the light columns; meta = the segment
+  std::vector<int4> trips;
+  std::vector<int32_t> gptr;
+  {
+    std::vector<MfxSeg> segs(seg_col.size());
+    std::vector<int64_t> cum(seg_col.size() + 1, 0);
+    for (size_t k = 0; k < seg_col.size(); k++) {
+      segs[k] = MfxSeg{seg_beg[k], seg_end[k], (int32_t)k};
+      cum[k + 1] = cum[k] + mfx_seg_trips(segs[k]);
+    }
+    if (cum.back() >= ((int64_t)1 << 31)) return mfx_fail(ctx, MFX_E_ARG, "mfx_ccdpp_begin: too many trips in the column view");
+    trips.reserve((size_t)cum.back());
+    const char* pe = getenv("MFX_CCD_PASS_WGS");
+    const int want_wgs = pe && atoi(pe) > 0 ? atoi(pe) : PASS_WGS;
+    const int64_t strip_trips = cum[(size_t)s->lseg0];
+    const int64_t per_wg = std::max<int64_t>(8 * GPW, (strip_trips + want_wgs - 1) / want_wgs);     // at least eight trips per group
+    const int64_t light_trips = cum.back() - strip_trips;
+    const int lwg = (int)std::min<int64_t>((light_trips + 8 * GPW - 1) / (8 * GPW), 512);
+    s->ngl = lwg * GPW;
+    if (lwg > 0) mfx_trips_layout(segs, (size_t)s->lseg0, seg_col.size(), lwg, GPW, trips, gptr);
+    for (int b = 0; b < nb; b++) {
+      const size_t k0 = (size_t)strip_seg0[(size_t)b], k1 = (size_t)strip_seg0[(size_t)b + 1];
+      const int64_t tb = cum[k1] - cum[k0];
+      if (tb == 0) continue;
+      const int nw = (int)std::max<int64_t>(1, (tb + per_wg / 2) / per_wg);
+      mfx_trips_layout(segs, k0, k1, nw, GPW, trips, gptr);
+      for (int w = 0; w < nw; w++) pw_blk.push_back(b);
+    }
+    gptr.push_back((int32_t)trips.size());
+  }
   std::vector<int32_t> col_ptr((size_t)nI + 1, 0), col_seg(seg_col.size());
   for (int32_t i = 0; i < nI; i++) col_ptr[i + 1] = col_ptr[i] + col_cnt[i];
   {
@@ -206,8 +250,8 @@ int mfx_ccd_cols_build(mfx_ctx* ctx) {
   if ((rc = up(ctx, &s->col_ptr, col_ptr))) return rc;
   if ((rc = up(ctx, &s->col_seg, col_seg))) return rc;
   if ((rc = up(ctx, &s->pw_blk, pw_blk))) return rc;
-  if ((rc = up(ctx, &s->pw_s0, pw_s0))) return rc;
-  if ((rc = up(ctx, &s->pw_s1, pw_s1))) return rc;
+  if ((rc = mfx_trips_upload(ctx, trips, &s->trips))) return rc;
+  if ((rc = up(ctx, &s->gptr, gptr))) return rc;
   if ((rc = up(ctx, &s->rw_blk, rw_blk))) return rc;
   if ((rc = up(ctx, &s->rw_e0, rw_e0))) return rc;
   if ((rc = up(ctx, &s->rw_e1, rw_e1))) return rc;
@@ -215,12 +259,20 @@ int mfx_ccd_cols_build(mfx_ctx* ctx) {
   s->npw = (int)pw_blk.size();
   s->nrw = (int)rw_blk.size();
   if ((rc = dev_alloc(ctx, &s->part, (size_t)s->nseg * 2))) return rc;
-  if ((rc = dev_alloc(ctx, &s->buser, (size_t)m.nnz))) return rc;
-  if ((rc = dev_alloc(ctx, &s->bcol, (size_t)m.nnz))) return rc;
+  const bool col16 = nI <= 65536;
+  if ((rc = dev_alloc(ctx, &s->buser, (size_t)s->light0 + 4))) return rc;
+  if ((rc = dev_alloc(ctx, &s->luser, (size_t)(m.nnz - (s->light0 & ~(int64_t)3)) + 4))) return rc;
+  if (col16) { if ((rc = dev_alloc(ctx, &s->bcol16, (size_t)m.nnz + 4))) return rc; }
+  else if ((rc = dev_alloc(ctx, &s->bcol32, (size_t)m.nnz + 4))) return rc;
   if ((rc = dev_alloc(ctx, &s->res, (size_t)m.nnz))) return rc;
+  HIPCHK(hipMemsetAsync(s->res + m.nnz, 0, 16, ctx->stream));    // read (masked) by the pass loop: finite
   if (m.nnz > 0) {
-    hipLaunchKernelGGL(strip_scatter_kernel, dim3(2048), dim3(256), 0, ctx->stream, m.colptr, m.colind, m.colval,
-                       s->off, s->dst, nI, nb, s->light0, s->buser, s->bcol, s->res);
+    if (col16)
+      hipLaunchKernelGGL(strip_scatter_kernel<uint16_t>, dim3(2048), dim3(256), 0, ctx->stream, m.colptr, m.colind, m.colval,
+                         s->off, s->dst, nI, nb, s->light0, s->buser, s->luser, s->bcol16, s->res);
+    else
+      hipLaunchKernelGGL(strip_scatter_kernel<int32_t>, dim3(2048), dim3(256), 0, ctx->stream, m.colptr, m.colind, m.colval,
+                         s->off, s->dst, nI, nb, s->light0, s->buser, s->luser, s->bcol32, s->res);
     HIPCHK(hipGetLastError());
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -235,60 +287,45 @@ __device__ __forceinline__ void stage_strip(float* lds, const float* __restrict_
   for (int q = (n4 << 2) + threadIdx.x; q < n; q += blockDim.x) lds[q] = v[first + q];
 }
 
-__device__ __forceinline__ double g16_sum(double v) {
-#pragma unroll
-  for (int m = 8; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  return v;
-}
+__device__ __forceinline__ double g16_sum(double v) { return mfx_row16_sum(v); }
 
-// column pass: one 16-lane group per (strip, column) segment, u_k strip in LDS
-__global__ __launch_bounds__(1024) void colpass_kernel(const int32_t* __restrict__ pw_blk,
-                                                       const int32_t* __restrict__ pw_s0,
-                                                       const int32_t* __restrict__ pw_s1,
-                                                       const int64_t* __restrict__ seg_beg,
-                                                       const int64_t* __restrict__ seg_end,
-                                                       const float* __restrict__ res,
-                                                       const int32_t* __restrict__ buser,
-                                                       const float* __restrict__ uk, int nU,
-                                                       double* __restrict__ part, int64_t nmax) {
-  __shared__ __attribute__((aligned(16))) float su[UB];
-  const int b = pw_blk[blockIdx.x];
-  stage_strip(su, uk, b * UB, min(UB, nU - b * UB));
-  __syncthreads();
-  const int j = threadIdx.x & 15, grp = threadIdx.x >> 4;
-  mfx_ccd_pass_loop(seg_beg, seg_end, (int64_t)pw_s0[blockIdx.x] + grp, (int64_t)pw_s1[blockIdx.x], 64, res, buser, su, j, nmax,
-                    [&](int64_t s, double num, double den) {
-                      num = g16_sum(num);
-                      den = g16_sum(den);
-                      if (j == 0) { part[2 * s] = num; part[2 * s + 1] = den; }
-                    });
-}
-
-// light columns: one 16-lane group per column (one segment), u_k gathered from L2 by the absolute user id
-__global__ __launch_bounds__(256) void colpass_light_kernel(const int64_t* __restrict__ seg_beg, const int64_t* __restrict__ seg_end,
-                                                            int32_t lseg0, int32_t nlseg, const float* __restrict__ res,
-                                                            const int32_t* __restrict__ buser, const float* __restrict__ uk,
-                                                            double* __restrict__ part, int64_t nmax) {
+// column pass: one 16-lane group per range of the trip list.  Workgroups [0, nlw): the light columns, u_k gathered from L2 by
+// the absolute user id; the others: one strip each, the strip of u_k in LDS and strip-local 16-bit user ids.  ONE launch, the
+// latency-bound light part (4 % of the entries, but 42 us on its own at C4) first, so that it runs under the strips.
+__global__ __launch_bounds__(1024) void colpass_kernel(const MfxTrips trips, const int32_t* __restrict__ gptr,
+                                                       const int32_t* __restrict__ pw_blk, int nlw, int g_count,
+                                                       const float* __restrict__ res, const uint16_t* __restrict__ buser,
+                                                       const int32_t* __restrict__ luser, const float* __restrict__ uk, int nU_strips,
+                                                       int nU, double* __restrict__ part) {
+  __shared__ __attribute__((aligned(16))) float su[UB + 4];
+  const bool strip = (int)blockIdx.x >= nlw;       // the light workgroups come first: they start first and run under the strips
+  if (strip) {
+    const int b = pw_blk[(int)blockIdx.x - nlw];
+    stage_strip(su, uk, b * UB, min(UB, nU_strips - b * UB));
+    if (threadIdx.x == 0) su[UB] = 0.0f;          // what masked entries gather
+    __syncthreads();
+  }
   const int j = threadIdx.x & 15;
-  const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-  if (grp >= nlseg) return;
-  mfx_ccd_pass_loop(seg_beg, seg_end, (int64_t)lseg0 + grp, (int64_t)lseg0 + grp + 1, 1, res, buser, uk, j, nmax,
-                    [&](int64_t s, double num, double den) {
-                      num = g16_sum(num);
-                      den = g16_sum(den);
-                      if (j == 0) { part[2 * s] = num; part[2 * s + 1] = den; }
-                    });
+  const int g = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
+  if (g >= g_count) return;
+  auto fin = [&](int, int seg, double num, double den) {
+    num = g16_sum(num);
+    den = g16_sum(den);
+    if (j == 0) mfx_store_unseen(part + 2 * (int64_t)seg, num, den);
+  };
+  if (strip) mfx_ccd_trip_loop(trips, gptr[g], gptr[g + 1], res, buser, su, UB, j, fin);
+  else mfx_ccd_trip_loop(trips, gptr[g], gptr[g + 1], res, luser, uk, nU, j, fin);      // uk[nU] = +0.0 (mfx_ccdpp_begin)
 }
 
 // residual update of the light region (MODE as colresid_kernel): u_k from L2
-template <int MODE>
-__global__ __launch_bounds__(256) void colresid_light_kernel(int64_t e0, int64_t e1, float* __restrict__ res, const int32_t* __restrict__ buser,
-                                                             const int32_t* __restrict__ bcol, const float* __restrict__ uk0,
+template <int MODE, typename ColT>
+__global__ __launch_bounds__(256) void colresid_light_kernel(int64_t e0, int64_t e1, float* __restrict__ res, const int32_t* __restrict__ luser,
+                                                             int64_t lshift, const ColT* __restrict__ bcol, const float* __restrict__ uk0,
                                                              const float* __restrict__ vk0, const float* __restrict__ uk1,
                                                              const float* __restrict__ vk1) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t t = e0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < e1; t += stride) {
-    const int u = buser[t], c = bcol[t];
+    const int u = luser[t - lshift], c = (int)bcol[t];
     const float p0 = uk0[u] * vk0[c];
     float r = res[t];
     if (MODE == 1) r = r + p0;
@@ -343,12 +380,12 @@ __global__ void coldivide_kernel(const double* __restrict__ sums, const double* 
 
 // residual update on the strip-major column view.  MODE +1: res += u0*v0, -1: res -= u0*v0,
 // 2: res = (res - u0*v0) + u1*v1 (deferred subtract fused with the next add-back)
-template <int MODE>
+template <int MODE, typename ColT>
 __global__ __launch_bounds__(1024) void colresid_kernel(const int32_t* __restrict__ rw_blk,
                                                         const int64_t* __restrict__ rw_e0,
                                                         const int64_t* __restrict__ rw_e1, float* __restrict__ res,
-                                                        const int32_t* __restrict__ buser,
-                                                        const int32_t* __restrict__ bcol,
+                                                        const uint16_t* __restrict__ buser,
+                                                        const ColT* __restrict__ bcol,
                                                         const float* __restrict__ uk0, const float* __restrict__ vk0,
                                                         const float* __restrict__ uk1, const float* __restrict__ vk1,
                                                         int nU) {
@@ -364,7 +401,7 @@ __global__ __launch_bounds__(1024) void colresid_kernel(const int32_t* __restric
   const int64_t e0 = rw_e0[blockIdx.x], e1 = rw_e1[blockIdx.x];
   for (int64_t t = (e0 & ~(int64_t)3) + 4 * (int64_t)threadIdx.x; t < e1; t += 4 * (int64_t)blockDim.x) {
     if (t >= e0 && t + 4 <= e1) {
-      const i4 lu = *(const i4*)(buser + t), c = *(const i4*)(bcol + t);
+      const i4 lu = MfxCcdTrip::load4(buser + t), c = MfxCcdTrip::load4(bcol + t);
       f4 r = *(const f4*)(res + t);
 #pragma unroll
       for (int q = 0; q < 4; q++) {
@@ -378,7 +415,7 @@ __global__ __launch_bounds__(1024) void colresid_kernel(const int32_t* __restric
       for (int q = 0; q < 4; q++) {
         const int64_t tt = t + q;
         if (tt < e0 || tt >= e1) continue;
-        const int lu = buser[tt], c = bcol[tt];
+        const int lu = (int)buser[tt], c = (int)bcol[tt];
         const float p0 = su[lu] * vk0[c];
         float r = res[tt];
         if (MODE == 1) r = r + p0;
@@ -393,14 +430,12 @@ __global__ __launch_bounds__(1024) void colresid_kernel(const int32_t* __restric
 int mfx_ccd_cols_pass(mfx_ctx* ctx, const float* uk, float* vk, float reg, float freq_thresh, int k) {
   ColState* s = st(ctx);
   const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
-  if (s->npw > 0 || s->nlseg > 0) {
+  if (s->npw > 0 || s->ngl > 0) {
     ProfScope ps(ctx, MFX_K_CCD_COL);
-    if (s->npw > 0)
-      hipLaunchKernelGGL(colpass_kernel, dim3(s->npw), dim3(1024), 0, ctx->stream, s->pw_blk, s->pw_s0, s->pw_s1,
-                         s->seg_beg, s->seg_end, s->res, s->buser, uk, m.nrows, s->part, s->nnz);
-    if (s->nlseg > 0)
-      hipLaunchKernelGGL(colpass_light_kernel, dim3((unsigned)(((int64_t)s->nlseg * 16 + 255) / 256)), dim3(256), 0, ctx->stream, s->seg_beg,
-                         s->seg_end, s->lseg0, s->nlseg, s->res, s->buser, uk, s->part, s->nnz);
+    // entry t of the blocked order sits at luser[t - (light0 & ~3)]
+    hipLaunchKernelGGL(colpass_kernel, dim3(s->npw + s->ngl / GPW), dim3(16 * GPW), 0, ctx->stream, s->trips, s->gptr, s->pw_blk, s->ngl / GPW,
+                       s->npw * GPW + s->ngl, s->res, (const uint16_t*)s->buser, (const int32_t*)(s->luser - (s->light0 & ~(int64_t)3)), uk,
+                       m.nrows, ctx->nU, s->part);
     const unsigned fb = (unsigned)(((int64_t)m.ncols * 16 + 255) / 256);
     if (!mfx_sharded(ctx)) {
       hipLaunchKernelGGL(colfinish_kernel<false>, dim3(fb), dim3(256), 0, ctx->stream, s->col_ptr, s->col_seg, s->part,
@@ -435,16 +470,30 @@ int mfx_ccd_cols_resid(mfx_ctx* ctx, int mode, const float* uk0, const float* vk
   ColState* s = st(ctx);
   const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
   if (s->nrw > 0) {
-#define MFX_CR(MD)                                                                                             \
-  hipLaunchKernelGGL(colresid_kernel<MD>, dim3(s->nrw), dim3(1024), 0, ctx->stream, s->rw_blk, s->rw_e0, s->rw_e1, \
-                     s->res, s->buser, s->bcol, uk0, vk0, uk1, vk1, m.nrows)
+#define MFX_CR(MD)                                                                                                                 \
+  do {                                                                                                                             \
+    if (s->bcol16)                                                                                                                 \
+      hipLaunchKernelGGL((colresid_kernel<MD, uint16_t>), dim3(s->nrw), dim3(1024), 0, ctx->stream, s->rw_blk, s->rw_e0, s->rw_e1, \
+                         s->res, s->buser, s->bcol16, uk0, vk0, uk1, vk1, m.nrows);                                                \
+    else                                                                                                                           \
+      hipLaunchKernelGGL((colresid_kernel<MD, int32_t>), dim3(s->nrw), dim3(1024), 0, ctx->stream, s->rw_blk, s->rw_e0, s->rw_e1,  \
+                         s->res, s->buser, s->bcol32, uk0, vk0, uk1, vk1, m.nrows);                                                \
+  } while (0)
     if (mode == 1) MFX_CR(1); else if (mode == 2) MFX_CR(2); else MFX_CR(-1);
 #undef MFX_CR
   }
   if (s->light0 < s->nnz) {
     const unsigned lb = (unsigned)std::min<int64_t>((s->nnz - s->light0 + 255) / 256, 4096);
-#define MFX_CL(MD) \
-  hipLaunchKernelGGL(colresid_light_kernel<MD>, dim3(lb), dim3(256), 0, ctx->stream, s->light0, s->nnz, s->res, s->buser, s->bcol, uk0, vk0, uk1, vk1)
+    const int64_t lsh = s->light0 & ~(int64_t)3;
+#define MFX_CL(MD)                                                                                                                \
+  do {                                                                                                                            \
+    if (s->bcol16)                                                                                                                \
+      hipLaunchKernelGGL((colresid_light_kernel<MD, uint16_t>), dim3(lb), dim3(256), 0, ctx->stream, s->light0, s->nnz, s->res,   \
+                         s->luser, lsh, s->bcol16, uk0, vk0, uk1, vk1);                                                           \
+    else                                                                                                                          \
+      hipLaunchKernelGGL((colresid_light_kernel<MD, int32_t>), dim3(lb), dim3(256), 0, ctx->stream, s->light0, s->nnz, s->res,    \
+                         s->luser, lsh, s->bcol32, uk0, vk0, uk1, vk1);                                                           \
+  } while (0)
     if (mode == 1) MFX_CL(1); else if (mode == 2) MFX_CL(2); else MFX_CL(-1);
 #undef MFX_CL
   }

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -41,6 +42,9 @@ struct RowSegs {
   int64_t nseg = 0, nmrow = 0, nslab = 0;
   bool built = false;
 };
+
+// trip list of a CCD++ pass (see mfx_ccd_trip_loop)
+struct MfxTrips { int32_t* q = nullptr; int32_t* pk = nullptr; int32_t* meta = nullptr; };
 
 struct ProfSlot {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
@@ -96,6 +100,12 @@ struct mfx_ctx {
   double* ccd_part = nullptr;
   int64_t ccd_part_cap = 0;
   int32_t* colid = nullptr;
+  uint16_t* ccd_ind16 = nullptr;   // rowind as 16-bit ids (CCD++ row view, when v_k fits LDS: at most 38 400 items)
+  MfxTrips ccd_trips;              // row view: trip list and the groups' ranges (mfx_ccd_trip_loop)
+  int32_t* ccd_gptr = nullptr;
+  int ccd_ngroups = 0;
+  int32_t* ccd_single = nullptr;   // rows with ONE segment; their (num, den) slot is nslab + position in this list
+  int64_t ccd_nsingle = 0;
   void* ccd_cols = nullptr;   // strip-major column view (ccd_cols.hip owns the type)
   void* cd = nullptr;         // trainCCD state (cd.hip owns the type)
   void* als_wide = nullptr;   // ALS for K > 64 (als_wide.hip owns the type)
@@ -156,7 +166,7 @@ template <typename T>
 static inline int dev_alloc(mfx_ctx* ctx, T** p, size_t n) {
   *p = nullptr;
   if (n == 0) n = 1;
-  HIPCHK(hipMalloc((void**)p, n * sizeof(T)));
+  HIPCHK(hipMalloc((void**)p, n * sizeof(T) + 16));   // 16 readable bytes behind every array: aligned 16-byte loads of a last partial quad
   return MFX_OK;
 }
 template <typename T>
@@ -194,75 +204,214 @@ __host__ __device__ static inline int64_t mfx_perm_index(int64_t t, int64_t n, i
 }
 
 
-// The CCD++ pass loop of one 16-lane group (lane j): for the segments s = s_first, s_first + s_step, ... < s_last,
-// (num, den) = (sum res*o, sum o*o) over the entries [seg_beg[s], seg_end[s]), o = other[ind[t]] -- float products, double
-// accumulation (modelMF.cpp:1069-1070, 1085-1086) -- handed lane-wise to fin(s, num, den), which finishes with its
-// butterfly over the group: a fixed association.
-// Every lane loads 16 ALIGNED bytes of indices and of residuals per trip (64 entries per group per trip; entries in front of
-// the segment or behind it are masked to +0.0).  Segments are short (C4: 200 entries per row, 270 per (strip, column)
-// piece), so the loop is software-pipelined ACROSS segments: while segment s is summed, the first trip of the next one and
-// the bounds of the one after are already in flight -- a group never sits idle on a dependent bounds -> data round trip.
+// The CCD++ pass of one 16-lane group (lane j): (num, den) = (sum res*o, sum o*o) over the entries of a segment,
+// o = other[ind[t]] -- float products, double accumulation (modelMF.cpp:1069-1070, 1085-1086) -- handed lane-wise to
+// fin(packed, meta, num, den), which finishes with its butterfly over the group: a fixed association.
+//
+// The passes are HBM-streaming and the segments are short (C4: 200 entries per row, 270 per (strip, column) piece), so what
+// matters is that loads stay in flight across segment ends.  The host flattens the segments into TRIPS (mfx_trips_*): a trip
+// is 64 entries of one segment starting at an aligned position; its 16-byte record holds the position, where the segment
+// lies inside it, and what fin needs.  A group works through a contiguous range of the trip list -- ranges are cut at
+// segment boundaries with equal numbers of trips, i.e. equal work.  The kernel loop has no data-dependent control flow
+// around its loads: step k issues the data loads of trip k+2 (16 ALIGNED bytes of residuals and 8 or 16 of indices per lane,
+// unconditionally; entries in front of the segment or behind it are masked when they are consumed), sums trip k, and issues
+// the record load of trip k+4.  It is unrolled four steps by hand: rotating the buffers with copies would make the compiler
+// wait for the loads it has just issued (measured on the first version: every wait was vmcnt(0), the waves were parked 80 %
+// of the time and the pass ran at 3.4 TB/s whatever the bytes per entry).
+// Arrays: every device allocation has 16 readable bytes behind it (dev_alloc); the residual pad must hold finite values
+// (mfx_ccdpp_begin zeroes it), because a masked entry still multiplies its residual -- by the +0.0 it gathers at `zero`, an
+// index at which `other` holds +0.0 (the callers keep such a slot behind the vector): the products are +-0 and leave the
+// double sums untouched; one compare and one select per entry instead of three selects.  (A NaN residual next to a segment
+// would leak into it; residuals are finite unless the model has diverged, and then Model::isTerminateModel's guard fires.)
+// IdxT: int32_t, or uint16_t where the gathered vector has at most 65536 entries (6 instead of 8 bytes per entry and trip).
+template <typename IdxT> struct MfxIdx4;
+template <> struct MfxIdx4<int32_t> {
+  typedef int raw __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ int get(raw v, int q) { return v[q]; }
+};
+template <> struct MfxIdx4<uint16_t> {
+  typedef unsigned raw __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ int get(raw v, int q) { return (int)((q & 1) ? (v[q >> 1] >> 16) : (v[q >> 1] & 0xffffu)); }
+};
+// four consecutive ids as ints (streaming kernels other than the passes)
 struct MfxCcdTrip {
-  typedef float f4 __attribute__((ext_vector_type(4)));
   typedef int i4 __attribute__((ext_vector_type(4)));
-  i4 x;
-  f4 r;
-  __device__ __forceinline__ void load(const float* __restrict__ res, const int32_t* __restrict__ ind, int64_t t, int64_t e, int64_t nmax) {
-    x = i4{0, 0, 0, 0};
-    r = f4{0.0f, 0.0f, 0.0f, 0.0f};
-    if (t >= e) return;
-    if (t + 4 <= nmax) {
-      x = *(const i4*)(ind + t);
-      r = *(const f4*)(res + t);
-    } else {
-#pragma unroll
-      for (int q = 0; q < 4; q++)
-        if (t + q < nmax) { x[q] = ind[t + q]; r[q] = res[t + q]; }
-    }
-  }
-  __device__ __forceinline__ void consume(const float* other, int64_t t, int64_t b, int64_t e, double& num, double& den) const {
-    float o[4], rr[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const bool ok = t + q >= b && t + q < e;
-      o[q] = other[ok ? x[q] : 0];
-      o[q] = ok ? o[q] : 0.0f;
-      rr[q] = ok ? r[q] : 0.0f;
-    }
-#pragma unroll
-    for (int q = 0; q < 4; q++) { num += (double)(rr[q] * o[q]); den += (double)(o[q] * o[q]); }
+  static __device__ __forceinline__ i4 load4(const int32_t* p) { return *(const i4*)p; }
+  static __device__ __forceinline__ i4 load4(const uint16_t* p) {
+    const MfxIdx4<uint16_t>::raw v = *(const MfxIdx4<uint16_t>::raw*)p;
+    return i4{MfxIdx4<uint16_t>::get(v, 0), MfxIdx4<uint16_t>::get(v, 1), MfxIdx4<uint16_t>::get(v, 2), MfxIdx4<uint16_t>::get(v, 3)};
   }
 };
-template <class Fin>
-__device__ __forceinline__ void mfx_ccd_pass_loop(const int64_t* __restrict__ seg_beg, const int64_t* __restrict__ seg_end, int64_t s_first,
-                                                  int64_t s_last, int64_t s_step, const float* __restrict__ res,
-                                                  const int32_t* __restrict__ ind, const float* other, int j, int64_t nmax, Fin&& fin) {
-  int64_t s = s_first;
-  if (s >= s_last) return;
-  int64_t b = seg_beg[s], e = seg_end[s];
-  int64_t sn = s + s_step, bn = 0, en = 0;
-  if (sn < s_last) { bn = seg_beg[sn]; en = seg_end[sn]; }
-  MfxCcdTrip cur, nxt, more;
-  cur.load(res, ind, (b & ~(int64_t)3) + 4 * j, e, nmax);
-  for (;;) {
-    const int64_t snn = sn + s_step;
-    int64_t bnn = 0, enn = 0;
-    if (snn < s_last) { bnn = seg_beg[snn]; enn = seg_end[snn]; }                        // bounds two segments ahead
-    nxt.load(res, ind, (bn & ~(int64_t)3) + 4 * j, sn < s_last ? en : bn, nmax);      // first trip of the next segment
-    double num = 0.0, den = 0.0;
-    int64_t t = (b & ~(int64_t)3) + 4 * j;
-    cur.consume(other, t, b, e, num, den);
-    for (t += 64; t < e; t += 128) {          // long segments: two trips in flight
-      cur.load(res, ind, t, e, nmax);
-      more.load(res, ind, t + 64, e, nmax);
-      cur.consume(other, t, b, e, num, den);
-      more.consume(other, t + 64, b, e, num, den);
-    }
-    fin(s, num, den);
-    if (sn >= s_last) break;
-    s = sn; b = bn; e = en; cur = nxt;
-    sn = snn; bn = bnn; en = enn;
+// sum over the 16 lanes of a DPP row, every lane gets it; levels xor 1, 2 (quad_perm), then the partner quad / half
+// (row_half_mirror, row_mirror: after the lower levels the lanes of a quad / half hold the same bits) -- no LDS round trips
+template <int CTRL>
+__device__ __forceinline__ double mfx_dpp_f64(double x) {
+  // (the form without an "old" operand: these controls read no lane outside the row, and an old value costs a move each)
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double mfx_row16_sum(double v) {
+  v += mfx_dpp_f64<0xB1>(v);
+  v += mfx_dpp_f64<0x4E>(v);
+  v += mfx_dpp_f64<0x141>(v);
+  v += mfx_dpp_f64<0x140>(v);
+  return v;
+}
+
+// Result stores of the pass kernels, issued as inline assembly ON PURPOSE: gfx9 counts loads and stores on one counter
+// (vmcnt), and with a store pending the compiler must assume out-of-order completion and turns every later wait for a load
+// into vmcnt(0) -- the whole prefetch pipeline drains at each segment end.  A store the compiler does not see keeps its load
+// counting exact, and the counting stays SAFE: loads complete in order among themselves, so "at most N operations outstanding"
+// with N later loads issued still implies the awaited load has arrived, whatever the stores do.  Nothing reads these
+// locations again inside the kernel; the end of the kernel makes them visible.
+__device__ __forceinline__ void mfx_store_unseen(float* p, float v) {
+  asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void mfx_store_unseen(double* p, double a, double b) {
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  const u4 v = {(unsigned)__double2loint(a), (unsigned)__double2hiint(a), (unsigned)__double2loint(b), (unsigned)__double2hiint(b)};
+  asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+}
+
+
+// trip record: x = position / 4, y = a | i << 2 | len << 7 | last << 18 | flag << 19 (a = segment start mod 4, i = trip
+// number inside the segment, len = entries of the segment <= 2047), z = meta.  On the device the three fields are three
+// arrays (MfxTrips): loaded as one 12-byte tuple, the register allocator split the tuple over the loop-carried registers with
+// copies at the loop end, and a copy of a value that has just been requested is a wait for it.
+
+constexpr int MFX_TRIP_LAST = 1 << 18, MFX_TRIP_FLAG = 1 << 19;
+struct MfxSeg { int64_t b, e; int32_t meta; };
+static inline int mfx_seg_trips(const MfxSeg& g) { return (int)std::max<int64_t>(1, (g.e - (g.b & ~(int64_t)3) + 63) / 64); }
+static inline void mfx_trips_append(std::vector<int4>& trips, const MfxSeg& g) {
+  const int64_t t0 = g.b & ~(int64_t)3;
+  const int a = (int)(g.b & 3), len = (int)(g.e - g.b), ntr = mfx_seg_trips(g);
+  for (int i = 0; i < ntr; i++) {
+    int4 r;
+    r.x = (int)(uint32_t)((t0 + 64 * (int64_t)i) >> 2);
+    r.y = a | (i << 2) | (len << 7) | (i == ntr - 1 ? MFX_TRIP_LAST : 0);
+    r.z = g.meta;
+    r.w = 0;
+    trips.push_back(r);
   }
+}
+// Lay the segments segs[k0, k1) -- given in MEMORY order -- out for nwg workgroups of gpw groups each: the workgroups get
+// consecutive runs of segments with equal numbers of trips; inside a workgroup every next segment goes to the group with
+// the fewest trips so far.  The groups of a workgroup therefore advance through ONE window of memory together (with a range
+// of its own per group, 32 768 groups were 32 768 streams of 256-byte reads: every access opened a DRAM row of its own and
+// the pass stayed at 3.5 TB/s whatever else was improved), and they finish together.  The trips of a group are consecutive
+// in the list; gptr receives nwg * gpw range starts (the caller appends the end of its last range).
+static inline void mfx_trips_layout(const std::vector<MfxSeg>& segs, size_t k0, size_t k1, int nwg, int gpw, std::vector<int4>& trips,
+                                    std::vector<int32_t>& gptr) {
+  int64_t total = 0;
+  for (size_t k = k0; k < k1; k++) total += mfx_seg_trips(segs[k]);
+  std::vector<std::vector<int32_t>> mine((size_t)gpw);
+  std::vector<int64_t> load((size_t)gpw);
+  size_t k = k0;
+  int64_t done = 0;
+  for (int w = 0; w < nwg; w++) {
+    const int64_t want = total * (w + 1) / nwg;
+    for (auto& v : mine) v.clear();
+    std::fill(load.begin(), load.end(), 0);
+    int g = 0;
+    while (k < k1 && (done < want || w == nwg - 1)) {
+      // least loaded group, scanning from the one after the last choice (ties go round-robin)
+      int best = g;
+      for (int q = 0; q < gpw; q++) { const int c = (g + q) % gpw; if (load[(size_t)c] < load[(size_t)best]) best = c; }
+      const int nt = mfx_seg_trips(segs[k]);
+      mine[(size_t)best].push_back((int32_t)k);
+      load[(size_t)best] += nt;
+      done += nt;
+      g = (best + 1) % gpw;
+      k++;
+    }
+    for (int q = 0; q < gpw; q++) {
+      gptr.push_back((int32_t)trips.size());
+      for (int32_t sidx : mine[(size_t)q]) mfx_trips_append(trips, segs[(size_t)sidx]);
+    }
+  }
+}
+static inline void mfx_trips_free(MfxTrips& t) { dev_free(t.q); dev_free(t.pk); dev_free(t.meta); }
+static inline int mfx_trips_upload(mfx_ctx* ctx, const std::vector<int4>& trips, MfxTrips* out) {
+  mfx_trips_free(*out);
+  std::vector<int32_t> a(trips.size()), b(trips.size()), c(trips.size());
+  for (size_t k = 0; k < trips.size(); k++) { a[k] = trips[k].x; b[k] = trips[k].y; c[k] = trips[k].z; }
+  int rc;
+  if ((rc = dev_alloc(ctx, &out->q, a.size())) || (rc = dev_alloc(ctx, &out->pk, a.size())) || (rc = dev_alloc(ctx, &out->meta, a.size()))) return rc;
+  if (!a.empty()) {
+    HIPCHK(hipMemcpy(out->q, a.data(), sizeof(int32_t) * a.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(out->pk, b.data(), sizeof(int32_t) * a.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(out->meta, c.data(), sizeof(int32_t) * a.size(), hipMemcpyHostToDevice));
+  }
+  return MFX_OK;
+}
+
+// Diagnostic builds (scripts/exp_ccd.sh; results are WRONG on purpose): what the pass time does when one part is taken out.
+// bit 0: no gathers (o = 1)  bit 1: no data loads  bit 2: no segment ends (fin never runs)  bit 3: no record loads
+// bit 4: float sums instead of double.  0 (the product): nothing of this is compiled.
+#ifndef MFX_CCD_EXP
+#define MFX_CCD_EXP 0
+#endif
+template <typename IdxT, class Fin>
+__device__ __forceinline__ void mfx_ccd_trip_loop(const MfxTrips trips, int n0, int n1, const float* __restrict__ res,
+                                                  const IdxT* __restrict__ ind, const float* other, int zero, int j, Fin&& fin) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef typename MfxIdx4<IdxT>::raw raw_t;
+  if (n0 >= n1) return;
+  struct Data { raw_t x; f4 r; };
+  struct Rec { int x, y, z; };
+  const int exp_q0 = (MFX_CCD_EXP & 8) ? trips.q[n0] : 0, exp_q1 = (MFX_CCD_EXP & 8) ? trips.q[n1 - 1] : 0, exp_m = (MFX_CCD_EXP & 8) ? trips.meta[n0] : 0;
+  auto rec = [&](int n) {                                                   // behind the range: the last record again (masked below)
+    const int nc = n < n1 ? n : n1 - 1;
+    Rec r;
+    if (MFX_CCD_EXP & 8) { r.x = min(exp_q0 + 16 * (n - n0), exp_q1); r.y = (64 << 7) | ((n & 3) == 3 ? MFX_TRIP_LAST : 0); r.z = exp_m; return r; }   // in-bounds: a group's trips ascend in memory
+    r.x = trips.q[nc]; r.y = trips.pk[nc]; r.z = trips.meta[nc];
+    return r;
+  };
+  auto data = [&](const Rec& r) {
+    Data d;
+    const int64_t t = ((int64_t)(uint32_t)r.x << 2) + 4 * j;
+    if (MFX_CCD_EXP & 2) { d.x = raw_t{}; d.x[0] = r.x; d.r = f4{1.0f, 2.0f, 3.0f, 4.0f}; return d; }
+    d.x = *(const raw_t*)(ind + t);
+    d.r = *(const f4*)(res + t);
+    return d;
+  };
+  double num = 0.0, den = 0.0;
+  // one step: gathers of trip n, then the prefetches (data of n + 2 from its record, which arrived two steps ago), then the sums
+#define MFX_TRIP_STEP(N, RC, DC, RN, DN)                                                                                  \
+  {                                                                                                                       \
+    const int pk = (N) < n1 ? RC.y : 0;                                                                                   \
+    const unsigned len = ((unsigned)pk >> 7) & 0x7ffu;                                                                    \
+    const unsigned rel = (unsigned)(64 * ((pk >> 2) & 31) - (pk & 3) + 4 * j);                                            \
+    float o[4];                                                                                                           \
+    _Pragma("unroll") for (int q = 0; q < 4; q++)                                                                         \
+      o[q] = (MFX_CCD_EXP & 1) ? (rel + (unsigned)q < len ? __int_as_float(MfxIdx4<IdxT>::get(DC.x, q) | 0x3f800000) : 0.0f) \
+                               : other[rel + (unsigned)q < len ? MfxIdx4<IdxT>::get(DC.x, q) : zero];                      \
+    const f4 rr = DC.r;                                                                                                   \
+    const int meta = RC.z;                                                                                                \
+    DN = data(RN);                                                                                                        \
+    if (MFX_CCD_EXP & 16) {                                                                                               \
+      float fn = 0.0f, fd = 0.0f;                                                                                         \
+      _Pragma("unroll") for (int q = 0; q < 4; q++) { fn += rr[q] * o[q]; fd += o[q] * o[q]; }                            \
+      num += (double)fn; den += (double)fd;                                                                               \
+    } else {                                                                                                              \
+      _Pragma("unroll") for (int q = 0; q < 4; q++) { num += (double)(rr[q] * o[q]); den += (double)(o[q] * o[q]); }    \
+    }                                                                                                                     \
+    if ((pk & MFX_TRIP_LAST) && !(MFX_CCD_EXP & 4)) {                                                                     \
+      fin(pk, meta, num, den);                                                                                            \
+      num = 0.0; den = 0.0;                                                                                               \
+    }                                                                                                                     \
+    RC = rec((N) + 4);   /* after the last use of the old record: the load lands in the same registers, no copy */        \
+  }
+  Rec r0 = rec(n0), r1 = rec(n0 + 1), r2 = rec(n0 + 2), r3 = rec(n0 + 3);
+  Data d0 = data(r0), d1 = data(r1), d2, d3;
+  for (int n = n0; n < n1; n += 4) {
+    MFX_TRIP_STEP(n, r0, d0, r2, d2)
+    MFX_TRIP_STEP(n + 1, r1, d1, r3, d3)
+    MFX_TRIP_STEP(n + 2, r2, d2, r0, d0)
+    MFX_TRIP_STEP(n + 3, r3, d3, r1, d1)
+  }
+#undef MFX_TRIP_STEP
 }
 
 static inline void mfx_tree_shape(int K, int* L, int* C) {

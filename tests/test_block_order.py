@@ -64,6 +64,7 @@ def test_tiled_order_without_any_concurrency_diverges_like_the_references_block_
     with mfx.Ctx(0) as ctx:
         ctx.set_csr(mfx.MAT_TRAIN, nU, nI, tr.rowptr, tr.rowind, tr.rowval)
         ctx.set_model(nU, nI, K)
+        ctx.compute_invalid()
         for lr in (LR, LR / 2):
             ctx.set_factors(U0, V0)
             ctx.sgd_epoch(lr, 0.02, 0.02, mode=mfx.SGD_TILED, order=mfx.ORDER_DEVICE, arith=mfx.ARITH_F32, seed=1, epoch=0,

@@ -276,9 +276,27 @@ def test_fast_sgd_paths_reach_the_reference_rmse(method):
     o = oracle_train(orc.M_SGD, d, K, 120, 1, 0.01, 0.02, 0.02)
     print(method, "test RMSE gpu %.5f cpu %.5f | val gpu %.5f cpu %.5f" % (h["test"], o["test"], h["val"], o["valbest"]))
     # Lock-free: after 120 iterations the best-validation models agree to -0.006..-0.002 over repeated runs
-    # (scripts/sgd_gap_variance.py).  At 40 iterations the gap is still 0.017-0.019 and a first-epoch NaN (racing updates
-    # at this learning rate on a 3000 x 2000 matrix; the reference's guard halves the rate) can double it.
+    # (scripts/sgd_gap_variance.py).  At this rate the block order (the reference's trainSGDPar order just as well:
+    # tests/test_block_order.py) leaves its first epoch non-finite and the reference's guard halves the rate once.
     assert abs(h["test"] - o["test"]) < 1.5e-2
+
+
+def test_forty_iterations_at_rate_001_default_policy_and_block_order():
+    """The round-1 comparison at 40 iterations, learnrate 0.01, 3000 x 2000.  (1) What the host classes do by default on a
+    matrix of this size (order replay) IS the reference's run: same iteration count, test RMSE within 1e-4 of the
+    left-to-right dots.  (2) The lock-free block order forced on it (MFX_EXACT=0) is compared with the reference's OWN
+    block-ordered trainer (trainSGDPar, oracle M_SGDPAR): both lose their first epoch to the guard at this rate."""
+    d, K = data(3000, 2000, 300000, seed=2), 16
+    o = oracle_train(orc.M_SGD, d, K, 40, 1, 0.01, 0.02, 0.02)
+    h = host_train("sgd", d, K, 40, 1, 0.01, 0.02, 0.02)
+    print("default policy: gpu %.6f cpu %.6f, final rate %g vs %g" % (h["test"], o["test"], h["lr"], o["learnRate"]))
+    assert abs(h["test"] - o["test"]) < 1e-4 and h["lr"] == o["learnRate"] == np.float32(0.01)
+    f = host_train("hogsgd", d, K, 40, 1, 0.01, 0.02, 0.02, env={"MFX_EXACT": "0"})
+    p = oracle_train(orc.M_SGDPAR, d, K, 40, 1, 0.01, 0.02, 0.02, nthreads=8)
+    print("block orders: tiled gpu %.5f (final rate %g), reference trainSGDPar %.5f (final rate %g), sequential %.5f"
+          % (f["test"], f["lr"], p["test"], p["learnRate"], o["test"]))
+    assert f["lr"] < 0.01 and p["learnRate"] < 0.01            # both were halved by the guard
+    assert abs(f["test"] - p["test"]) < 3e-2
 
 
 def test_mf_cli_end_to_end(tmp_path):
