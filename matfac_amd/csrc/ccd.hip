@@ -159,11 +159,7 @@ __global__ __launch_bounds__(1024) void ccd_pass_kernel(const MfxTrips trips, co
   const int grp = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
   if (grp >= ngroups) return;
   // (the global vectors of a CCD++ session carry one more element, +0.0: mfx_ccdpp_begin)
-  mfx_ccd_trip_loop(trips, gptr[grp], gptr[grp + 1], res, ind, other, nother, j, [&](int, int slot, double num, double den) {
-    num = group16_sum(num);
-    den = group16_sum(den);
-    if (j == 0) mfx_store_unseen(part + 2 * (int64_t)slot, num, den);
-  });
+  mfx_ccd_trip_loop(trips, gptr[grp], gptr[grp + 1], res, ind, other, nother, j, part);
 }
 
 // single-segment rows: u_k[row] = num / (reg + den) from the row's slot

@@ -308,13 +308,8 @@ __global__ __launch_bounds__(1024) void colpass_kernel(const MfxTrips trips, con
   const int j = threadIdx.x & 15;
   const int g = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
   if (g >= g_count) return;
-  auto fin = [&](int, int seg, double num, double den) {
-    num = g16_sum(num);
-    den = g16_sum(den);
-    if (j == 0) mfx_store_unseen(part + 2 * (int64_t)seg, num, den);
-  };
-  if (strip) mfx_ccd_trip_loop(trips, gptr[g], gptr[g + 1], res, buser, su, UB, j, fin);
-  else mfx_ccd_trip_loop(trips, gptr[g], gptr[g + 1], res, luser, uk, nU, j, fin);      // uk[nU] = +0.0 (mfx_ccdpp_begin)
+  if (strip) mfx_ccd_trip_loop(trips, gptr[g], gptr[g + 1], res, buser, su, UB, j, part);
+  else mfx_ccd_trip_loop(trips, gptr[g], gptr[g + 1], res, luser, uk, nU, j, part);      // uk[nU] = +0.0 (mfx_ccdpp_begin)
 }
 
 // residual update of the light region (MODE as colresid_kernel): u_k from L2

@@ -352,9 +352,13 @@ static inline int mfx_trips_upload(mfx_ctx* ctx, const std::vector<int4>& trips,
 #ifndef MFX_CCD_EXP
 #define MFX_CCD_EXP 0
 #endif
-template <typename IdxT, class Fin>
+// The sums of a finished segment go to part[2 * meta], part[2 * meta + 1] -- ONE STEP LATER: the hardware counts the store on
+// the same counter as the loads, so a store issued at the end of a step sits between the next step's wait and the data it waits
+// for (the wait then lasts until the store is acknowledged or a younger load returns: about 1 us per segment end, which was a
+// third of the pass).  Issued a step later it is older than everything that step waits for.
+template <typename IdxT>
 __device__ __forceinline__ void mfx_ccd_trip_loop(const MfxTrips trips, int n0, int n1, const float* __restrict__ res,
-                                                  const IdxT* __restrict__ ind, const float* other, int zero, int j, Fin&& fin) {
+                                                  const IdxT* __restrict__ ind, const float* other, int zero, int j, double* __restrict__ part) {
   typedef float f4 __attribute__((ext_vector_type(4)));
   typedef typename MfxIdx4<IdxT>::raw raw_t;
   if (n0 >= n1) return;
@@ -376,7 +380,8 @@ __device__ __forceinline__ void mfx_ccd_trip_loop(const MfxTrips trips, int n0, 
     d.r = *(const f4*)(res + t);
     return d;
   };
-  double num = 0.0, den = 0.0;
+  double num = 0.0, den = 0.0, pnum = 0.0, pden = 0.0;
+  int pslot = -1;                 // pending result (lane j == 0 of the group)
   // one step: gathers of trip n, then the prefetches (data of n + 2 from its record, which arrived two steps ago), then the sums
 #define MFX_TRIP_STEP(N, RC, DC, RN, DN)                                                                                  \
   {                                                                                                                       \
@@ -389,6 +394,7 @@ __device__ __forceinline__ void mfx_ccd_trip_loop(const MfxTrips trips, int n0, 
                                : other[rel + (unsigned)q < len ? MfxIdx4<IdxT>::get(DC.x, q) : zero];                      \
     const f4 rr = DC.r;                                                                                                   \
     const int meta = RC.z;                                                                                                \
+    if (pslot >= 0) { mfx_store_unseen(part + 2 * (int64_t)pslot, pnum, pden); pslot = -1; }                              \
     DN = data(RN);                                                                                                        \
     if (MFX_CCD_EXP & 16) {                                                                                               \
       float fn = 0.0f, fd = 0.0f;                                                                                         \
@@ -398,7 +404,8 @@ __device__ __forceinline__ void mfx_ccd_trip_loop(const MfxTrips trips, int n0, 
       _Pragma("unroll") for (int q = 0; q < 4; q++) { num += (double)(rr[q] * o[q]); den += (double)(o[q] * o[q]); }    \
     }                                                                                                                     \
     if ((pk & MFX_TRIP_LAST) && !(MFX_CCD_EXP & 4)) {                                                                     \
-      fin(pk, meta, num, den);                                                                                            \
+      pnum = mfx_row16_sum(num); pden = mfx_row16_sum(den);                                                               \
+      pslot = j == 0 ? meta : -1;                                                                                         \
       num = 0.0; den = 0.0;                                                                                               \
     }                                                                                                                     \
     RC = rec((N) + 4);   /* after the last use of the old record: the load lands in the same registers, no copy */        \
@@ -411,6 +418,7 @@ __device__ __forceinline__ void mfx_ccd_trip_loop(const MfxTrips trips, int n0, 
     MFX_TRIP_STEP(n + 2, r2, d2, r0, d0)
     MFX_TRIP_STEP(n + 3, r3, d3, r1, d1)
   }
+  if (pslot >= 0) mfx_store_unseen(part + 2 * (int64_t)pslot, pnum, pden);
 #undef MFX_TRIP_STEP
 }
 

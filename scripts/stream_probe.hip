@@ -3,6 +3,8 @@
 // Pattern 0: a wave reads 1 KB contiguous per load, consecutive waves consecutive KBs (grid-stride).
 // Pattern 1: every 16-lane group reads its own contiguous range (256 B per load): 4 streams per wave, as many streams as groups.
 // Pattern 2: as 1, but the 64 groups of a workgroup share a window: group g reads 256 B pieces g, g + 64, ... of the window.
+// Pattern 3: as 1 with every piece shifted by 48 bytes: a 256-byte piece touches three 128-byte lines (the CCD++ trips are
+// 16-byte aligned, not line aligned).  Pattern 4: as 3 plus a second array read 8 bytes per lane (the 16-bit ids).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -26,14 +28,27 @@ __global__ __launch_bounds__(1024) void probe(const f4* __restrict__ a, long n4,
     const long ngrp = (long)gridDim.x * (blockDim.x >> 4);
     const long g = (long)blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
     const long per = n4 / 16 / ngrp;              // 256-byte pieces per group
-    if (PAT == 1) {
+    if (PAT == 1 || PAT == 3) {
       const long p0 = g * per;
       for (long p = 0; p + U <= per; p += U) {
         f4 v[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) v[u] = a[(p0 + p + u) * 16 + j];
+        for (int u = 0; u < U; u++) v[u] = a[(p0 + p + u) * 16 + j + (PAT == 3 ? 3 : 0)];
 #pragma unroll
         for (int u = 0; u < U; u++) acc += v[u];
+      }
+    } else if (PAT == 4) {
+      // two thirds of the buffer as the 16-byte stream, one third as the 8-byte stream
+      const long per4 = per * 2 / 3;
+      const long p0 = g * per4;
+      const float2* b = (const float2*)(a + (n4 / 16 * 2 / 3 + 16) * 16);
+      for (long p = 0; p + U <= per4; p += U) {
+        f4 v[U];
+        float2 w[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { v[u] = a[(p0 + p + u) * 16 + j + 3]; w[u] = b[(p0 + p + u) * 16 + j + 5]; }
+#pragma unroll
+        for (int u = 0; u < U; u++) { acc += v[u]; acc[0] += w[u].x + w[u].y; }
       }
     } else {
       const long w0 = (long)blockIdx.x * (blockDim.x >> 4) * per;   // window of this workgroup, in pieces
@@ -78,6 +93,9 @@ int main() {
     run<1, 4>(a, n4, out, blocks, 1024);
     run<2, 2>(a, n4, out, blocks, 1024);
     run<2, 4>(a, n4, out, blocks, 1024);
+    run<3, 2>(a, n4, out, blocks, 1024);
+    run<3, 4>(a, n4, out, blocks, 1024);
+    run<4, 2>(a, n4, out, blocks, 1024);
   }
   return 0;
 }
