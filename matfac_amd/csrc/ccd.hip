@@ -229,7 +229,7 @@ extern "C" int mfx_ccdpp_begin(mfx_ctx* ctx) {
   if (nnz) {
     HIPCHK(hipMemcpyAsync(ctx->res_row, m.rowval, sizeof(float) * nnz, hipMemcpyDeviceToDevice, ctx->stream));
   }
-  HIPCHK(hipMemsetAsync(ctx->res_row + nnz, 0, 16, ctx->stream));   // the pad behind the residuals is read (masked) by the pass loop: finite
+  HIPCHK(hipMemsetAsync(ctx->res_row + nnz, 0, MFX_ALLOC_PAD, ctx->stream));   // the pad behind the residuals is read (masked) by the pass loop: finite
   if (nnz && lds_fits(((size_t)ctx->nI + 1) * sizeof(float))) {
     if ((rc = dev_alloc(ctx, &ctx->ccd_ind16, nnz))) return rc;
     hipLaunchKernelGGL(narrow_ids_kernel, dim3(2048), dim3(256), 0, ctx->stream, m.rowind, (int64_t)nnz, ctx->ccd_ind16);

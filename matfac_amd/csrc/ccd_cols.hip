@@ -35,7 +35,7 @@ struct ColState {
   int64_t* dst = nullptr;           // [nb][nI] blocked position of segment (b,i)
   // Index widths (the kernels stream these arrays, so their width is a share of the time): a strip-local user id is below
   // UB = 8192 -> 16 bits, always; the column id is 16 bits when there are at most 65 536 columns; the light region keeps absolute
-  // 32-bit user ids in its own array (entry t of the blocked order sits at luser[t - (light0 & ~3)]: 16-byte loads stay aligned).
+  // 32-bit user ids in its own array (entry t of the blocked order sits at luser[t - (light0 & ~63)]: 16-byte loads stay aligned).
   uint16_t* buser = nullptr;        // blocked, strips only: user - b*UB
   int32_t* luser = nullptr;         // light region: absolute user id
   uint16_t* bcol16 = nullptr;       // blocked: column id (ncols <= 65536) ...
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void strip_scatter_kernel(const int64_t* __res
     const int64_t d = dst[(int64_t)b * ncols + i];
     const bool is_light = d >= light0;                // light columns keep the absolute user id (u_k comes from L2)
     for (int64_t t = j; t < n; t += 16) {
-      if (is_light) luser[d + t - (light0 & ~(int64_t)3)] = colind[src + t];
+      if (is_light) luser[d + t - (light0 & ~(int64_t)63)] = colind[src + t];
       else buser[d + t] = (uint16_t)(colind[src + t] - b * UB);
       bcol[d + t] = (ColT)i;
       res[d + t] = colval[src + t];
@@ -260,12 +260,12 @@ int mfx_ccd_cols_build(mfx_ctx* ctx) {
   s->nrw = (int)rw_blk.size();
   if ((rc = dev_alloc(ctx, &s->part, (size_t)s->nseg * 2))) return rc;
   const bool col16 = nI <= 65536;
-  if ((rc = dev_alloc(ctx, &s->buser, (size_t)s->light0 + 4))) return rc;
-  if ((rc = dev_alloc(ctx, &s->luser, (size_t)(m.nnz - (s->light0 & ~(int64_t)3)) + 4))) return rc;
+  if ((rc = dev_alloc(ctx, &s->buser, (size_t)s->light0 + 4))) return rc;      // (+ MFX_ALLOC_PAD: the last strip trips run past light0)
+  if ((rc = dev_alloc(ctx, &s->luser, (size_t)(m.nnz - (s->light0 & ~(int64_t)63)) + 4))) return rc;
   if (col16) { if ((rc = dev_alloc(ctx, &s->bcol16, (size_t)m.nnz + 4))) return rc; }
   else if ((rc = dev_alloc(ctx, &s->bcol32, (size_t)m.nnz + 4))) return rc;
   if ((rc = dev_alloc(ctx, &s->res, (size_t)m.nnz))) return rc;
-  HIPCHK(hipMemsetAsync(s->res + m.nnz, 0, 16, ctx->stream));    // read (masked) by the pass loop: finite
+  HIPCHK(hipMemsetAsync(s->res + m.nnz, 0, MFX_ALLOC_PAD, ctx->stream));    // read (masked) by the pass loop: finite
   if (m.nnz > 0) {
     if (col16)
       hipLaunchKernelGGL(strip_scatter_kernel<uint16_t>, dim3(2048), dim3(256), 0, ctx->stream, m.colptr, m.colind, m.colval,
@@ -427,9 +427,9 @@ int mfx_ccd_cols_pass(mfx_ctx* ctx, const float* uk, float* vk, float reg, float
   const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
   if (s->npw > 0 || s->ngl > 0) {
     ProfScope ps(ctx, MFX_K_CCD_COL);
-    // entry t of the blocked order sits at luser[t - (light0 & ~3)]
+    // entry t of the blocked order sits at luser[t - (light0 & ~63)]
     hipLaunchKernelGGL(colpass_kernel, dim3(s->npw + s->ngl / GPW), dim3(16 * GPW), 0, ctx->stream, s->trips, s->gptr, s->pw_blk, s->ngl / GPW,
-                       s->npw * GPW + s->ngl, s->res, (const uint16_t*)s->buser, (const int32_t*)(s->luser - (s->light0 & ~(int64_t)3)), uk,
+                       s->npw * GPW + s->ngl, s->res, (const uint16_t*)s->buser, (const int32_t*)(s->luser - (s->light0 & ~(int64_t)63)), uk,
                        m.nrows, ctx->nU, s->part);
     const unsigned fb = (unsigned)(((int64_t)m.ncols * 16 + 255) / 256);
     if (!mfx_sharded(ctx)) {
@@ -479,7 +479,7 @@ int mfx_ccd_cols_resid(mfx_ctx* ctx, int mode, const float* uk0, const float* vk
   }
   if (s->light0 < s->nnz) {
     const unsigned lb = (unsigned)std::min<int64_t>((s->nnz - s->light0 + 255) / 256, 4096);
-    const int64_t lsh = s->light0 & ~(int64_t)3;
+    const int64_t lsh = s->light0 & ~(int64_t)63;
 #define MFX_CL(MD)                                                                                                                \
   do {                                                                                                                            \
     if (s->bcol16)                                                                                                                \

@@ -162,11 +162,13 @@ struct ProfScope {
   ~ProfScope();
 };
 
+constexpr size_t MFX_ALLOC_PAD = 512;      // bytes; >= 96 entries of 4 bytes (a trip may start 31 entries early and end 63 late)
 template <typename T>
 static inline int dev_alloc(mfx_ctx* ctx, T** p, size_t n) {
   *p = nullptr;
   if (n == 0) n = 1;
-  HIPCHK(hipMalloc((void**)p, n * sizeof(T) + 16));   // 16 readable bytes behind every array: aligned 16-byte loads of a last partial quad
+  HIPCHK(hipMalloc((void**)p, n * sizeof(T) + MFX_ALLOC_PAD));   // readable bytes behind every array: the streaming kernels load whole aligned
+                                                                 // 64-entry trips and mask what lies outside (mfx_ccd_trip_loop)
   return MFX_OK;
 }
 template <typename T>
@@ -218,8 +220,8 @@ __host__ __device__ static inline int64_t mfx_perm_index(int64_t t, int64_t n, i
 // the record load of trip k+4.  It is unrolled four steps by hand: rotating the buffers with copies would make the compiler
 // wait for the loads it has just issued (measured on the first version: every wait was vmcnt(0), the waves were parked 80 %
 // of the time and the pass ran at 3.4 TB/s whatever the bytes per entry).
-// Arrays: every device allocation has 16 readable bytes behind it (dev_alloc); the residual pad must hold finite values
-// (mfx_ccdpp_begin zeroes it), because a masked entry still multiplies its residual -- by the +0.0 it gathers at `zero`, an
+// Arrays: every device allocation has MFX_ALLOC_PAD readable bytes behind it (dev_alloc); the residual pad must hold finite
+// values (mfx_ccdpp_begin zeroes it), because a masked entry still multiplies its residual -- by the +0.0 it gathers at `zero`, an
 // index at which `other` holds +0.0 (the callers keep such a slot behind the vector): the products are +-0 and leave the
 // double sums untouched; one compare and one select per entry instead of three selects.  (A NaN residual next to a segment
 // would leak into it; residuals are finite unless the model has diverged, and then Model::isTerminateModel's guard fires.)
@@ -275,21 +277,27 @@ __device__ __forceinline__ void mfx_store_unseen(double* p, double a, double b) 
 }
 
 
-// trip record: x = position / 4, y = a | i << 2 | len << 7 | last << 18 | flag << 19 (a = segment start mod 4, i = trip
-// number inside the segment, len = entries of the segment <= 2047), z = meta.  On the device the three fields are three
+// trip record: x = position / 4, y = a | i << 5 | len << 10 | last << 21 (a = segment start - trip start of its first trip < 32,
+// i = trip number inside the segment, len = entries of the segment <= 2047), z = meta.  On the device the three fields are three
 // arrays (MfxTrips): loaded as one 12-byte tuple, the register allocator split the tuple over the loop-carried registers with
 // copies at the loop end, and a copy of a value that has just been requested is a wait for it.
 
-constexpr int MFX_TRIP_LAST = 1 << 18, MFX_TRIP_FLAG = 1 << 19;
+constexpr int MFX_TRIP_LAST = 1 << 21;
+// A trip starts on a 128-byte line of the residuals (32 entries; MFX_CCD_ALIGN overrides at build time): the trips of a
+// segment then share no line, and a line is requested from L2 once per trip instead of once per trip that touches part of it.
+#ifndef MFX_CCD_ALIGN
+#define MFX_CCD_ALIGN 32
+#endif
+constexpr int64_t MFX_TRIP_ALIGN = MFX_CCD_ALIGN;
 struct MfxSeg { int64_t b, e; int32_t meta; };
-static inline int mfx_seg_trips(const MfxSeg& g) { return (int)std::max<int64_t>(1, (g.e - (g.b & ~(int64_t)3) + 63) / 64); }
+static inline int mfx_seg_trips(const MfxSeg& g) { return (int)std::max<int64_t>(1, (g.e - (g.b & ~(MFX_TRIP_ALIGN - 1)) + 63) / 64); }
 static inline void mfx_trips_append(std::vector<int4>& trips, const MfxSeg& g) {
-  const int64_t t0 = g.b & ~(int64_t)3;
-  const int a = (int)(g.b & 3), len = (int)(g.e - g.b), ntr = mfx_seg_trips(g);
+  const int64_t t0 = g.b & ~(MFX_TRIP_ALIGN - 1);
+  const int a = (int)(g.b & (MFX_TRIP_ALIGN - 1)), len = (int)(g.e - g.b), ntr = mfx_seg_trips(g);
   for (int i = 0; i < ntr; i++) {
     int4 r;
     r.x = (int)(uint32_t)((t0 + 64 * (int64_t)i) >> 2);
-    r.y = a | (i << 2) | (len << 7) | (i == ntr - 1 ? MFX_TRIP_LAST : 0);
+    r.y = a | (i << 5) | (len << 10) | (i == ntr - 1 ? MFX_TRIP_LAST : 0);
     r.z = g.meta;
     r.w = 0;
     trips.push_back(r);
@@ -368,7 +376,7 @@ __device__ __forceinline__ void mfx_ccd_trip_loop(const MfxTrips trips, int n0, 
   auto rec = [&](int n) {                                                   // behind the range: the last record again (masked below)
     const int nc = n < n1 ? n : n1 - 1;
     Rec r;
-    if (MFX_CCD_EXP & 8) { r.x = min(exp_q0 + 16 * (n - n0), exp_q1); r.y = (64 << 7) | ((n & 3) == 3 ? MFX_TRIP_LAST : 0); r.z = exp_m; return r; }   // in-bounds: a group's trips ascend in memory
+    if (MFX_CCD_EXP & 8) { r.x = min(exp_q0 + 16 * (n - n0), exp_q1); r.y = (64 << 10) | ((n & 3) == 3 ? MFX_TRIP_LAST : 0); r.z = exp_m; return r; }   // in-bounds: a group's trips ascend in memory
     r.x = trips.q[nc]; r.y = trips.pk[nc]; r.z = trips.meta[nc];
     return r;
   };
@@ -386,8 +394,8 @@ __device__ __forceinline__ void mfx_ccd_trip_loop(const MfxTrips trips, int n0, 
 #define MFX_TRIP_STEP(N, RC, DC, RN, DN)                                                                                  \
   {                                                                                                                       \
     const int pk = (N) < n1 ? RC.y : 0;                                                                                   \
-    const unsigned len = ((unsigned)pk >> 7) & 0x7ffu;                                                                    \
-    const unsigned rel = (unsigned)(64 * ((pk >> 2) & 31) - (pk & 3) + 4 * j);                                            \
+    const unsigned len = ((unsigned)pk >> 10) & 0x7ffu;                                                                   \
+    const unsigned rel = (unsigned)(64 * ((pk >> 5) & 31) - (pk & 31) + 4 * j);                                           \
     float o[4];                                                                                                           \
     _Pragma("unroll") for (int q = 0; q < 4; q++)                                                                         \
       o[q] = (MFX_CCD_EXP & 1) ? (rel + (unsigned)q < len ? __int_as_float(MfxIdx4<IdxT>::get(DC.x, q) | 0x3f800000) : 0.0f) \
