@@ -390,9 +390,11 @@ __device__ __forceinline__ void mfx_ccd_trip_loop(const MfxTrips trips, int n0, 
   };
   double num = 0.0, den = 0.0, pnum = 0.0, pden = 0.0;
   int pslot = -1;                 // pending result (lane j == 0 of the group)
-  // one step: gathers of trip n, then the prefetches (data of n + 2 from its record, which arrived two steps ago), then the sums
+  // one step: the prefetch (data of n + 2 from its record, which arrived two steps ago), the gathers of trip n, the sums
 #define MFX_TRIP_STEP(N, RC, DC, RN, DN)                                                                                  \
   {                                                                                                                       \
+    if (pslot >= 0) { mfx_store_unseen(part + 2 * (int64_t)pslot, pnum, pden); pslot = -1; }                              \
+    DN = data(RN);       /* first: the wave then waits for trip n with n + 1 AND n + 2 in flight */                       \
     const int pk = (N) < n1 ? RC.y : 0;                                                                                   \
     const unsigned len = ((unsigned)pk >> 10) & 0x7ffu;                                                                   \
     const unsigned rel = (unsigned)(64 * ((pk >> 5) & 31) - (pk & 31) + 4 * j);                                           \
@@ -402,8 +404,6 @@ __device__ __forceinline__ void mfx_ccd_trip_loop(const MfxTrips trips, int n0, 
                                : other[rel + (unsigned)q < len ? MfxIdx4<IdxT>::get(DC.x, q) : zero];                      \
     const f4 rr = DC.r;                                                                                                   \
     const int meta = RC.z;                                                                                                \
-    if (pslot >= 0) { mfx_store_unseen(part + 2 * (int64_t)pslot, pnum, pden); pslot = -1; }                              \
-    DN = data(RN);                                                                                                        \
     if (MFX_CCD_EXP & 16) {                                                                                               \
       float fn = 0.0f, fd = 0.0f;                                                                                         \
       _Pragma("unroll") for (int q = 0; q < 4; q++) { fn += rr[q] * o[q]; fd += o[q] * o[q]; }                            \

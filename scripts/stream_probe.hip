@@ -5,6 +5,8 @@
 // Pattern 2: as 1, but the 64 groups of a workgroup share a window: group g reads 256 B pieces g, g + 64, ... of the window.
 // Pattern 3: as 1 with every piece shifted by 48 bytes: a 256-byte piece touches three 128-byte lines (the CCD++ trips are
 // 16-byte aligned, not line aligned).  Pattern 4: as 3 plus a second array read 8 bytes per lane (the 16-bit ids).
+// Pattern 5: as 4 plus THREE 4-byte loads per step that every lane of a group takes from the same address (the trip records
+// of the CCD++ passes): bytes unchanged, 5 instead of 2 vector-memory instructions per step.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -36,6 +38,23 @@ __global__ __launch_bounds__(1024) void probe(const f4* __restrict__ a, long n4,
         for (int u = 0; u < U; u++) v[u] = a[(p0 + p + u) * 16 + j + (PAT == 3 ? 3 : 0)];
 #pragma unroll
         for (int u = 0; u < U; u++) acc += v[u];
+      }
+    } else if (PAT == 5) {
+      const long per4 = per * 2 / 3;
+      const long p0 = g * per4;
+      const float2* b = (const float2*)(a + (n4 / 16 * 2 / 3 + 16) * 16);
+      const float* r0 = (const float*)a + g * 64, *r1 = r0 + 16 * 1024 * 1024, *r2 = r1 + 16 * 1024 * 1024;
+      for (long p = 0; p + U <= per4; p += U) {
+        f4 v[U];
+        float2 w[U];
+        float x[U], y[U], z[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          v[u] = a[(p0 + p + u) * 16 + j + 3]; w[u] = b[(p0 + p + u) * 16 + j + 5];
+          x[u] = r0[(p + u) & 63]; y[u] = r1[(p + u) & 63]; z[u] = r2[(p + u) & 63];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) { acc += v[u]; acc[0] += w[u].x + w[u].y + x[u] + y[u] + z[u]; }
       }
     } else if (PAT == 4) {
       // two thirds of the buffer as the 16-byte stream, one third as the 8-byte stream
@@ -96,6 +115,9 @@ int main() {
     run<3, 2>(a, n4, out, blocks, 1024);
     run<3, 4>(a, n4, out, blocks, 1024);
     run<4, 2>(a, n4, out, blocks, 1024);
+    run<5, 1>(a, n4, out, blocks, 1024);
+    run<5, 2>(a, n4, out, blocks, 1024);
+    run<4, 1>(a, n4, out, blocks, 1024);
   }
   return 0;
 }
