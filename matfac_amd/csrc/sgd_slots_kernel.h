@@ -252,7 +252,9 @@ struct SlotSteps {
 // It also carries the two test hooks of include/mfx.h: `tile_only` >= 0 restricts a launch to that tile and `one`
 // makes ONE lane group visit a slot's ratings one at a time (MFX_SGD_F_ONE_GROUP).
 constexpr int DRAIN_WGS = 128;
-template <int L, int C, int ARITH, bool SWEEP, bool OWN_U, int VAR>
+// ALLW: every wave of the workgroup takes part (compile-time chunk stride; a run-time stride cost 3.6 % at C2 -- measured A/B on one
+// box: 19.2 vs 19.9 G updates/s); otherwise `aw` waves do (small tiles, see mfx_launch_sgd_tiled).
+template <int L, int C, int ARITH, bool SWEEP, bool OWN_U, int VAR, bool ALLW = false>
 __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kernel(const int4* __restrict__ rec,
                                                            const int64_t* __restrict__ slot_beg,
                                                            const int32_t* __restrict__ slot_ibeg,
@@ -336,8 +338,8 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
       const uint32_t ks0 = k0 + (uint32_t)slot * 0x632be5abU, ks1 = k1 ^ mfx_mix32((uint32_t)slot + 77U);
       // one group (test hook): wave 0 alone, L ratings per chunk, rating cb+s in entry s*G (group 0's entry of step s)
       // aw = waves of the workgroup that take part (16 unless the tile has few lock-free rows: mfx_launch_sgd_tiled)
-      const int64_t cb0 = onegrp ? (wave == 0 ? 0 : R) : (wave < aw ? (int64_t)wave * 64 : R);
-      const int64_t cstep = onegrp ? L : (int64_t)aw * 64;
+      const int64_t cb0 = onegrp ? (wave == 0 ? 0 : R) : ALLW ? (int64_t)wave * 64 : (wave < aw ? (int64_t)wave * 64 : R);
+      const int64_t cstep = onegrp ? L : ALLW ? (WG / 64) * 64 : (int64_t)aw * 64;
       for (int64_t cb = cb0; cb < R; cb += cstep) {
         const int64_t t = onegrp ? cb + lane / G : cb + lane;
         const bool ok = onegrp ? (lane % G == 0 && t < R) : t < R;
@@ -435,9 +437,14 @@ static int launch_slots(mfx_ctx* ctx, SlotList* S, const mfx_sgd_opts* o, int bl
   }
   for (int round = 0; round < NUB && !(o->flags & MFX_SGD_F_DRAIN_ONLY); round++) {
     ProfScope ps(ctx, MFX_K_SGD);
-    hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, false, OWN_U, VAR>), dim3(blocks), dim3(WG), 0, ctx->stream,
-                       (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->tile_slot, S->ctr, round,
-                       oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1, at, visit, -1, 0, S->active_waves);
+    if (S->active_waves == WG / 64)
+      hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, false, OWN_U, VAR, true>), dim3(blocks), dim3(WG), 0, ctx->stream,
+                         (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->tile_slot, S->ctr, round,
+                         oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1, at, visit, -1, 0, S->active_waves);
+    else
+      hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, false, OWN_U, VAR, false>), dim3(blocks), dim3(WG), 0, ctx->stream,
+                         (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->tile_slot, S->ctr, round,
+                         oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1, at, visit, -1, 0, S->active_waves);
   }
   {
     // the drain: one launch; the same diagonals keyed on the workgroup index (an item row keeps a single owner)
