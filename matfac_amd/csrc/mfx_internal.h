@@ -356,7 +356,8 @@ static inline int mfx_trips_upload(mfx_ctx* ctx, const std::vector<int4>& trips,
 
 // Diagnostic builds (scripts/exp_ccd.sh; results are WRONG on purpose): what the pass time does when one part is taken out.
 // bit 0: no gathers (o = 1)  bit 1: no data loads  bit 2: no segment ends (fin never runs)  bit 3: no record loads
-// bit 4: float sums instead of double.  0 (the product): nothing of this is compiled.
+// bit 4: float sums instead of double  bit 5: memory operations only (no masks, gathers, doubles).  0 (the product): nothing of
+// this is compiled.
 #ifndef MFX_CCD_EXP
 #define MFX_CCD_EXP 0
 #endif
@@ -404,7 +405,10 @@ __device__ __forceinline__ void mfx_ccd_trip_loop(const MfxTrips trips, int n0, 
                                : other[rel + (unsigned)q < len ? MfxIdx4<IdxT>::get(DC.x, q) : zero];                      \
     const f4 rr = DC.r;                                                                                                   \
     const int meta = RC.z;                                                                                                \
-    if (MFX_CCD_EXP & 16) {                                                                                               \
+    if (MFX_CCD_EXP & 32) {   /* memory operations only: the loaded values are summed without masks, gathers or doubles */  \
+      float fs = rr[0] + rr[1] + rr[2] + rr[3] + __int_as_float(MfxIdx4<IdxT>::get(DC.x, 0) + MfxIdx4<IdxT>::get(DC.x, 3));   \
+      num += (double)fs;                                                                                                  \
+    } else if (MFX_CCD_EXP & 16) {                                                                                        \
       float fn = 0.0f, fd = 0.0f;                                                                                         \
       _Pragma("unroll") for (int q = 0; q < 4; q++) { fn += rr[q] * o[q]; fd += o[q] * o[q]; }                            \
       num += (double)fn; den += (double)fd;                                                                               \
