@@ -148,10 +148,10 @@ __device__ __forceinline__ double group16_sum(double v) { return mfx_row16_sum(v
 // is taken by the finishing kernels: a double division is ~35 instructions, and with four groups per wavefront three steps out
 // of four end a segment somewhere in the wave -- it was a quarter of the pass.  (trainCCDPPFreqAdap's rule applies to items
 // only: modelMF.cpp:1336-1342 -- the row pass never sees a threshold.)
-template <bool LDSO>
+template <bool LDSO, bool BUF>
 __global__ __launch_bounds__(1024) void ccd_pass_kernel(const MfxTrips trips, const int32_t* __restrict__ gptr, int ngroups,
                                                        const float* __restrict__ res,
-                                                       const typename ItemIdx<LDSO>::type* __restrict__ ind,
+                                                       const typename ItemIdx<LDSO>::type* __restrict__ ind, uint32_t res_bytes,
                                                        const float* __restrict__ otherg, int nother, double* __restrict__ part) {
   if (LDSO) stage_vector(otherg, nother);
   const float* other = LDSO ? ccd_lds : otherg;
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(1024) void ccd_pass_kernel(const MfxTrips trips, co
   const int grp = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
   if (grp >= ngroups) return;
   // (the global vectors of a CCD++ session carry one more element, +0.0: mfx_ccdpp_begin)
-  mfx_ccd_trip_loop(trips, gptr[grp], gptr[grp + 1], res, ind, other, nother, j, part);
+  mfx_ccd_trip_loop<BUF>(trips, gptr[grp], gptr[grp + 1], res, ind, res_bytes, other, nother, j, part);
 }
 
 // single-segment rows: u_k[row] = num / (reg + den) from the row's slot
@@ -309,19 +309,21 @@ static int run_pass(mfx_ctx* ctx, int side, float reg, float freq_thresh, int k)
     ProfScope ps(ctx, MFX_K_CCD_ROW);
     const size_t lds = ((size_t)nother + 1) * sizeof(float);
     const int blocks = (ctx->ccd_ngroups + 63) / 64;
+    const uint64_t rbytes = ((uint64_t)m.nnz + 64) * 4;             // buffer loads (lanes outside a segment skip their access) below 4 GB
+    const bool buf = rbytes < ((uint64_t)1 << 32) && !getenv("MFX_CCD_NOBUF");
+#define MFX_ROWPASS(LD, BF, LDSB, IND)                                                                                          \
+  hipLaunchKernelGGL((ccd_pass_kernel<LD, BF>), dim3(blocks), dim3(1024), LDSB, ctx->stream, ctx->ccd_trips, ctx->ccd_gptr, ctx->ccd_ngroups, \
+                     res, IND, (uint32_t)rbytes, other, nother, ctx->ccd_part)
     if (lds_fits(lds)) {   // the gathered vector fits in LDS (items: C2 107 KB, C4 71 KB)
-      HIPCHK(set_lds(ctx, (const void*)ccd_pass_kernel<true>, lds));
-      if (getenv("MFX_DEBUG") && k == 0) {
-        int occ = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)ccd_pass_kernel<true>, 1024, lds);
-        fprintf(stderr, "[mfx] row pass: %d workgroups of 1024 threads, %zu bytes of LDS each, %d resident per CU\n", blocks, lds, occ);
-      }
-      hipLaunchKernelGGL(ccd_pass_kernel<true>, dim3(blocks), dim3(1024), lds, ctx->stream, ctx->ccd_trips, ctx->ccd_gptr, ctx->ccd_ngroups,
-                         res, (const uint16_t*)ctx->ccd_ind16, other, nother, ctx->ccd_part);
+      HIPCHK(set_lds(ctx, (const void*)ccd_pass_kernel<true, true>, lds));
+      HIPCHK(set_lds(ctx, (const void*)ccd_pass_kernel<true, false>, lds));
+      if (buf) MFX_ROWPASS(true, true, lds, (const uint16_t*)ctx->ccd_ind16);
+      else MFX_ROWPASS(true, false, lds, (const uint16_t*)ctx->ccd_ind16);
     } else {
-      hipLaunchKernelGGL(ccd_pass_kernel<false>, dim3(blocks), dim3(1024), 0, ctx->stream, ctx->ccd_trips, ctx->ccd_gptr, ctx->ccd_ngroups,
-                         res, ind, other, nother, ctx->ccd_part);
+      if (buf) MFX_ROWPASS(false, true, 0, ind);
+      else MFX_ROWPASS(false, false, 0, ind);
     }
+#undef MFX_ROWPASS
     if (ctx->ccd_nsingle > 0)
       hipLaunchKernelGGL(ccd_divide_kernel, dim3((unsigned)((ctx->ccd_nsingle + 255) / 256)), dim3(256), 0, ctx->stream, ctx->ccd_single,
                          ctx->ccd_nsingle, ctx->ccd_part + 2 * sg->nslab, reg, mine);

@@ -292,9 +292,10 @@ __device__ __forceinline__ double g16_sum(double v) { return mfx_row16_sum(v); }
 // column pass: one 16-lane group per range of the trip list.  Workgroups [0, nlw): the light columns, u_k gathered from L2 by
 // the absolute user id; the others: one strip each, the strip of u_k in LDS and strip-local 16-bit user ids.  ONE launch, the
 // latency-bound light part (4 % of the entries, but 42 us on its own at C4) first, so that it runs under the strips.
+template <bool BUF>
 __global__ __launch_bounds__(1024) void colpass_kernel(const MfxTrips trips, const int32_t* __restrict__ gptr,
                                                        const int32_t* __restrict__ pw_blk, int nlw, int g_count,
-                                                       const float* __restrict__ res, const uint16_t* __restrict__ buser,
+                                                       const float* __restrict__ res, uint32_t res_bytes, const uint16_t* __restrict__ buser,
                                                        const int32_t* __restrict__ luser, const float* __restrict__ uk, int nU_strips,
                                                        int nU, double* __restrict__ part) {
   __shared__ __attribute__((aligned(16))) float su[UB + 4];
@@ -308,8 +309,8 @@ __global__ __launch_bounds__(1024) void colpass_kernel(const MfxTrips trips, con
   const int j = threadIdx.x & 15;
   const int g = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
   if (g >= g_count) return;
-  if (strip) mfx_ccd_trip_loop(trips, gptr[g], gptr[g + 1], res, buser, su, UB, j, part);
-  else mfx_ccd_trip_loop(trips, gptr[g], gptr[g + 1], res, luser, uk, nU, j, part);      // uk[nU] = +0.0 (mfx_ccdpp_begin)
+  if (strip) mfx_ccd_trip_loop<BUF>(trips, gptr[g], gptr[g + 1], res, buser, res_bytes, su, UB, j, part);
+  else mfx_ccd_trip_loop<BUF>(trips, gptr[g], gptr[g + 1], res, luser, res_bytes, uk, nU, j, part);      // uk[nU] = +0.0 (mfx_ccdpp_begin)
 }
 
 // residual update of the light region (MODE as colresid_kernel): u_k from L2
@@ -428,9 +429,13 @@ int mfx_ccd_cols_pass(mfx_ctx* ctx, const float* uk, float* vk, float reg, float
   if (s->npw > 0 || s->ngl > 0) {
     ProfScope ps(ctx, MFX_K_CCD_COL);
     // entry t of the blocked order sits at luser[t - (light0 & ~63)]
-    hipLaunchKernelGGL(colpass_kernel, dim3(s->npw + s->ngl / GPW), dim3(16 * GPW), 0, ctx->stream, s->trips, s->gptr, s->pw_blk, s->ngl / GPW,
-                       s->npw * GPW + s->ngl, s->res, (const uint16_t*)s->buser, (const int32_t*)(s->luser - (s->light0 & ~(int64_t)63)), uk,
-                       m.nrows, ctx->nU, s->part);
+    const uint64_t rbytes = ((uint64_t)s->nnz + 64) * 4;
+#define MFX_COLPASS(BF)                                                                                                              \
+  hipLaunchKernelGGL(colpass_kernel<BF>, dim3(s->npw + s->ngl / GPW), dim3(16 * GPW), 0, ctx->stream, s->trips, s->gptr, s->pw_blk, s->ngl / GPW, \
+                     s->npw * GPW + s->ngl, s->res, (uint32_t)rbytes, (const uint16_t*)s->buser,                                      \
+                     (const int32_t*)(s->luser - (s->light0 & ~(int64_t)63)), uk, m.nrows, ctx->nU, s->part)
+    if (rbytes < ((uint64_t)1 << 32) && !getenv("MFX_CCD_NOBUF")) MFX_COLPASS(true); else MFX_COLPASS(false);
+#undef MFX_COLPASS
     const unsigned fb = (unsigned)(((int64_t)m.ncols * 16 + 255) / 256);
     if (!mfx_sharded(ctx)) {
       hipLaunchKernelGGL(colfinish_kernel<false>, dim3(fb), dim3(256), 0, ctx->stream, s->col_ptr, s->col_seg, s->part,

@@ -365,9 +365,10 @@ static inline int mfx_trips_upload(mfx_ctx* ctx, const std::vector<int4>& trips,
 // the same counter as the loads, so a store issued at the end of a step sits between the next step's wait and the data it waits
 // for (the wait then lasts until the store is acknowledged or a younger load returns: about 1 us per segment end, which was a
 // third of the pass).  Issued a step later it is older than everything that step waits for.
-template <typename IdxT>
+template <bool BUF, typename IdxT>
 __device__ __forceinline__ void mfx_ccd_trip_loop(const MfxTrips trips, int n0, int n1, const float* __restrict__ res,
-                                                  const IdxT* __restrict__ ind, const float* other, int zero, int j, double* __restrict__ part) {
+                                                  const IdxT* __restrict__ ind, uint32_t res_bytes, const float* other, int zero, int j,
+                                                  double* __restrict__ part) {
   typedef float f4 __attribute__((ext_vector_type(4)));
   typedef typename MfxIdx4<IdxT>::raw raw_t;
   if (n0 >= n1) return;
@@ -381,10 +382,26 @@ __device__ __forceinline__ void mfx_ccd_trip_loop(const MfxTrips trips, int n0, 
     r.x = trips.q[nc]; r.y = trips.pk[nc]; r.z = trips.meta[nc];
     return r;
   };
-  auto data = [&](const Rec& r) {
+  // BUF (arrays below 4 GB): buffer loads, and a lane whose four entries all lie outside the segment asks for an offset behind
+  // the buffer -- the hardware returns zeros without a memory access.  A segment of 208 entries is covered by four 64-entry
+  // trips; without this the vector memory pipe moves 256 entries for it (measured: 1.23 x the arrays).
+  const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)res, 0, BUF ? (int)res_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_ind = __builtin_amdgcn_make_buffer_rsrc((void*)ind, 0, BUF ? (int)(res_bytes / 4 * sizeof(IdxT)) : 0, 0x00020000);
+  auto data = [&](const Rec& r, bool live) {
     Data d;
     const int64_t t = ((int64_t)(uint32_t)r.x << 2) + 4 * j;
     if (MFX_CCD_EXP & 2) { d.x = raw_t{}; d.x[0] = r.x; d.r = f4{1.0f, 2.0f, 3.0f, 4.0f}; return d; }
+    if (BUF) {
+      const unsigned len = ((unsigned)r.y >> 10) & 0x7ffu;
+      const unsigned rel = (unsigned)(64 * ((r.y >> 5) & 31) - (r.y & 31) + 4 * j);
+      const bool need = live && rel + 3u < len + 3u;             // some entry of [rel, rel + 4) lies in [0, len)
+      const unsigned t32 = (unsigned)t;
+      typedef unsigned u4 __attribute__((ext_vector_type(4)));
+      d.r = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, need ? t32 * 4u : 0xfffffff0u, 0, 0));
+      if constexpr (sizeof(IdxT) == 2) d.x = __builtin_bit_cast(raw_t, __builtin_amdgcn_raw_buffer_load_b64(rs_ind, need ? t32 * 2u : 0xfffffff0u, 0, 0));
+      else d.x = __builtin_bit_cast(raw_t, __builtin_amdgcn_raw_buffer_load_b128(rs_ind, need ? t32 * 4u : 0xfffffff0u, 0, 0));
+      return d;
+    }
     d.x = *(const raw_t*)(ind + t);
     d.r = *(const f4*)(res + t);
     return d;
@@ -395,7 +412,7 @@ __device__ __forceinline__ void mfx_ccd_trip_loop(const MfxTrips trips, int n0, 
 #define MFX_TRIP_STEP(N, RC, DC, RN, DN)                                                                                  \
   {                                                                                                                       \
     if (pslot >= 0) { mfx_store_unseen(part + 2 * (int64_t)pslot, pnum, pden); pslot = -1; }                              \
-    DN = data(RN);       /* first: the wave then waits for trip n with n + 1 AND n + 2 in flight */                       \
+    DN = data(RN, (N) + 2 < n1);   /* first: the wave then waits for trip n with n + 1 AND n + 2 in flight */             \
     const int pk = (N) < n1 ? RC.y : 0;                                                                                   \
     const unsigned len = ((unsigned)pk >> 10) & 0x7ffu;                                                                   \
     const unsigned rel = (unsigned)(64 * ((pk >> 5) & 31) - (pk & 31) + 4 * j);                                           \
@@ -423,7 +440,7 @@ __device__ __forceinline__ void mfx_ccd_trip_loop(const MfxTrips trips, int n0, 
     RC = rec((N) + 4);   /* after the last use of the old record: the load lands in the same registers, no copy */        \
   }
   Rec r0 = rec(n0), r1 = rec(n0 + 1), r2 = rec(n0 + 2), r3 = rec(n0 + 3);
-  Data d0 = data(r0), d1 = data(r1), d2, d3;
+  Data d0 = data(r0, true), d1 = data(r1, n0 + 1 < n1), d2, d3;
   for (int n = n0; n < n1; n += 4) {
     MFX_TRIP_STEP(n, r0, d0, r2, d2)
     MFX_TRIP_STEP(n + 1, r1, d1, r3, d3)
