@@ -356,7 +356,8 @@ static inline int mfx_trips_upload(mfx_ctx* ctx, const std::vector<int4>& trips,
 
 // Diagnostic builds (scripts/exp_ccd.sh; results are WRONG on purpose): what the pass time does when one part is taken out.
 // bit 0: no gathers (o = 1)  bit 1: no data loads  bit 2: no segment ends (fin never runs)  bit 3: no record loads
-// bit 4: float sums instead of double  bit 5: memory operations only (no masks, gathers, doubles).  0 (the product): nothing of
+// bit 4: float sums instead of double  bit 5: memory operations only (no masks, gathers, doubles)  bit 6: synthetic records, trip n
+// = entries [64 n, 64 n + 64) (a clean stream per group).  0 (the product): nothing of
 // this is compiled.
 #ifndef MFX_CCD_EXP
 #define MFX_CCD_EXP 0
@@ -374,10 +375,11 @@ __device__ __forceinline__ void mfx_ccd_trip_loop(const MfxTrips trips, int n0, 
   if (n0 >= n1) return;
   struct Data { raw_t x; f4 r; };
   struct Rec { int x, y, z; };
-  const int exp_q0 = (MFX_CCD_EXP & 8) ? trips.q[n0] : 0, exp_q1 = (MFX_CCD_EXP & 8) ? trips.q[n1 - 1] : 0, exp_m = (MFX_CCD_EXP & 8) ? trips.meta[n0] : 0;
+  const int exp_q0 = (MFX_CCD_EXP & 8) ? trips.q[n0] : 0, exp_q1 = (MFX_CCD_EXP & 8) ? trips.q[n1 - 1] : 0, exp_m = (MFX_CCD_EXP & (8 | 64)) ? trips.meta[n0] : 0;
   auto rec = [&](int n) {                                                   // behind the range: the last record again (masked below)
     const int nc = n < n1 ? n : n1 - 1;
     Rec r;
+    if (MFX_CCD_EXP & 64) { r.x = (int)((unsigned)n % (res_bytes / 256u - 2u)) * 16; r.y = (64 << 10) | ((n & 3) == 3 ? MFX_TRIP_LAST : 0); r.z = exp_m; return r; }   // trip n reads entries [64 n, 64 n + 64): every line once, one stream per group
     if (MFX_CCD_EXP & 8) { r.x = min(exp_q0 + 16 * (n - n0), exp_q1); r.y = (64 << 10) | ((n & 3) == 3 ? MFX_TRIP_LAST : 0); r.z = exp_m; return r; }   // in-bounds: a group's trips ascend in memory
     r.x = trips.q[nc]; r.y = trips.pk[nc]; r.z = trips.meta[nc];
     return r;

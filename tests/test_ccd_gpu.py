@@ -125,3 +125,35 @@ def test_column_view_strips_and_light_columns_agree(light, monkeypatch):
     order = np.argsort(tr.rowind, kind="stable")
     assert np.array_equal(grr[order], grc)
 
+
+
+@pytest.mark.parametrize("nobuf", ["", "1"])
+@pytest.mark.parametrize("nI", [500, 70000])
+def test_wide_item_axis_and_plain_load_paths(nI, nobuf, monkeypatch):
+    """The pass kernels have two index widths and two load paths.  70 000 items: v_k does not fit in LDS (gathered from L2),
+    item and column ids are 32 bits; 500 items: 16-bit ids, v_k in LDS.  MFX_CCD_NOBUF=1 takes the plain global loads that
+    matrices of 2^30 ratings and more use (no per-lane skip outside a segment).  Same tolerances as above on all four."""
+    if nobuf:
+        monkeypatch.setenv("MFX_CCD_NOBUF", nobuf)
+    K = 8
+    d, tr, (cp, ci, cv), U0, V0 = _setup(12000, nI, 200000, K, seed=5 + nI)
+    nU, nIt = d["nUsers"], d["nItems"]
+    uReg, iReg = 0.3, 0.2
+    Uo, Vo = U0.copy(), V0.copy()
+    Uo[:] = 0
+    rr, rc = tr.rowval.copy(), cv.copy()
+    with Ctx(0) as ctx:
+        invU, invI = load_ctx(ctx, d, K, U0, V0)
+        ctx.ccdpp_begin()
+        for it in range(2):
+            for k in range(3):
+                ctx.ccdpp_rank1(k, uReg, iReg, add_back=it > 0, inner=5)
+                orc.ccdpp_rank1(k, Uo, Vo, nU, nIt, tr.ncols, tr.rowptr, tr.rowind, rr, cp, ci, rc, invU, invI, uReg, iReg, it > 0, 5,
+                                -1.0, nthreads=4)
+                U, V = ctx.get_factors()
+                assert ulp_diff(U[:, k], Uo[:, k]).max() <= 2 and ulp_diff(V[:, k], Vo[:, k]).max() <= 2, (it, k)
+        grr, grc = ctx.debug_residuals(tr.nnz)
+        ctx.ccdpp_end()
+    assert np.abs(grr - rr).max() < 1e-5 and np.abs(grc - rc).max() < 1e-5
+    order = np.argsort(tr.rowind, kind="stable")
+    assert np.array_equal(grr[order], grc)
