@@ -376,7 +376,11 @@ __device__ __forceinline__ void mfx_ccd_trip_loop(const MfxTrips trips, int n0, 
   struct Data { raw_t x; f4 r; };
   struct Rec { int x, y, z; };
   const int exp_q0 = (MFX_CCD_EXP & 8) ? trips.q[n0] : 0, exp_q1 = (MFX_CCD_EXP & 8) ? trips.q[n1 - 1] : 0, exp_m = (MFX_CCD_EXP & (8 | 64)) ? trips.meta[n0] : 0;
-  auto rec = [&](int n) {                                                   // behind the range: the last record again (masked below)
+  // Records are fetched four trips at a time: lane j of the group loads record base + (j & 3) (three loads per FOUR steps
+  // instead of per step: small loads cost the vector memory pipe as much as wide ones -- scripts/stream_probe.hip pattern 5),
+  // a step takes its record from lane s of the row with a DPP row_share.
+  auto rec = [&](int base) {                                                // behind the range: the last record again (masked below)
+    const int n = base + (j & 3);
     const int nc = n < n1 ? n : n1 - 1;
     Rec r;
     if (MFX_CCD_EXP & 64) { r.x = (int)((unsigned)n % (res_bytes / 256u - 2u)) * 16; r.y = (64 << 10) | ((n & 3) == 3 ? MFX_TRIP_LAST : 0); r.z = exp_m; return r; }   // trip n reads entries [64 n, 64 n + 64): every line once, one stream per group
@@ -389,7 +393,7 @@ __device__ __forceinline__ void mfx_ccd_trip_loop(const MfxTrips trips, int n0, 
   // trips; without this the vector memory pipe moves 256 entries for it (measured: 1.23 x the arrays).
   const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)res, 0, BUF ? (int)res_bytes : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_ind = __builtin_amdgcn_make_buffer_rsrc((void*)ind, 0, BUF ? (int)(res_bytes / 4 * sizeof(IdxT)) : 0, 0x00020000);
-  auto data = [&](const Rec& r, bool live) {
+  auto data = [&](const Rec& r, bool live) {      // r: the record of the trip, the same in all lanes of the group
     Data d;
     const int64_t t = ((int64_t)(uint32_t)r.x << 2) + 4 * j;
     if (MFX_CCD_EXP & 2) { d.x = raw_t{}; d.x[0] = r.x; d.r = f4{1.0f, 2.0f, 3.0f, 4.0f}; return d; }
@@ -410,12 +414,17 @@ __device__ __forceinline__ void mfx_ccd_trip_loop(const MfxTrips trips, int n0, 
   };
   double num = 0.0, den = 0.0, pnum = 0.0, pden = 0.0;
   int pslot = -1;                 // pending result (lane j == 0 of the group)
-  // one step: the prefetch (data of n + 2 from its record, which arrived two steps ago), the gathers of trip n, the sums
-#define MFX_TRIP_STEP(N, RC, DC, RN, DN)                                                                                  \
+  // record S of a batch (lane S of the row), the same in all lanes afterwards
+#define MFX_REC_OF(BATCH, S)                                                                                              \
+  Rec{__builtin_amdgcn_mov_dpp(BATCH.x, 0x150 + (S), 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(BATCH.y, 0x150 + (S), 0xF, 0xF, true), \
+      __builtin_amdgcn_mov_dpp(BATCH.z, 0x150 + (S), 0xF, 0xF, true)}
+  // one step: the prefetch (data of n + 2; its batch was requested at least four steps ago), the gathers of trip n, the sums
+#define MFX_TRIP_STEP(N, CURB, S, DC, NEXTB, NEXTS, DN)                                                                         \
   {                                                                                                                       \
     if (pslot >= 0) { mfx_store_unseen(part + 2 * (int64_t)pslot, pnum, pden); pslot = -1; }                              \
-    DN = data(RN, (N) + 2 < n1);   /* first: the wave then waits for trip n with n + 1 AND n + 2 in flight */             \
-    const int pk = (N) < n1 ? RC.y : 0;                                                                                   \
+    DN = data(MFX_REC_OF(NEXTB, NEXTS), (N) + 2 < n1);   /* first: the wave then waits for trip n with n + 1 AND n + 2 in flight */ \
+    const Rec rc = MFX_REC_OF(CURB, S);                                                                                   \
+    const int pk = (N) < n1 ? rc.y : 0;                                                                                   \
     const unsigned len = ((unsigned)pk >> 10) & 0x7ffu;                                                                   \
     const unsigned rel = (unsigned)(64 * ((pk >> 5) & 31) - (pk & 31) + 4 * j);                                           \
     float o[4];                                                                                                           \
@@ -423,7 +432,7 @@ __device__ __forceinline__ void mfx_ccd_trip_loop(const MfxTrips trips, int n0, 
       o[q] = (MFX_CCD_EXP & 1) ? (rel + (unsigned)q < len ? __int_as_float(MfxIdx4<IdxT>::get(DC.x, q) | 0x3f800000) : 0.0f) \
                                : other[rel + (unsigned)q < len ? MfxIdx4<IdxT>::get(DC.x, q) : zero];                      \
     const f4 rr = DC.r;                                                                                                   \
-    const int meta = RC.z;                                                                                                \
+    const int meta = rc.z;                                                                                                \
     if (MFX_CCD_EXP & 32) {   /* memory operations only: the loaded values are summed without masks, gathers or doubles */  \
       float fs = rr[0] + rr[1] + rr[2] + rr[3] + __int_as_float(MfxIdx4<IdxT>::get(DC.x, 0) + MfxIdx4<IdxT>::get(DC.x, 3));   \
       num += (double)fs;                                                                                                  \
@@ -439,18 +448,26 @@ __device__ __forceinline__ void mfx_ccd_trip_loop(const MfxTrips trips, int n0, 
       pslot = j == 0 ? meta : -1;                                                                                         \
       num = 0.0; den = 0.0;                                                                                               \
     }                                                                                                                     \
-    RC = rec((N) + 4);   /* after the last use of the old record: the load lands in the same registers, no copy */        \
   }
-  Rec r0 = rec(n0), r1 = rec(n0 + 1), r2 = rec(n0 + 2), r3 = rec(n0 + 3);
-  Data d0 = data(r0, true), d1 = data(r1, n0 + 1 < n1), d2, d3;
-  for (int n = n0; n < n1; n += 4) {
-    MFX_TRIP_STEP(n, r0, d0, r2, d2)
-    MFX_TRIP_STEP(n + 1, r1, d1, r3, d3)
-    MFX_TRIP_STEP(n + 2, r2, d2, r0, d0)
-    MFX_TRIP_STEP(n + 3, r3, d3, r1, d1)
+  Rec ra = rec(n0), rb = rec(n0 + 4);        // batches: trips n .. n + 3 and n + 4 .. n + 7
+  Data d0 = data(MFX_REC_OF(ra, 0), true), d1 = data(MFX_REC_OF(ra, 1), n0 + 1 < n1), d2, d3;
+  // eight steps per turn, the two batches trading places: a batch is re-loaded in place once its last step is over (a copy
+  // `ra = rb` makes the compiler load the new batch into temporaries and wait for them at the loop end)
+  for (int n = n0; n < n1; n += 8) {
+    MFX_TRIP_STEP(n, ra, 0, d0, ra, 2, d2)
+    MFX_TRIP_STEP(n + 1, ra, 1, d1, ra, 3, d3)
+    MFX_TRIP_STEP(n + 2, ra, 2, d2, rb, 0, d0)
+    MFX_TRIP_STEP(n + 3, ra, 3, d3, rb, 1, d1)
+    ra = rec(n + 8);
+    MFX_TRIP_STEP(n + 4, rb, 0, d0, rb, 2, d2)
+    MFX_TRIP_STEP(n + 5, rb, 1, d1, rb, 3, d3)
+    MFX_TRIP_STEP(n + 6, rb, 2, d2, ra, 0, d0)
+    MFX_TRIP_STEP(n + 7, rb, 3, d3, ra, 1, d1)
+    rb = rec(n + 12);
   }
   if (pslot >= 0) mfx_store_unseen(part + 2 * (int64_t)pslot, pnum, pden);
 #undef MFX_TRIP_STEP
+#undef MFX_REC_OF
 }
 
 static inline void mfx_tree_shape(int K, int* L, int* C) {
