@@ -73,6 +73,20 @@ __global__ void narrow_ids_kernel(const int32_t* __restrict__ src, int64_t n, ui
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) dst[t] = (uint16_t)src[t];
 }
 
+// a[x[0..3]] for four CONSECUTIVE entries of the row view: their rows ascend, and with ~200 entries per row a quad almost always
+// lies in one row or two.  Two gathers (first and last entry) serve it then; an entry whose row is neither (rows of one or two
+// entries) takes its own.  (A 4-byte gather occupies the vector memory pipe like a 16-byte load: four of them per quad were
+// half of this kernel's memory instructions.)
+typedef int mfx_i4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void gather_sorted4(const float* __restrict__ a, mfx_i4 x, float (&o)[4]) {
+  o[0] = a[x[0]];
+  o[3] = a[x[3]];
+  o[1] = x[1] == x[0] ? o[0] : o[3];
+  o[2] = x[2] == x[0] ? o[0] : o[3];
+  if (x[1] != x[0] && x[1] != x[3]) o[1] = a[x[1]];
+  if (x[2] != x[0] && x[2] != x[3]) o[2] = a[x[2]];
+}
+
 template <int SIGN, bool LDSB>
 __global__ __launch_bounds__(1024) void resid_update_kernel(float* __restrict__ res, const int32_t* __restrict__ ia,
                                                             const typename ItemIdx<LDSB>::type* __restrict__ ib,
@@ -87,9 +101,11 @@ __global__ __launch_bounds__(1024) void resid_update_kernel(float* __restrict__ 
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride) {
     const i4 x = ((const i4*)ia)[q], y = MfxCcdTrip::load4(ib + 4 * q);
     f4 r = ((const f4*)res)[q];
+    float au[4];
+    gather_sorted4(a, x, au);
 #pragma unroll
     for (int e = 0; e < 4; e++) {
-      const float prod = a[x[e]] * b[y[e]];
+      const float prod = au[e] * b[y[e]];
       r[e] = SIGN > 0 ? r[e] + prod : r[e] - prod;
     }
     ((f4*)res)[q] = r;
@@ -129,10 +145,13 @@ __global__ __launch_bounds__(1024) void resid_fused_kernel(float* __restrict__ r
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride) {
     const i4 x = ((const i4*)ia)[q], y = MfxCcdTrip::load4(ib + 4 * q);
     f4 r = ((const f4*)res)[q];
+    float au0[4], au1[4];
+    gather_sorted4(a0, x, au0);
+    gather_sorted4(a1, x, au1);
 #pragma unroll
     for (int e = 0; e < 4; e++) {
-      const float p0 = a0[x[e]] * b0[y[e]];
-      const float p1 = a1[x[e]] * b1[y[e]];
+      const float p0 = au0[e] * b0[y[e]];
+      const float p1 = au1[e] * b1[y[e]];
       r[e] = (r[e] - p0) + p1;
     }
     ((f4*)res)[q] = r;

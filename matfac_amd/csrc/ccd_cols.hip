@@ -399,12 +399,25 @@ __global__ __launch_bounds__(1024) void colresid_kernel(const int32_t* __restric
     if (t >= e0 && t + 4 <= e1) {
       const i4 lu = MfxCcdTrip::load4(buser + t), c = MfxCcdTrip::load4(bcol + t);
       f4 r = *(const f4*)(res + t);
+      // the column ids of four consecutive entries ascend (column by column inside a strip): two gathers serve a quad that
+      // lies in one column or two, an entry in a third column takes its own (see gather_sorted4 in ccd.hip)
+      float v0[4], v1[4];
+      v0[0] = vk0[c[0]]; v0[3] = vk0[c[3]];
+      v0[1] = c[1] == c[0] ? v0[0] : v0[3]; v0[2] = c[2] == c[0] ? v0[0] : v0[3];
+      if (c[1] != c[0] && c[1] != c[3]) v0[1] = vk0[c[1]];
+      if (c[2] != c[0] && c[2] != c[3]) v0[2] = vk0[c[2]];
+      if (MODE == 2) {
+        v1[0] = vk1[c[0]]; v1[3] = vk1[c[3]];
+        v1[1] = c[1] == c[0] ? v1[0] : v1[3]; v1[2] = c[2] == c[0] ? v1[0] : v1[3];
+        if (c[1] != c[0] && c[1] != c[3]) v1[1] = vk1[c[1]];
+        if (c[2] != c[0] && c[2] != c[3]) v1[2] = vk1[c[2]];
+      }
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        const float p0 = su[lu[q]] * vk0[c[q]];   // u_k(u)*v_k(item): float product (modelMF.cpp:1053, :1114)
+        const float p0 = su[lu[q]] * v0[q];   // u_k(u)*v_k(item): float product (modelMF.cpp:1053, :1114)
         if (MODE == 1) r[q] = r[q] + p0;
         else r[q] = r[q] - p0;
-        if (MODE == 2) r[q] = r[q] + su[UB + lu[q]] * vk1[c[q]];
+        if (MODE == 2) r[q] = r[q] + su[UB + lu[q]] * v1[q];
       }
       *(f4*)(res + t) = r;
     } else {
