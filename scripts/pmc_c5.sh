@@ -20,7 +20,7 @@ out, rnd = sys.argv[1], sys.argv[2]
 vals = {}
 for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
-        if "sgd_slots_kernel" in row["Kernel_Name"] and ", false, false, 0>" in row["Kernel_Name"]:
+        if "sgd_slots_kernel" in row["Kernel_Name"] and ", false, false, 0" in row["Kernel_Name"]:
             vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
 m = {k: sum(v) / len(v) for k, v in vals.items()}
 line = [l for l in open(os.path.join(out, "FETCH_SIZE.log")) if l.startswith("{")][-1]
