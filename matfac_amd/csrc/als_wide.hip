@@ -364,19 +364,20 @@ __global__ __launch_bounds__(P * P) void alsw_solve_kernel(const int32_t* __rest
 // Left-looking block LDL^T of the K x K system (K = 64 C).  For block column J:
 //   * every block (I, J), I >= J, is loaded in the accumulator layout phase A wrote it in and receives
 //         A(I,J) -= sum_{k<J} (L(I,k) D_k) L(J,k)^T                      -- 32 steps of v_mfma_f32_32x32x2_f32 per tile and k;
-//     both operands come from the wave's workspace in HBM/L2, where finished blocks are kept "k-major"
-//     (Lt[kk][i] = L(I,k)[i][kk]): for one MFMA step the 64 lanes read two contiguous 128-byte rows;
+//     both operands come from the wave's workspace in HBM/L2, where finished blocks are kept ROW-major; MFMA step t sums the
+//     columns t (lower half of the wave) and 32 + t (upper half), so a lane reads 32 consecutive columns of its rows idx and
+//     32 + idx, four per load;
 //   * the block goes through a padded LDS image (64 x 65 floats per wave) to change layout: the diagonal block to
 //     "lane i owns row i" (its missing upper-right tile is read transposed: the block is symmetric), an off-diagonal block
 //     to "lane j owns COLUMN j";
 //   * diagonal block: unpivoted right-looking LDL^T in registers, the block's right-hand side riding along (as als.hip);
 //     afterwards lane k holds L(k, m<k), d_k and the pivot row d_k L(j>k, k) -- kept in registers for the panel below and
 //     written to the workspace for the back substitution;
-//   * off-diagonal block (the panel): with B^T in "lane j owns row j", L_JJ Z = B^T is a forward substitution ACROSS lanes --
-//     step m broadcasts row m (64 v_readlane) and every lane j > m subtracts L(j,m) times it; Y = D^-1 Z is L(I,J)^T, so
-//     lane j writes its 64 registers as row j of the k-major block (and -Z as the pre-scaled copy the MFMA's first operand reads).
-// Forward substitution happens on the way (block right-hand sides are corrected with k-major matrix-vector products), the
-// back substitution walks the block columns from the last: w = L(I,J)^T x_I is lane-local in the k-major rows.
+//   * off-diagonal block (the panel): lane i owns row i of B; X (D L^T) = B is solved row by row -- step j fixes x_j d_j = b_j and
+//     the later columns lose x_j (d_j L(c,j)), the scalar being entry c of lane j's pivot row (one v_readlane per (step, column));
+//     lane i then writes its row of L(I,J) and of -L(I,J) D_J (the copy the MFMA's first operand reads) as 16 wide stores each.
+// Forward substitution happens on the way (a block's right-hand side is corrected with the lane's own rows of the finished
+// blocks), the back substitution walks the block columns from the last: w = L(I,J)^T x_I reads a column of every row.
 namespace {
 constexpr int IMG_LD = 65;                 // row stride of the LDS image (floats): row- and column-wise reads are conflict-free
 struct BlkAcc { f32x16 t00, t01, t10, t11; };
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(256, 2) void alsw_bsolve_kernel(const int32_t* __re
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, half = lane >> 5, idx = lane & 31;
   float* img = img_all[wv];
   const int64_t wave = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
-  // workspace of this wave: off-diagonal blocks k-major (Lt) and pre-scaled (-D L)^T, diagonal blocks as factored rows
+  // workspace of this wave: off-diagonal blocks row-major, L and the pre-scaled -L D; diagonal blocks as factored rows
   const BufF W(wsp + wave * ws_stride);
   // byte offsets inside the workspace
   auto LT = [&](int I, int J) { return (I * (I - 1) / 2 + J) * (2 * BLK) * 4; };          // I > J
@@ -467,10 +468,16 @@ __global__ __launch_bounds__(256, 2) void alsw_bsolve_kernel(const int32_t* __re
       for (int sg = 0; sg < nsg; sg++) rJ += BufF(sl0 + sg * stride).ld(l4, (NPAIRS * BLK + 64 * J) * 4);
 #pragma unroll 1
       for (int k = 0; k < J; k++) {
-        const int lt = LT(J, k);
+        const int lt = LT(J, k);                      // row `lane` of L(J,k)
         const float zk = W.ld(l4, VEC + (0 * C + k) * 256);
-#pragma unroll 8
-        for (int kk = 0; kk < 64; kk++) rJ = __builtin_fmaf(-W.ld(l4, lt + kk * 256), alsb_bcast(zk, kk), rJ);
+#pragma unroll 4
+        for (int q = 0; q < 64; q += 4) {
+          const f32x4w v = W.ld4(l256, lt + q * 4);
+          rJ = __builtin_fmaf(-v[0], alsb_bcast(zk, q), rJ);
+          rJ = __builtin_fmaf(-v[1], alsb_bcast(zk, q + 1), rJ);
+          rJ = __builtin_fmaf(-v[2], alsb_bcast(zk, q + 2), rJ);
+          rJ = __builtin_fmaf(-v[3], alsb_bcast(zk, q + 3), rJ);
+        }
       }
       float a[64];     // the factored diagonal block of this column: lane l = row l (see above)
       float dJ = 1.0f;
@@ -497,17 +504,22 @@ __global__ __launch_bounds__(256, 2) void alsw_bsolve_kernel(const int32_t* __re
         // ---- minus the contributions of the finished block columns (the diagonal block computes its unused tile too: one code path)
 #pragma unroll 1
         for (int k = 0; k < ((dbg & 4) ? 0 : J); k++) {
-          const int pa = LTD(I, k);         // (-D_k L(I,k))^T, k-major
-          const int pb = LT(J, k);          // L(J,k)^T
-          const int vo = (half * 64 + idx) * 4;
-#pragma unroll 4
-          for (int s2 = 0; s2 < 32; s2++) {
-            const int o = 2 * s2 * 256;
-            const float a0 = W.ld(vo, pa + o), a1 = W.ld(vo, pa + o + 128), y0 = W.ld(vo, pb + o), y1 = W.ld(vo, pb + o + 128);
-            g.t00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, y0, g.t00, 0, 0, 0);
-            g.t01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, y1, g.t01, 0, 0, 0);
-            g.t10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, y0, g.t10, 0, 0, 0);
-            g.t11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, y1, g.t11, 0, 0, 0);
+          const int pa = LTD(I, k);         // -D_k L(I,k), row-major
+          const int pb = LT(J, k);          // L(J,k)
+          // MFMA step t sums the two columns t (lower half of the wave) and 32 + t (upper half): a lane reads 32 consecutive
+          // columns of its rows idx and 32 + idx, FOUR per load -- 32 wide loads per block product instead of 128 single ones
+          const int vo = (idx * 64 + half * 32) * 4;
+#pragma unroll 2
+          for (int tq = 0; tq < 8; tq++) {
+            const f32x4w a0 = W.ld4(vo, pa + tq * 16), a1 = W.ld4(vo, pa + 8192 + tq * 16);
+            const f32x4w y0 = W.ld4(vo, pb + tq * 16), y1 = W.ld4(vo, pb + 8192 + tq * 16);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+              g.t00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], y0[e], g.t00, 0, 0, 0);
+              g.t01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], y1[e], g.t01, 0, 0, 0);
+              g.t10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], y0[e], g.t10, 0, 0, 0);
+              g.t11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], y1[e], g.t11, 0, 0, 0);
+            }
           }
         }
         if (I == J) {
@@ -549,13 +561,18 @@ __global__ __launch_bounds__(256, 2) void alsw_bsolve_kernel(const int32_t* __re
           if (!(dbg & 2))
 #pragma unroll
           for (int j = 0; j < 64; j++) {
-            const float zj = y[j];                                  // x_j d_j
-            const float xj = zj * alsb_bcast(rdv, j);
-            W.st(-zj, l4, ltd + j * 256);                           // k-major: row j, element `lane`
-            W.st(xj, l4, lt + j * 256);
+            const float xj = y[j] * alsb_bcast(rdv, j);             // y[j] = x_j d_j is final from here on
 #pragma unroll
             for (int c = j + 1; c < 64; c++) y[c] = __builtin_fmaf(-xj, alsb_bcast(a[c], j), y[c]);
             __builtin_amdgcn_sched_barrier(0);
+          }
+          // row `lane` of L(I,J) D_J is y; the two copies go out as 16 wide stores each (row-major blocks)
+#pragma unroll
+          for (int q = 0; q < 64; q += 4) {
+            W.st4(f32x4w{-y[q], -y[q + 1], -y[q + 2], -y[q + 3]}, l256, ltd + q * 4);
+            W.st4(f32x4w{y[q] * alsb_bcast(rdv, q), y[q + 1] * alsb_bcast(rdv, q + 1), y[q + 2] * alsb_bcast(rdv, q + 2),
+                         y[q + 3] * alsb_bcast(rdv, q + 3)},
+                  l256, lt + q * 4);
           }
         }
       }
@@ -569,16 +586,10 @@ __global__ __launch_bounds__(256, 2) void alsw_bsolve_kernel(const int32_t* __re
       float w = 0.0f;
 #pragma unroll 1
       for (int I = J + 1; I < C; I++) {
-        const int lt = LT(I, J);                      // row `lane` of the k-major block = column `lane` of L(I,J)
+        const int lt = LT(I, J);                      // column `lane` of L(I,J): element `lane` of every row
         const float xI = W.ld(l4, VEC + (2 * C + I) * 256);
-#pragma unroll 4
-        for (int q = 0; q < 64; q += 4) {
-          const f32x4w v = W.ld4(l256, lt + q * 4);
-          w = __builtin_fmaf(v[0], alsb_bcast(xI, q), w);
-          w = __builtin_fmaf(v[1], alsb_bcast(xI, q + 1), w);
-          w = __builtin_fmaf(v[2], alsb_bcast(xI, q + 2), w);
-          w = __builtin_fmaf(v[3], alsb_bcast(xI, q + 3), w);
-        }
+#pragma unroll 8
+        for (int i = 0; i < 64; i++) w = __builtin_fmaf(W.ld(l4, lt + i * 256), alsb_bcast(xI, i), w);
       }
       float a[64];
 #pragma unroll
@@ -688,7 +699,7 @@ int mfx_als_wide_half_sweep(mfx_ctx* ctx, int side, float reg) {
                            val, Y, ctx->ld, st->slabs, stride, (int)yrows);
       HIPCHK(hipGetLastError());
     }
-    // blocked LDL^T (one wavefront per row, block products on the MFMA) from three blocks on: K = 192: 36 vs 60 ms, K = 256: 72 vs
+    // blocked LDL^T (one wavefront per row, block products on the MFMA) from three blocks on: K = 192: 35 vs 60 ms, K = 256: 67 vs
     // 94 ms per iteration at the C2 matrix; at two blocks (K <= 128) the register-resident workgroup kernel below is still ahead
     // (10.9 vs 14.5 ms).  MFX_ALS_SOLVER=blocked / unblocked overrides.
     const char* sv = getenv("MFX_ALS_SOLVER");
