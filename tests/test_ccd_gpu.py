@@ -157,3 +157,33 @@ def test_wide_item_axis_and_plain_load_paths(nI, nobuf, monkeypatch):
     assert np.abs(grr - rr).max() < 1e-5 and np.abs(grc - rc).max() < 1e-5
     order = np.argsort(tr.rowind, kind="stable")
     assert np.array_equal(grr[order], grc)
+
+
+def test_random_small_shapes_against_the_oracle():
+    """The trip lists, the masked whole-trip loads and the record batches on shapes that stress their edges: fewer ratings
+    than one trip, rows and columns without ratings, one-entry segments next to 1024-entry ones, a light region that is
+    empty or everything.  Twelve random shapes, three rank-one steps each, oracle tolerances as above."""
+    rng = np.random.default_rng(2024)
+    shapes = [(3, 2, 4), (70, 9, 65), (200, 300, 700), (5000, 40, 30000), (40, 5000, 30000), (9000, 33, 9000)]
+    shapes += [(int(rng.integers(50, 3000)), int(rng.integers(5, 900)), int(rng.integers(100, 40000))) for _ in range(6)]
+    for nU, nI, nnz in shapes:
+        nnz = min(nnz, nU * nI // 2 + 1)
+        K = 4
+        d, tr, (cp, ci, cv), U0, V0 = _setup(nU, nI, nnz, K, seed=nU + nI)
+        nUs, nIs = d["nUsers"], d["nItems"]
+        Uo, Vo = U0.copy(), V0.copy()
+        Uo[:] = 0
+        rr, rc = tr.rowval.copy(), cv.copy()
+        with Ctx(0) as ctx:
+            invU, invI = load_ctx(ctx, d, K, U0, V0)
+            ctx.ccdpp_begin()
+            for k in range(3):
+                ctx.ccdpp_rank1(k, 0.3, 0.2, add_back=False, inner=3)
+                orc.ccdpp_rank1(k, Uo, Vo, nUs, nIs, tr.ncols, tr.rowptr, tr.rowind, rr, cp, ci, rc, invU, invI, 0.3, 0.2, False, 3, -1.0,
+                                nthreads=2)
+            U, V = ctx.get_factors()
+            grr, grc = ctx.debug_residuals(tr.nnz)
+            ctx.ccdpp_end()
+        shape = (nU, nI, tr.nnz)
+        assert ulp_diff(U[:, :3], Uo[:, :3]).max() <= 2 and ulp_diff(V[:, :3], Vo[:, :3]).max() <= 2, shape
+        assert np.abs(grr - rr).max() < 1e-5 and np.abs(grc - rc).max() < 1e-5, shape
