@@ -501,6 +501,17 @@ def bench_ccd(np, with_cpu):
            "roofline": {"bound": "hbm", "achieved": bytes_per_k / per_k / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": bytes_per_k / per_k / 1e9 / HBM_PEAK_GBS, "bytes_per_factor": bytes_per_k, "traffic": None,
                         "kernel": "ccd_pass_kernel / ccd_cols pass / resid_update_kernel (whole rank-one step, wall clock)"}}
+    # memory-side bytes of one rank-one step from the committed counter passes (scripts/pmc_c4.sh), time from this run
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_c4_pmc.json")) as f:
+            pmc = json.load(f)
+        rec["roofline"]["traffic"] = pmc["hbm_bytes_per_factor"]
+        rec["roofline"]["traffic_GBs"] = pmc["hbm_bytes_per_factor"] / per_k / 1e9
+        rec["roofline"]["traffic_frac_of_peak"] = pmc["hbm_bytes_per_factor"] / per_k / 1e9 / HBM_PEAK_GBS
+        rec["roofline"]["traffic_source"] = ("profiles/r02_c4_pmc.json: sum over the kernels of a rank-one step of (FETCH_SIZE x2 + WRITE_SIZE) per launch "
+                                             "x launches per step, separate --pmc passes of scripts/bench_als_ccd.py; time from this run")
+    except (OSError, KeyError, ValueError):
+        pass
     if with_cpu:
         from oracle import binding as orc
         threads = orc.max_threads()
