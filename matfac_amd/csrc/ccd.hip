@@ -9,8 +9,12 @@
 //   residual   res_ui +-= u_k[u] v_k[i] on both views                   (:1032-1056, :1095-1116)
 // Arithmetic as in the reference: the products are float*float, num/denom accumulate
 // in double, the quotient is rounded to float once.  A 16-lane group reduces one row
-// segment (<= MFX_SEG ratings); rows with several segments are finished in segment
-// order by a second launch, so every sum has a fixed association (reproducible).
+// segment (<= MFX_SEG ratings) at a time, working through its range of the TRIP LIST
+// (mfx_internal.h: mfx_ccd_trip_loop -- 64-entry trips, records fetched four at a time,
+// data prefetched two trips ahead, whole trips loaded and masked); the sums of a segment
+// go to a slot and the quotients are taken by the finishing kernels in a fixed order, so
+// every sum has a fixed association (reproducible).  Item ids are 16 bits wherever v_k
+// is staged in LDS.
 #include <algorithm>
 
 #include "mfx_internal.h"

@@ -14,6 +14,8 @@
 // entries, and two thirds of the 1 M (strip, column) segments, each 1..16 entries long -- the pass spent its time on
 // per-segment latency, not on bytes) stay OUT of the strip scheme: their entries are kept contiguous behind the strips,
 // users ascending (the reference's CSC order), one segment per column, and u_k is gathered from L2 for them.
+// Both regions are worked through as trip lists (mfx_internal.h) by ONE launch: the light workgroups first, then the
+// strips' workgroups in proportion to their trips.
 #include <algorithm>
 #include <cstdlib>
 #include <vector>
