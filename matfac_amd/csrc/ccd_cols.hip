@@ -14,6 +14,8 @@
 // entries, and two thirds of the 1 M (strip, column) segments, each 1..16 entries long -- the pass spent its time on
 // per-segment latency, not on bytes) stay OUT of the strip scheme: their entries are kept contiguous behind the strips,
 // users ascending (the reference's CSC order), one segment per column, and u_k is gathered from L2 for them.
+// (That was round 2's first answer to the short pieces; with the trip lists the strips handle them better, and the default
+// threshold is 0 -- every column goes through the strips.  The region stays as the MFX_CCD_LIGHT knob and in the tests.)
 // Both regions are worked through as trip lists (mfx_internal.h) by ONE launch: the light workgroups first, then the
 // strips' workgroups in proportion to their trips.
 #include <algorithm>
@@ -25,7 +27,9 @@
 namespace {
 constexpr int UB = 8192;          // users per strip: 32 KB of u_k (two vectors fit for the fused update)
 constexpr int CSEG = 1024;        // entries per segment
-constexpr int LIGHT = 1024;       // columns with at most this many entries are handled whole, outside the strips
+constexpr int LIGHT = 0;          // columns with at most this many entries are handled whole, outside the strips (MFX_CCD_LIGHT).
+                                  // 0 since the trip lists: short (strip, column) pieces no longer cost per-segment latency, and the
+                                  // light region's L2 gathers do (C4: 2.29 vs 2.40 ms per factor at 1024, C2 shape 0.86 vs 0.89)
 constexpr int GPW = 64;            // 16-lane groups per pass workgroup (1024 threads)
 constexpr int PASS_WGS = 1024;    // pass workgroups over all strips (two rounds of the 512 resident ones; MFX_CCD_PASS_WGS)
 constexpr int64_t ENT_PER_WG = 128 * 1024;
