@@ -43,13 +43,18 @@ __global__ void expand_colid_kernel(const int64_t* __restrict__ colptr, int32_t 
 }
 
 // column k of a factor matrix <-> dense vector
-__global__ void extract_col_kernel(const float* __restrict__ X, int32_t n, int ld, int k, float* __restrict__ xk) {
+// (both factor matrices in ONE launch: a rank-one step is ~25 launches of 5..250 us, and every launch costs ~3 us of gap)
+__global__ void extract_col_kernel(const float* __restrict__ X, int32_t n, const float* __restrict__ Y, int32_t m, int ld, int k,
+                                   float* __restrict__ xk, float* __restrict__ yk) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < n) xk[t] = X[t * ld + k];
+  else if (t - n < m) yk[t - n] = Y[(t - n) * ld + k];
 }
-__global__ void store_col_kernel(float* __restrict__ X, int32_t n, int ld, int k, const float* __restrict__ xk) {
+__global__ void store_col_kernel(float* __restrict__ X, int32_t n, float* __restrict__ Y, int32_t m, int ld, int k,
+                                 const float* __restrict__ xk, const float* __restrict__ yk) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < n) X[t * ld + k] = xk[t];
+  else if (t - n < m) Y[(t - n) * ld + k] = yk[t - n];
 }
 
 // res[e] (+/-)= a[rowOf[e]] * b[colOf[e]]   -- float product, then float add/sub.
@@ -185,24 +190,24 @@ __global__ __launch_bounds__(1024) void ccd_pass_kernel(const MfxTrips trips, co
   mfx_ccd_trip_loop<BUF>(trips, gptr[grp], gptr[grp + 1], res, ind, res_bytes, other, nother, j, part);
 }
 
-// single-segment rows: u_k[row] = num / (reg + den) from the row's slot
-__global__ __launch_bounds__(256) void ccd_divide_kernel(const int32_t* __restrict__ single, int64_t nsingle, const double* __restrict__ part,
-                                                         float reg, float* __restrict__ mine) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nsingle) return;
-  mine[single[i]] = (float)(part[2 * i] / ((double)reg + part[2 * i + 1]));
-}
-
-// rows with several segments: partials summed by a 16-lane group, lane-strided in segment order then a fixed
-// butterfly (a single thread walking ~100 partials made this 57 us launch 13 % of a factor)
-__global__ __launch_bounds__(256) void ccd_finish_kernel(const int32_t* __restrict__ mrow,
+// The quotients of a row pass, ONE launch: the first `dblocks` workgroups take the single-segment rows (u_k[row] = num / (reg +
+// den) from the row's slot, one thread each); the others the rows with several segments -- partials summed by a 16-lane
+// group, lane-strided in segment order then a fixed butterfly (a single thread walking ~100 partials made this 57 us launch
+// 13 % of a factor).
+__global__ __launch_bounds__(256) void ccd_finish_kernel(const int32_t* __restrict__ single, int64_t nsingle, const double* __restrict__ spart,
+                                                         int dblocks, const int32_t* __restrict__ mrow,
                                                          const int32_t* __restrict__ mrow_first,
                                                          const int32_t* __restrict__ mrow_n, int64_t nmrow,
                                                          const double* __restrict__ part, float reg,
                                                          float* __restrict__ mine, const int64_t* __restrict__ ptr,
                                                          float freq_thresh, int k) {
+  if ((int)blockIdx.x < dblocks) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nsingle) mine[single[i]] = (float)(spart[2 * i] / ((double)reg + spart[2 * i + 1]));
+    return;
+  }
   const int j = threadIdx.x & 15;
-  const int64_t m = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int64_t m = ((int64_t)((int)blockIdx.x - dblocks) * blockDim.x + threadIdx.x) >> 4;
   if (m >= nmrow) return;
   double num = 0.0, den = 0.0;
   const int first = mrow_first[m], n = mrow_n[m];
@@ -347,14 +352,13 @@ static int run_pass(mfx_ctx* ctx, int side, float reg, float freq_thresh, int k)
       else MFX_ROWPASS(false, false, 0, ind);
     }
 #undef MFX_ROWPASS
-    if (ctx->ccd_nsingle > 0)
-      hipLaunchKernelGGL(ccd_divide_kernel, dim3((unsigned)((ctx->ccd_nsingle + 255) / 256)), dim3(256), 0, ctx->stream, ctx->ccd_single,
-                         ctx->ccd_nsingle, ctx->ccd_part + 2 * sg->nslab, reg, mine);
     HIPCHK(hipGetLastError());
   }
-  if (sg->nmrow > 0) {
-    hipLaunchKernelGGL(ccd_finish_kernel, dim3((unsigned)((sg->nmrow * 16 + 255) / 256)), dim3(256), 0, ctx->stream,
-                       sg->mrow, sg->mrow_first, sg->mrow_n, sg->nmrow, ctx->ccd_part, reg, mine, ptr,
+  if (ctx->ccd_nsingle > 0 || sg->nmrow > 0) {
+    const int dblocks = (int)((ctx->ccd_nsingle + 255) / 256);
+    const int fblocks = (int)((sg->nmrow * 16 + 255) / 256);
+    hipLaunchKernelGGL(ccd_finish_kernel, dim3((unsigned)(dblocks + fblocks)), dim3(256), 0, ctx->stream, ctx->ccd_single, ctx->ccd_nsingle,
+                       ctx->ccd_part + 2 * sg->nslab, dblocks, sg->mrow, sg->mrow_first, sg->mrow_n, sg->nmrow, ctx->ccd_part, reg, mine, ptr,
                        freq_thresh, k);
     HIPCHK(hipGetLastError());
   }
@@ -417,10 +421,9 @@ extern "C" int mfx_ccdpp_rank1(mfx_ctx* ctx, int32_t k, int32_t inner, float uRe
   NEED(k >= 0 && k < ctx->K, MFX_E_ARG, "mfx_ccdpp_rank1: k=%d outside [0,%d)", k, ctx->K);
   NEED(inner >= 0, MFX_E_ARG, "mfx_ccdpp_rank1: inner=%d", inner);
   HIPCHK(hipSetDevice(ctx->device));
-  const int bu = (ctx->nU + 255) / 256, bi = (ctx->nI + 255) / 256;
+  const int bui = (int)(((int64_t)ctx->nU + ctx->nI + 255) / 256);
   // u_k = uFac.col(k); v_k = iFac.col(k)  (modelMF.cpp:1028-1029)
-  hipLaunchKernelGGL(extract_col_kernel, dim3(bu), dim3(256), 0, ctx->stream, ctx->U, ctx->nU, ctx->ld, k, ctx->uk);
-  hipLaunchKernelGGL(extract_col_kernel, dim3(bi), dim3(256), 0, ctx->stream, ctx->V, ctx->nI, ctx->ld, k, ctx->vk);
+  hipLaunchKernelGGL(extract_col_kernel, dim3(bui), dim3(256), 0, ctx->stream, ctx->U, ctx->nU, ctx->V, ctx->nI, ctx->ld, k, ctx->uk, ctx->vk);
   HIPCHK(hipGetLastError());
   int rc;
   if (ctx->ccd_pending && add_back) {                       // previous factor's :1095-1116 + this one's :1032-1056
@@ -435,8 +438,7 @@ extern "C" int mfx_ccdpp_rank1(mfx_ctx* ctx, int32_t k, int32_t inner, float uRe
     if ((rc = run_pass(ctx, 1, iReg, freq_thresh, k))) return rc;
   }
   // uFac.col(k) = u_k; iFac.col(k) = v_k  (:1119-1120)
-  hipLaunchKernelGGL(store_col_kernel, dim3(bu), dim3(256), 0, ctx->stream, ctx->U, ctx->nU, ctx->ld, k, ctx->uk);
-  hipLaunchKernelGGL(store_col_kernel, dim3(bi), dim3(256), 0, ctx->stream, ctx->V, ctx->nI, ctx->ld, k, ctx->vk);
+  hipLaunchKernelGGL(store_col_kernel, dim3(bui), dim3(256), 0, ctx->stream, ctx->U, ctx->nU, ctx->V, ctx->nI, ctx->ld, k, ctx->uk, ctx->vk);
   HIPCHK(hipGetLastError());
   // res -= u_k v_k^T (:1095-1116) is deferred: keep (u_k, v_k) aside
   std::swap(ctx->uk, ctx->uk_pend);

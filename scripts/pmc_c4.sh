@@ -18,8 +18,8 @@ for f in glob.glob(out + "/*/**/*counter_collection.csv", recursive=True):
         n = r["Kernel_Name"].split("(")[0].replace("void ", "")
         acc[n][r["Counter_Name"]].append(float(r["Counter_Value"]))
 # launches per rank-one step in steady state (add_back: the deferred subtract of the previous factor fused with the add-back)
-per_factor = {"ccd_pass_kernel": 5, "ccd_divide_kernel": 5, "ccd_finish_kernel": 5, "colpass_kernel": 5, "colfinish_kernel": 5,
-              "resid_fused_kernel": 1, "colresid_kernel<2": 1, "colresid_light_kernel<2": 1, "extract_col_kernel": 2, "store_col_kernel": 2}
+per_factor = {"ccd_pass_kernel": 5, "ccd_finish_kernel": 5, "colpass_kernel": 5, "colfinish_kernel": 5,
+              "resid_fused_kernel": 1, "colresid_kernel<2": 1, "colresid_light_kernel<2": 1, "extract_col_kernel": 1, "store_col_kernel": 1}
 kern, total = {}, 0.0
 for n, c in acc.items():
     key = next((k for k in per_factor if n.startswith(k)), None)
