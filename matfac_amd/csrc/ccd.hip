@@ -10,7 +10,7 @@
 // Arithmetic as in the reference: the products are float*float, num/denom accumulate
 // in double, the quotient is rounded to float once.  A 16-lane group reduces one row
 // segment (<= MFX_SEG ratings) at a time, working through its range of the TRIP LIST
-// (mfx_internal.h: mfx_ccd_trip_loop -- 64-entry trips, records fetched four at a time,
+// (mfx_internal.h: mfx_ccd_trip_loop -- 128-entry trips, records fetched four at a time,
 // data prefetched two trips ahead, whole trips loaded and masked); the sums of a segment
 // go to a slot and the quotients are taken by the finishing kernels in a fixed order, so
 // every sum has a fixed association (reproducible).  Item ids are 16 bits wherever v_k
@@ -176,6 +176,7 @@ __device__ __forceinline__ double group16_sum(double v) { return mfx_row16_sum(v
 // is taken by the finishing kernels: a double division is ~35 instructions, and with four groups per wavefront three steps out
 // of four end a segment somewhere in the wave -- it was a quarter of the pass.  (trainCCDPPFreqAdap's rule applies to items
 // only: modelMF.cpp:1336-1342 -- the row pass never sees a threshold.)
+constexpr int ROW_TRIP_E = 128;      // entries per trip of the row view: 8 per lane (mfx_internal.h)
 template <bool LDSO, bool BUF>
 __global__ __launch_bounds__(1024) void ccd_pass_kernel(const MfxTrips trips, const int32_t* __restrict__ gptr, int ngroups,
                                                        const float* __restrict__ res,
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(1024) void ccd_pass_kernel(const MfxTrips trips, co
   const int grp = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
   if (grp >= ngroups) return;
   // (the global vectors of a CCD++ session carry one more element, +0.0: mfx_ccdpp_begin)
-  mfx_ccd_trip_loop<BUF>(trips, gptr[grp], gptr[grp + 1], res, ind, res_bytes, other, nother, j, part);
+  mfx_ccd_trip_loop<BUF, ROW_TRIP_E / 16>(trips, gptr[grp], gptr[grp + 1], res, ind, res_bytes, other, nother, j, part);
 }
 
 // The quotients of a row pass, ONE launch: the first `dblocks` workgroups take the single-segment rows (u_k[row] = num / (reg +
@@ -269,7 +270,7 @@ extern "C" int mfx_ccdpp_begin(mfx_ctx* ctx) {
   HIPCHK(hipMemsetAsync(ctx->U, 0, sizeof(float) * (size_t)ctx->nU * ctx->ld, ctx->stream));
   RowSegs* sg;
   if ((rc = mfx_get_segments(ctx, 0, &sg))) return rc;
-  // the row view's trip list: segments in memory order (a trip's aligned 64 entries overlap its neighbours' -- adjacent in
+  // the row view's trip list: segments in memory order (a trip's aligned 128 entries overlap its neighbours' -- adjacent in
   // time they hit in L2), cut into one range per group of the launch
   if (sg->nseg > 0) {
     std::vector<int64_t> sb((size_t)sg->nseg), se((size_t)sg->nseg);
@@ -292,7 +293,7 @@ extern "C" int mfx_ccdpp_begin(mfx_ctx* ctx) {
       int32_t slot = sslab[q];
       if (slot < 0) { slot = (int32_t)(sg->nslab + (int64_t)single.size()); single.push_back(srow[q]); }
       segs.push_back(MfxSeg{sb[q], se[q], slot});
-      ntrips += mfx_seg_trips(segs.back());
+      ntrips += mfx_seg_trips(segs.back(), ROW_TRIP_E);
     }
     NEED(sg->nslab + (int64_t)single.size() < ((int64_t)1 << 31), MFX_E_ARG, "mfx_ccdpp_begin: too many segments");
     if ((rc = dev_alloc(ctx, &ctx->ccd_single, single.size()))) return rc;
@@ -309,7 +310,7 @@ extern "C" int mfx_ccdpp_begin(mfx_ctx* ctx) {
     const int nwg = (int)std::max<int64_t>(1, std::min<int64_t>((ntrips + 8 * 64 - 1) / (8 * 64), max_wg));   // at least eight trips per group
     const int ng = nwg * 64;
     trips.reserve((size_t)ntrips);
-    mfx_trips_layout(segs, 0, segs.size(), nwg, 64, trips, gptr);
+    mfx_trips_layout(segs, 0, segs.size(), nwg, 64, ROW_TRIP_E, trips, gptr);
     gptr.push_back((int32_t)trips.size());
     if ((rc = mfx_trips_upload(ctx, trips, &ctx->ccd_trips))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->ccd_gptr, gptr.size()))) return rc;

@@ -31,6 +31,7 @@ constexpr int LIGHT = 0;          // columns with at most this many entries are 
                                   // 0 since the trip lists: short (strip, column) pieces no longer cost per-segment latency, and the
                                   // light region's L2 gathers do (C4: 2.29 vs 2.40 ms per factor at 1024, C2 shape 0.86 vs 0.89)
 constexpr int GPW = 64;            // 16-lane groups per pass workgroup (1024 threads)
+constexpr int COL_TRIP_E = 64;     // entries per trip of the column view: 4 per lane (mfx_internal.h)
 constexpr int PASS_WGS = 1024;    // pass workgroups over all strips (two rounds of the 512 resident ones; MFX_CCD_PASS_WGS)
 constexpr int64_t ENT_PER_WG = 128 * 1024;
 
@@ -221,7 +222,7 @@ int mfx_ccd_cols_build(mfx_ctx* ctx) {
     std::vector<int64_t> cum(seg_col.size() + 1, 0);
     for (size_t k = 0; k < seg_col.size(); k++) {
       segs[k] = MfxSeg{seg_beg[k], seg_end[k], (int32_t)k};
-      cum[k + 1] = cum[k] + mfx_seg_trips(segs[k]);
+      cum[k + 1] = cum[k] + mfx_seg_trips(segs[k], COL_TRIP_E);
     }
     if (cum.back() >= ((int64_t)1 << 31)) return mfx_fail(ctx, MFX_E_ARG, "mfx_ccdpp_begin: too many trips in the column view");
     trips.reserve((size_t)cum.back());
@@ -232,13 +233,13 @@ int mfx_ccd_cols_build(mfx_ctx* ctx) {
     const int64_t light_trips = cum.back() - strip_trips;
     const int lwg = (int)std::min<int64_t>((light_trips + 8 * GPW - 1) / (8 * GPW), 512);
     s->ngl = lwg * GPW;
-    if (lwg > 0) mfx_trips_layout(segs, (size_t)s->lseg0, seg_col.size(), lwg, GPW, trips, gptr);
+    if (lwg > 0) mfx_trips_layout(segs, (size_t)s->lseg0, seg_col.size(), lwg, GPW, COL_TRIP_E, trips, gptr);
     for (int b = 0; b < nb; b++) {
       const size_t k0 = (size_t)strip_seg0[(size_t)b], k1 = (size_t)strip_seg0[(size_t)b + 1];
       const int64_t tb = cum[k1] - cum[k0];
       if (tb == 0) continue;
       const int nw = (int)std::max<int64_t>(1, (tb + per_wg / 2) / per_wg);
-      mfx_trips_layout(segs, k0, k1, nw, GPW, trips, gptr);
+      mfx_trips_layout(segs, k0, k1, nw, GPW, COL_TRIP_E, trips, gptr);
       for (int w = 0; w < nw; w++) pw_blk.push_back(b);
     }
     gptr.push_back((int32_t)trips.size());
@@ -315,8 +316,8 @@ __global__ __launch_bounds__(1024) void colpass_kernel(const MfxTrips trips, con
   const int j = threadIdx.x & 15;
   const int g = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
   if (g >= g_count) return;
-  if (strip) mfx_ccd_trip_loop<BUF>(trips, gptr[g], gptr[g + 1], res, buser, res_bytes, su, UB, j, part);
-  else mfx_ccd_trip_loop<BUF>(trips, gptr[g], gptr[g + 1], res, luser, res_bytes, uk, nU, j, part);      // uk[nU] = +0.0 (mfx_ccdpp_begin)
+  if (strip) mfx_ccd_trip_loop<BUF, COL_TRIP_E / 16>(trips, gptr[g], gptr[g + 1], res, buser, res_bytes, su, UB, j, part);
+  else mfx_ccd_trip_loop<BUF, COL_TRIP_E / 16>(trips, gptr[g], gptr[g + 1], res, luser, res_bytes, uk, nU, j, part);      // uk[nU] = +0.0 (mfx_ccdpp_begin)
 }
 
 // residual update of the light region (MODE as colresid_kernel): u_k from L2

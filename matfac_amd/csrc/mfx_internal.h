@@ -162,7 +162,7 @@ struct ProfScope {
   ~ProfScope();
 };
 
-constexpr size_t MFX_ALLOC_PAD = 512;      // bytes; >= 96 entries of 4 bytes (a trip may start 31 entries early and end 63 late)
+constexpr size_t MFX_ALLOC_PAD = 1024;     // bytes; >= 160 entries of 4 bytes (a trip may start 31 entries early and end 127 late)
 template <typename T>
 static inline int dev_alloc(mfx_ctx* ctx, T** p, size_t n) {
   *p = nullptr;
@@ -289,14 +289,20 @@ constexpr int MFX_TRIP_LAST = 1 << 21;
 #define MFX_CCD_ALIGN 32
 #endif
 constexpr int64_t MFX_TRIP_ALIGN = MFX_CCD_ALIGN;
+// Entries per lane and trip: 8 -- two 16-byte residual loads and ONE 16-byte load of eight 16-bit ids per lane, 128 entries per
+// trip.  (With 4 per lane the id load was 8 bytes and there were twice the records: vector memory instructions per entry are
+// what these kernels pay for.)  MFX_CCD_EPL=4 at build time gives the 64-entry trips back.
+// The row view (segments of ~200 entries) takes 8, the column view (many (strip, column) pieces of a few entries, where a step
+// costs its instructions whether its lanes are live or not) 4: measured both ways, row pass 0.148 -> 0.129 ms, column pass
+// 0.167 -> 0.175.  E = entries per trip = 16 lanes x entries per lane is a parameter of the builders and of the loop.
 struct MfxSeg { int64_t b, e; int32_t meta; };
-static inline int mfx_seg_trips(const MfxSeg& g) { return (int)std::max<int64_t>(1, (g.e - (g.b & ~(MFX_TRIP_ALIGN - 1)) + 63) / 64); }
-static inline void mfx_trips_append(std::vector<int4>& trips, const MfxSeg& g) {
+static inline int mfx_seg_trips(const MfxSeg& g, int E) { return (int)std::max<int64_t>(1, (g.e - (g.b & ~(MFX_TRIP_ALIGN - 1)) + E - 1) / E); }
+static inline void mfx_trips_append(std::vector<int4>& trips, const MfxSeg& g, int E) {
   const int64_t t0 = g.b & ~(MFX_TRIP_ALIGN - 1);
-  const int a = (int)(g.b & (MFX_TRIP_ALIGN - 1)), len = (int)(g.e - g.b), ntr = mfx_seg_trips(g);
+  const int a = (int)(g.b & (MFX_TRIP_ALIGN - 1)), len = (int)(g.e - g.b), ntr = mfx_seg_trips(g, E);
   for (int i = 0; i < ntr; i++) {
     int4 r;
-    r.x = (int)(uint32_t)((t0 + 64 * (int64_t)i) >> 2);
+    r.x = (int)(uint32_t)((t0 + E * (int64_t)i) >> 2);
     r.y = a | (i << 5) | (len << 10) | (i == ntr - 1 ? MFX_TRIP_LAST : 0);
     r.z = g.meta;
     r.w = 0;
@@ -309,10 +315,10 @@ static inline void mfx_trips_append(std::vector<int4>& trips, const MfxSeg& g) {
 // of its own per group, 32 768 groups were 32 768 streams of 256-byte reads: every access opened a DRAM row of its own and
 // the pass stayed at 3.5 TB/s whatever else was improved), and they finish together.  The trips of a group are consecutive
 // in the list; gptr receives nwg * gpw range starts (the caller appends the end of its last range).
-static inline void mfx_trips_layout(const std::vector<MfxSeg>& segs, size_t k0, size_t k1, int nwg, int gpw, std::vector<int4>& trips,
+static inline void mfx_trips_layout(const std::vector<MfxSeg>& segs, size_t k0, size_t k1, int nwg, int gpw, int E, std::vector<int4>& trips,
                                     std::vector<int32_t>& gptr) {
   int64_t total = 0;
-  for (size_t k = k0; k < k1; k++) total += mfx_seg_trips(segs[k]);
+  for (size_t k = k0; k < k1; k++) total += mfx_seg_trips(segs[k], E);
   std::vector<std::vector<int32_t>> mine((size_t)gpw);
   std::vector<int64_t> load((size_t)gpw);
   size_t k = k0;
@@ -326,7 +332,7 @@ static inline void mfx_trips_layout(const std::vector<MfxSeg>& segs, size_t k0, 
       // least loaded group, scanning from the one after the last choice (ties go round-robin)
       int best = g;
       for (int q = 0; q < gpw; q++) { const int c = (g + q) % gpw; if (load[(size_t)c] < load[(size_t)best]) best = c; }
-      const int nt = mfx_seg_trips(segs[k]);
+      const int nt = mfx_seg_trips(segs[k], E);
       mine[(size_t)best].push_back((int32_t)k);
       load[(size_t)best] += nt;
       done += nt;
@@ -335,7 +341,7 @@ static inline void mfx_trips_layout(const std::vector<MfxSeg>& segs, size_t k0, 
     }
     for (int q = 0; q < gpw; q++) {
       gptr.push_back((int32_t)trips.size());
-      for (int32_t sidx : mine[(size_t)q]) mfx_trips_append(trips, segs[(size_t)sidx]);
+      for (int32_t sidx : mine[(size_t)q]) mfx_trips_append(trips, segs[(size_t)sidx], E);
     }
   }
 }
@@ -366,14 +372,17 @@ static inline int mfx_trips_upload(mfx_ctx* ctx, const std::vector<int4>& trips,
 // the same counter as the loads, so a store issued at the end of a step sits between the next step's wait and the data it waits
 // for (the wait then lasts until the store is acknowledged or a younger load returns: about 1 us per segment end, which was a
 // third of the pass).  Issued a step later it is older than everything that step waits for.
-template <bool BUF, typename IdxT>
+template <bool BUF, int EPL, typename IdxT>
 __device__ __forceinline__ void mfx_ccd_trip_loop(const MfxTrips trips, int n0, int n1, const float* __restrict__ res,
                                                   const IdxT* __restrict__ ind, uint32_t res_bytes, const float* other, int zero, int j,
                                                   double* __restrict__ part) {
   typedef float f4 __attribute__((ext_vector_type(4)));
   typedef typename MfxIdx4<IdxT>::raw raw_t;
   if (n0 >= n1) return;
-  struct Data { raw_t x; f4 r; };
+  static_assert(EPL == 4 || EPL == 8, "entries per lane");
+  constexpr int H = EPL / 4;                      // 4-entry quads per lane and trip
+  constexpr int MFX_TRIP_EPL = EPL, MFX_TRIP_E = 16 * EPL;
+  struct Data { raw_t x[H]; f4 r[H]; };
   struct Rec { int x, y, z; };
   const int exp_q0 = (MFX_CCD_EXP & 8) ? trips.q[n0] : 0, exp_q1 = (MFX_CCD_EXP & 8) ? trips.q[n1 - 1] : 0, exp_m = (MFX_CCD_EXP & (8 | 64)) ? trips.meta[n0] : 0;
   // Records are fetched four trips at a time: lane j of the group loads record base + (j & 3) (three loads per FOUR steps
@@ -383,8 +392,8 @@ __device__ __forceinline__ void mfx_ccd_trip_loop(const MfxTrips trips, int n0, 
     const int n = base + (j & 3);
     const int nc = n < n1 ? n : n1 - 1;
     Rec r;
-    if (MFX_CCD_EXP & 64) { r.x = (int)((unsigned)n % (res_bytes / 256u - 2u)) * 16; r.y = (64 << 10) | ((n & 3) == 3 ? MFX_TRIP_LAST : 0); r.z = exp_m; return r; }   // trip n reads entries [64 n, 64 n + 64): every line once, one stream per group
-    if (MFX_CCD_EXP & 8) { r.x = min(exp_q0 + 16 * (n - n0), exp_q1); r.y = (64 << 10) | ((n & 3) == 3 ? MFX_TRIP_LAST : 0); r.z = exp_m; return r; }   // in-bounds: a group's trips ascend in memory
+    if (MFX_CCD_EXP & 64) { r.x = (int)((unsigned)n % (res_bytes / (4u * MFX_TRIP_E) - 2u)) * (MFX_TRIP_E / 4); r.y = (MFX_TRIP_E << 10) | ((n & 3) == 3 ? MFX_TRIP_LAST : 0); r.z = exp_m; return r; }   // trip n reads entries [E n, E n + E): every line once, one stream per group
+    if (MFX_CCD_EXP & 8) { r.x = min(exp_q0 + (MFX_TRIP_E / 4) * (n - n0), exp_q1); r.y = (MFX_TRIP_E << 10) | ((n & 3) == 3 ? MFX_TRIP_LAST : 0); r.z = exp_m; return r; }   // in-bounds: a group's trips ascend in memory
     r.x = trips.q[nc]; r.y = trips.pk[nc]; r.z = trips.meta[nc];
     return r;
   };
@@ -395,21 +404,43 @@ __device__ __forceinline__ void mfx_ccd_trip_loop(const MfxTrips trips, int n0, 
   const __amdgpu_buffer_rsrc_t rs_ind = __builtin_amdgcn_make_buffer_rsrc((void*)ind, 0, BUF ? (int)(res_bytes / 4 * sizeof(IdxT)) : 0, 0x00020000);
   auto data = [&](const Rec& r, bool live) {      // r: the record of the trip, the same in all lanes of the group
     Data d;
-    const int64_t t = ((int64_t)(uint32_t)r.x << 2) + 4 * j;
-    if (MFX_CCD_EXP & 2) { d.x = raw_t{}; d.x[0] = r.x; d.r = f4{1.0f, 2.0f, 3.0f, 4.0f}; return d; }
-    if (BUF) {
-      const unsigned len = ((unsigned)r.y >> 10) & 0x7ffu;
-      const unsigned rel = (unsigned)(64 * ((r.y >> 5) & 31) - (r.y & 31) + 4 * j);
-      const bool need = live && rel + 3u < len + 3u;             // some entry of [rel, rel + 4) lies in [0, len)
-      const unsigned t32 = (unsigned)t;
-      typedef unsigned u4 __attribute__((ext_vector_type(4)));
-      d.r = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, need ? t32 * 4u : 0xfffffff0u, 0, 0));
-      if constexpr (sizeof(IdxT) == 2) d.x = __builtin_bit_cast(raw_t, __builtin_amdgcn_raw_buffer_load_b64(rs_ind, need ? t32 * 2u : 0xfffffff0u, 0, 0));
-      else d.x = __builtin_bit_cast(raw_t, __builtin_amdgcn_raw_buffer_load_b128(rs_ind, need ? t32 * 4u : 0xfffffff0u, 0, 0));
+    const int64_t t = ((int64_t)(uint32_t)r.x << 2) + MFX_TRIP_EPL * j;
+    if (MFX_CCD_EXP & 2) {
+#pragma unroll
+      for (int h = 0; h < H; h++) { d.x[h] = raw_t{}; d.x[h][0] = r.x; d.r[h] = f4{1.0f, 2.0f, 3.0f, 4.0f}; }
       return d;
     }
-    d.x = *(const raw_t*)(ind + t);
-    d.r = *(const f4*)(res + t);
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    if (BUF) {
+      const unsigned len = ((unsigned)r.y >> 10) & 0x7ffu;
+      const unsigned rel = (unsigned)(MFX_TRIP_E * ((r.y >> 5) & 31) - (r.y & 31) + MFX_TRIP_EPL * j);
+      const unsigned t32 = (unsigned)t;
+      bool any = false;
+#pragma unroll
+      for (int h = 0; h < H; h++) {
+        const bool need = live && rel + 4u * h + 3u < len + 3u;             // some entry of the quad lies in [0, len)
+        any |= need;
+        d.r[h] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, need ? (t32 + 4u * h) * 4u : 0xfffffff0u, 0, 0));
+        if constexpr (sizeof(IdxT) == 4) d.x[h] = __builtin_bit_cast(raw_t, __builtin_amdgcn_raw_buffer_load_b128(rs_ind, need ? (t32 + 4u * h) * 4u : 0xfffffff0u, 0, 0));
+        else if constexpr (H == 1) d.x[h] = __builtin_bit_cast(raw_t, __builtin_amdgcn_raw_buffer_load_b64(rs_ind, need ? t32 * 2u : 0xfffffff0u, 0, 0));
+      }
+      if constexpr (sizeof(IdxT) == 2 && H == 2) {       // eight 16-bit ids: ONE 16-byte load
+        const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_ind, any ? t32 * 2u : 0xfffffff0u, 0, 0);
+        d.x[0] = raw_t{v[0], v[1]};
+        d.x[1] = raw_t{v[2], v[3]};
+      }
+      return d;
+    }
+#pragma unroll
+    for (int h = 0; h < H; h++) d.r[h] = *(const f4*)(res + t + 4 * h);
+    if constexpr (sizeof(IdxT) == 2 && H == 2) {
+      const u4 v = *(const u4*)(ind + t);
+      d.x[0] = raw_t{v[0], v[1]};
+      d.x[1] = raw_t{v[2], v[3]};
+    } else {
+#pragma unroll
+      for (int h = 0; h < H; h++) d.x[h] = *(const raw_t*)(ind + t + 4 * h);
+    }
     return d;
   };
   double num = 0.0, den = 0.0, pnum = 0.0, pden = 0.0;
@@ -426,22 +457,24 @@ __device__ __forceinline__ void mfx_ccd_trip_loop(const MfxTrips trips, int n0, 
     const Rec rc = MFX_REC_OF(CURB, S);                                                                                   \
     const int pk = (N) < n1 ? rc.y : 0;                                                                                   \
     const unsigned len = ((unsigned)pk >> 10) & 0x7ffu;                                                                   \
-    const unsigned rel = (unsigned)(64 * ((pk >> 5) & 31) - (pk & 31) + 4 * j);                                           \
-    float o[4];                                                                                                           \
-    _Pragma("unroll") for (int q = 0; q < 4; q++)                                                                         \
-      o[q] = (MFX_CCD_EXP & 1) ? (rel + (unsigned)q < len ? __int_as_float(MfxIdx4<IdxT>::get(DC.x, q) | 0x3f800000) : 0.0f) \
-                               : other[rel + (unsigned)q < len ? MfxIdx4<IdxT>::get(DC.x, q) : zero];                      \
-    const f4 rr = DC.r;                                                                                                   \
+    const unsigned rel = (unsigned)(MFX_TRIP_E * ((pk >> 5) & 31) - (pk & 31) + MFX_TRIP_EPL * j);                        \
     const int meta = rc.z;                                                                                                \
-    if (MFX_CCD_EXP & 32) {   /* memory operations only: the loaded values are summed without masks, gathers or doubles */  \
-      float fs = rr[0] + rr[1] + rr[2] + rr[3] + __int_as_float(MfxIdx4<IdxT>::get(DC.x, 0) + MfxIdx4<IdxT>::get(DC.x, 3));   \
-      num += (double)fs;                                                                                                  \
-    } else if (MFX_CCD_EXP & 16) {                                                                                        \
-      float fn = 0.0f, fd = 0.0f;                                                                                         \
-      _Pragma("unroll") for (int q = 0; q < 4; q++) { fn += rr[q] * o[q]; fd += o[q] * o[q]; }                            \
-      num += (double)fn; den += (double)fd;                                                                               \
-    } else {                                                                                                              \
-      _Pragma("unroll") for (int q = 0; q < 4; q++) { num += (double)(rr[q] * o[q]); den += (double)(o[q] * o[q]); }    \
+    _Pragma("unroll") for (int h = 0; h < H; h++) {                                                                       \
+      float o[4];                                                                                                         \
+      _Pragma("unroll") for (int q = 0; q < 4; q++)                                                                       \
+        o[q] = (MFX_CCD_EXP & 1) ? (rel + (unsigned)(4 * h + q) < len ? __int_as_float(MfxIdx4<IdxT>::get(DC.x[h], q) | 0x3f800000) : 0.0f) \
+                                 : other[rel + (unsigned)(4 * h + q) < len ? MfxIdx4<IdxT>::get(DC.x[h], q) : zero];       \
+      const f4 rr = DC.r[h];                                                                                              \
+      if (MFX_CCD_EXP & 32) { /* memory operations only: the loaded values are summed without masks, gathers or doubles */ \
+        float fs = rr[0] + rr[1] + rr[2] + rr[3] + __int_as_float(MfxIdx4<IdxT>::get(DC.x[h], 0) + MfxIdx4<IdxT>::get(DC.x[h], 3)); \
+        num += (double)fs;                                                                                                \
+      } else if (MFX_CCD_EXP & 16) {                                                                                      \
+        float fn = 0.0f, fd = 0.0f;                                                                                       \
+        _Pragma("unroll") for (int q = 0; q < 4; q++) { fn += rr[q] * o[q]; fd += o[q] * o[q]; }                          \
+        num += (double)fn; den += (double)fd;                                                                             \
+      } else {                                                                                                            \
+        _Pragma("unroll") for (int q = 0; q < 4; q++) { num += (double)(rr[q] * o[q]); den += (double)(o[q] * o[q]); }  \
+      }                                                                                                                   \
     }                                                                                                                     \
     if ((pk & MFX_TRIP_LAST) && !(MFX_CCD_EXP & 4)) {                                                                     \
       pnum = mfx_row16_sum(num); pden = mfx_row16_sum(den);                                                               \
