@@ -1,0 +1,45 @@
+"""Host logic of the CCD++ passes: the trip lists (matfac_amd/csrc/mfx_internal.h).  tests/native/trips_check.hip is compiled
+with hipcc and run on the CPU (no kernel is launched): every segment appears once, its trips decode to its entries exactly
+once, a group's range never ends inside a segment, trips start on 32-entry lines, workgroups carry equal numbers of trips."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "native", "trips_check.hip")
+
+
+@pytest.fixture(scope="module")
+def checker(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("trips") / "trips_check")
+    cmd = ["/opt/rocm/bin/hipcc", "-O1", "-std=c++17", "--offload-arch=gfx950", "-w", "-I" + os.path.join(ROOT, "include"),
+           "-I" + os.path.join(ROOT, "matfac_amd", "csrc"), SRC, "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return exe
+
+
+def _segments(rng, n, max_len, gap):
+    """n segments in memory order: lengths 1..max_len (a quarter of them of one or two entries), `gap` of them leave a hole."""
+    lens = rng.integers(1, max_len + 1, n)
+    short = rng.random(n) < 0.25
+    lens[short] = rng.integers(1, 3, short.sum())
+    holes = np.where(rng.random(n) < gap, rng.integers(1, 200, n), 0)
+    b = np.cumsum(np.concatenate([[0], (lens + holes)[:-1]])) + holes
+    return np.stack([b, b + lens], 1)
+
+
+@pytest.mark.parametrize("E", [64, 128])
+@pytest.mark.parametrize("n,max_len,nwg,gpw", [(1, 5, 1, 64), (7, 1024, 1, 64), (3000, 1024, 5, 64), (20000, 300, 16, 64), (5000, 40, 3, 16)])
+def test_trip_lists_cover_every_segment_once(checker, E, n, max_len, nwg, gpw):
+    rng = np.random.default_rng(n + E)
+    segs = _segments(rng, n, max_len, 0.1)
+    text = "".join("%d %d\n" % (b, e) for b, e in segs)
+    r = subprocess.run([checker, str(E), str(nwg), str(gpw)], input=text, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout + r.stderr
+    parts = r.stdout.split()
+    wmin, wmax = int(parts[parts.index("min") + 1]), int(parts[parts.index("max") + 1])
+    longest = -(-(max_len + 31) // E)
+    assert wmax - wmin <= 2 * longest + 1          # workgroups are cut at segment ends: within two segments of each other
