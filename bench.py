@@ -331,7 +331,11 @@ def sgd_roofline(K, nnz, launches_per_step, avg_ms, launches, kernel):
         r["valu_issue"] = {"wave_instructions_per_update": per_update, "achieved": ach, "peak": VALU_PEAK_GINST,
                            "unit": "G wave-instr/s", "frac": ach / VALU_PEAK_GINST,
                            "note": "SQ_INSTS_VALU per launch from %s / updates of that launch; peak = 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 "
-                                   "cycles per wave64 instruction" % PMC_SUMMARY}
+                                   "cycles per wave64 instruction" % PMC_SUMMARY,
+                           # the same instruction stream priced with the issue costs scripts/valu_probe.hip measured on this chip
+                           # (v_mul/add/logic 2.44, v_fma 3.9, conversions and DPP 4.3, packed f32 4.67 cycles per SIMD) over the
+                           # mix of the round kernel's step (49 / 7.5 / 21 / 27 %): 3.65 cycles per instruction on average
+                           "at_measured_issue_cost": {"cycles_per_instruction": 3.65, "frac": ach * 3.65 / (256 * 4 * 2.4)}}
     if cands:
         b = max(cands, key=lambda x: x[4])
         r.update({"bound": b[0], "achieved": b[1], "peak": b[2], "unit": b[3], "frac": b[4]})
