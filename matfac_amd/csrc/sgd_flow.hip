@@ -31,6 +31,8 @@ namespace {
 
 constexpr int FL_WG = 256;            // threads per workgroup
 constexpr int FL_WG_PER_CU = 4;       // 16 waves per CU: resident for any rank shape (<= 128 VGPRs)
+constexpr int FL_SLOT_SHIFT = 26;     // tagged schedule: queue record .y = owned row | LDS slot << 26
+constexpr int FL_ROW_MASK = (1 << FL_SLOT_SHIFT) - 1;
 
 struct FlowState {
   int4* q = nullptr;                  // queue records {other-side row, owned row, rating bits, expected version}, group-major
@@ -52,20 +54,26 @@ struct FlowState {
   int64_t dcap = 0;
   int32_t *degU = nullptr, *degI = nullptr, *downer = nullptr;
   int64_t* dstart = nullptr;
-  int64_t rows_cap = 0;
-  std::vector<int32_t> hdeg;
+  int64_t deg_cap = 0, own_cap = 0;   // capacities of degU (nU + nI) and of downer / dstart (max(nU, nI) [+ 1]), tracked separately
+  std::vector<int32_t> hdeg, hpacked;
   std::vector<int64_t> hstart;
+  // tagged schedule (sgd_flow_tag_kernel): granule copy {value, tag} of the other side's table; LDS slot of every owned row
+  float* tagbuf = nullptr;
+  int64_t tag_cap = 0;                // floats
+  std::vector<uint8_t> oslot;
+  bool tagged = false;                // the queues of the last build carry the LDS slot in the top two bits of .w
 };
 FlowState* fl(mfx_ctx* ctx) { return (FlowState*)ctx->flow; }
 
 __global__ void flow_gather_kernel(const uint32_t* __restrict__ lpos, const uint32_t* __restrict__ vexp, int64_t n,
                                    const int32_t* __restrict__ eu, const int32_t* __restrict__ ei, const float* __restrict__ er,
-                                   int own_user, int4* __restrict__ q) {
+                                   int own_user, const int32_t* __restrict__ owner, int4* __restrict__ q) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
     const uint32_t s = lpos[t];
     const int u = eu[s], i = ei[s];
-    q[t] = make_int4(own_user ? i : u, own_user ? u : i, __float_as_int(er[s]), (int)vexp[t]);
+    const uint32_t slot = owner ? (uint32_t)owner[own_user ? u : i] >> FL_SLOT_SHIFT : 0u;   // tagged schedule: LDS slot of the owned row
+    q[t] = make_int4(own_user ? i : u, (int)((uint32_t)(own_user ? u : i) | slot << FL_SLOT_SHIFT), __float_as_int(er[s]), (int)vexp[t]);
   }
 }
 
@@ -249,7 +257,322 @@ __global__ __launch_bounds__(FL_WG, FL_WG_PER_CU) void bias_flow_kernel(const in
   }
 }
 
-int build_flow(mfx_ctx* ctx, int64_t first, int64_t count, int64_t groups) {
+// ---------------------------------------------------------------------------------------------------------------------
+// The tagged schedule (default for the plain update, K <= 256): the same queues, a faster hand-off.
+//
+// The version-counter kernel above pays four dependent memory round trips per visit (record, version, rows, store
+// acknowledgement before the version may move): 1.9 us per step of the hottest item's chain, 93 ms per C2 epoch.  Here
+//   * the other side's table is used through a GRANULE COPY: every float travels as an aligned 8-byte {value, tag} pair,
+//     tag = number of visits the row has received so far in this epoch.  A visit that expects version k re-reads the row
+//     until all its tags equal k -- the data is the flag (cdna_hip_programming.md Guideline 16, form R2): no separate
+//     version word, no acknowledgement wait, one write-through store instruction per 16 bytes and lane;
+//   * ONE QUEUE PER WAVEFRONT (lanes 0 .. L-1 hold the rows, the other lanes ride along with offsets behind the buffers):
+//     everything about a record is wave-uniform, so records are read out of a 64-record register block with v_readlane into
+//     scalar registers, row offsets are scalar arithmetic and every branch is a scalar branch.  (A first version kept four
+//     16-lane queues per wave with their windows in LDS: its 780 instructions and 15 dependent LDS round trips per iteration
+//     made the hottest queue's wave ISSUE-bound at 0.9 us per visit although 95 % of its iterations retired two visits and
+//     the counted wait cost nothing; float instead of double arithmetic changed 5 %.);
+//   * the rows of the next LA queue positions are requested while the head is visited (a static pipeline: LA landing
+//     register sets, the loop unrolled LA times), so along an item's chain the user rows are on chip when their turn comes;
+//   * the owned row of consecutive visits stays in REGISTERS; other owned rows of the queue live in the wave's LDS (QR
+//     slots, placed by the queue builder) and go back to their table when they are displaced and at the end;
+//   * all polls, record loads and tagged stores are inline assembly the compiler's wait-count pass does not see (it would
+//     turn every wait into vmcnt(0), i.e. wait for the stores' acknowledgements): a step waits with a COUNTED
+//     s_waitcnt vmcnt(N), N = the vector-memory instructions that are guaranteed to have been issued behind the poll it
+//     needs -- every step issues the same number, an unused one with an offset behind its buffer (no memory access);
+//   * a position whose row does not carry the expected tags yet is probed with ONE 16-byte load (lane 0, first granule)
+//     until the tag shows up, then read whole: a stalled queue costs a 64-byte request per round trip, not a row.
+// Progress: as above -- the earliest unvisited rating of the list is at the head of its queue, and a wave that waits, waits
+// for its queue head only.
+typedef int desc4 __attribute__((ext_vector_type(4)));
+// Diagnostic build -DMFX_FLOW_STATS (scripts/flow_stats.sh): per queue {visits, visits that had to wait for their row,
+// probes, owned-row switches, owned rows loaded from the table, shader cycles in the loop, cycles spent waiting for rows, blocks}
+#ifdef MFX_FLOW_STATS
+__device__ unsigned long long fl_stats[65536 * 8];
+#define FL_STAT(i, v) st_[i] += (v)
+#else
+#define FL_STAT(i, v)
+#endif
+constexpr uint32_t FL_OOB = 0xfffffff0u;       // behind every buffer: loads return zeros, stores are dropped
+
+__device__ __forceinline__ desc4 fl_desc(const void* p, uint32_t bytes) {
+  const uint64_t a = (uint64_t)p;
+  return desc4{(int)(uint32_t)a, (int)((uint32_t)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+}
+template <bool SC1>
+__device__ __forceinline__ uint4v fl_load(desc4 rs, uint32_t off) {
+  uint4v v;
+  if (SC1) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen sc1" : "=v"(v) : "v"(off), "s"(rs) : "memory");
+  else asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v) : "v"(off), "s"(rs) : "memory");
+  return v;
+}
+template <bool SC1>
+__device__ __forceinline__ void fl_store(desc4 rs, uint32_t off, uint4v v) {
+  // (s_nop 1: a store of more than 64 bits needs a wait state before its data registers may be overwritten)
+  if (SC1) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen sc1\n\ts_nop 1" ::"v"(v), "v"(off), "s"(rs) : "memory");
+  else asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(off), "s"(rs) : "memory");
+}
+
+template <int L, int C>
+struct F2 {
+  static constexpr int LD = 4 * L * C;
+  static constexpr int LA = C <= 2 ? 4 : 2;        // rows of the other side in flight (queue positions ahead of the head)
+  static constexpr int QR = C <= 2 ? 32 : 16;      // owned rows kept in LDS per queue
+  static constexpr int NB = 64;                    // records per register block
+  static constexpr int WS = QR * LD * 4 + QR * 4;  // LDS bytes per wave: QR rows | their row ids
+  static constexpr int LDS = WS * (FL_WG / 64);
+  static constexpr int WGS = C <= 1 ? 4 : 2;       // workgroups per CU (registers: launch bounds; LDS: LDS * WGS <= 160 KiB)
+  static constexpr int NSTEP = 4 * C;              // vector-memory instructions of a step: 2 C tagged stores, 2 C row requests
+  static_assert(LDS * WGS <= 163840 && (LA - 1) * NSTEP <= 63 && NB % LA == 0, "tagged dataflow configuration");
+};
+
+template <int L, int C, int ARITH>
+__global__ __launch_bounds__(FL_WG, (F2<L, C>::WGS)) void sgd_flow_tag_kernel(const int4* __restrict__ q, const int64_t* __restrict__ qoff,
+                                                                              uint32_t qbytes, float* T, uint32_t tbytes, float* O, uint32_t obytes,
+                                                                              int own_user, float lr, float uReg, float iReg, unsigned* flag) {
+  typedef F2<L, C> P;
+  constexpr int LD = P::LD, LA = P::LA, QR = P::QR, NB = P::NB;
+  extern __shared__ __attribute__((aligned(16))) char fl_smem[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane % L;
+  const bool act = lane < L;                     // the lanes that hold the rows; the others ask for nothing and store nothing
+  float4v* qv = (float4v*)(fl_smem + (size_t)wv * P::WS);          // [QR][C][L]
+  int* qt = (int*)(fl_smem + (size_t)wv * P::WS + QR * LD * 4);    // [QR]
+  const int64_t grp = (int64_t)blockIdx.x * (FL_WG / 64) + __builtin_amdgcn_readfirstlane(wv);
+  uint32_t pos = (uint32_t)qoff[grp];
+  const uint32_t end = (uint32_t)qoff[grp + 1];
+  if (lane < QR) qt[lane] = -1;
+  const desc4 dq = fl_desc(q, qbytes), dt = fl_desc(T, tbytes), dob = fl_desc(O, obytes);
+  const uint32_t lane_off = act ? (uint32_t)(j * 16) : FL_OOB;       // this lane's 16 bytes inside a 16 L-byte piece
+  uint4v Tr[LA][2 * C];                          // landing registers: slot = queue position % LA
+#pragma unroll
+  for (int k = 0; k < LA; k++)
+#pragma unroll
+    for (int h = 0; h < 2 * C; h++) Tr[k][h] = uint4v{0u, 0u, 0u, 0u};
+  float4v ov[C];                                 // the owned row of the last visit (registers), its id and its LDS slot
+#pragma unroll
+  for (int c = 0; c < C; c++) ov[c] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+  int cur_row = -1, cur_slot = 0;
+  bool aborted = false;
+#ifdef MFX_FLOW_STATS
+  unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
+#endif
+
+  // request the row of record `rc` (row id in .x) into landing slot K, or nothing (offsets behind the buffer) when !live
+#define FL_REQUEST(K, ROWX, LIVE)                                                                                     \
+  {                                                                                                                   \
+    const uint32_t rb_ = (LIVE) ? (uint32_t)(ROWX) * (uint32_t)(8 * LD) : FL_OOB;                                     \
+    _Pragma("unroll") for (int c = 0; c < C; c++) _Pragma("unroll") for (int h = 0; h < 2; h++)                       \
+        Tr[K][2 * c + h] = fl_load<true>(dt, ((LIVE) && act) ? rb_ + (uint32_t)(c * 32 * L + h * 16 * L) + lane_off : FL_OOB); \
+  }
+  // one queue position: S = index in the block (uniform), K = S % LA (static), NWAIT = requests and stores issued behind its poll
+#define FL_STEP(K, S, NWAIT)                                                                                          \
+  {                                                                                                                   \
+    const int s_ = (S);                                                                                               \
+    const bool live_ = s_ < nb;                                                                                       \
+    uint32_t stbase_ = FL_OOB, ntag_ = 0;                                                                             \
+    float4v tv[C];                                                                                                    \
+    _Pragma("unroll") for (int c = 0; c < C; c++) tv[c] = float4v{0.0f, 0.0f, 0.0f, 0.0f};                            \
+    if (live_ && !aborted) {                                                                                          \
+      const int sl_ = s_ & 63;                                                                                        \
+      const int rx_ = __builtin_amdgcn_readlane(rec.x, sl_), ry_ = __builtin_amdgcn_readlane(rec.y, sl_);             \
+      const int rz_ = __builtin_amdgcn_readlane(rec.z, sl_);                                                          \
+      const uint32_t exp_ = (uint32_t)__builtin_amdgcn_readlane(rec.w, sl_);                                          \
+      const int orow_ = ry_ & FL_ROW_MASK, slot_ = (int)((uint32_t)ry_ >> FL_SLOT_SHIFT) & (QR - 1);                  \
+      if (orow_ != cur_row) {               /* another owned row: the held one goes to its LDS slot, this one comes in */ \
+        FL_STAT(3, 1);                                                                                                \
+        if (cur_row >= 0 && act) {                                                                                    \
+          _Pragma("unroll") for (int c = 0; c < C; c++) qv[(cur_slot * C + c) * L + j] = ov[c];                       \
+        }                                                                                                             \
+        const int have_ = __builtin_amdgcn_readfirstlane(qt[slot_]);                                                  \
+        if (have_ == orow_) {                                                                                         \
+          _Pragma("unroll") for (int c = 0; c < C; c++) ov[c] = qv[(slot_ * C + c) * L + j];                          \
+        } else {                            /* not in LDS: the slot's row goes back to the table, this one is loaded */ \
+          FL_STAT(4, 1);                                                                                              \
+          if (have_ >= 0) {                                                                                           \
+            _Pragma("unroll") for (int c = 0; c < C; c++)                                                             \
+                fl_store<false>(dob, act ? (uint32_t)have_ * (uint32_t)(4 * LD) + (uint32_t)(c * 16 * L) + lane_off : FL_OOB, \
+                                __builtin_bit_cast(uint4v, qv[(slot_ * C + c) * L + j]));                             \
+          }                                                                                                           \
+          uint4v in_[C];                                                                                              \
+          _Pragma("unroll") for (int c = 0; c < C; c++)                                                               \
+              in_[c] = fl_load<false>(dob, act ? (uint32_t)orow_ * (uint32_t)(4 * LD) + (uint32_t)(c * 16 * L) + lane_off : FL_OOB); \
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                            \
+          _Pragma("unroll") for (int c = 0; c < C; c++) {                                                             \
+            asm volatile("" : "+v"(in_[c]));                                                                          \
+            ov[c] = __builtin_bit_cast(float4v, in_[c]);                                                              \
+          }                                                                                                           \
+          if (lane == 0) qt[slot_] = orow_;                                                                           \
+        }                                                                                                             \
+        cur_row = orow_;                                                                                              \
+        cur_slot = slot_;                                                                                             \
+      }                                                                                                               \
+      /* the row of the other side: requested LA positions ago */                                                     \
+      asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NWAIT) : "memory");                                                    \
+      _Pragma("unroll") for (int h = 0; h < 2 * C; h++) asm volatile("" : "+v"(Tr[K][h]));                            \
+      bool ok_ = !act;                                                                                                \
+      {                                                                                                               \
+        bool t_ = true;                                                                                               \
+        _Pragma("unroll") for (int h = 0; h < 2 * C; h++) t_ = t_ && Tr[K][h].y == exp_ && Tr[K][h].w == exp_;        \
+        ok_ = ok_ || t_;                                                                                              \
+      }                                                                                                               \
+      if (__builtin_amdgcn_ballot_w64(ok_) != ~0ull) {       /* not there yet: probe the first granule, then read the row again */ \
+        FL_STAT(1, 1);                                                                                                \
+        FL_STATS_T0                                                                                                   \
+        const uint32_t rb_ = (uint32_t)rx_ * (uint32_t)(8 * LD);                                                      \
+        long long t_last_ = wall_clock64();                                                                           \
+        int spins_ = 0;                                                                                               \
+        for (;;) {                                                                                                    \
+          uint4v pr_ = fl_load<true>(dt, lane == 0 ? rb_ : FL_OOB);                                                   \
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(pr_)::"memory");                                                   \
+          FL_STAT(2, 1);                                                                                              \
+          if ((uint32_t)__builtin_amdgcn_readfirstlane(pr_.y) == exp_) {                                              \
+            _Pragma("unroll") for (int c = 0; c < C; c++) _Pragma("unroll") for (int h = 0; h < 2; h++)               \
+                Tr[K][2 * c + h] = fl_load<true>(dt, act ? rb_ + (uint32_t)(c * 32 * L + h * 16 * L) + lane_off : FL_OOB); \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                          \
+            _Pragma("unroll") for (int h = 0; h < 2 * C; h++) asm volatile("" : "+v"(Tr[K][h]));                      \
+            bool t_ = true;                                                                                           \
+            _Pragma("unroll") for (int h = 0; h < 2 * C; h++) t_ = t_ && Tr[K][h].y == exp_ && Tr[K][h].w == exp_;    \
+            if (__builtin_amdgcn_ballot_w64(t_ || !act) == ~0ull) break;                                              \
+          }                                                                                                           \
+          if ((++spins_ & 63) == 0) {                                                                                 \
+            if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { aborted = true; break; }       \
+            if (wall_clock64() - t_last_ > 200000000LL) {      /* 100 MHz constant clock: 2 s on one queue head */    \
+              __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                               \
+              aborted = true;                                                                                         \
+              break;                                                                                                  \
+            }                                                                                                         \
+          }                                                                                                           \
+        }                                                                                                             \
+        FL_STATS_T1                                                                                                   \
+      }                                                                                                               \
+      if (!aborted) {                                                                                                 \
+        _Pragma("unroll") for (int c = 0; c < C; c++)                                                                 \
+            tv[c] = float4v{__uint_as_float(Tr[K][2 * c].x), __uint_as_float(Tr[K][2 * c].z), __uint_as_float(Tr[K][2 * c + 1].x), \
+                            __uint_as_float(Tr[K][2 * c + 1].z)};                                                     \
+        if (own_user) {                                                                                               \
+          const float est_ = group_dot<L, C>(ov, tv);                                                                 \
+          sgd_axpys<C, ARITH>(ov, tv, __int_as_float(rz_), est_, lr, uReg, iReg);                                     \
+        } else {                                                                                                      \
+          const float est_ = group_dot<L, C>(tv, ov);                                                                 \
+          sgd_axpys<C, ARITH>(tv, ov, __int_as_float(rz_), est_, lr, uReg, iReg);                                     \
+        }                                                                                                             \
+        stbase_ = act ? (uint32_t)rx_ * (uint32_t)(8 * LD) + lane_off : FL_OOB;                                       \
+        ntag_ = exp_ + 1u;                                                                                            \
+        FL_STAT(0, 1);                                                                                                \
+      }                                                                                                               \
+    }                                                                                                                 \
+    /* the other side's row with its new tag, write-through (always 2 C instructions), then the request for position S + LA */ \
+    _Pragma("unroll") for (int c = 0; c < C; c++) _Pragma("unroll") for (int h = 0; h < 2; h++)                       \
+        fl_store<true>(dt, stbase_ == FL_OOB ? FL_OOB : stbase_ + (uint32_t)(c * 32 * L + h * 16 * L),               \
+                       uint4v{__float_as_uint(tv[c][2 * h]), ntag_, __float_as_uint(tv[c][2 * h + 1]), ntag_});      \
+    {                                                                                                                 \
+      const int sn_ = s_ + LA;                                                                                        \
+      const bool ln_ = sn_ < nb && !aborted;                                                                          \
+      const int rxn_ = __builtin_amdgcn_readlane(rec.x, sn_ & 63);                                                    \
+      FL_REQUEST(K, rxn_, ln_)                                                                                        \
+    }                                                                                                                 \
+  }
+#ifdef MFX_FLOW_STATS
+#define FL_STATS_T0 const unsigned long long st_w = __builtin_amdgcn_s_memtime();
+#define FL_STATS_T1 st_[6] += __builtin_amdgcn_s_memtime() - st_w;
+#else
+#define FL_STATS_T0
+#define FL_STATS_T1
+#endif
+
+  while (pos < end && !aborted) {
+    // ---- a block of up to 64 records: lane l holds record pos + l ----------------------------------------------------
+    const int nb = (int)min((uint32_t)NB, end - pos);
+    uint4v rb = fl_load<false>(dq, lane < nb ? (pos + (uint32_t)lane) * 16u : FL_OOB);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(rb)::"memory");
+    const int4 rec = make_int4((int)rb.x, (int)rb.y, (int)rb.z, (int)rb.w);
+    FL_STAT(7, 1);
+    // the first LA rows
+#pragma unroll
+    for (int k = 0; k < LA; k++) {
+      const int rxn = __builtin_amdgcn_readlane(rec.x, k);
+      FL_REQUEST(k, rxn, k < nb)
+    }
+    // the first LA positions: behind the request of position k lie the later requests of the prologue and k full steps
+    if constexpr (LA == 4) {
+      FL_STEP(0, 0, 3 * 2 * C + 0 * P::NSTEP)
+      FL_STEP(1, 1, 2 * 2 * C + 1 * P::NSTEP)
+      FL_STEP(2, 2, 1 * 2 * C + 2 * P::NSTEP)
+      FL_STEP(3, 3, 0 * 2 * C + 3 * P::NSTEP)
+    } else {
+      FL_STEP(0, 0, 1 * 2 * C + 0 * P::NSTEP)
+      FL_STEP(1, 1, 0 * 2 * C + 1 * P::NSTEP)
+    }
+    for (int s0 = LA; s0 < nb; s0 += LA) {
+      if constexpr (LA == 4) {
+        FL_STEP(0, s0, 3 * P::NSTEP)
+        FL_STEP(1, s0 + 1, 3 * P::NSTEP)
+        FL_STEP(2, s0 + 2, 3 * P::NSTEP)
+        FL_STEP(3, s0 + 3, 3 * P::NSTEP)
+      } else {
+        FL_STEP(0, s0, P::NSTEP)
+        FL_STEP(1, s0 + 1, P::NSTEP)
+      }
+    }
+    // Nothing may be in flight when the landing registers leave the pipeline: the requests of the block's last LA steps (offsets
+    // behind the buffer: zeros) still WRITE their registers when they return, and behind this point the compiler is free to use
+    // those registers for something else -- a flush address, as the first C2 run of this kernel showed with a store to address 0.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < LA; k++)
+#pragma unroll
+      for (int h = 0; h < 2 * C; h++) asm volatile("" : "+v"(Tr[k][h]));
+    pos += (uint32_t)nb;
+  }
+#undef FL_STEP
+#undef FL_REQUEST
+#ifdef MFX_FLOW_STATS
+  st_[5] = __builtin_amdgcn_s_memtime() - st_t0;
+  if (lane == 0 && grp < 65536)
+    for (int i = 0; i < 8; i++) fl_stats[grp * 8 + i] = st_[i];
+#endif
+  // the owned rows go back to their table: the held one through its LDS slot, then every slot in use
+  if (cur_row >= 0 && act) {
+#pragma unroll
+    for (int c = 0; c < C; c++) qv[(cur_slot * C + c) * L + j] = ov[c];
+  }
+  for (int sI = 0; sI < QR; sI++) {
+    const int have = __builtin_amdgcn_readfirstlane(qt[sI]);
+    if (have >= 0 && act) {
+#pragma unroll
+      for (int c = 0; c < C; c++) *(float4v*)(O + (int64_t)have * LD + c * 4 * L + 4 * j) = qv[(sI * C + c) * L + j];
+    }
+  }
+}
+
+// granule copy of a factor table and back: row r, chunk c, lane j, half h (elements 4j+2h, 4j+2h+1 of the chunk) at byte
+// r*8*LD + c*32*L + h*16*L + j*16 as {value, tag, value, tag}
+__global__ void flow_tag_kernel(const float* __restrict__ X, int64_t n, int L, int C, float* __restrict__ T) {
+  const int64_t per = (int64_t)L * C, total = n * per, stride = (int64_t)gridDim.x * blockDim.x;
+  const int LD = 4 * L * C;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t r = t / per;
+    const int c = (int)((t % per) / L), j = (int)(t % L);
+    const float4v v = *(const float4v*)(X + r * LD + c * 4 * L + 4 * j);
+    uint4v* d = (uint4v*)(T + r * 2 * LD) + c * 2 * L + j;
+    d[0] = uint4v{__float_as_uint(v.x), 0u, __float_as_uint(v.y), 0u};
+    d[L] = uint4v{__float_as_uint(v.z), 0u, __float_as_uint(v.w), 0u};
+  }
+}
+__global__ void flow_untag_kernel(const float* __restrict__ T, int64_t n, int L, int C, float* __restrict__ X) {
+  const int64_t per = (int64_t)L * C, total = n * per, stride = (int64_t)gridDim.x * blockDim.x;
+  const int LD = 4 * L * C;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t r = t / per;
+    const int c = (int)((t % per) / L), j = (int)(t % L);
+    const uint4v* d = (const uint4v*)(T + r * 2 * LD) + c * 2 * L + j;
+    const uint4v a = d[0], b = d[L];
+    *(float4v*)(X + r * LD + c * 4 * L + 4 * j) = float4v{__uint_as_float(a.x), __uint_as_float(a.z), __uint_as_float(b.x), __uint_as_float(b.z)};
+  }
+}
+
+int build_flow(mfx_ctx* ctx, int64_t first, int64_t count, int64_t groups, bool tagged) {
   FlowState* S = fl(ctx);
   const auto t0 = std::chrono::steady_clock::now();
   int rc;
@@ -291,10 +614,13 @@ int build_flow(mfx_ctx* ctx, int64_t first, int64_t count, int64_t groups) {
     typedef std::pair<int64_t, int32_t> Load;   // (ratings so far, group)
     std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap;
     for (int64_t gI = 0; gI < groups; gI++) heap.push(Load(0, (int32_t)gI));
+    std::vector<int32_t> nrows((size_t)groups, 0);
+    S->oslot.assign((size_t)nOwn, 0);
     for (int32_t r : rows) {
       Load l = heap.top();
       heap.pop();
       S->owner[(size_t)r] = l.second;
+      S->oslot[(size_t)r] = (uint8_t)(nrows[(size_t)l.second]++ & 63);   // the row's place in its queue's LDS cache (tagged schedule)
       l.first += degOwn[(size_t)r];
       heap.push(l);
     }
@@ -326,12 +652,24 @@ int build_flow(mfx_ctx* ctx, int64_t first, int64_t count, int64_t groups) {
   HIPCHK(hipMemcpyAsync(S->qoff, off, sizeof(int64_t) * ((size_t)groups + 1), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(S->lpos, S->hpos.data(), sizeof(uint32_t) * (size_t)count, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(S->vexp, S->hver.data(), sizeof(uint32_t) * (size_t)count, hipMemcpyHostToDevice, ctx->stream));
+  if (tagged) {       // the LDS slots of the owned rows, packed as the device builder packs them
+    if (S->own_cap < std::max<int64_t>(ctx->nU, ctx->nI)) {
+      dev_free(S->downer); dev_free(S->dstart);
+      S->own_cap = 0;
+      if ((rc = dev_alloc(ctx, &S->downer, (size_t)std::max(ctx->nU, ctx->nI))) || (rc = dev_alloc(ctx, &S->dstart, (size_t)std::max(ctx->nU, ctx->nI) + 1)))
+        return rc;
+      S->own_cap = std::max(ctx->nU, ctx->nI);
+    }
+    S->hpacked.resize((size_t)nOwn);
+    for (int64_t r = 0; r < nOwn; r++) S->hpacked[(size_t)r] = (int32_t)((uint32_t)S->owner[(size_t)r] | (uint32_t)S->oslot[(size_t)r] << FL_SLOT_SHIFT);
+    HIPCHK(hipMemcpyAsync(S->downer, S->hpacked.data(), sizeof(int32_t) * (size_t)nOwn, hipMemcpyHostToDevice, ctx->stream));
+  }
   const int blocks = (int)std::min<int64_t>((count + 255) / 256, 8192);
   hipLaunchKernelGGL(flow_gather_kernel, dim3(blocks), dim3(256), 0, ctx->stream, S->lpos, S->vexp, count, ctx->eu + first,
-                     ctx->ei + first, ctx->er + first, own_user, S->q);
+                     ctx->ei + first, ctx->er + first, own_user, tagged ? (const int32_t*)S->downer : (const int32_t*)nullptr, S->q);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(ctx->stream));    // the staging vectors are reused by the next call
-  S->groups = groups; S->longest = longest; S->own_user = own_user;
+  S->groups = groups; S->longest = longest; S->own_user = own_user; S->tagged = tagged;
   S->prep_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   if (getenv("MFX_DEBUG"))
     fprintf(stderr, "[mfx] dataflow replay: %lld ratings on %lld groups (%s rows owned), longest queue %lld, longest chains %d users / %d items, "
@@ -354,7 +692,7 @@ __global__ void flow_keys_kernel(const int32_t* __restrict__ rows, const int32_t
                                  uint32_t* __restrict__ val) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
-    key[t] = owner ? (uint32_t)owner[rows[t]] : (uint32_t)rows[t];
+    key[t] = owner ? (uint32_t)owner[rows[t]] & (uint32_t)FL_ROW_MASK : (uint32_t)rows[t];
     val[t] = (uint32_t)t;
   }
 }
@@ -364,13 +702,16 @@ __global__ void flow_rank_kernel(const uint32_t* __restrict__ k1, const uint32_t
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) vert[v1[k]] = (uint32_t)(k - start[k1[k]]);
 }
+// owner != NULL (tagged schedule): the LDS slot of the owned row rides in the top six bits of .y
 __global__ void flow_gather2_kernel(const uint32_t* __restrict__ lpos, const uint32_t* __restrict__ vert, int64_t n, const int32_t* __restrict__ eu,
-                                    const int32_t* __restrict__ ei, const float* __restrict__ er, int own_user, int4* __restrict__ q) {
+                                    const int32_t* __restrict__ ei, const float* __restrict__ er, int own_user, const int32_t* __restrict__ owner,
+                                    int4* __restrict__ q) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
     const uint32_t s = lpos[t];
     const int u = eu[s], i = ei[s];
-    q[t] = make_int4(own_user ? i : u, own_user ? u : i, __float_as_int(er[s]), (int)vert[s]);
+    const uint32_t slot = owner ? (uint32_t)owner[own_user ? u : i] >> FL_SLOT_SHIFT : 0u;
+    q[t] = make_int4(own_user ? i : u, (int)((uint32_t)(own_user ? u : i) | slot << FL_SLOT_SHIFT), __float_as_int(er[s]), (int)vert[s]);
   }
 }
 // qoff[g] = number of sorted queue keys < g
@@ -390,7 +731,7 @@ static int bits_for(uint64_t n) {
   return b;
 }
 
-int build_flow_device(mfx_ctx* ctx, int64_t first, int64_t count, int64_t groups) {
+int build_flow_device(mfx_ctx* ctx, int64_t first, int64_t count, int64_t groups, bool tagged) {
   FlowState* S = fl(ctx);
   const auto t0 = std::chrono::steady_clock::now();
   int rc;
@@ -415,13 +756,18 @@ int build_flow_device(mfx_ctx* ctx, int64_t first, int64_t count, int64_t groups
     S->sort_tmp_bytes = bytes;
     S->dcap = count;
   }
-  if (S->rows_cap < nU + nI) {
-    dev_free(S->degU); dev_free(S->downer); dev_free(S->dstart);
-    S->rows_cap = 0;
-    if ((rc = dev_alloc(ctx, &S->degU, (size_t)(nU + nI))) || (rc = dev_alloc(ctx, &S->downer, (size_t)std::max(nU, nI))) ||
-        (rc = dev_alloc(ctx, &S->dstart, (size_t)std::max(nU, nI) + 1)))
-      return rc;
-    S->rows_cap = nU + nI;
+  // (the two capacities are separate: a context reused with a differently skewed model can grow max(nU, nI) while nU + nI shrinks)
+  if (S->deg_cap < nU + nI) {
+    dev_free(S->degU);
+    S->deg_cap = 0;
+    if ((rc = dev_alloc(ctx, &S->degU, (size_t)(nU + nI)))) return rc;
+    S->deg_cap = nU + nI;
+  }
+  if (S->own_cap < std::max(nU, nI)) {
+    dev_free(S->downer); dev_free(S->dstart);
+    S->own_cap = 0;
+    if ((rc = dev_alloc(ctx, &S->downer, (size_t)std::max(nU, nI))) || (rc = dev_alloc(ctx, &S->dstart, (size_t)std::max(nU, nI) + 1))) return rc;
+    S->own_cap = std::max(nU, nI);
   }
   S->degI = S->degU + nU;
   if (S->goff_cap < groups + 1) {
@@ -456,10 +802,12 @@ int build_flow_device(mfx_ctx* ctx, int64_t first, int64_t count, int64_t groups
     typedef std::pair<int64_t, int32_t> Load;
     std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap;
     for (int64_t gI = 0; gI < groups; gI++) heap.push(Load(0, (int32_t)gI));
+    std::vector<int32_t> nrows((size_t)groups, 0);
     for (int32_t r : rows) {
       Load l = heap.top();
       heap.pop();
-      S->owner[(size_t)r] = l.second;
+      // bits 26-31: the row's place in its queue's LDS cache (tagged schedule)
+      S->owner[(size_t)r] = (int32_t)((uint32_t)l.second | (uint32_t)(nrows[(size_t)l.second]++ & 63) << FL_SLOT_SHIFT);
       l.first += degOwn[r];
       heap.push(l);
     }
@@ -490,14 +838,15 @@ int build_flow_device(mfx_ctx* ctx, int64_t first, int64_t count, int64_t groups
   HIPCHK(rocprim::radix_sort_pairs(S->sort_tmp, bytes, S->k0, S->k1, S->v0, S->lpos, (size_t)count, 0, bits_for((uint64_t)groups), ctx->stream));
   hipLaunchKernelGGL(flow_bounds_kernel, dim3((unsigned)std::min<int64_t>((groups + 256) / 256, 4096)), dim3(256), 0, ctx->stream, S->k1, count,
                      groups + 1, S->qoff);
-  hipLaunchKernelGGL(flow_gather2_kernel, dim3(grid), dim3(256), 0, ctx->stream, S->lpos, S->vert, count, eu, ei, er, own_user, S->q);
+  hipLaunchKernelGGL(flow_gather2_kernel, dim3(grid), dim3(256), 0, ctx->stream, S->lpos, S->vert, count, eu, ei, er, own_user,
+                     tagged ? (const int32_t*)S->downer : (const int32_t*)nullptr, S->q);
   HIPCHK(hipGetLastError());
   S->hoff.resize((size_t)groups + 1);
   HIPCHK(hipMemcpyAsync(S->hoff.data(), S->qoff, sizeof(int64_t) * ((size_t)groups + 1), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   int64_t longest = 0;
   for (int64_t gI = 0; gI < groups; gI++) longest = std::max(longest, S->hoff[(size_t)gI + 1] - S->hoff[(size_t)gI]);
-  S->groups = groups; S->longest = longest; S->own_user = own_user;
+  S->groups = groups; S->longest = longest; S->own_user = own_user; S->tagged = tagged;
   S->prep_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   if (getenv("MFX_DEBUG"))
     fprintf(stderr, "[mfx] dataflow replay (device construction): %lld ratings on %lld queues (%s rows owned), longest queue %lld, longest chains "
@@ -542,6 +891,72 @@ int launch_flow_lc(mfx_ctx* ctx, const mfx_sgd_opts* o, int blocks) {
   return MFX_OK;
 }
 
+// ---- tagged schedule: granule copy of the other side, the launch, and the copy back ---------------------------------
+template <int L, int C, int ARITH>
+int launch_flow_tag_lca(mfx_ctx* ctx, const mfx_sgd_opts* o, int blocks) {
+  typedef F2<L, C> P;
+  FlowState* S = fl(ctx);
+  const int64_t nOth = S->own_user ? ctx->nI : ctx->nU;
+  float* X = S->own_user ? ctx->V : ctx->U;          // the other side: read and written through its granule copy
+  float* O = S->own_user ? ctx->U : ctx->V;          // the owned side
+  auto kern = sgd_flow_tag_kernel<L, C, ARITH>;
+  static bool attr_done = false;                     // per instantiation
+  if (!attr_done) {
+    HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, P::LDS));
+    attr_done = true;
+  }
+  int per_cu = 0;
+  HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, FL_WG, (size_t)P::LDS));
+  int dev = 0, cus = 0;
+  HIPCHK(hipGetDevice(&dev));
+  HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  NEED((int64_t)per_cu * cus >= blocks, MFX_E_STATE, "sgd dataflow (tagged): %d workgroups do not fit the device (%d per CU x %d CUs)", blocks,
+       per_cu, cus);
+  const int64_t total = nOth * L * C;
+  const int tgrid = (int)std::min<int64_t>((total + 255) / 256, 8192);
+  hipLaunchKernelGGL(flow_tag_kernel, dim3(tgrid), dim3(256), 0, ctx->stream, (const float*)X, nOth, L, C, S->tagbuf);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(FL_WG), (size_t)P::LDS, ctx->stream, (const int4*)S->q, S->qoff,
+                     (uint32_t)((uint64_t)S->hoff.back() * 16u), S->tagbuf, (uint32_t)((uint64_t)nOth * 8u * P::LD), O,
+                     (uint32_t)((uint64_t)(S->own_user ? ctx->nU : ctx->nI) * 4u * P::LD), S->own_user, o->learnRate, o->uReg, o->iReg, S->flag);
+  hipLaunchKernelGGL(flow_untag_kernel, dim3(tgrid), dim3(256), 0, ctx->stream, (const float*)S->tagbuf, nOth, L, C, X);
+  HIPCHK(hipGetLastError());
+  return MFX_OK;
+}
+template <int L, int C>
+int launch_flow_tag_lc(mfx_ctx* ctx, const mfx_sgd_opts* o, int blocks) {
+  if constexpr (C <= 4) {
+    FlowState* S = fl(ctx);
+    const int64_t need = (S->own_user ? (int64_t)ctx->nI : (int64_t)ctx->nU) * 2 * F2<L, C>::LD;
+    if (S->tag_cap < need) {
+      dev_free(S->tagbuf);
+      S->tag_cap = 0;
+      int rc = dev_alloc(ctx, &S->tagbuf, (size_t)need);
+      if (rc) return rc;
+      S->tag_cap = need;
+    }
+    ProfScope ps(ctx, MFX_K_SGD);
+    switch (o->arith) {
+      case MFX_ARITH_REF64: return launch_flow_tag_lca<L, C, MFX_ARITH_REF64>(ctx, o, blocks);
+      case MFX_ARITH_REF64F: return launch_flow_tag_lca<L, C, MFX_ARITH_REF64F>(ctx, o, blocks);
+      default: return launch_flow_tag_lca<L, C, MFX_ARITH_F32>(ctx, o, blocks);
+    }
+  } else {
+    return mfx_fail(ctx, MFX_E_ARG, "sgd dataflow (tagged): K <= 256");
+  }
+}
+// workgroups per CU of the tagged kernel for a rank shape (0: not built)
+int flow_tag_wgs(int L, int C) {
+  if (L == 4) return F2<4, 1>::WGS;
+  if (L == 8) return F2<8, 1>::WGS;
+  switch (C) {
+    case 1: return F2<16, 1>::WGS;
+    case 2: return F2<16, 2>::WGS;
+    case 3: return F2<16, 3>::WGS;
+    case 4: return F2<16, 4>::WGS;
+  }
+  return 0;
+}
+
 }  // namespace
 
 void mfx_flow_free_internal(mfx_ctx* ctx) {
@@ -549,7 +964,7 @@ void mfx_flow_free_internal(mfx_ctx* ctx) {
   if (!S) return;
   dev_free(S->q); dev_free(S->qoff); dev_free(S->lpos); dev_free(S->vexp); dev_free(S->ver); dev_free(S->flag);
   dev_free(S->k0); dev_free(S->k1); dev_free(S->v0); dev_free(S->v1); dev_free(S->vert); dev_free(S->sort_tmp);
-  dev_free(S->degU); dev_free(S->downer); dev_free(S->dstart);
+  dev_free(S->degU); dev_free(S->downer); dev_free(S->dstart); dev_free(S->tagbuf);
   delete S;
   ctx->flow = nullptr;
 }
@@ -565,26 +980,37 @@ int mfx_launch_sgd_flow(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int6
   HIPCHK(hipGetDevice(&dev));
   HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   const int L = ctx->L, C = ctx->C;
+  // the tagged schedule serves the plain update up to K = 256 while a buffer descriptor reaches the granule copy (twice the
+  // table) and the queue; MFX_FLOW_TAGGED=0 keeps the version-counter kernel (the cross-check, and what the variants run on)
+  const bool variant = ctx->ifw || ctx->tmf_u || ctx->dimreg;
+  const char* tg = getenv("MFX_FLOW_TAGGED");
+  const bool tagged = !variant && flow_tag_wgs(L, C) > 0 && !(tg && tg[0] == '0') &&
+                      (uint64_t)std::max(ctx->nU, ctx->nI) * ctx->ld * 8 < (1ull << 32) && count < ((int64_t)1 << 28);
+  int wgs = tagged ? flow_tag_wgs(L, C) : FL_WG_PER_CU;
+  if (const char* e = getenv("MFX_FLOW_WGS")) wgs = std::max(1, std::min(wgs, atoi(e)));
   // every workgroup resident: the queues cannot starve each other; no more queues than there are rows to own
-  const int64_t per_block = (int64_t)(FL_WG / 64) * (64 / L);
-  const int blocks = (int)std::min<int64_t>((int64_t)std::max(1, cus) * FL_WG_PER_CU, (std::max(ctx->nU, ctx->nI) + per_block - 1) / per_block);
+  const int64_t per_block = tagged ? (int64_t)(FL_WG / 64) : (int64_t)(FL_WG / 64) * (64 / L);   // tagged: one queue per wavefront
+  int blocks = (int)std::min<int64_t>((int64_t)std::max(1, cus) * wgs, (std::max(ctx->nU, ctx->nI) + per_block - 1) / per_block);
+  if (const char* e = getenv("MFX_FLOW_BLOCKS")) blocks = std::max(1, std::min(blocks, atoi(e)));   // test knob: few queues, many owned rows each
   const int64_t groups = (int64_t)blocks * per_block;
   // queues and versions are built on the device; MFX_FLOW_HOST=1 keeps the host statement of the same lists (the cross-check)
-  int rc = getenv("MFX_FLOW_HOST") ? build_flow(ctx, first, count, groups) : build_flow_device(ctx, first, count, groups);
+  int rc = getenv("MFX_FLOW_HOST") ? build_flow(ctx, first, count, groups, tagged) : build_flow_device(ctx, first, count, groups, tagged);
   if (rc) return rc;
-  if (L == 4) rc = launch_flow_lc<4, 1>(ctx, o, blocks);
-  else if (L == 8) rc = launch_flow_lc<8, 1>(ctx, o, blocks);
+#define MFX_FLOW_GO(LL, CC) rc = tagged ? launch_flow_tag_lc<LL, CC>(ctx, o, blocks) : launch_flow_lc<LL, CC>(ctx, o, blocks)
+  if (L == 4) MFX_FLOW_GO(4, 1);
+  else if (L == 8) MFX_FLOW_GO(8, 1);
   else switch (C) {
-    case 1: rc = launch_flow_lc<16, 1>(ctx, o, blocks); break;
-    case 2: rc = launch_flow_lc<16, 2>(ctx, o, blocks); break;
-    case 3: rc = launch_flow_lc<16, 3>(ctx, o, blocks); break;
-    case 4: rc = launch_flow_lc<16, 4>(ctx, o, blocks); break;
+    case 1: MFX_FLOW_GO(16, 1); break;
+    case 2: MFX_FLOW_GO(16, 2); break;
+    case 3: MFX_FLOW_GO(16, 3); break;
+    case 4: MFX_FLOW_GO(16, 4); break;
     case 5: rc = launch_flow_lc<16, 5>(ctx, o, blocks); break;
     case 6: rc = launch_flow_lc<16, 6>(ctx, o, blocks); break;
     case 7: rc = launch_flow_lc<16, 7>(ctx, o, blocks); break;
     case 8: rc = launch_flow_lc<16, 8>(ctx, o, blocks); break;
     default: return mfx_fail(ctx, MFX_E_ARG, "sgd dataflow: unsupported rank shape L=%d C=%d", L, C);
   }
+#undef MFX_FLOW_GO
   if (rc) return rc;
   unsigned flag = 0;
   HIPCHK(hipMemcpyAsync(&flag, fl(ctx)->flag, sizeof flag, hipMemcpyDeviceToHost, ctx->stream));
@@ -599,8 +1025,8 @@ int mfx_launch_bias_flow(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int
   HIPCHK(hipGetDevice(&dev));
   HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   const int blocks = (int)std::min<int64_t>((int64_t)std::max(1, cus) * FL_WG_PER_CU, (std::max(ctx->nU, ctx->nI) + FL_WG - 1) / FL_WG);
-  int rc = getenv("MFX_FLOW_HOST") ? build_flow(ctx, first, count, (int64_t)blocks * FL_WG)     // one lane = one queue
-                                   : build_flow_device(ctx, first, count, (int64_t)blocks * FL_WG);
+  int rc = getenv("MFX_FLOW_HOST") ? build_flow(ctx, first, count, (int64_t)blocks * FL_WG, false)     // one lane = one queue
+                                   : build_flow_device(ctx, first, count, (int64_t)blocks * FL_WG, false);
   if (rc) return rc;
   FlowState* S = fl(ctx);
   {
@@ -626,6 +1052,12 @@ bool mfx_flow_info(mfx_ctx* ctx, int64_t info[4], double* prep_ms) {
   return true;
 }
 
+#ifdef MFX_FLOW_STATS
+extern "C" int mfx_debug_flow_stats(unsigned long long* out, int64_t ngroups) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(fl_stats), sizeof(unsigned long long) * 8 * (size_t)ngroups) == hipSuccess ? 0 : -1;
+}
+#endif
+
 // test hook: the queues of the last dataflow epoch (records {other-side row, owned row, rating bits, expected version})
 extern "C" int mfx_debug_flow_queues(mfx_ctx* ctx, int32_t* records, int64_t cap, int64_t* qoff, int64_t* n_records, int64_t* n_groups) {
   if (!ctx) return MFX_E_ARG;
@@ -640,6 +1072,8 @@ extern "C" int mfx_debug_flow_queues(mfx_ctx* ctx, int32_t* records, int64_t cap
   if (!records) return MFX_OK;
   NEED(cap >= off.back(), MFX_E_ARG, "mfx_debug_flow_queues: cap too small");
   HIPCHK(hipMemcpy(records, S->q, sizeof(int4) * (size_t)off.back(), hipMemcpyDeviceToHost));
+  if (S->tagged)      // the LDS slot of the owned row rides in the top six bits of the owned row's field
+    for (int64_t t = 0; t < off.back(); t++) records[4 * t + 1] &= FL_ROW_MASK;
   if (qoff) memcpy(qoff, off.data(), sizeof(int64_t) * off.size());
   return MFX_OK;
 }

@@ -226,13 +226,16 @@ def test_tiled_epoch_list_is_tile_grouped_permutation():
     assert np.all(np.diff(tile) >= 0)
 
 
-@pytest.fixture(params=["flow", "flow-host", "levels"])
+@pytest.fixture(params=["flow", "flow-ver", "flow-host", "flow-ver-host", "levels"])
 def exact_sched(request, monkeypatch):
-    """the schedules behind MFX_SGD_LEVELS: dataflow (default; queues and versions built on the device, or by the host
-    statement of the same lists) and dependency levels with a grid barrier"""
+    """the schedules behind MFX_SGD_LEVELS: dataflow (default: tagged rows + lookahead window up to K = 256; "ver": the
+    version-counter kernel, MFX_FLOW_TAGGED=0; queues built on the device, or by the host statement of the same lists)
+    and dependency levels with a grid barrier"""
     monkeypatch.setenv("MFX_EXACT_SCHED", "levels" if request.param == "levels" else "flow")
-    if request.param == "flow-host":
+    if request.param.endswith("host"):
         monkeypatch.setenv("MFX_FLOW_HOST", "1")
+    if "ver" in request.param:
+        monkeypatch.setenv("MFX_FLOW_TAGGED", "0")
     return "levels" if request.param == "levels" else "flow"
 
 
@@ -265,6 +268,38 @@ def test_level_schedule_is_the_sequential_loop_bit_for_bit(K, arith, exact_sched
             if exact_sched == "levels":
                 assert 0 < info[2] < info[1]                  # both phases ran
             assert info[1] >= np.bincount(tr.rowind).max()    # levels / longest queue >= the longest item chain
+        U, V = ctx.get_factors()
+    assert np.array_equal(U, Uo)
+    assert np.array_equal(V, Vo)
+
+
+@pytest.mark.parametrize("K", [10, 64, 128, 200])
+@pytest.mark.parametrize("tagged", ["1", "0"])
+def test_dataflow_with_many_owned_rows_per_queue(K, tagged, monkeypatch):
+    """Few queues (MFX_FLOW_BLOCKS=2: 32 to 128 lane groups for 600 item rows): every group owns more rows than its LDS cache
+    holds, so owned rows are displaced, written back and re-loaded all the time; same-user ratings sit next to each other in
+    a queue (a position that waits for the group's own previous store).  Bit for bit the oracle's sequential pass."""
+    monkeypatch.setenv("MFX_FLOW_BLOCKS", "2")
+    monkeypatch.setenv("MFX_FLOW_TAGGED", tagged)
+    d = small(nU=500, nI=600, nnz=60_000, K=K, seed=11)
+    tr = d["train"]
+    nU, nI = d["nUsers"], d["nItems"]
+    U0, V0 = orc.init_factors(1, nU, nI, K)
+    U0 *= 30
+    V0 *= 30
+    ru = tr.rowids()
+    mt = orc.MT(5)
+    order = np.arange(tr.nnz, dtype=np.uint64)
+    Uo, Vo = U0.copy(), V0.copy()
+    with Ctx(0) as ctx:
+        load_ctx(ctx, d, K, U0, V0)
+        for ep in range(2):
+            mt.shuffle_u64(order)
+            ctx.sgd_set_order(order)
+            ctx.sgd_epoch(0.005, 0.01, 0.01, mode=mfx.SGD_LEVELS, order=mfx.ORDER_HOST, arith=mfx.ARITH_REF64)
+            orc.sgd_pass(Uo, Vo, ru, tr.rowind, tr.rowval, order, 0.005, 0.01, 0.01, orc.ARITH_REF64, orc.DOT_TREE)
+        info, _ = ctx.debug_levels_info()
+        assert info[0] == 1 and info[2] <= 2 * 64
         U, V = ctx.get_factors()
     assert np.array_equal(U, Uo)
     assert np.array_equal(V, Vo)
