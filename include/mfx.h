@@ -168,7 +168,7 @@ int mfx_debug_epoch_list(mfx_ctx* ctx, int32_t* u, int32_t* i, float* r, int64_t
  * building it                                                                                                  */
 int mfx_debug_levels_info(mfx_ctx* ctx, int64_t info[4], double* prep_ms);
 /* test hook: the queues of the last dataflow epoch: records = int32[4] per rating {other-side row, owned row, rating bits,
- * expected version}, queue g = records [qoff[g], qoff[g+1]); records == NULL queries the two counts                     */
+ * expected version (= the rank of the rating in the other-side row's chain)}, queue g = records [qoff[g], qoff[g+1]); records == NULL queries the two counts                     */
 int mfx_debug_flow_queues(mfx_ctx* ctx, int32_t* records, int64_t cap, int64_t* qoff, int64_t* n_records, int64_t* n_groups);
 /* test hook: digest of the slot lists the last MFX_SGD_TILED epoch ran on.  counts = {slots, ratings, row
  * references, rows per slot}; sums = FNV-1a of {rating records, slot_beg, slot_ibeg, slot rows, tile_slot} */
@@ -177,6 +177,10 @@ int mfx_debug_slots_digest(mfx_ctx* ctx, int64_t counts[4], uint64_t sums[5]);
  * per-slot permutation) accumulated by epochs run with MFX_SGD_F_COUNT_VISITS; zeroes the counters.  n receives
  * the number of records; counts may be NULL to query n.                                                         */
 int mfx_debug_visit_counts(mfx_ctx* ctx, uint32_t* counts, int64_t cap, int64_t* n);
+/* test hook: raises the sticky abort flag of the tiled schedule's drain on the device, as a drain that gave up at its grid
+ * barrier does.  The next tiled epoch copies it back; the first call that synchronises after that (mfx_synchronize,
+ * mfx_eval*, mfx_get_factors, or the next tiled epoch) returns MFX_E_HIP once, and the flag is cleared.                  */
+int mfx_debug_raise_drain_abort(mfx_ctx* ctx);
 /* test hook: the column view of the train matrix as the device holds it (given or built by mfx_set_csr) */
 int mfx_debug_col_view(mfx_ctx* ctx, int64_t* colptr, int32_t* colind, float* colval);
 

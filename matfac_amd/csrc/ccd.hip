@@ -310,8 +310,14 @@ extern "C" int mfx_ccdpp_begin(mfx_ctx* ctx) {
     const int nwg = (int)std::max<int64_t>(1, std::min<int64_t>((ntrips + 8 * 64 - 1) / (8 * 64), max_wg));   // at least eight trips per group
     const int ng = nwg * 64;
     trips.reserve((size_t)ntrips);
-    mfx_trips_layout(segs, 0, segs.size(), nwg, 64, ROW_TRIP_E, trips, gptr);
+    int64_t max_end = 0;
+    mfx_trips_layout(segs, 0, segs.size(), nwg, 64, ROW_TRIP_E, trips, gptr, &max_end);
     gptr.push_back((int32_t)trips.size());
+    // whole trips are loaded from the residuals (4 bytes per entry) and from the ids (2 or 4): they must lie inside the allocations
+    static_assert((ROW_TRIP_E - 1) * sizeof(float) <= MFX_ALLOC_PAD, "a row-view trip must fit the allocation pad");
+    NEED(mfx_trips_fit(max_end, m.nnz, sizeof(float)) && mfx_trips_fit(max_end, m.nnz, sizeof(int32_t)), MFX_E_STATE,
+         "mfx_ccdpp_begin: a trip of the row view reads %lld entries behind the %lld of its arrays (allocation pad %zu bytes)",
+         (long long)(max_end - m.nnz), (long long)m.nnz, MFX_ALLOC_PAD);
     if ((rc = mfx_trips_upload(ctx, trips, &ctx->ccd_trips))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->ccd_gptr, gptr.size()))) return rc;
     HIPCHK(hipMemcpy(ctx->ccd_gptr, gptr.data(), sizeof(int32_t) * gptr.size(), hipMemcpyHostToDevice));

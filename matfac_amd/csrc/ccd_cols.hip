@@ -233,16 +233,25 @@ int mfx_ccd_cols_build(mfx_ctx* ctx) {
     const int64_t light_trips = cum.back() - strip_trips;
     const int lwg = (int)std::min<int64_t>((light_trips + 8 * GPW - 1) / (8 * GPW), 512);
     s->ngl = lwg * GPW;
-    if (lwg > 0) mfx_trips_layout(segs, (size_t)s->lseg0, seg_col.size(), lwg, GPW, COL_TRIP_E, trips, gptr);
+    int64_t strip_end = 0, light_end = 0;      // positions behind the last entry the trips of the two regions load
+    if (lwg > 0) mfx_trips_layout(segs, (size_t)s->lseg0, seg_col.size(), lwg, GPW, COL_TRIP_E, trips, gptr, &light_end);
     for (int b = 0; b < nb; b++) {
       const size_t k0 = (size_t)strip_seg0[(size_t)b], k1 = (size_t)strip_seg0[(size_t)b + 1];
       const int64_t tb = cum[k1] - cum[k0];
       if (tb == 0) continue;
       const int nw = (int)std::max<int64_t>(1, (tb + per_wg / 2) / per_wg);
-      mfx_trips_layout(segs, k0, k1, nw, GPW, COL_TRIP_E, trips, gptr);
+      mfx_trips_layout(segs, k0, k1, nw, GPW, COL_TRIP_E, trips, gptr, &strip_end);
       for (int w = 0; w < nw; w++) pw_blk.push_back(b);
     }
     gptr.push_back((int32_t)trips.size());
+    // whole trips are loaded: strips from res (float[nnz]) and buser (uint16[light0 + 4]), the light region from res and
+    // luser (int32, shifted by light0 & ~63): every one of them must lie inside its allocation (mfx_trips_fit)
+    static_assert((COL_TRIP_E - 1) * sizeof(float) <= MFX_ALLOC_PAD, "a column-view trip must fit the allocation pad");
+    if (!(mfx_trips_fit(std::max(strip_end, light_end), m.nnz, sizeof(float)) && mfx_trips_fit(strip_end, s->light0 + 4, sizeof(uint16_t)) &&
+          mfx_trips_fit(light_end, m.nnz + 4, sizeof(int32_t))))
+      return mfx_fail(ctx, MFX_E_STATE, "mfx_ccdpp_begin: a trip of the column view reads behind its arrays (strips to %lld of %lld, light "
+                      "columns to %lld of %lld; allocation pad %zu bytes)", (long long)strip_end, (long long)s->light0, (long long)light_end,
+                      (long long)m.nnz, MFX_ALLOC_PAD);
   }
   std::vector<int32_t> col_ptr((size_t)nI + 1, 0), col_seg(seg_col.size());
   for (int32_t i = 0; i < nI; i++) col_ptr[i + 1] = col_ptr[i] + col_cnt[i];

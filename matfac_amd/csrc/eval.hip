@@ -293,6 +293,7 @@ int mfx_launch_eval(mfx_ctx* ctx, const DevCSR& m, const float* U, const float* 
   HIPCHK(hipMemcpyAsync(ctx->red_out, dout, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   eval_unpack(ctx->red_out, out);
+  if (int rc = mfx_slots_check_abort(ctx)) return rc;      // an evaluation of factors an aborted drain left behind is an error
   return MFX_OK;
 }
 
@@ -312,5 +313,6 @@ int mfx_launch_eval2(mfx_ctx* ctx, const DevCSR& ma, int norms_a, const DevCSR& 
   HIPCHK(hipStreamSynchronize(ctx->stream));
   eval_unpack(ctx->red_out, out_a);
   eval_unpack(ctx->red_out + 4, out_b);
+  if (int rc = mfx_slots_check_abort(ctx)) return rc;
   return MFX_OK;
 }

@@ -128,7 +128,7 @@ int mfx_synchronize(mfx_ctx* ctx) {
   if (!ctx) return MFX_E_ARG;
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  return MFX_OK;
+  return mfx_slots_check_abort(ctx);
 }
 
 }  // extern "C"
@@ -329,6 +329,7 @@ extern "C" int mfx_get_factors(mfx_ctx* ctx, int snapshot, float* U, float* V, i
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   int rc;
+  if ((rc = mfx_slots_check_abort(ctx))) return rc;      // factors of an epoch whose drain gave up are not handed out silently
   if (U && (rc = download_mat(ctx, snapshot ? ctx->Ubest : ctx->U, U, ctx->nU, layout))) return rc;
   if (V && (rc = download_mat(ctx, snapshot ? ctx->Vbest : ctx->V, V, ctx->nI, layout))) return rc;
   return MFX_OK;

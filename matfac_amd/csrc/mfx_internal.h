@@ -162,7 +162,8 @@ struct ProfScope {
   ~ProfScope();
 };
 
-constexpr size_t MFX_ALLOC_PAD = 1024;     // bytes; >= 160 entries of 4 bytes (a trip may start 31 entries early and end 127 late)
+constexpr size_t MFX_ALLOC_PAD = 1024;     // bytes; a trip ends up to E - 1 = 127 entries behind its segment (508 bytes of a 4-byte array); checked
+                                           // per trip list by mfx_trips_fit, not only sized here
 template <typename T>
 static inline int dev_alloc(mfx_ctx* ctx, T** p, size_t n) {
   *p = nullptr;
@@ -273,7 +274,9 @@ __device__ __forceinline__ void mfx_store_unseen(float* p, float v) {
 __device__ __forceinline__ void mfx_store_unseen(double* p, double a, double b) {
   typedef unsigned u4 __attribute__((ext_vector_type(4)));
   const u4 v = {(unsigned)__double2loint(a), (unsigned)__double2hiint(a), (unsigned)__double2loint(b), (unsigned)__double2hiint(b)};
-  asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+  // (s_nop 0: a store of more than 64 bits needs one wait state before a VALU may overwrite its data registers, and the
+  // hazard recognizer does not look inside an asm statement -- tests/test_trips_cpu.py checks the disassembly)
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
 }
 
 
@@ -297,7 +300,9 @@ constexpr int64_t MFX_TRIP_ALIGN = MFX_CCD_ALIGN;
 // 0.167 -> 0.175.  E = entries per trip = 16 lanes x entries per lane is a parameter of the builders and of the loop.
 struct MfxSeg { int64_t b, e; int32_t meta; };
 static inline int mfx_seg_trips(const MfxSeg& g, int E) { return (int)std::max<int64_t>(1, (g.e - (g.b & ~(MFX_TRIP_ALIGN - 1)) + E - 1) / E); }
-static inline void mfx_trips_append(std::vector<int4>& trips, const MfxSeg& g, int E) {
+// returns the position behind the last entry the segment's trips LOAD (whole trips are loaded, what lies outside the segment is
+// masked): up to E - 1 entries behind the segment's end
+static inline int64_t mfx_trips_append(std::vector<int4>& trips, const MfxSeg& g, int E) {
   const int64_t t0 = g.b & ~(MFX_TRIP_ALIGN - 1);
   const int a = (int)(g.b & (MFX_TRIP_ALIGN - 1)), len = (int)(g.e - g.b), ntr = mfx_seg_trips(g, E);
   for (int i = 0; i < ntr; i++) {
@@ -308,6 +313,13 @@ static inline void mfx_trips_append(std::vector<int4>& trips, const MfxSeg& g, i
     r.w = 0;
     trips.push_back(r);
   }
+  return t0 + (int64_t)E * ntr;
+}
+// The invariant the allocation pad exists for (and that a 16-byte pad broke in round 2, gpurun_out/r2_ccd14.log: a trip of the
+// last row's segment read up to 63 entries = 252 bytes behind hipMalloc's end; the fault surfaced at the next synchronisation,
+// in mfx_eval): an array of `n` entries of `elem` bytes that trips up to position `max_end` are loaded from must have them.
+static inline bool mfx_trips_fit(int64_t max_end, int64_t n, size_t elem) {
+  return max_end <= n || (size_t)(max_end - n) * elem <= MFX_ALLOC_PAD;
 }
 // Lay the segments segs[k0, k1) -- given in MEMORY order -- out for nwg workgroups of gpw groups each: the workgroups get
 // consecutive runs of segments with equal numbers of trips; inside a workgroup every next segment goes to the group with
@@ -315,8 +327,9 @@ static inline void mfx_trips_append(std::vector<int4>& trips, const MfxSeg& g, i
 // of its own per group, 32 768 groups were 32 768 streams of 256-byte reads: every access opened a DRAM row of its own and
 // the pass stayed at 3.5 TB/s whatever else was improved), and they finish together.  The trips of a group are consecutive
 // in the list; gptr receives nwg * gpw range starts (the caller appends the end of its last range).
+// *max_end (if given) is raised to the position behind the last entry any trip loads (mfx_trips_fit).
 static inline void mfx_trips_layout(const std::vector<MfxSeg>& segs, size_t k0, size_t k1, int nwg, int gpw, int E, std::vector<int4>& trips,
-                                    std::vector<int32_t>& gptr) {
+                                    std::vector<int32_t>& gptr, int64_t* max_end = nullptr) {
   int64_t total = 0;
   for (size_t k = k0; k < k1; k++) total += mfx_seg_trips(segs[k], E);
   std::vector<std::vector<int32_t>> mine((size_t)gpw);
@@ -341,7 +354,10 @@ static inline void mfx_trips_layout(const std::vector<MfxSeg>& segs, size_t k0, 
     }
     for (int q = 0; q < gpw; q++) {
       gptr.push_back((int32_t)trips.size());
-      for (int32_t sidx : mine[(size_t)q]) mfx_trips_append(trips, segs[(size_t)sidx], E);
+      for (int32_t sidx : mine[(size_t)q]) {
+        const int64_t end = mfx_trips_append(trips, segs[(size_t)sidx], E);
+        if (max_end && end > *max_end) *max_end = end;
+      }
     }
   }
 }
@@ -530,6 +546,7 @@ void mfx_bias_free_internal(mfx_ctx* ctx);
 bool mfx_flow_info(mfx_ctx* ctx, int64_t info[4], double* prep_ms);
 void mfx_flow_free_internal(mfx_ctx* ctx);
 int mfx_slots_materialise_order(mfx_ctx* ctx);
+int mfx_slots_check_abort(mfx_ctx* ctx);      // sticky abort flag of the tiled schedule's drain (sgd_slots.hip)
 void mfx_slots_free_internal(mfx_ctx* ctx);
 int mfx_launch_eval(mfx_ctx* ctx, const DevCSR& m, const float* U, const float* V,
                     int with_norms, mfx_eval_out* out);

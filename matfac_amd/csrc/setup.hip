@@ -317,7 +317,10 @@ int mfx_slots_build_device(mfx_ctx* ctx, SlotList* S, int rows, int side) {
   if ((rc = dev_alloc(ctx, &S->rec, (size_t)nnz * 4)) || (rc = dev_alloc(ctx, &S->slot_beg, (size_t)nslots + 1)) ||
       (rc = dev_alloc(ctx, &S->slot_ibeg, (size_t)nslots + 1)) || (rc = dev_alloc(ctx, &S->tile_slot, (size_t)NTILE + 1)))
     return rc;
-  if (!S->ctr && (rc = dev_alloc(ctx, &S->ctr, (size_t)NTILE + 2))) return rc;
+  if (!S->ctr) {     // [NTILE] slot counters, barrier counter, abort flag, and the STICKY abort flag (zeroed here, cleared only when reported)
+    if ((rc = dev_alloc(ctx, &S->ctr, (size_t)NTILE + 3))) return rc;
+    HIPCHK(hipMemsetAsync(S->ctr, 0, (NTILE + 3) * sizeof(unsigned), ctx->stream));
+  }
   static_assert(NTILE + 1 <= TB, "tile_slot is written by the first workgroup");
   hipLaunchKernelGGL(slot_heads_kernel, dim3(grid_for(R)), dim3(TB), 0, st, head, hs, dst, R, nslots, nnz, trun, NTILE,
                      S->slot_beg, S->slot_ibeg, S->tile_slot);

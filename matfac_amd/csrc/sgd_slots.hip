@@ -155,7 +155,10 @@ static int build_slots(mfx_ctx* ctx, SlotList* S, int rows, int side) {
   if ((rc = up(ctx, &S->slot_ibeg, slot_ibeg))) return rc;
   if ((rc = up(ctx, &S->slot_items, slot_items))) return rc;
   if ((rc = up(ctx, &S->tile_slot, tile_slot))) return rc;
-  if (!S->ctr && (rc = dev_alloc(ctx, &S->ctr, (size_t)NTILE + 2))) return rc;
+  if (!S->ctr) {
+    if ((rc = dev_alloc(ctx, &S->ctr, (size_t)NTILE + 3))) return rc;
+    HIPCHK(hipMemsetAsync(S->ctr, 0, (NTILE + 3) * sizeof(unsigned), ctx->stream));      // [NTILE + 2]: the sticky abort flag
+  }
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (getenv("MFX_DEBUG")) {
     int64_t mx = 0, small = 0;
@@ -259,10 +262,9 @@ int mfx_launch_sgd_tiled(mfx_ctx* ctx, const mfx_sgd_opts* o) {
     HIPCHK(hipHostMalloc((void**)&S->abort_host, sizeof(unsigned), hipHostMallocDefault));
     *S->abort_host = 0;
   }
-  if (*(volatile unsigned*)S->abort_host) {
-    *S->abort_host = 0;
-    return mfx_fail(ctx, MFX_E_HIP, "MFX_SGD_TILED: the drain of the previous epoch gave up at its grid barrier (no progress for 2 s; "
-                    "is the device shared with another resident kernel?) -- that epoch may have left ratings unvisited");
+  {
+    const int rc = mfx_slots_check_abort(ctx);      // what the copies that have ARRIVED say; the flag is sticky, a later check sees the rest
+    if (rc) return rc;
   }
   if ((o->flags & MFX_SGD_F_COUNT_VISITS) && !S->visit) {
     int rc;
@@ -291,6 +293,34 @@ int mfx_launch_sgd_tiled(mfx_ctx* ctx, const mfx_sgd_opts* o) {
     case 8: return mfx_slots_launch_16x8(ctx, S, side, o, blocks, k0, k1);
   }
   return mfx_fail(ctx, MFX_E_ARG, "sgd tiled: unsupported rank shape L=%d C=%d", L, C);
+}
+
+// Reports (once) a drain that gave up at its grid barrier.  Called behind the stream synchronisations of the C entry points
+// (mfx_synchronize, mfx_eval*, mfx_get_factors) -- there the copy of the last epoch's flag has arrived -- and at the start of
+// a tiled epoch.  The device flag is sticky: it is cleared here, when it is reported, and nowhere else.
+int mfx_slots_check_abort(mfx_ctx* ctx) {
+  SlotState* st = state(ctx);
+  if (!st) return MFX_OK;
+  for (int side = 0; side < 2; side++) {
+    SlotList& S = st->side[side];
+    if (!S.abort_host || !*(volatile unsigned*)S.abort_host) continue;
+    *S.abort_host = 0;
+    if (S.ctr) HIPCHK(hipMemsetAsync(S.ctr + NTILE + 2, 0, sizeof(unsigned), ctx->stream));
+    return mfx_fail(ctx, MFX_E_HIP, "MFX_SGD_TILED: the drain of an epoch gave up at its grid barrier (no progress for 2 s; is the device "
+                    "shared with another resident kernel?) -- that epoch may have left ratings unvisited");
+  }
+  return MFX_OK;
+}
+
+extern "C" int mfx_debug_raise_drain_abort(mfx_ctx* ctx) {
+  if (!ctx) return MFX_E_ARG;
+  SlotState* st = state(ctx);
+  NEED(st && st->side[st->last_side].built && st->side[st->last_side].ctr, MFX_E_STATE, "mfx_debug_raise_drain_abort: no tiled epoch has run");
+  HIPCHK(hipSetDevice(ctx->device));
+  const unsigned one = 1;
+  HIPCHK(hipMemcpyAsync(st->side[st->last_side].ctr + NTILE + 2, &one, sizeof one, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return MFX_OK;
 }
 
 // fills ctx->eu/ei/er with the order the last tiled epoch visited (test hook)

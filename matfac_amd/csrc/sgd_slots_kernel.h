@@ -251,7 +251,7 @@ struct SlotSteps {
 // memory (sc1 loads and write-through stores: the workgroups of one tile may sit on several XCDs).
 // It also carries the two test hooks of include/mfx.h: `tile_only` >= 0 restricts a launch to that tile and `one`
 // makes ONE lane group visit a slot's ratings one at a time (MFX_SGD_F_ONE_GROUP).
-constexpr int DRAIN_WGS = 128;
+constexpr int DRAIN_WGS = 128;        // at most; the launch takes what is resident on THIS device (launch_slots)
 // ALLW: every wave of the workgroup takes part (compile-time chunk stride; a run-time stride cost 3.6 % at C2 -- measured A/B on one
 // box: 19.2 vs 19.9 G updates/s); otherwise `aw` waves do (small tiles, see mfx_launch_sgd_tiled).
 template <int L, int C, int ARITH, bool SWEEP, bool OWN_U, int VAR, bool ALLW = false>
@@ -288,7 +288,12 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
       s_bad = 1;
     __syncthreads();
     const bool left = s_bad != 0;
-    if (grid_barrier<0>(ctr + NTILE, gridDim.x)) return;
+    if (grid_barrier<0>(ctr + NTILE, gridDim.x)) {
+      // gave up: ctr[NTILE + 2] is the STICKY copy of the abort flag -- the per-epoch memset does not touch it, the host clears it
+      // only when it has reported it (mfx_slots_check_abort)
+      if (tid == 0) __hip_atomic_store(&ctr[NTILE + 2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
     if (!left) return;
   }
   const int r_end = drain ? NUB : round + 1;
@@ -412,7 +417,10 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
       __syncthreads();
     }
     // the next diagonal re-owns these item rows from other workgroups (other XCDs): L2 write-back, barrier, invalidate
-    if (drain && rr + 1 < r_end && grid_barrier<0>(ctr + NTILE, (unsigned)(rr + 2) * gridDim.x)) return;
+    if (drain && rr + 1 < r_end && grid_barrier<0>(ctr + NTILE, (unsigned)(rr + 2) * gridDim.x)) {
+      if (tid == 0) __hip_atomic_store(&ctr[NTILE + 2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
   }
 }
 
@@ -447,16 +455,30 @@ static int launch_slots(mfx_ctx* ctx, SlotList* S, const mfx_sgd_opts* o, int bl
                          oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1, at, visit, -1, 0, S->active_waves);
   }
   {
-    // the drain: one launch; the same diagonals keyed on the workgroup index (an item row keeps a single owner)
+    // the drain: one launch; the same diagonals keyed on the workgroup index (an item row keeps a single owner).  Its grid
+    // barriers need every workgroup RESIDENT: the grid is what this device (or partition: a CPX / QPX partition has 32 - 64
+    // CUs) holds of this kernel, a multiple of 8 (the diagonals are keyed on blockIdx & 7), at most DRAIN_WGS.
+    static int drain_wgs = 0;                          // per instantiation
+    if (drain_wgs == 0) {
+      int per_cu = 0, dev = 0, cus = 0;
+      HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sgd_slots_kernel<L, C, ARITH, true, OWN_U, VAR>, WG, 0));
+      HIPCHK(hipGetDevice(&dev));
+      HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+      const int fit = std::min(DRAIN_WGS, std::max(0, per_cu) * std::max(0, cus)) / 8 * 8;
+      NEED(fit >= 8, MFX_E_STATE, "MFX_SGD_TILED: fewer than 8 workgroups of the drain are resident on this device (%d per CU x %d CUs)", per_cu, cus);
+      if (const char* e = getenv("MFX_SGD_DRAIN_WGS")) drain_wgs = std::max(8, std::min(fit, atoi(e) / 8 * 8));   // test knob
+      else drain_wgs = fit;
+    }
     ProfScope ps(ctx, MFX_K_SGD_SWEEP);
-    hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, true, OWN_U, VAR>), dim3(DRAIN_WGS), dim3(WG), 0, ctx->stream,
+    hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, true, OWN_U, VAR>), dim3(drain_wgs), dim3(WG), 0, ctx->stream,
                        (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->tile_slot, S->ctr, 0,
                        oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1, at, visit, -1, 0, S->active_waves);
   }
   HIPCHK(hipGetLastError());
-  // a drain whose barrier gave up (2 s without progress: the device is shared with another resident kernel) leaves its
-  // flag in ctr[NTILE + 1]; it is copied back without waiting and looked at by the NEXT call on this context
-  if (S->abort_host) HIPCHK(hipMemcpyAsync(S->abort_host, S->ctr + NTILE + 1, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+  // a drain whose barrier gave up (2 s without progress: the device is shared with another resident kernel) leaves a STICKY
+  // flag in ctr[NTILE + 2] (the per-epoch memset above clears ctr[0 .. NTILE + 2) only); its copy is looked at behind every
+  // stream synchronisation of the C entry points and at the start of the next epoch (mfx_slots_check_abort)
+  if (S->abort_host) HIPCHK(hipMemcpyAsync(S->abort_host, S->ctr + NTILE + 2, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
   return MFX_OK;
 }
 

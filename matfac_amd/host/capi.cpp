@@ -178,13 +178,12 @@ extern "C" int mfh_write_rand_mat_csr(const char* file, const double* U, const d
 }
 
 // ModelMFBias::train on in-memory matrices (the bias-only sibling): last and best bias vectors, stats as mfh_train
-extern "C" int mfh_train_bias(int32_t nrows, const int64_t* tr_ptr, const int32_t* tr_ind, const float* tr_val, int32_t tr_ncols,
-                              const int64_t* va_ptr, const int32_t* va_ind, const float* va_val, int32_t va_ncols, const int64_t* te_ptr,
-                              const int32_t* te_ind, const float* te_val, int32_t te_ncols, int32_t K, int32_t maxIter, int32_t seed,
-                              float learnRate, float uReg, float iReg, float* ubLast, float* ibLast, float* ubBest, float* ibBest,
-                              double* stats) {
+static int mfh_train_bias_impl(int32_t nrows, const int64_t* tr_ptr, const int32_t* tr_ind, const float* tr_val, int32_t tr_ncols,
+                               const int64_t* va_ptr, const int32_t* va_ind, const float* va_val, int32_t va_ncols, const int64_t* te_ptr,
+                               const int32_t* te_ind, const float* te_val, int32_t te_ncols, int32_t K, int32_t maxIter, int32_t seed,
+                               float learnRate, float uReg, float iReg, float* ubLast, float* ibLast, float* ubBest, float* ibBest,
+                               double* stats) {
   std::string e, pfx = "";
-  setenv("MFX_NO_SAVE", "1", 1);
   Params params(K, maxIter, K, seed, uReg, iReg, learnRate, 0.0f, 0.0f, e, e, e, e, e, e, e, e, pfx);
   Data data(csr_from_arrays(nrows, tr_ncols, tr_ptr, tr_ind, tr_val), csr_from_arrays(nrows, te_ncols, te_ptr, te_ind, te_val),
             csr_from_arrays(nrows, va_ncols, va_ptr, va_ind, va_val), pfx.c_str());
@@ -192,12 +191,7 @@ extern "C" int mfh_train_bias(int32_t nrows, const int64_t* tr_ptr, const int32_
   params.nItems = data.nItems;
   ModelMFBias model(params, params.seed), best(params, params.seed);
   std::unordered_set<int> iu, ii;
-  try {
-    model.train(data, best, iu, ii);
-  } catch (const MfxError& e) {
-    fprintf(stderr, "\n%s\n", e.what());
-    return e.code < 0 ? e.code : -2;
-  }
+  model.train(data, best, iu, ii);
   if (ubLast) memcpy(ubLast, model.uBias.data(), sizeof(float) * (size_t)data.nUsers);
   if (ibLast) memcpy(ibLast, model.iBias.data(), sizeof(float) * (size_t)data.nItems);
   if (ubBest) memcpy(ubBest, best.uBias.data(), sizeof(float) * (size_t)data.nUsers);
@@ -209,7 +203,30 @@ extern "C" int mfh_train_bias(int32_t nrows, const int64_t* tr_ptr, const int32_
     stats[3] = model.learnRate;
     stats[4] = model.lastIters;
   }
-  unsetenv("MFX_NO_SAVE");
   return 0;
+}
+// (the whole body behind one try: the RMSE calls of the statistics can throw MfxError too, and no exception may leave a C entry
+// point; MFX_NO_SAVE is restored on every way out)
+extern "C" int mfh_train_bias(int32_t nrows, const int64_t* tr_ptr, const int32_t* tr_ind, const float* tr_val, int32_t tr_ncols,
+                              const int64_t* va_ptr, const int32_t* va_ind, const float* va_val, int32_t va_ncols, const int64_t* te_ptr,
+                              const int32_t* te_ind, const float* te_val, int32_t te_ncols, int32_t K, int32_t maxIter, int32_t seed,
+                              float learnRate, float uReg, float iReg, float* ubLast, float* ibLast, float* ubBest, float* ibBest,
+                              double* stats) {
+  const char* had = getenv("MFX_NO_SAVE");
+  const std::string prev = had ? had : "";
+  setenv("MFX_NO_SAVE", "1", 1);
+  int rc;
+  try {
+    rc = mfh_train_bias_impl(nrows, tr_ptr, tr_ind, tr_val, tr_ncols, va_ptr, va_ind, va_val, va_ncols, te_ptr, te_ind, te_val, te_ncols, K,
+                             maxIter, seed, learnRate, uReg, iReg, ubLast, ibLast, ubBest, ibBest, stats);
+  } catch (const MfxError& e) {
+    fprintf(stderr, "\n%s\n", e.what());
+    rc = e.code < 0 ? e.code : -2;
+  } catch (const std::exception& e) {
+    fprintf(stderr, "\n%s\n", e.what());
+    rc = -2;
+  }
+  if (had) setenv("MFX_NO_SAVE", prev.c_str(), 1); else unsetenv("MFX_NO_SAVE");
+  return rc;
 }
 

@@ -537,19 +537,28 @@ void ModelMF::trainSGDParSVD(const Data& d, Model& b, IntSet& iu, IntSet& ii) { 
 void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestModel, IntSet& invalidUsers,
                   IntSet& invalidItems) {
   std::cout << "\nModelMF::" << name << " trainSeed: " << trainSeed;
-  // MFX_EXACT: replay the reference's own visiting order bit by bit -- 1: level-scheduled (MFX_SGD_LEVELS, parallel),
+  // MFX_EXACT: replay the reference's own visiting order bit by bit -- 1: dataflow-scheduled (MFX_SGD_LEVELS, parallel),
   // 2: one lane group in list order (MFX_SGD_SERIAL, the slow statement of the same thing)
-  //            0: never -- the lock-free tiled schedule (a different, valid visiting order; its result moves inside the
-  //               reference's own seed-to-seed spread only once the matrix is large, tests/test_parity_spread_gpu.py)
-  // unset: the plain SGD trainers replay the reference's order when the train matrix has at most MFX_EXACT_BELOW ratings
-  // (default 2 M: there the replay costs milliseconds per epoch and the lock-free schedule, which keeps >= 64 ratings of
-  // a workgroup in flight, collides on the few hundred rows of a tile); larger matrices take the tiled schedule.
+  //            0: never -- the lock-free tiled schedule (a different visiting order with thousands of ratings in flight: its
+  //               test RMSE agrees with the reference's to ~1e-2, in either direction -- tests/test_parity_spread_gpu.py)
+  // unset: every trainer keeps ITS OWN semantics.
+  //   * ModelMF::train, trainUShuffle, trainSGDPar are sequential / deterministic in the reference (modelMF.cpp:83-105, 637-659,
+  //     273-304): they replay the reference's order -- the numbers ARE the reference's -- up to MFX_EXACT_SEQ_BELOW train ratings
+  //     (default 32 M: the ML-20M shape replays at 0.96 G updates/s, 21 ms per epoch, next to the reference's own std::shuffle
+  //     of the index list on the host, 0.4 s); larger matrices take the lock-free tiled schedule unless MFX_EXACT=1;
+  //   * hogTrain is lock-free in the reference (:1747-1763) and the sibling models' loops sit in OpenMP-parallel block loops: they
+  //     take the lock-free tiled schedule, except on small matrices (up to MFX_EXACT_BELOW = 2 M ratings), where >= 64 ratings of
+  //     a workgroup in flight collide on the few hundred rows of a tile and the one-thread replay is both exact and cheap.
   const char* exactEnv = getenv("MFX_EXACT");
   const bool plainSgd = kind == K_SGD || kind == K_HOG || kind == K_SGDU || kind == K_SGDPAR || kind == K_IFW || kind == K_TMF ||
                         kind == K_TMFD || kind == K_SGDPARSVD;       // every SGD trainer, the sibling models included
+  const bool sequentialSgd = kind == K_SGD || kind == K_SGDU || kind == K_SGDPAR;
   const char* belowEnv = getenv("MFX_EXACT_BELOW");
+  const char* seqBelowEnv = getenv("MFX_EXACT_SEQ_BELOW");
   const int64_t exactBelow = belowEnv ? atoll(belowEnv) : 2000000;
-  const bool exact = exactEnv ? atoi(exactEnv) != 0 : (plainSgd && data.trainMat->nnz() <= exactBelow);
+  const int64_t exactSeqBelow = seqBelowEnv ? atoll(seqBelowEnv) : (belowEnv ? std::max<int64_t>(exactBelow, 0) : 32000000);
+  const bool exact = exactEnv ? atoi(exactEnv) != 0
+                              : (plainSgd && data.trainMat->nnz() <= (sequentialSgd ? exactSeqBelow : exactBelow));
   const int replayMode = (exactEnv && atoi(exactEnv) == 2) ? MFX_SGD_SERIAL : MFX_SGD_LEVELS;
   if (plainSgd) std::cout << " [" << (exact ? (replayMode == MFX_SGD_SERIAL ? "order replay, serial" : "order replay, dataflow schedule") : "lock-free tiled schedule") << "]";
   const csr_t* trainMat = data.trainMat;

@@ -175,6 +175,9 @@ class Ctx:
         self._chk(self.lib.mfx_debug_visit_counts(self.h, c.ctypes.data_as(C.c_void_p), C.c_int64(n.value), C.byref(n)))
         return c
 
+    def debug_raise_drain_abort(self):
+        self._chk(self.lib.mfx_debug_raise_drain_abort(self.h))
+
     def debug_slots_digest(self):
         counts = (C.c_int64 * 4)()
         sums = (C.c_uint64 * 5)()

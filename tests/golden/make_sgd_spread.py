@@ -47,9 +47,36 @@ def run(d, method, train_seed, nthreads, CFG=CFG):
                 best_iter=int(r["bestIter"]))
 
 
+def _sgdpar_row(args):
+    mid, seed = args
+    cfg = CFG_MID if mid else CFG
+    return run(problem(cfg), orc.M_SGDPAR, seed, SGDPAR_PARTS, cfg)
+
+
+SGDPAR_PARTS = 8      # T of trainSGDPar (= omp_get_max_threads() in the reference): users and items dealt into 8 parts
+
+
 if __name__ == "__main__":
     mid = len(sys.argv) > 1 and sys.argv[1] == "mid"
     cfg = CFG_MID if mid else CFG
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "sgd_spread_%s.json" % ("mid" if mid else "c1"))
+    if "sgdpar" in sys.argv[1:]:
+        # add the rows of the reference's OWN stratified trainer (ModelMF::trainSGDPar, modelMF.cpp:154-350, via the oracle's
+        # orc_strat_create / orc_strat_epoch: T = 8 parts, a fresh random matching per round) to the existing file: the
+        # schedule the lock-free tiled kernel is modelled on.  Deterministic per seed (blocks of a round share no rows).
+        #     python tests/golden/make_sgd_spread.py [mid] sgdpar
+        import multiprocessing as mp
+        out = json.load(open(path))
+        with mp.Pool(5) as pool:
+            out["sgdpar"] = pool.map(_sgdpar_row, [(mid, seed) for seed in range(1, 6)])
+        t = np.array([x["test_rmse"] for x in out["sgdpar"]])
+        out["sgdpar_parts"] = SGDPAR_PARTS
+        out["sgdpar_test_rmse_mean"] = float(t.mean())
+        out["sgdpar_test_rmse_std"] = float(t.std(ddof=1))
+        json.dump(out, open(path, "w"), indent=1)
+        print("sgdpar (T = %d) %.5f +- %.5f   sequential %.5f +- %.5f" % (SGDPAR_PARTS, t.mean(), t.std(ddof=1), out["sequential_test_rmse_mean"],
+                                                                    out["sequential_test_rmse_std"]))
+        sys.exit(0)
     d = problem(cfg)
     out = dict(config=cfg, train_nnz=d["train"].nnz, sequential=[], hogwild=[])
     for seed in range(1, 6 if mid else 9):

@@ -16,8 +16,20 @@ int main(int argc, char** argv) {
   while (scanf("%lld %lld", &b, &e) == 2) segs.push_back(MfxSeg{b, e, (int32_t)segs.size()});
   std::vector<int4> trips;
   std::vector<int32_t> gptr;
-  mfx_trips_layout(segs, 0, segs.size(), nwg, gpw, E, trips, gptr);
+  int64_t max_end = 0;
+  mfx_trips_layout(segs, 0, segs.size(), nwg, gpw, E, trips, gptr, &max_end);
   gptr.push_back((int32_t)trips.size());
+  // the allocation-pad invariant (mfx_trips_fit): the reported max_end is the true one, it lies less than E entries behind the last
+  // segment, and arrays of 2- and 4-byte entries that end with the last segment hold every loaded trip inside their pad
+  {
+    long long n = 0, true_end = 0;
+    for (const MfxSeg& g : segs) n = g.e > n ? g.e : n;
+    for (const int4& r : trips) { const long long t0 = ((long long)(unsigned)r.x << 2); true_end = t0 + E > true_end ? t0 + E : true_end; }
+    if (max_end != true_end) { printf("FAIL: max_end %lld, trips load up to %lld\n", (long long)max_end, true_end); return 1; }
+    if (max_end - n >= E) { printf("FAIL: trips load %lld entries behind the last segment (E = %d)\n", (long long)max_end - n, E); return 1; }
+    if (!mfx_trips_fit(max_end, n, 2) || !mfx_trips_fit(max_end, n, 4)) { printf("FAIL: a trip leaves the allocation pad (%lld behind %lld)\n", (long long)max_end - n, n); return 1; }
+    if (mfx_trips_fit(n + (long long)MFX_ALLOC_PAD / 4 + 1, n, 4)) { printf("FAIL: mfx_trips_fit accepts a read behind the pad\n"); return 1; }
+  }
   if ((int)gptr.size() != nwg * gpw + 1) { printf("FAIL: %zu range starts for %d groups\n", gptr.size() - 1, nwg * gpw); return 1; }
   std::vector<int> seen(segs.size(), 0);
   std::vector<long long> covered(segs.size(), 0);

@@ -248,3 +248,32 @@ def test_als_gathers_from_a_factor_table_beyond_4_gb(K):
     V_big = sweep(nU_big, ids, U_big)
     assert np.array_equal(V_big, V_small)
     assert np.abs(V_small - V0).max() > 1e-3            # the sweep did something
+
+
+def test_c5_shard_shape_visits_every_rating_once_stays_finite_and_learns():
+    """One GPU's share of BASELINE.json config 5 (10 M x 1 M, 1 B ratings, rank 256 over 8 GPUs): 1.25 M users x 1 M items,
+    125 M train ratings, K = 256 -- U is 1.28 GB (row offsets beyond 2^31 bytes, tables beyond every cache), V 1.02 GB.
+    The lock-free tiled epoch (what bench.py's secondary record and the N-GPU run time at this shape) consumes every rating
+    record exactly once, as counted by the update loop itself, the factors stay finite and the model learns."""
+    K = 256
+    shape = dict(nU=1_250_000, nI=1_000_000, nnz=int(125_000_000 / 0.8), K=K)
+    d = synth.make(shape, seed=1, r0_i=0.002)
+    d["nItems"] = shape["nI"]
+    tr = d["train"]
+    assert tr.nnz > 120_000_000 and d["nUsers"] * K * 4 > (1 << 30)
+    ctx, U0, V0 = _ctx(d, K)
+    del U0, V0
+    v0 = ctx.rmse(mfx.MAT_VAL)
+    t0 = ctx.rmse(mfx.MAT_TRAIN)
+    for ep in range(2):
+        ctx.sgd_epoch(0.0025, 0.01, 0.01, mode=mfx.SGD_TILED, seed=1, epoch=ep, flags=mfx.SGD_F_COUNT_VISITS)
+        visits = ctx.debug_visit_counts()
+        assert visits.size == tr.nnz and visits.min() == 1 and visits.max() == 1
+        del visits
+    v1, t1 = ctx.rmse(mfx.MAT_VAL), ctx.rmse(mfx.MAT_TRAIN)
+    print("C5 shard (%d x %d, %d train ratings, K=%d): val RMSE %.4f -> %.4f, train RMSE %.4f -> %.4f after 2 epochs"
+          % (d["nUsers"], d["nItems"], tr.nnz, K, v0, v1, t0, t1))
+    assert np.isfinite(v1) and np.isfinite(t1) and v1 < 0.5 * v0 and t1 < 0.5 * t0
+    # finite everywhere: the norms of the evaluation pass run over every row of both tables (a NaN or Inf anywhere would show)
+    assert np.isfinite(ctx.objective(0.01, 0.01))
+    ctx.close()

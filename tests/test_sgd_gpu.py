@@ -44,13 +44,19 @@ def test_hogwild_conflict_free_batch_bit_exact(K, arith):
     assert np.array_equal(V, Vo)
 
 
+@pytest.mark.parametrize("n", [3000, 9000])
 @pytest.mark.parametrize("K", [10, 32, 64, 128, 192, 256])
 @pytest.mark.parametrize("arith", ARITHS)
-def test_tiled_conflict_free_batch_matches_oracle(K, arith):
+def test_tiled_conflict_free_batch_matches_oracle(K, arith, n):
     """The kernel instantiations the host default and bench.py run (sgd_slots_kernel<.., ARITH_F32, item rows
     owned, fixed point>: the delta branch for K <= 128, the LEAN re-read branch beyond) and the two double-bracket
-    ones, each against the oracle's pass with the SAME arithmetic (modelMF.cpp:1755-1762 / :91-103 / :288-299)."""
-    n = 3000
+    ones, each against the oracle's pass with the SAME arithmetic (modelMF.cpp:1755-1762 / :91-103 / :288-299).
+    n = 3000: few lock-free rows per tile, `aw` < 16 waves take part (ALLW = false); n = 9000 (>= 8192 users): every wave takes
+    part -- the template instantiation <.., ALLW = true> that bench.py's C2 run launches (profiles/r02_bench_kernel_stats.csv)."""
+    if n > 3000:
+        if K not in (10, 32, 64, 256):
+            pytest.skip("the all-waves instantiation is checked at one rank per lane shape (K = 10, 32, 64) and at the LEAN branch (256)")
+        n = 2048 * (64 // (4 if K <= 16 else 8 if K <= 32 else 16)) + 808       # all 16 waves from 256 * (64 / L) lock-free rows per tile on
     tr = _conflict_free_matrix(n, K, seed=K + 1)
     rng = np.random.default_rng(200 + K)
     U0 = rng.normal(0, 0.3, (n, K)).astype(np.float32)
@@ -303,6 +309,91 @@ def test_dataflow_with_many_owned_rows_per_queue(K, tagged, monkeypatch):
         U, V = ctx.get_factors()
     assert np.array_equal(U, Uo)
     assert np.array_equal(V, Vo)
+
+
+@pytest.mark.parametrize("tagged", ["1", "0"])
+def test_exact_replay_on_a_context_reused_with_a_skewed_second_shape(tagged, monkeypatch):
+    """mfx_set_model twice on ONE context: (600, 600) then (1100, 50) -- nU + nI shrinks while max(nU, nI) grows, the case in which
+    the dataflow builder's per-row device tables were too small (round-2 advice); the second model's epoch must be the oracle's."""
+    monkeypatch.setenv("MFX_FLOW_TAGGED", tagged)
+    K = 32
+    with Ctx(0) as ctx:
+        for nU_, nI_, nnz_ in ((600, 600, 20_000), (1100, 50, 25_000)):
+            d = small(nU=nU_, nI=nI_, nnz=nnz_, K=K, seed=13)
+            tr = d["train"]
+            nU, nI = d["nUsers"], d["nItems"]
+            U0, V0 = orc.init_factors(1, nU, nI, K)
+            load_ctx(ctx, d, K, U0, V0)
+            order = np.arange(tr.nnz, dtype=np.uint64)
+            orc.MT(3).shuffle_u64(order)
+            ctx.sgd_set_order(order)
+            ctx.sgd_epoch(0.005, 0.01, 0.01, mode=mfx.SGD_LEVELS, order=mfx.ORDER_HOST, arith=mfx.ARITH_REF64)
+            U, V = ctx.get_factors()
+            Uo, Vo = U0.copy(), V0.copy()
+            orc.sgd_pass(Uo, Vo, tr.rowids(), tr.rowind, tr.rowval, order, 0.005, 0.01, 0.01, orc.ARITH_REF64, orc.DOT_TREE)
+            assert np.array_equal(U, Uo) and np.array_equal(V, Vo), (nU_, nI_)
+
+
+def test_a_drain_that_gave_up_is_reported_once_by_the_next_synchronising_call():
+    """The abort flag of the tiled schedule's drain is sticky on the device: epochs queued back to back cannot clear it, and it
+    is reported -- once -- by whatever synchronises next (round-2 advice: it used to be overwritten by the next epoch's memset)."""
+    from matfac_amd.mfx import MfxError
+    d = small(nU=3000, nI=2000, nnz=120_000, K=64, seed=4)
+    K = 64
+    U0, V0 = orc.init_factors(1, d["nUsers"], d["nItems"], K)
+    with Ctx(0) as ctx:
+        load_ctx(ctx, d, K, U0, V0)
+        ctx.sgd_epoch(0.005, 0.01, 0.01, mode=mfx.SGD_TILED, order=mfx.ORDER_DEVICE, arith=mfx.ARITH_F32, seed=1, epoch=0)
+        ctx.synchronize()
+        ctx.debug_raise_drain_abort()                  # what a drain does when its grid barrier sees no progress for 2 s
+        for ep in (1, 2, 3):                           # three epochs queued behind it: the flag survives their memsets
+            ctx.sgd_epoch(0.005, 0.01, 0.01, mode=mfx.SGD_TILED, order=mfx.ORDER_DEVICE, arith=mfx.ARITH_F32, seed=1, epoch=ep)
+        with pytest.raises(MfxError) as e:
+            ctx.synchronize()
+        assert "drain" in str(e.value)
+        ctx.synchronize()                              # reported once, then cleared
+        ctx.sgd_epoch(0.005, 0.01, 0.01, mode=mfx.SGD_TILED, order=mfx.ORDER_DEVICE, arith=mfx.ARITH_F32, seed=1, epoch=4)
+        assert np.isfinite(ctx.rmse(mfx.MAT_VAL))      # mfx_eval checks the flag too: clean now
+        # ... and the evaluation is one of the calls that report it
+        ctx.debug_raise_drain_abort()
+        ctx.sgd_epoch(0.005, 0.01, 0.01, mode=mfx.SGD_TILED, order=mfx.ORDER_DEVICE, arith=mfx.ARITH_F32, seed=1, epoch=5)
+        with pytest.raises(MfxError):
+            ctx.rmse(mfx.MAT_VAL)
+        U, V = ctx.get_factors()
+        assert np.isfinite(U).all() and np.isfinite(V).all()
+
+
+@pytest.mark.parametrize("wgs", ["8", "32"])
+def test_drain_on_a_small_resident_grid_visits_every_rating_once(wgs, monkeypatch):
+    """The drain sizes its grid to what is resident on the device (a CPX / QPX partition holds 32 - 64 CUs, not 128 workgroups);
+    MFX_SGD_DRAIN_WGS makes a 256-CU device run the small grids: a whole epoch through the drain alone, every record once, the
+    oracle's factors on a conflict-free matrix."""
+    import subprocess, sys, os
+    code = (
+        "import numpy as np\n"
+        "from matfac_amd import Ctx, mfx\n"
+        "from oracle import binding as orc\n"
+        "from tests.test_sgd_gpu import _conflict_free_matrix\n"
+        "n, K = 9000, 64\n"
+        "tr = _conflict_free_matrix(n, K, 5)\n"
+        "u, i, r = tr.rowids(), tr.rowind, tr.rowval\n"
+        "U0, V0 = orc.init_factors(1, n, n, K)\n"
+        "U0 *= 30; V0 *= 30\n"
+        "with Ctx(0) as ctx:\n"
+        "    ctx.set_csr(mfx.MAT_TRAIN, n, n, tr.rowptr, tr.rowind, tr.rowval)\n"
+        "    ctx.set_model(n, n, K); ctx.set_factors(U0, V0); ctx.compute_invalid()\n"
+        "    ctx.sgd_epoch(0.005, 0.01, 0.01, mode=mfx.SGD_TILED, order=mfx.ORDER_DEVICE, arith=mfx.ARITH_F32, seed=1, epoch=0,\n"
+        "                  flags=mfx.SGD_F_COUNT_VISITS | mfx.SGD_F_DRAIN_ONLY)\n"
+        "    v = ctx.debug_visit_counts(); U, V = ctx.get_factors()\n"
+        "Uo, Vo = U0.copy(), V0.copy()\n"
+        "orc.sgd_pass(Uo, Vo, u, i, r, None, 0.005, 0.01, 0.01, orc.ARITH_F32, orc.DOT_TREE)\n"
+        "assert np.all(v == 1), (v.min(), v.max())\n"
+        "assert np.abs(U - Uo).max() <= 2e-7 and np.abs(V - Vo).max() <= 2e-7\n"
+        "print('OK')\n")
+    env = dict(os.environ, MFX_SGD_DRAIN_WGS=wgs)       # read once per process: a child process per grid size (two in all)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_level_schedule_sub_range_and_natural_order(exact_sched):

@@ -43,3 +43,28 @@ def test_trip_lists_cover_every_segment_once(checker, E, n, max_len, nwg, gpw):
     wmin, wmax = int(parts[parts.index("min") + 1]), int(parts[parts.index("max") + 1])
     longest = -(-(max_len + 31) // E)
     assert wmax - wmin <= 2 * longest + 1          # workgroups are cut at segment ends: within two segments of each other
+
+
+def _device_asm(src, tmp_path):
+    out = str(tmp_path / (os.path.basename(src) + ".s"))
+    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-ffp-contract=off", "--offload-arch=gfx950", "-w", "-I" + os.path.join(ROOT, "include"),
+           "-I" + os.path.join(ROOT, "matfac_amd", "csrc"), "-S", "--cuda-device-only", "-o", out, src]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return open(out).read()
+
+
+@pytest.mark.parametrize("src,store", [("ccd.hip", "global_store_dwordx4"), ("sgd_flow.hip", "buffer_store_dwordx4")])
+def test_wide_stores_written_as_inline_assembly_carry_their_wait_state(src, store, tmp_path):
+    """A store of more than 64 bits needs a wait state before a VALU may overwrite its data registers, and the compiler's hazard
+    recognizer does not look inside an asm statement: every 16-byte store between ;;#ASMSTART and ;;#ASMEND must be followed by its
+    own s_nop INSIDE the statement (mfx_store_unseen in mfx_internal.h, fl_store in sgd_flow.hip; round-2 advice)."""
+    import re
+    text = _device_asm(os.path.join(ROOT, "matfac_amd", "csrc", src), tmp_path)
+    blocks = re.findall(r";;#ASMSTART\n(.*?);;#ASMEND", text, flags=re.S)
+    wide = [b for b in blocks if store in b]
+    assert len(wide) > 0, "no inline-assembly %s found in %s" % (store, src)
+    for b in wide:
+        lines = [l.strip() for l in b.strip().split("\n") if l.strip()]
+        k = [i for i, l in enumerate(lines) if l.startswith(store)]
+        assert k and all(i + 1 < len(lines) and lines[i + 1].startswith("s_nop") for i in k), b
