@@ -140,7 +140,8 @@ typedef struct {
                           1 and 2 are experiments: measured worse / unstable       */
   int64_t first, count; /* sub-range of the epoch list; count <= 0: everything  */
   int32_t flags;       /* MFX_SGD_F_* (0 for production runs)                    */
-  int32_t reserved;    /* 0                                                      */
+  int32_t item_part;   /* 0: the whole train matrix; p + 1: only the ratings whose item belongs to item
+                          part p of mfx_sgd_set_item_parts (MFX_SGD_TILED; the multi-GPU rotation)  */
 } mfx_sgd_opts;
 /* Test hooks of MFX_SGD_TILED (tests/test_sgd_gpu.py, tests/test_fullsize_gpu.py):
  *  ONE_GROUP     the slots are visited tile by tile and slot by slot by ONE lane group, one rating at a
@@ -300,6 +301,16 @@ int mfx_bias_eval(mfx_ctx* ctx, int which, int snapshot, mfx_eval_out* out);
  * V <- V_sync + sum_over_ranks (V - V_sync)   (MFX_REDUCE_DELTA_SUM)   or
  * V <- mean_over_ranks V                       (MFX_REDUCE_AVERAGE).              */
 enum { MFX_REDUCE_DELTA_SUM = 0, MFX_REDUCE_AVERAGE = 1 };
+/* Item-part rotation (the reference's own stratification, modelMF.cpp:273-304, at GPU granularity): the items are cut into
+ * nparts parts (item i belongs to part i % nparts), an epoch on N = nparts ranks is N sub-epochs -- in sub-epoch s rank g runs
+ * mfx_sgd_epoch with item_part = ((g + s) % N) + 1 on the ONLY current copy of that part's rows and then hands them on:
+ * mfx_rotate_item_part(send, recv) sends the rows of part `send` to rank g - 1 and receives the rows of part `recv` from rank
+ * g + 1 (a ring shift of 1/N of V; RCCL send/recv).  No update is lost, summed twice or down-weighted.  After the last
+ * sub-epoch mfx_allgather_item_parts(part) -- every rank r contributes the part (part - rank + r) mod N it holds -- makes V
+ * complete and identical on all ranks (needed before an evaluation).  nparts = 0 or 1 switches the parts off.            */
+int mfx_sgd_set_item_parts(mfx_ctx* ctx, int nparts);
+int mfx_rotate_item_part(mfx_ctx* ctx, int send_part, int recv_part);
+int mfx_allgather_item_parts(mfx_ctx* ctx, int my_part);
 #define MFX_UNIQUE_ID_BYTES 128
 int mfx_comm_unique_id(void* id128);
 int mfx_comm_init(mfx_ctx* ctx, int nranks, int rank, const void* id128);

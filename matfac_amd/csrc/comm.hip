@@ -22,6 +22,10 @@ typedef int (*fn_get_uid)(UniqueId*);
 typedef int (*fn_init_rank)(void**, int, UniqueId, int);
 typedef int (*fn_destroy)(void*);
 typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*fn_sendrecv)(void*, size_t, int, int, void*, hipStream_t);          // ncclSend (const void*) / ncclRecv
+typedef int (*fn_group)();
+typedef int (*fn_allgather)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef int (*fn_reducescatter)(const void*, void*, size_t, int, int, void*, hipStream_t);
 typedef const char* (*fn_errstr)(int);
 struct Rccl {
   void* h = nullptr;
@@ -29,6 +33,10 @@ struct Rccl {
   fn_init_rank init_rank = nullptr;
   fn_destroy destroy = nullptr;
   fn_allreduce allreduce = nullptr;
+  fn_sendrecv send = nullptr, recv = nullptr;
+  fn_group group_start = nullptr, group_end = nullptr;
+  fn_allgather allgather = nullptr;
+  fn_reducescatter reducescatter = nullptr;
   fn_errstr errstr = nullptr;
   std::string err;
 };
@@ -52,7 +60,14 @@ bool load_rccl() {
   g_rccl.destroy = (fn_destroy)dlsym(g_rccl.h, "ncclCommDestroy");
   g_rccl.allreduce = (fn_allreduce)dlsym(g_rccl.h, "ncclAllReduce");
   g_rccl.errstr = (fn_errstr)dlsym(g_rccl.h, "ncclGetErrorString");
-  if (!g_rccl.get_uid || !g_rccl.init_rank || !g_rccl.destroy || !g_rccl.allreduce) {
+  g_rccl.send = (fn_sendrecv)dlsym(g_rccl.h, "ncclSend");
+  g_rccl.recv = (fn_sendrecv)dlsym(g_rccl.h, "ncclRecv");
+  g_rccl.group_start = (fn_group)dlsym(g_rccl.h, "ncclGroupStart");
+  g_rccl.group_end = (fn_group)dlsym(g_rccl.h, "ncclGroupEnd");
+  g_rccl.allgather = (fn_allgather)dlsym(g_rccl.h, "ncclAllGather");
+  g_rccl.reducescatter = (fn_reducescatter)dlsym(g_rccl.h, "ncclReduceScatter");
+  if (!g_rccl.get_uid || !g_rccl.init_rank || !g_rccl.destroy || !g_rccl.allreduce || !g_rccl.send || !g_rccl.recv || !g_rccl.group_start ||
+      !g_rccl.group_end || !g_rccl.allgather || !g_rccl.reducescatter) {
     g_rccl.err = "librccl lacks a required symbol";
     dlclose(g_rccl.h);
     g_rccl.h = nullptr;
@@ -206,7 +221,7 @@ extern "C" int mfx_comm_destroy(mfx_ctx* ctx) {
 // V_sync tracks the last agreed item factors; it is (re)initialised from V the first
 // time and after every exchange.
 static int ensure_sync_buffers(mfx_ctx* ctx) {
-  const size_t n = (size_t)ctx->nI * ctx->ld;
+  const size_t n = (size_t)ctx->nI * ctx->ld;      // (comm_tmp is shared with the item-part rotation, which may have sized it larger)
   int rc;
   if (!ctx->comm_tmp || ctx->comm_tmp_cap < n) {   // mfx_set_model may have grown the item table since the last exchange
     dev_free(ctx->comm_tmp);
@@ -252,6 +267,118 @@ extern "C" int mfx_allreduce_item_factors(mfx_ctx* ctx, int op) {
                        1.0f / (float)ctx->nranks, n4);
   }
   HIPCHK(hipGetLastError());
+  return MFX_OK;
+}
+
+// ---- item-part rotation (include/mfx.h) ----------------------------------------------------------------------------
+// rows p, p + N, p + 2N, ... of V <-> a packed slab of `rows` x ld floats
+__global__ void part_pack_kernel(const float* __restrict__ V, int64_t nI, int ld4, int part, int nparts, float* __restrict__ slab) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int64_t rows = (nI - part + nparts - 1) / nparts, total = rows * ld4, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t k = t / ld4, c = t % ld4;
+    ((f4*)slab)[t] = ((const f4*)V)[((int64_t)part + k * nparts) * ld4 + c];
+  }
+}
+__global__ void part_unpack_kernel(float* __restrict__ V, int64_t nI, int ld4, int part, int nparts, const float* __restrict__ slab) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int64_t rows = (nI - part + nparts - 1) / nparts, total = rows * ld4, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t k = t / ld4, c = t % ld4;
+    ((f4*)V)[((int64_t)part + k * nparts) * ld4 + c] = ((const f4*)slab)[t];
+  }
+}
+// comm_tmp holds N + 1 slabs of `slab` floats each (slab = ceil(nI / N) rows x ld: the same size for every part)
+static int ensure_part_buffers(mfx_ctx* ctx, int64_t* slab_out) {
+  const int N = ctx->nranks;
+  const int64_t slab = (((int64_t)ctx->nI + N - 1) / N) * ctx->ld;
+  const size_t need = (size_t)slab * ((size_t)N + 1);
+  if (!ctx->comm_tmp || ctx->comm_tmp_cap < need) {
+    dev_free(ctx->comm_tmp);
+    ctx->comm_tmp_cap = 0;
+    int rc = dev_alloc(ctx, &ctx->comm_tmp, need);
+    if (rc) return rc;
+    ctx->comm_tmp_cap = need;
+  }
+  *slab_out = slab;
+  return MFX_OK;
+}
+static int part_grid(int64_t slab) { return (int)std::min<int64_t>((slab / 4 + 255) / 256 + 1, 4096); }
+
+extern "C" int mfx_rotate_item_part(mfx_ctx* ctx, int send_part, int recv_part) {
+  if (!ctx) return MFX_E_ARG;
+  NEED(ctx->V, MFX_E_STATE, "mfx_rotate_item_part: no model");
+  const int N = ctx->nranks;
+  if (N <= 1 || (!ctx->comm && !ctx->ext_reduce)) return MFX_OK;      // one rank: it keeps every part
+  NEED(ctx->item_parts == N, MFX_E_STATE, "mfx_rotate_item_part: mfx_sgd_set_item_parts(%d) must name as many parts as there are ranks (%d)",
+       ctx->item_parts, N);
+  NEED(send_part >= 0 && send_part < N && recv_part >= 0 && recv_part < N, MFX_E_ARG, "mfx_rotate_item_part: parts %d, %d of %d", send_part, recv_part, N);
+  HIPCHK(hipSetDevice(ctx->device));
+  int64_t slab;
+  int rc = ensure_part_buffers(ctx, &slab);
+  if (rc) return rc;
+  const int ld4 = ctx->ld / 4, grid = part_grid(slab);
+  float* out = ctx->comm_tmp;                 // slab 0: what leaves; slab 1 (RCCL) or slabs 1 .. N (external reducer): what arrives
+  hipLaunchKernelGGL(part_pack_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const float*)ctx->V, (int64_t)ctx->nI, ld4, send_part, N, out);
+  HIPCHK(hipGetLastError());
+  const float* in;
+  if (ctx->comm) {
+    const int prev = (ctx->rank + N - 1) % N, next = (ctx->rank + 1) % N;
+    int r = g_rccl.group_start();
+    NEED(r == 0, MFX_E_COMM, "ncclGroupStart: %s", rccl_err(r));
+    r = g_rccl.send(out, (size_t)slab, kNcclFloat, prev, ctx->comm, ctx->stream);
+    const int r2 = g_rccl.recv(out + slab, (size_t)slab, kNcclFloat, next, ctx->comm, ctx->stream);
+    const int r3 = g_rccl.group_end();
+    NEED(r == 0 && r2 == 0 && r3 == 0, MFX_E_COMM, "ncclSend / ncclRecv: %s", rccl_err(r ? r : (r2 ? r2 : r3)));
+    in = out + slab;
+  } else {
+    // a caller-supplied all-reduce only (gloo / MPI callers, the two-process tests): every rank writes its slab into the place of
+    // its destination rank in an otherwise zero buffer of N slabs; the sum hands every rank the slab meant for it (N times the
+    // bytes of a send / receive: the rehearsal path, not the product path)
+    float* big = out + slab;
+    HIPCHK(hipMemsetAsync(big, 0, sizeof(float) * (size_t)slab * N, ctx->stream));
+    HIPCHK(hipMemcpyAsync(big + (size_t)((ctx->rank + N - 1) % N) * slab, out, sizeof(float) * (size_t)slab, hipMemcpyDeviceToDevice, ctx->stream));
+    if ((rc = mfx_comm_allreduce(ctx, big, (size_t)slab * N, 0))) return rc;
+    in = big + (size_t)ctx->rank * slab;
+  }
+  hipLaunchKernelGGL(part_unpack_kernel, dim3(grid), dim3(256), 0, ctx->stream, ctx->V, (int64_t)ctx->nI, ld4, recv_part, N, in);
+  HIPCHK(hipGetLastError());
+  return MFX_OK;
+}
+
+extern "C" int mfx_allgather_item_parts(mfx_ctx* ctx, int my_part) {
+  if (!ctx) return MFX_E_ARG;
+  NEED(ctx->V, MFX_E_STATE, "mfx_allgather_item_parts: no model");
+  const int N = ctx->nranks;
+  if (N <= 1 || (!ctx->comm && !ctx->ext_reduce)) return MFX_OK;
+  NEED(ctx->item_parts == N, MFX_E_STATE, "mfx_allgather_item_parts: mfx_sgd_set_item_parts(%d) must name as many parts as there are ranks (%d)",
+       ctx->item_parts, N);
+  NEED(my_part >= 0 && my_part < N, MFX_E_ARG, "mfx_allgather_item_parts: part %d of %d", my_part, N);
+  HIPCHK(hipSetDevice(ctx->device));
+  int64_t slab;
+  int rc = ensure_part_buffers(ctx, &slab);
+  if (rc) return rc;
+  const int ld4 = ctx->ld / 4, grid = part_grid(slab);
+  float* mine = ctx->comm_tmp;
+  float* big = ctx->comm_tmp + slab;          // slab r of `big`: what rank r contributed, i.e. part (my_part - rank + r) mod N
+  hipLaunchKernelGGL(part_pack_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const float*)ctx->V, (int64_t)ctx->nI, ld4, my_part, N, mine);
+  HIPCHK(hipGetLastError());
+  if (ctx->comm) {
+    const int r = g_rccl.allgather(mine, big, (size_t)slab, kNcclFloat, ctx->comm, ctx->stream);
+    NEED(r == 0, MFX_E_COMM, "ncclAllGather: %s", rccl_err(r));
+  } else {
+    HIPCHK(hipMemsetAsync(big, 0, sizeof(float) * (size_t)slab * N, ctx->stream));
+    HIPCHK(hipMemcpyAsync(big + (size_t)ctx->rank * slab, mine, sizeof(float) * (size_t)slab, hipMemcpyDeviceToDevice, ctx->stream));
+    if ((rc = mfx_comm_allreduce(ctx, big, (size_t)slab * N, 0))) return rc;
+  }
+  for (int r = 0; r < N; r++) {
+    if (r == ctx->rank) continue;
+    const int part = ((my_part - ctx->rank + r) % N + N) % N;
+    hipLaunchKernelGGL(part_unpack_kernel, dim3(grid), dim3(256), 0, ctx->stream, ctx->V, (int64_t)ctx->nI, ld4, part, N,
+                       (const float*)(big + (size_t)r * slab));
+  }
+  HIPCHK(hipGetLastError());
+  if (ctx->Vsync) HIPCHK(hipMemcpyAsync(ctx->Vsync, ctx->V, sizeof(float) * (size_t)ctx->nI * ctx->ld, hipMemcpyDeviceToDevice, ctx->stream));
   return MFX_OK;
 }
 

@@ -76,6 +76,7 @@ struct mfx_ctx {
   int64_t ulist_cap = 0;
   // MFX_SGD_TILED: slot lists (sgd_slots.hip owns the type)
   void* slots = nullptr;
+  int item_parts = 0;        // mfx_sgd_set_item_parts: > 1 = the multi-GPU rotation runs epochs part by part
   // MFX_SGD_LEVELS: level lists (sgd_levels.hip owns the type)
   void* levels = nullptr;
   bool last_exact_flow = false;   // which schedule the last MFX_SGD_LEVELS epoch ran on

@@ -211,9 +211,61 @@ __global__ void tile_bounds_kernel(const uint32_t* __restrict__ tile2, int64_t R
   trun[t] = lo;
 }
 
-int mfx_slots_build_device(mfx_ctx* ctx, SlotList* S, int rows, int side) {
+// ---- item parts: the train ratings grouped by part = item % nparts, CSR order inside a part (stable radix sort) ----------
+__global__ void part_keys_kernel(const int32_t* __restrict__ rowind, int64_t nnz, int nparts, uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x) {
+    key[e] = (uint64_t)((uint32_t)rowind[e] % (uint32_t)nparts);
+    val[e] = (uint32_t)e;
+  }
+}
+__global__ void part_gather_kernel(const uint32_t* __restrict__ order, int64_t nnz, const int32_t* __restrict__ rowid, const int32_t* __restrict__ rowind,
+                                   const float* __restrict__ rowval, int32_t* __restrict__ pu, int32_t* __restrict__ pi, float* __restrict__ pv) {
+  for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < nnz; o += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t e = order[o];
+    pu[o] = rowid[e]; pi[o] = rowind[e]; pv[o] = rowval[e];
+  }
+}
+__global__ void part_bounds_kernel(const uint64_t* __restrict__ keys, int64_t nnz, int nparts, int64_t* __restrict__ poff) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p > nparts) return;
+  int64_t lo = 0, hi = nnz;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if ((int64_t)keys[mid] < p) lo = mid + 1; else hi = mid;
+  }
+  poff[p] = lo;
+}
+int mfx_slots_group_by_part(mfx_ctx* ctx, SlotState* S, int nparts) {
   const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
   const int64_t nnz = m.nnz;
+  NEED(nnz > 0 && nnz < ((int64_t)1 << 31), MFX_E_ARG, "item parts: need 0 < nnz < 2^31");
+  NEED(nparts >= 2 && nparts <= 1024, MFX_E_ARG, "item parts: nparts=%d", nparts);
+  Scratch sc;
+  int rc;
+  hipStream_t st = ctx->stream;
+  uint64_t *k0, *k1;
+  uint32_t *v0, *v1;
+  int64_t* dpoff;
+  if ((rc = sc.get(ctx, &k0, (size_t)nnz)) || (rc = sc.get(ctx, &k1, (size_t)nnz)) || (rc = sc.get(ctx, &v0, (size_t)nnz)) ||
+      (rc = sc.get(ctx, &v1, (size_t)nnz)) || (rc = sc.get(ctx, &dpoff, (size_t)nparts + 1)))
+    return rc;
+  hipLaunchKernelGGL(part_keys_kernel, dim3(grid_for(nnz)), dim3(TB), 0, st, m.rowind, nnz, nparts, k0, v0);
+  if ((rc = sort_pairs(ctx, sc, k0, k1, v0, v1, (size_t)nnz, bits_for((uint64_t)nparts)))) return rc;
+  dev_free(S->pu); dev_free(S->pi); dev_free(S->pv);
+  if ((rc = dev_alloc(ctx, &S->pu, (size_t)nnz)) || (rc = dev_alloc(ctx, &S->pi, (size_t)nnz)) || (rc = dev_alloc(ctx, &S->pv, (size_t)nnz))) return rc;
+  hipLaunchKernelGGL(part_gather_kernel, dim3(grid_for(nnz)), dim3(TB), 0, st, v1, nnz, m.rowid, m.rowind, m.rowval, S->pu, S->pi, S->pv);
+  hipLaunchKernelGGL(part_bounds_kernel, dim3((nparts + TB) / TB), dim3(TB), 0, st, k1, nnz, nparts, dpoff);
+  HIPCHK(hipGetLastError());
+  S->poff.assign((size_t)nparts + 1, 0);
+  HIPCHK(hipMemcpyAsync(S->poff.data(), dpoff, sizeof(int64_t) * ((size_t)nparts + 1), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  S->nparts = nparts;
+  return MFX_OK;
+}
+
+int mfx_slots_build_device(mfx_ctx* ctx, SlotList* S, int rows, int side, const RatingView& view) {
+  const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
+  const int64_t nnz = view.n;
   NEED(nnz > 0 && nnz < ((int64_t)1 << 31), MFX_E_ARG, "slot lists on the device: need 0 < nnz < 2^31");
   const int32_t nown = side == 0 ? m.ncols : m.nrows;
   const int ownbits = bits_for((uint64_t)std::max(nown, 1)), tilebits = bits_for(NTILE);
@@ -227,7 +279,7 @@ int mfx_slots_build_device(mfx_ctx* ctx, SlotList* S, int rows, int side) {
   if ((rc = sc.get(ctx, &k0, (size_t)nnz)) || (rc = sc.get(ctx, &k1, (size_t)nnz)) || (rc = sc.get(ctx, &v0, (size_t)nnz)) ||
       (rc = sc.get(ctx, &v1, (size_t)nnz)))
     return rc;
-  hipLaunchKernelGGL(slot_keys_kernel, dim3(grid_for(nnz)), dim3(TB), 0, st, m.rowid, m.rowind, nnz, side, ownbits, k0, v0);
+  hipLaunchKernelGGL(slot_keys_kernel, dim3(grid_for(nnz)), dim3(TB), 0, st, view.u, view.i, nnz, side, ownbits, k0, v0);
   if ((rc = sort_pairs(ctx, sc, k0, k1, v0, v1, (size_t)nnz, ownbits + tilebits))) return rc;
 
   // 2. runs: (tile, owned row) -> number of ratings; k0 / v0 are free again and hold the unique keys / counts
@@ -325,8 +377,8 @@ int mfx_slots_build_device(mfx_ctx* ctx, SlotList* S, int rows, int side) {
   hipLaunchKernelGGL(slot_heads_kernel, dim3(grid_for(R)), dim3(TB), 0, st, head, hs, dst, R, nslots, nnz, trun, NTILE,
                      S->slot_beg, S->slot_ibeg, S->tile_slot);
   // 5. the ratings in slot order
-  hipLaunchKernelGGL(slot_scatter_kernel, dim3(grid_for(nnz)), dim3(TB), 0, st, dst, R, nnz, src2, v1, li, own2, m.rowid, m.rowind,
-                     m.rowval, side, (int4*)S->rec);
+  hipLaunchKernelGGL(slot_scatter_kernel, dim3(grid_for(nnz)), dim3(TB), 0, st, dst, R, nnz, src2, v1, li, own2, view.u, view.i,
+                     view.r, side, (int4*)S->rec);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(st));
   if (getenv("MFX_DEBUG"))

@@ -3,6 +3,8 @@
 #ifndef MFX_SGD_SLOTS_H_
 #define MFX_SGD_SLOTS_H_
 
+#include <vector>
+
 #include "mfx_internal.h"
 
 constexpr int CAP_R = 1024;   // ratings per slot
@@ -33,11 +35,21 @@ struct SlotList {
   int active_waves = WG / 64;      // waves of a workgroup that work on a slot (fewer when a tile has few lock-free rows)
   bool built = false;
 };
+// The ratings a slot list is built from: the whole train matrix (CSR arrays) or one ITEM PART of it (mfx_sgd_set_item_parts:
+// the multi-GPU rotation runs an epoch as nparts sub-epochs, each on the ratings whose item i has i % nparts == part).
+struct RatingView { const int32_t* u = nullptr; const int32_t* i = nullptr; const float* r = nullptr; int64_t n = 0; };
 // side 0: item rows owned (slots item-major), side 1: user rows owned (slots user-major)
 struct SlotState {
   SlotList side[2];
   uint32_t last_k0 = 0, last_k1 = 0;
-  int last_side = 0;
+  int last_side = 0, last_part = -1;       // last_part >= 0: the last epoch ran on parts[last_part]
+  // item parts: the train ratings grouped by part (COO copy, part p = [poff[p], poff[p+1])) and one slot list per part
+  int nparts = 0;
+  int32_t *pu = nullptr, *pi = nullptr;
+  float* pv = nullptr;
+  std::vector<int64_t> poff;
+  std::vector<SlotList> parts;
+  SlotList& last() { return last_part >= 0 ? parts[(size_t)last_part] : side[last_side]; }
 };
 
 // position t of a slot's visiting order (Feistel permutation of [0, R) keyed per epoch and slot)
@@ -55,7 +67,9 @@ MFX_SLOTS_DECL(4, 1) MFX_SLOTS_DECL(8, 1) MFX_SLOTS_DECL(16, 1) MFX_SLOTS_DECL(1
 MFX_SLOTS_DECL(16, 5) MFX_SLOTS_DECL(16, 6) MFX_SLOTS_DECL(16, 7) MFX_SLOTS_DECL(16, 8)
 #undef MFX_SLOTS_DECL
 
-// builds S on the device from the train matrix (setup.hip); same lists as the host builder in sgd_slots.hip
-int mfx_slots_build_device(mfx_ctx* ctx, SlotList* S, int rows, int side);
+// builds S on the device from the ratings of `view` (setup.hip); same lists as the host builder in sgd_slots.hip
+int mfx_slots_build_device(mfx_ctx* ctx, SlotList* S, int rows, int side, const RatingView& view);
+// the train ratings grouped by item part (i % nparts), stable in CSR order: fills st->pu/pi/pv/poff (setup.hip)
+int mfx_slots_group_by_part(mfx_ctx* ctx, SlotState* st, int nparts);
 
 #endif

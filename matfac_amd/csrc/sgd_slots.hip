@@ -35,11 +35,14 @@ static SlotState* state(mfx_ctx* ctx) { return (SlotState*)ctx->slots; }
 void mfx_slots_free_internal(mfx_ctx* ctx) {
   SlotState* st = state(ctx);
   if (!st) return;
-  for (SlotList& s : st->side) {
+  auto drop = [](SlotList& s) {
     dev_free(s.rec); dev_free(s.slot_beg); dev_free(s.slot_ibeg); dev_free(s.slot_items); dev_free(s.attr); dev_free(s.visit);
     dev_free(s.tile_slot); dev_free(s.ctr);
     if (s.abort_host) (void)hipHostFree(s.abort_host);
-  }
+  };
+  for (SlotList& s : st->side) drop(s);
+  for (SlotList& s : st->parts) drop(s);
+  dev_free(st->pu); dev_free(st->pi); dev_free(st->pv);
   delete st;
   ctx->slots = nullptr;
 }
@@ -55,18 +58,18 @@ static int up(mfx_ctx* ctx, T** dst, const std::vector<T>& v) {
   return MFX_OK;
 }
 
-static int build_slots(mfx_ctx* ctx, SlotList* S, int rows, int side) {
+static int build_slots(mfx_ctx* ctx, SlotList* S, int rows, int side, const RatingView& view) {
   const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
-  const int64_t nnz = m.nnz;
+  const int64_t nnz = view.n;
   // the device builder (setup.hip) makes the same lists; this host version is the readable statement of
   // them, the cross-check of tests/test_setup_gpu.py (MFX_SLOTS_HOST=1) and the path for nnz >= 2^31
-  if (nnz > 0 && nnz < ((int64_t)1 << 31) && !getenv("MFX_SLOTS_HOST")) return mfx_slots_build_device(ctx, S, rows, side);
+  if (nnz > 0 && nnz < ((int64_t)1 << 31) && !getenv("MFX_SLOTS_HOST")) return mfx_slots_build_device(ctx, S, rows, side, view);
   std::vector<int32_t> ru((size_t)nnz), ri((size_t)nnz);
   std::vector<float> rv((size_t)nnz);
   if (nnz) {
-    HIPCHK(hipMemcpy(ru.data(), m.rowid, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(ri.data(), m.rowind, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(rv.data(), m.rowval, sizeof(float) * (size_t)nnz, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ru.data(), view.u, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ri.data(), view.i, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(rv.data(), view.r, sizeof(float) * (size_t)nnz, hipMemcpyDeviceToHost));
   }
   // own[] = index on the owned side (grouping key), oth[] = index on the lock-free side
   const std::vector<int32_t>& own = side == 0 ? ri : ru;
@@ -226,10 +229,35 @@ int mfx_launch_sgd_tiled(mfx_ctx* ctx, const mfx_sgd_opts* o) {
   NEED(ob < (1ull << 32), MFX_E_ARG, "MFX_SGD_TILED: a factor matrix exceeds 4 GiB (buffer addressing)");
   SlotState* st = state(ctx);
   if (!st) { st = new SlotState; ctx->slots = st; }
+  const DevCSR& tm = ctx->mat[MFX_MAT_TRAIN];
+  RatingView view;
+  view.u = tm.rowid; view.i = tm.rowind; view.r = tm.rowval; view.n = tm.nnz;
   SlotList* S = &st->side[side];
+  const int part = o->item_part - 1;
+  if (o->item_part != 0) {
+    // one item part of the train matrix (the multi-GPU rotation): its ratings come from the part-grouped copy
+    NEED(ctx->item_parts > 1 && part >= 0 && part < ctx->item_parts, MFX_E_ARG, "MFX_SGD_TILED: item_part %d without mfx_sgd_set_item_parts (%d parts)",
+         o->item_part, ctx->item_parts);
+    NEED(side == 0, MFX_E_ARG, "MFX_SGD_TILED: item parts need own = 0 (item rows owned)");
+    if (st->nparts != ctx->item_parts || !st->pu) {
+      for (SlotList& s : st->parts) {
+        dev_free(s.rec); dev_free(s.slot_beg); dev_free(s.slot_ibeg); dev_free(s.slot_items); dev_free(s.attr); dev_free(s.visit);
+        dev_free(s.tile_slot); dev_free(s.ctr);
+        if (s.abort_host) (void)hipHostFree(s.abort_host);
+      }
+      st->parts.clear();
+      int rc = mfx_slots_group_by_part(ctx, st, ctx->item_parts);
+      if (rc) return rc;
+      st->parts.resize((size_t)ctx->item_parts);
+    }
+    S = &st->parts[(size_t)part];
+    view.u = st->pu + st->poff[(size_t)part]; view.i = st->pi + st->poff[(size_t)part]; view.r = st->pv + st->poff[(size_t)part];
+    view.n = st->poff[(size_t)part + 1] - st->poff[(size_t)part];
+    if (view.n == 0) return MFX_OK;           // this rank's users hold no rating of the part
+  }
   const int rows = std::min(64, std::max(8, 4096 / ctx->ld));
-  if (!S->built || S->rows != rows || S->nnz != ctx->mat[MFX_MAT_TRAIN].nnz) {
-    int rc = build_slots(ctx, S, rows, side);
+  if (!S->built || S->rows != rows || S->nnz != view.n) {
+    int rc = build_slots(ctx, S, rows, side, view);
     if (rc) return rc;
   }
   // sibling models: the weight / rank of every rating rides next to its record
@@ -273,7 +301,7 @@ int mfx_launch_sgd_tiled(mfx_ctx* ctx, const mfx_sgd_opts* o) {
   }
   const uint32_t k0 = mfx_mix32(o->seed ^ 0x3c6ef372U) + (uint32_t)o->epoch * 0x9e3779b9U;
   const uint32_t k1 = mfx_mix32(o->seed * 0x85ebca6bU + 0xdaa66d2bU) ^ mfx_mix32((uint32_t)o->epoch + 0x1b873593U);
-  st->last_k0 = k0; st->last_k1 = k1; st->last_side = side;
+  st->last_k0 = k0; st->last_k1 = k1; st->last_side = side; st->last_part = o->item_part != 0 ? part : -1;
   int blocks = env_blocks();
   // `blocks` counts 256-thread workgroups (include/mfx.h); this kernel runs WG-thread ones
   if (blocks <= 0) blocks = o->blocks > 0 ? std::min(o->blocks, 8192) : std::max(8, std::min(2048, ctx->nU / 64));
@@ -301,8 +329,8 @@ int mfx_launch_sgd_tiled(mfx_ctx* ctx, const mfx_sgd_opts* o) {
 int mfx_slots_check_abort(mfx_ctx* ctx) {
   SlotState* st = state(ctx);
   if (!st) return MFX_OK;
-  for (int side = 0; side < 2; side++) {
-    SlotList& S = st->side[side];
+  for (size_t k = 0; k < 2 + st->parts.size(); k++) {
+    SlotList& S = k < 2 ? st->side[k] : st->parts[k - 2];
     if (!S.abort_host || !*(volatile unsigned*)S.abort_host) continue;
     *S.abort_host = 0;
     if (S.ctr) HIPCHK(hipMemsetAsync(S.ctr + NTILE + 2, 0, sizeof(unsigned), ctx->stream));
@@ -312,13 +340,20 @@ int mfx_slots_check_abort(mfx_ctx* ctx) {
   return MFX_OK;
 }
 
+extern "C" int mfx_sgd_set_item_parts(mfx_ctx* ctx, int nparts) {
+  if (!ctx) return MFX_E_ARG;
+  NEED(nparts >= 0 && nparts <= 1024, MFX_E_ARG, "mfx_sgd_set_item_parts: nparts=%d", nparts);
+  ctx->item_parts = nparts >= 2 ? nparts : 0;       // the part lists are (re)built by the next epoch that names a part
+  return MFX_OK;
+}
+
 extern "C" int mfx_debug_raise_drain_abort(mfx_ctx* ctx) {
   if (!ctx) return MFX_E_ARG;
   SlotState* st = state(ctx);
-  NEED(st && st->side[st->last_side].built && st->side[st->last_side].ctr, MFX_E_STATE, "mfx_debug_raise_drain_abort: no tiled epoch has run");
+  NEED(st && st->last().built && st->last().ctr, MFX_E_STATE, "mfx_debug_raise_drain_abort: no tiled epoch has run");
   HIPCHK(hipSetDevice(ctx->device));
   const unsigned one = 1;
-  HIPCHK(hipMemcpyAsync(st->side[st->last_side].ctr + NTILE + 2, &one, sizeof one, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(st->last().ctr + NTILE + 2, &one, sizeof one, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return MFX_OK;
 }
@@ -326,8 +361,8 @@ extern "C" int mfx_debug_raise_drain_abort(mfx_ctx* ctx) {
 // fills ctx->eu/ei/er with the order the last tiled epoch visited (test hook)
 int mfx_slots_materialise_order(mfx_ctx* ctx) {
   SlotState* st = state(ctx);
-  NEED(st && st->side[st->last_side].built, MFX_E_STATE, "no tiled epoch has run");
-  SlotList* S = &st->side[st->last_side];
+  NEED(st && st->last().built, MFX_E_STATE, "no tiled epoch has run");
+  SlotList* S = &st->last();
   const int blocks = (int)std::min<int64_t>(std::max<int64_t>(S->nslots, 1), 4096);
   hipLaunchKernelGGL(slots_epoch_list_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const int4*)S->rec,
                      S->slot_beg, S->nslots, st->last_side, st->last_k0, st->last_k1, ctx->eu, ctx->ei, ctx->er);
@@ -340,9 +375,9 @@ extern "C" int mfx_debug_visit_counts(mfx_ctx* ctx, uint32_t* counts, int64_t ca
   if (!ctx) return MFX_E_ARG;
   SlotState* st = state(ctx);
   NEED(n, MFX_E_ARG, "mfx_debug_visit_counts: n NULL");
-  NEED(st && st->side[st->last_side].built && st->side[st->last_side].visit, MFX_E_STATE,
+  NEED(st && st->last().built && st->last().visit, MFX_E_STATE,
        "mfx_debug_visit_counts: no tiled epoch has run with MFX_SGD_F_COUNT_VISITS");
-  SlotList& S = st->side[st->last_side];
+  SlotList& S = st->last();
   *n = S.nnz;
   if (!counts) return MFX_OK;
   NEED(cap >= S.nnz, MFX_E_ARG, "mfx_debug_visit_counts: cap too small");
@@ -368,10 +403,10 @@ static int digest_dev(mfx_ctx* ctx, const T* dev, size_t n, uint64_t* out) {
 extern "C" int mfx_debug_slots_digest(mfx_ctx* ctx, int64_t counts[4], uint64_t sums[5]) {
   if (!ctx) return MFX_E_ARG;
   SlotState* st = state(ctx);
-  NEED(st && st->side[st->last_side].built && counts && sums, MFX_E_STATE, "mfx_debug_slots_digest: no tiled epoch has run");
+  NEED(st && st->last().built && counts && sums, MFX_E_STATE, "mfx_debug_slots_digest: no tiled epoch has run");
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  const SlotList& S = st->side[st->last_side];
+  const SlotList& S = st->last();
   std::vector<int32_t> ib((size_t)S.nslots + 1);
   HIPCHK(hipMemcpy(ib.data(), S.slot_ibeg, sizeof(int32_t) * ib.size(), hipMemcpyDeviceToHost));
   const int64_t refs = ib[(size_t)S.nslots];

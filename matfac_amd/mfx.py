@@ -32,7 +32,7 @@ class SgdOpts(C.Structure):
     _fields_ = [("mode", C.c_int32), ("order", C.c_int32), ("arith", C.c_int32),
                 ("learnRate", C.c_float), ("uReg", C.c_float), ("iReg", C.c_float),
                 ("seed", C.c_uint32), ("epoch", C.c_int32), ("blocks", C.c_int32), ("own", C.c_int32),
-                ("first", C.c_int64), ("count", C.c_int64), ("flags", C.c_int32), ("reserved", C.c_int32)]
+                ("first", C.c_int64), ("count", C.c_int64), ("flags", C.c_int32), ("item_part", C.c_int32)]
 
 
 class EvalOut(C.Structure):
@@ -139,8 +139,8 @@ class Ctx:
         self._chk(self.lib.mfx_sgd_set_order(self.h, k[1], C.c_int64(k[0].size)))
 
     def sgd_epoch(self, lr, uReg, iReg, mode=SGD_HOGWILD, order=ORDER_DEVICE, arith=ARITH_F32, seed=1,
-                  epoch=0, first=0, count=0, blocks=0, own=0, flags=0):
-        o = SgdOpts(mode, order, arith, lr, uReg, iReg, seed, epoch, blocks, own, first, count, flags, 0)
+                  epoch=0, first=0, count=0, blocks=0, own=0, flags=0, item_part=0):
+        o = SgdOpts(mode, order, arith, lr, uReg, iReg, seed, epoch, blocks, own, first, count, flags, item_part)
         self._chk(self.lib.mfx_sgd_epoch(self.h, C.byref(o)))
 
     def debug_epoch_list(self):
@@ -349,6 +349,16 @@ class Ctx:
 
     def allreduce_item_factors(self, op=REDUCE_DELTA_SUM):
         self._chk(self.lib.mfx_allreduce_item_factors(self.h, op))
+
+    # item-part rotation (include/mfx.h): parts = item % nparts, one part per rank and sub-epoch
+    def set_item_parts(self, nparts):
+        self._chk(self.lib.mfx_sgd_set_item_parts(self.h, int(nparts)))
+
+    def rotate_item_part(self, send_part, recv_part):
+        self._chk(self.lib.mfx_rotate_item_part(self.h, int(send_part), int(recv_part)))
+
+    def allgather_item_parts(self, my_part):
+        self._chk(self.lib.mfx_allgather_item_parts(self.h, int(my_part)))
 
     def allreduce_f64(self, vals):
         a = np.ascontiguousarray(vals, np.float64).copy()

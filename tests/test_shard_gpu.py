@@ -125,3 +125,88 @@ def test_two_shards_equal_one_context(tmp_path):
         V = mdist.delta_sum(V, parts)
     assert np.array_equal(r[0]["sgd_V"], r[1]["sgd_V"])
     assert np.array_equal(cat("sgd_U"), U) and np.array_equal(r[0]["sgd_V"], V)
+
+
+# ---- the rotating exchange through the library (mfx_sgd_set_item_parts / mfx_rotate_item_part / mfx_allgather_item_parts) ----
+def _rot_worker(rank, world, port, out_dir, one_group):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tr, nI, U0, V0 = _problem()
+    b = mdist.user_blocks(tr.rowptr, world)
+    lo, hi = int(b[rank]), int(b[rank + 1])
+    sh = mdist.take_rows(tr, lo, hi)
+    lists = {}
+    with Ctx(0) as ctx:
+        ctx.comm_init_external(world, rank, lambda a: dist.all_reduce(torch.from_numpy(a), op=dist.ReduceOp.SUM))
+        ctx.set_csr(mfx.MAT_TRAIN, sh.nrows, nI, sh.rowptr, sh.rowind, sh.rowval)
+        ctx.set_model(sh.nrows, nI, K)
+        ctx.set_factors(U0[lo:hi], V0)
+        ctx.compute_invalid()
+        ctx.set_item_parts(world)
+        steps, held = mdist.rotation_schedule(rank, world)
+        visits = 0
+        for ep in range(2):
+            for part, send, recv in steps:
+                flags = mfx.SGD_F_COUNT_VISITS | (mfx.SGD_F_ONE_GROUP if one_group else 0)
+                ctx.sgd_epoch(0.002, 0.05, 0.05, mode=mfx.SGD_TILED, order=mfx.ORDER_DEVICE, arith=mfx.ARITH_REF64, seed=5, epoch=ep,
+                              flags=flags, item_part=part + 1)
+                v = ctx.debug_visit_counts()
+                assert np.all(v == 1)
+                visits += int(v.size)
+                u, i, r = ctx.debug_epoch_list()
+                assert np.all(i % world == part)                       # only ratings of the part
+                lists["e%d_p%d" % (ep, part)] = np.stack([u, i, r.view(np.int32)])
+                if send is not None:
+                    ctx.rotate_item_part(send, recv)
+            ctx.allgather_item_parts(held)
+        assert visits == 2 * sh.nnz                                    # every rating of the block once per epoch
+        U, V = ctx.get_factors()
+    np.savez(os.path.join(out_dir, "rot%d.npz" % rank), lo=lo, hi=hi, U=U, V=V, **lists)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("one_group", [True, False])
+def test_two_ranks_rotating_item_parts_through_the_library(tmp_path, one_group):
+    """Two processes, one GPU, gloo behind mfx_comm_init_external: an epoch = 2 part-restricted tiled epochs with a ring shift in
+    between and the closing all-gather.  Every rating is visited exactly once per epoch (counted by the kernel), a sub-epoch
+    touches only its part's items, both replicas of V agree bit for bit afterwards -- and with ONE lane group per slot (the
+    deterministic test mode: the list mfx_debug_epoch_list returns IS the visiting order) the factors are the oracle's
+    sequential replay of the recorded lists, sub-epoch by sub-epoch, rank by rank."""
+    import multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cx = mp.get_context("spawn")
+    procs = [cx.Process(target=_rot_worker, args=(g, 2, port, str(tmp_path), one_group)) for g in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(280)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    r = [np.load(str(tmp_path / ("rot%d.npz" % g))) for g in range(2)]
+    assert np.array_equal(r[0]["V"], r[1]["V"])                        # complete and identical after the all-gather
+    tr, nI, U0, V0 = _problem()
+    assert np.isfinite(r[0]["V"]).all() and np.isfinite(r[0]["U"]).all() and np.isfinite(r[1]["U"]).all()
+    assert np.abs(r[0]["V"] - V0).max() > 1e-3
+    if not one_group:
+        return
+    U, V = U0.copy(), V0.copy()
+    for ep in range(2):
+        for s_ in range(2):
+            for g in range(2):
+                part = mdist.rotation_schedule(g, 2)[0][s_][0]
+                u, i, rb = r[g]["e%d_p%d" % (ep, part)]
+                lo = int(r[g]["lo"])
+                Ug = U[lo:int(r[g]["hi"])]
+                orc.sgd_pass(Ug, V, u.astype(np.int32), i.astype(np.int32), rb.view(np.float32), None, 0.002, 0.05, 0.05, orc.ARITH_REF64,
+                             orc.DOT_TREE)
+    # (the owned item rows are accumulated in 2^-24 fixed point in LDS: the random walk of their roundings, as in
+    # tests/test_sgd_gpu.py's one-group replay)
+    assert np.abs(r[0]["V"] - V).max() < 2e-5
+    for g in range(2):
+        assert np.abs(r[g]["U"] - U[int(r[g]["lo"]):int(r[g]["hi"])]).max() < 2e-5
