@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0
 MFMA_F32_PEAK_TF = 157.3
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0      # G wave-instructions/s
+L2_GATHER_PEAK_GBS = 17800.0               # rows gathered out of the XCDs' L2s: 16.8 - 18.8 TB/s chip-wide (MI355X_MICROARCH.md, 'Indexed rows')
 PMC_SUMMARY = os.path.join("profiles", "r02_pmc_summary.json")
 
 
@@ -55,6 +56,9 @@ def main():
     ap.add_argument("--arith", default="f32", choices=["f32", "ref64"])
     ap.add_argument("--mode", default="tiled", choices=["tiled", "hogwild"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--exchange", default="rotate", choices=["rotate", "allreduce"],
+                    help="N > 1: rotate = item parts handed round a ring, every update applied once with its full step (default); "
+                         "allreduce = replicas of V averaged with one all-reduce per epoch (what north_star names; every item step / N)")
     ap.add_argument("--blocks", type=int, default=0, help="workgroups in flight (0 = library heuristic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the ALS / CCD++ / C5-shard records (N = 1 only)")
@@ -104,7 +108,17 @@ def main():
     # the NAMED shape is the training matrix: generate train/val/test = 80/10/10 around it
     shape["nnz"] = int(shape["nnz"] * args.scale / 0.8)
     t0 = time.time()
-    if args.scaling == "strong" and N > 1:
+    if args.workload == "C5":
+        # BASELINE.json config 5: ONE 10 M x 1 M matrix (8 fixed shards of 1.25 M users), strong scaling by construction
+        if synth.C5_SHARDS % N != 0:
+            raise SystemExit("--workload C5 is defined as %d user shards: --gpus must divide it" % synth.C5_SHARDS)
+        per = synth.C5_SHARDS // N
+        if (shape["nU"] // N) * 4 * ((K + 63) // 64 * 64) >= (1 << 32):
+            raise SystemExit("--workload C5 at rank %d needs the user shard's factor table below 4 GiB (buffer addressing of the tiled "
+                             "kernel): use --gpus >= %d" % (K, 4 if K > 128 else 2))
+        args.scaling = "strong"
+        tr, va, nU = synth.make_c5_shards(rank * per, per, seed=1, scale=args.scale)
+    elif args.scaling == "strong" and N > 1:
         full = synth.make(shape, seed=1, shard=0)                 # the same matrix on every rank ...
         b = mdist.user_blocks(full["train"].rowptr, N)            # ... cut by train ratings
         tr = mdist.take_rows(full["train"], b[rank], b[rank + 1])
@@ -126,11 +140,11 @@ def main():
     _, V0 = synth.init_factors(1, 1, nI, K, want_u=False)            # V replica: identical everywhere
     ctx.set_factors(U0, V0)
     ctx.compute_invalid()
-    exchange = "RCCL item-factor all-reduce"
+    exchange = "RCCL over xGMI"
     if multi:
         import torch
         if use_gloo:
-            exchange = "gloo all-reduce staged through the host (rehearsal)"
+            exchange = "gloo, staged through the host (rehearsal)"
             ctx.comm_init_external(N, rank, lambda a: dist.all_reduce(torch.from_numpy(a), op=dist.ReduceOp.SUM))
         else:
             # the library's own RCCL communicator (device buffers, on its stream).  Every rank reports whether it came
@@ -156,7 +170,7 @@ def main():
             flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag[0]) == 0:
-                exchange = "torch.distributed all-reduce staged through the host (library RCCL init failed)"
+                exchange = "torch.distributed, staged through the host (library RCCL init failed)"
                 if ok:
                     ctx.comm_destroy()
 
@@ -176,7 +190,19 @@ def main():
     nnz = tr.nnz
     mode = mfx.SGD_TILED if args.mode == "tiled" else mfx.SGD_HOGWILD
 
+    rotate = multi and args.exchange == "rotate" and mode == mfx.SGD_TILED
+    if multi:
+        exchange = ("item parts (item %% %d) handed round a ring -- one part per rank and sub-epoch, send/recv of 1/%d of V, all-gather after the "
+                    "last sub-epoch: every update applied once with its full step" % (N, N) if rotate
+                    else "item-factor all-reduce: replicas of V averaged once per epoch") + " [" + exchange + "]"
+    if rotate:
+        ctx.set_item_parts(N)
+
     def step(ep, exch=True):
+        if rotate and exch:
+            mdist.rotating_epoch(ctx, rank, N, lr, ureg, ireg, mode=mode, order=mfx.ORDER_DEVICE, arith=arith, seed=1, epoch=ep,
+                                 blocks=args.blocks)
+            return
         ctx.sgd_epoch(lr, ureg, ireg, mode=mode, order=mfx.ORDER_DEVICE, arith=arith, seed=1, epoch=ep,
                       blocks=args.blocks)
         if multi and exch:
@@ -250,13 +276,13 @@ def main():
             "config": {"workload": "%s: %s synthetic CSR, %s, train nnz=%d %s, rank=%d, %s LOCK-FREE SGD epoch (hogTrain analogue: device "
                                    "reshuffle + update kernel%s); a lock-free variant: test RMSE within 1e-2 of the sequential reference, "
                                    "two-sided (rmse_parity.*.gpu_lock_free_tiled_*); the path that reproduces ModelMF::train to 1e-6 is exact_replay"
-                                   % (args.workload, {"C1": "ML-100K-shape", "C2": "ML-20M-shape", "C4": "Netflix-shape"}.get(args.workload, ""),
+                                   % (args.workload, {"C1": "ML-100K-shape", "C2": "ML-20M-shape", "C4": "Netflix-shape", "C5": "10Mx1M (BASELINE config 5)"}.get(args.workload, ""),
                                       ("%dx%d per GPU (weak scaling: one such user block per GPU over the same items)" % (nU, nI)) if args.scaling == "weak" or N == 1
                                       else ("ONE %dx%d matrix cut into %d nnz-balanced user blocks (strong scaling)" % (shape["nU"], nI, N)),
                                       nnz if N == 1 or args.scaling == "weak" else total_nnz, "per GPU" if args.scaling == "weak" or N == 1 else "in total",
                                       K, "XCD-tiled" if mode == mfx.SGD_TILED else "flat", ", " + exchange if multi else ""),
                        "learnrate": lr, "ureg": ureg, "ireg": ireg, "arith": args.arith,
-                       "parallelism": "user-block x%d" % N},
+                       "parallelism": "user-block x%d" % N, "exchange": (args.exchange if multi else None)},
             "roofline": sgd_roofline(K, nnz, launches_per_step, avg_ms, sgd_launches, kernel),
             "permute_ms_per_step": perm_ms / max(1, profiled_steps),
             "val_rmse_after": val_rmse, "train_rmse_after": tr_rmse,
@@ -343,11 +369,15 @@ def pmc(kernel):
 def sgd_roofline(K, nnz, launches_per_step, avg_ms, launches, kernel):
     """What bounds the dominant kernel, with fractions that cannot exceed 1.
 
-    SURVEY 8(d)'s algorithmic figure (16K+12 bytes per update) assumes both rows of every update come from and go
-    back to HBM.  At C2 they do not: the item rows of a slot live in LDS and the 42 MB of factors stay in L2 /
-    Infinity Cache, so that figure exceeds the HBM peak and bounds nothing (kept as `algorithmic`).  The counters show
-    two candidates: bytes that really cross the L2's memory side (FETCH_SIZE x2 + WRITE_SIZE), and vector
-    instructions issued.  `bound` names the larger fraction."""
+    SURVEY 8(d)'s algorithmic figure (16K+12 bytes per update) assumes both rows of every update come from and go back to HBM.
+    At C2 they do not: the item rows of a slot live in LDS and the 42 MB of factors stay in L2 / Infinity Cache, so that figure
+    exceeds the HBM peak and bounds nothing (kept as `algorithmic`).  Three candidates are priced instead, `bound` names the
+    largest fraction:
+      l2-memory-side  bytes that cross the L2's memory side (FETCH_SIZE x2 + WRITE_SIZE: fabric requests, Infinity-Cache hits
+                      INCLUDED -- not HBM traffic at this working set) against the 8 TB/s HBM peak as the conservative ceiling;
+      l2-rows         the lock-free rows every update moves through its XCD's L2 (one 4K-byte row read, one written) against the
+                      16.8 - 18.8 TB/s the guide measured for row gathers served by L2 (MI355X_MICROARCH.md, 'Indexed rows');
+      valu-issue      vector instructions per update at the issue costs measured on this chip (scripts/valu_probe.hip)."""
     avg_s = avg_ms * 1e-3
     per_launch = nnz / launches_per_step
     alg_bytes = (16 * K + 12) * per_launch
@@ -362,32 +392,36 @@ def sgd_roofline(K, nnz, launches_per_step, avg_ms, launches, kernel):
     if c and "hbm_bytes_per_launch" in c:
         traffic = c["hbm_bytes_per_launch"] * (per_launch / c.get("updates_per_launch", per_launch))
         fr = traffic / avg_s / 1e9 / HBM_PEAK_GBS
-        cands.append(("hbm", traffic / avg_s / 1e9, HBM_PEAK_GBS, "GB/s", fr))
+        cands.append(("l2-memory-side", traffic / avg_s / 1e9, HBM_PEAK_GBS, "GB/s", fr))
         r["traffic"] = traffic
-        r["traffic_source"] = ("%s: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per launch, separate --pmc passes of "
-                               "this command; time from this run's HIP events" % PMC_SUMMARY)
+        r["traffic_source"] = ("%s: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per launch (fabric requests of the L2s, Infinity-Cache hits "
+                               "included), separate --pmc passes of this command; time from this run's HIP events" % PMC_SUMMARY)
         r["l2_hit_rate"] = c.get("l2_hit_rate")
+        r["l2_memory_side"] = {"achieved": traffic / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fr}
     else:
         r["traffic"] = None
+    ld = (K + 63) // 64 * 64 if K > 32 else (32 if K > 16 else 16)
+    row_bytes = 2 * 4 * ld * per_launch            # the lock-free row of every update: read once, written once, through one L2
+    l2_ach = row_bytes / avg_s / 1e9
+    cands.append(("l2-rows", l2_ach, L2_GATHER_PEAK_GBS, "GB/s", l2_ach / L2_GATHER_PEAK_GBS))
+    r["l2_rows"] = {"bytes_per_update": 2 * 4 * ld, "achieved": l2_ach, "peak": L2_GATHER_PEAK_GBS, "unit": "GB/s", "frac": l2_ach / L2_GATHER_PEAK_GBS,
+                    "note": "user rows through the XCD's L2 (sc1 loads, plain stores); peak = middle of the 16.8 - 18.8 TB/s measured for "
+                            "L2-served row gathers (MI355X_MICROARCH.md)"}
     if c and "SQ_INSTS_VALU" in c.get("counters_mean_per_launch", {}):
         valu = c["counters_mean_per_launch"]["SQ_INSTS_VALU"]
         per_update = valu / c.get("updates_per_launch", per_launch)
         ach = per_update * per_launch / avg_s / 1e9
-        cands.append(("valu-issue", ach, VALU_PEAK_GINST, "G wave-instr/s", ach / VALU_PEAK_GINST))
-        r["valu_issue"] = {"wave_instructions_per_update": per_update, "achieved": ach, "peak": VALU_PEAK_GINST,
-                           "unit": "G wave-instr/s", "frac": ach / VALU_PEAK_GINST,
-                           "note": "SQ_INSTS_VALU per launch from %s / updates of that launch; peak = 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 "
-                                   "cycles per wave64 instruction" % PMC_SUMMARY,
-                           # the same instruction stream priced with the issue costs scripts/valu_probe.hip measured on this chip
-                           # (v_mul/add/logic 2.44, v_fma 3.9, conversions and DPP 4.3, packed f32 4.67 cycles per SIMD) over the
-                           # mix of the round kernel's step (49 / 7.5 / 21 / 27 %): 3.65 cycles per instruction on average
-                           "at_measured_issue_cost": {"cycles_per_instruction": 3.65, "frac": ach * 3.65 / (256 * 4 * 2.4)}}
-    if cands:
-        b = max(cands, key=lambda x: x[4])
-        r.update({"bound": b[0], "achieved": b[1], "peak": b[2], "unit": b[3], "frac": b[4]})
-    else:   # no committed counters for this kernel: only the model line exists
-        a = r["algorithmic"]
-        r.update({"bound": "hbm", "achieved": a["achieved"], "peak": a["peak"], "unit": a["unit"], "frac": a["frac"]})
+        # priced at the issue costs scripts/valu_probe.hip measured on this chip (v_mul/add/logic 2.44, v_fma 3.9, conversions and DPP
+        # 4.3, packed f32 4.67 cycles per SIMD) over the mix of the round kernel's step (49 / 7.5 / 21 / 27 %): 3.65 cycles on average
+        fr = ach * 3.65 / (256 * 4 * 2.4)
+        cands.append(("valu-issue", ach, 256 * 4 * 2.4 / 3.65, "G wave-instr/s", fr))
+        r["valu_issue"] = {"wave_instructions_per_update": per_update, "achieved": ach, "peak": 256 * 4 * 2.4 / 3.65,
+                           "unit": "G wave-instr/s", "frac": fr, "cycles_per_instruction": 3.65,
+                           "note": "SQ_INSTS_VALU per launch from %s / updates of that launch; peak = 256 CUs x 4 SIMD-32 x 2.4 GHz / the "
+                                   "3.65 cycles a wave64 instruction of this mix takes to issue (measured); at the nominal 2 cycles: frac %.3f"
+                                   % (PMC_SUMMARY, ach / VALU_PEAK_GINST)}
+    b = max(cands, key=lambda x: x[4])
+    r.update({"bound": b[0], "achieved": b[1], "peak": b[2], "unit": b[3], "frac": b[4]})
     return r
 
 

@@ -14,7 +14,11 @@ SHAPES = {
     "C1": dict(nU=943, nI=1682, nnz=100_000, K=10),             # MovieLens-100K shape
     "C2": dict(nU=138_493, nI=26_744, nnz=20_000_263, K=64),    # MovieLens-20M shape
     "C4": dict(nU=480_189, nI=17_770, nnz=100_000_000, K=128),  # Netflix shape
+    # BASELINE.json config 5: 10 M x 1 M, 1 B ratings, rank 256 -- ONE matrix defined as 8 fixed user shards of 1.25 M users
+    # (make_c5_shards): the union is the same whatever the number of GPUs it is cut over
+    "C5": dict(nU=10_000_000, nI=1_000_000, nnz=1_000_000_000, K=256),
 }
+C5_SHARDS = 8
 
 
 class CSR:
@@ -92,6 +96,30 @@ def make(shape="C2", seed=1, scale=1.0, alpha_u=1.38, alpha_i=2.3, noise=0.5, K0
         return out
     finally:
         lib.mfh_synth_free(h)
+
+
+def concat_rows(mats):
+    """CSR matrices over the same columns stacked on top of each other (user blocks of one matrix)."""
+    ptr = [np.zeros(1, np.int64)]
+    off = 0
+    for m in mats:
+        ptr.append(m.rowptr[1:] + off)
+        off += m.nnz
+    return CSR(sum(m.nrows for m in mats), mats[0].ncols, np.concatenate(ptr), np.concatenate([m.rowind for m in mats]),
+               np.concatenate([m.rowval for m in mats]))
+
+
+def make_c5_shards(first, count, seed=1, scale=1.0):
+    """User shards [first, first + count) of the C5 matrix (8 shards of 1.25 M users x 1 M items, 156 M ratings each before the
+    80/10/10 split): what one of N = 8 / count GPUs holds under strong scaling.  Returns train / val CSR and the user count."""
+    s = SHAPES["C5"]
+    per = dict(nU=s["nU"] // C5_SHARDS, nI=s["nI"], nnz=int(s["nnz"] / 0.8 * scale) // C5_SHARDS, K=s["K"])
+    tr, va = [], []
+    for j in range(first, first + count):
+        d = make(per, seed=seed, shard=j, r0_i=0.002)
+        tr.append(d["train"]); va.append(d["val"])
+        del d
+    return concat_rows(tr), concat_rows(va), per["nU"] * count
 
 
 def init_factors(seed, nUsers, nItems, K, want_u=True, want_v=True):

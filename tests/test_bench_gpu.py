@@ -30,15 +30,22 @@ def test_single_gpu_line_has_the_contract_fields():
     assert d["n_gpus"] == 1 and d["steps"] == 24 and d["vs_baseline"] is None and d["dtype"] == "f32" and "workload" in d["config"]
     r = d["roofline"]
     assert r["launches_per_step"] == 8 and r["launches"] == 8 * 3          # events around every 8th epoch's 8 round launches
-    assert 0 < r["frac"] <= 1.0 and r["bound"] in ("hbm", "valu-issue")
+    assert 0 < r["frac"] <= 1.0 and r["bound"] in ("l2-memory-side", "l2-rows", "valu-issue")
+    assert 0 < r["l2_rows"]["frac"] <= 1.0
     assert r["algorithmic"]["frac"] > 0 and r["avg_launch_ms"] > 0
     assert d["value"] > 1e9
 
 
+@pytest.mark.parametrize("exchange", ["rotate", "allreduce"])
 @pytest.mark.parametrize("scaling", ["weak", "strong"])
-def test_two_ranks_on_one_gpu_through_gloo(scaling):
-    d = _bench(["--gpus", "2", "--steps", "6", "--warmup", "1", "--scale", "0.1", "--scaling", scaling], env={"BENCH_COMM": "gloo"})
-    assert d["n_gpus"] == 2 and d["scaling"] == scaling
+def test_two_ranks_on_one_gpu_through_gloo(scaling, exchange):
+    d = _bench(["--gpus", "2", "--steps", "6", "--warmup", "1", "--scale", "0.1", "--scaling", scaling, "--exchange", exchange],
+               env={"BENCH_COMM": "gloo"})
+    assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["config"]["exchange"] == exchange
+    print("N = 2 (%s, %s): val RMSE after %.4f, same epochs without exchange %.4f" % (scaling, exchange, d["val_rmse_after"],
+                                                                                   d["val_rmse_after_same_epochs_without_exchange"]))
+    if exchange == "rotate":      # every update applied once with its full step: not behind the run without any exchange
+        assert d["val_rmse_after"] < d["val_rmse_after_same_epochs_without_exchange"] + 0.02
     assert ("strong" in d["config"]["workload"]) == (scaling == "strong")
     assert d["value"] > 1e8 and d["val_rmse_after"] > 0 and d["val_rmse_after_same_epochs_without_exchange"] > 0
     assert "cpu_baseline" not in d and "secondary" not in d

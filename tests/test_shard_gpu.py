@@ -128,13 +128,26 @@ def test_two_shards_equal_one_context(tmp_path):
 
 
 # ---- the rotating exchange through the library (mfx_sgd_set_item_parts / mfx_rotate_item_part / mfx_allgather_item_parts) ----
+def _rot_problem():
+    """40 000 ratings of pairwise distinct users over 300 items: every item row is updated ~130 times, no user row twice -- so
+    that with ONE lane group per slot the visiting order alone determines the result (the kernel requests the lock-free rows
+    of the next two steps ahead of time: a user met twice in a row would see its row one update late, by design)."""
+    n, nI = 40000, 300
+    rng = np.random.default_rng(31)
+    tr = synth.CSR(n, nI, np.arange(n + 1, dtype=np.int64), rng.integers(0, nI, n).astype(np.int32),
+                   (rng.integers(1, 11, n) * 0.5).astype(np.float32))
+    U0 = rng.normal(0, 0.3, (n, K)).astype(np.float32)
+    V0 = rng.normal(0, 0.3, (nI, K)).astype(np.float32)
+    return tr, nI, U0, V0
+
+
 def _rot_worker(rank, world, port, out_dir, one_group):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    tr, nI, U0, V0 = _problem()
+    tr, nI, U0, V0 = _rot_problem()
     b = mdist.user_blocks(tr.rowptr, world)
     lo, hi = int(b[rank]), int(b[rank + 1])
     sh = mdist.take_rows(tr, lo, hi)
@@ -148,7 +161,7 @@ def _rot_worker(rank, world, port, out_dir, one_group):
         ctx.set_item_parts(world)
         steps, held = mdist.rotation_schedule(rank, world)
         visits = 0
-        for ep in range(2):
+        for ep in range(1):
             for part, send, recv in steps:
                 flags = mfx.SGD_F_COUNT_VISITS | (mfx.SGD_F_ONE_GROUP if one_group else 0)
                 ctx.sgd_epoch(0.002, 0.05, 0.05, mode=mfx.SGD_TILED, order=mfx.ORDER_DEVICE, arith=mfx.ARITH_REF64, seed=5, epoch=ep,
@@ -162,7 +175,7 @@ def _rot_worker(rank, world, port, out_dir, one_group):
                 if send is not None:
                     ctx.rotate_item_part(send, recv)
             ctx.allgather_item_parts(held)
-        assert visits == 2 * sh.nnz                                    # every rating of the block once per epoch
+        assert visits == sh.nnz                                        # every rating of the block once per epoch
         U, V = ctx.get_factors()
     np.savez(os.path.join(out_dir, "rot%d.npz" % rank), lo=lo, hi=hi, U=U, V=V, **lists)
     dist.barrier()
@@ -190,13 +203,13 @@ def test_two_ranks_rotating_item_parts_through_the_library(tmp_path, one_group):
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     r = [np.load(str(tmp_path / ("rot%d.npz" % g))) for g in range(2)]
     assert np.array_equal(r[0]["V"], r[1]["V"])                        # complete and identical after the all-gather
-    tr, nI, U0, V0 = _problem()
+    tr, nI, U0, V0 = _rot_problem()
     assert np.isfinite(r[0]["V"]).all() and np.isfinite(r[0]["U"]).all() and np.isfinite(r[1]["U"]).all()
     assert np.abs(r[0]["V"] - V0).max() > 1e-3
     if not one_group:
         return
     U, V = U0.copy(), V0.copy()
-    for ep in range(2):
+    for ep in range(1):
         for s_ in range(2):
             for g in range(2):
                 part = mdist.rotation_schedule(g, 2)[0][s_][0]
@@ -207,6 +220,8 @@ def test_two_ranks_rotating_item_parts_through_the_library(tmp_path, one_group):
                              orc.DOT_TREE)
     # (the owned item rows are accumulated in 2^-24 fixed point in LDS: the random walk of their roundings, as in
     # tests/test_sgd_gpu.py's one-group replay)
-    assert np.abs(r[0]["V"] - V).max() < 2e-5
+    print("rotation vs sequential replay: max |dV| %.3g" % np.abs(r[0]["V"] - V).max())
+    assert np.abs(V - V0).max() > 0.05
+    assert np.abs(r[0]["V"] - V).max() < 5e-6
     for g in range(2):
-        assert np.abs(r[g]["U"] - U[int(r[g]["lo"]):int(r[g]["hi"])]).max() < 2e-5
+        assert np.abs(r[g]["U"] - U[int(r[g]["lo"]):int(r[g]["hi"])]).max() < 5e-6
