@@ -29,7 +29,7 @@ HBM_PEAK_GBS = 8000.0
 MFMA_F32_PEAK_TF = 157.3
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0      # G wave-instructions/s
 L2_GATHER_PEAK_GBS = 17800.0               # rows gathered out of the XCDs' L2s: 16.8 - 18.8 TB/s chip-wide (MI355X_MICROARCH.md, 'Indexed rows')
-PMC_SUMMARY = os.path.join("profiles", "r02_pmc_summary.json")
+PMC_SUMMARY = os.path.join("profiles", "r03_pmc_summary.json")
 
 
 def self_launch(args):
