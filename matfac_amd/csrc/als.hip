@@ -175,6 +175,13 @@ __device__ __forceinline__ void gram_accumulate(GramAcc& g, const float* __restr
   }
 }
 
+
+// v_permlane32_swap as inline assembly WITH its wait states: gfx950 wants two between a VALU write of a VGPR and a permlane swap
+// that reads it, and two more before a VALU reads what the swap wrote; the compiler's hazard recognizer does not look inside an
+// asm statement, and the operands here are "+v" copies the compiler makes right in front of it (`v_mov v145, v62` directly
+// followed by the swap: what a round-3 rebuild produced in als_reduce_kernel -- rows with more than one segment came out 5 % off,
+// rows solved by als_segment_kernel did not; the round-2 build happened to put the copy elsewhere).
+#define MFX_SWAP32(A, B) asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(A), "+v"(B))
 // Turn the tile layout into "lane i owns row i", add reg, solve, return x_i in lane i.
 __device__ __forceinline__ float gram_solve(const GramAcc& g, int K, float reg, int lane, float* tr) {
   // a[2p], a[2p+1] = A(lane, 2p), A(lane, 2p+1): pairs, so that the trailing update is one packed fma per two columns
@@ -209,18 +216,18 @@ __device__ __forceinline__ float gram_solve(const GramAcc& g, int K, float reg, 
   for (int r = 0; r < 16; r++) {
     const int I0 = (r & 3) + 8 * (r >> 2);   // row with bit 2 clear; I0+4 has it set
     float lo = g.t[0][0][r], hi = g.t[0][1][r];
-    asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+    MFX_SWAP32(lo, hi);
     a[I0 >> 1][I0 & 1] = lo;
     a[(I0 + 4) >> 1][I0 & 1] = hi;
     // rows 32 + I0 and 32 + I0 + 4: the lanes of the first 32 columns bring the transposed values (register r of a lane
     // in the lower half is row 32 + I0 of its column, in the upper half row 32 + I0 + 4 of the partner's), the others t[1][1]
     float lo2 = tx[r], hi2 = g.t[1][1][r];
-    asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(lo2), "+v"(hi2));
+    MFX_SWAP32(lo2, hi2);
     a[(32 + I0) >> 1][I0 & 1] = lo2;
     a[(32 + I0 + 4) >> 1][I0 & 1] = hi2;
   }
   float z0 = g.b0, z1 = g.b1;
-  asm volatile("v_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(z0), "+v"(z1));
+  MFX_SWAP32(z0, z1);
   float z = z0 + z1;
   // YTY(j,j) += reg for j < K (modelMF.cpp:831-833); padded dimensions (all zero) become identity rows
   const float regv = lane < K ? reg : 1.0f;
@@ -230,28 +237,33 @@ __device__ __forceinline__ float gram_solve(const GramAcc& g, int K, float reg, 
   // a_ik / d_k and subtract l_ik * (pivot row k, read from lane k) from their row; lanes <= k stand still, so that
   // lane k keeps d_k in a[k] and the pivot row d_k * l_jk (j > k) in a[j] -- column k of L, which the back
   // substitution below wants in one lane.  The right-hand side rides along as one more column (L y = b).
+  // (Round 3 wrote the trailing update out with the scalars alternating between two register pairs, so that no fma needs an
+  // `s_nop 1` behind its two readlanes -- 1 100 fewer s_nop per solve, bit-identical, 3.98 instead of 3.99 ms per C3 iteration: with
+  // two waves per SIMD the partner wave issues in those slots.  What the solve costs is its 2 016 readlanes and 1 008 packed fmas.)
   float d = 1.0f;
+  {
 #pragma unroll
-  for (int k = 0; k < 64; k++) {
-    const float dk = rdlane(a[k >> 1][k & 1], k);
-    float rk = __builtin_amdgcn_rcpf(dk);
-    rk = __builtin_fmaf(__builtin_fmaf(-dk, rk, 1.0f), rk, rk);
-    // the lane number is re-materialised per step: with a loop-invariant one the compiler forms all 128 lane masks up
-    // front and spills them (two v_readlane per use instead of one v_cmp)
-    int lv = lane;
-    asm volatile("" : "+v"(lv));
-    const float lik = lv > k ? a[k >> 1][k & 1] * rk : 0.0f;
-    if ((k & 1) == 0) a[k >> 1][1] = __builtin_fmaf(-lik, rdlane(a[k >> 1][1], k), a[k >> 1][1]);
-    const f32x2 l2 = {lik, lik};
+    for (int k = 0; k < 64; k++) {
+      const float dk = rdlane(a[k >> 1][k & 1], k);
+      float rk = __builtin_amdgcn_rcpf(dk);
+      rk = __builtin_fmaf(__builtin_fmaf(-dk, rk, 1.0f), rk, rk);
+      // the lane number is re-materialised per step: with a loop-invariant one the compiler forms all 128 lane masks up
+      // front and spills them (two v_readlane per use instead of one v_cmp)
+      int lv = lane;
+      asm volatile("" : "+v"(lv));
+      const float lik = lv > k ? a[k >> 1][k & 1] * rk : 0.0f;
+      if ((k & 1) == 0) a[k >> 1][1] = __builtin_fmaf(-lik, rdlane(a[k >> 1][1], k), a[k >> 1][1]);
+      const f32x2 l2 = {lik, lik};
 #pragma unroll
-    for (int p = (k >> 1) + 1; p < 32; p++) {
-      const f32x2 row = {rdlane(a[p][0], k), rdlane(a[p][1], k)};
-      a[p] = __builtin_elementwise_fma(-l2, row, a[p]);   // v_pk_fma_f32 with the scalar pair as one source
+      for (int p = (k >> 1) + 1; p < 32; p++) {
+        const f32x2 row = {rdlane(a[p][0], k), rdlane(a[p][1], k)};
+        a[p] = __builtin_elementwise_fma(-l2, row, a[p]);   // v_pk_fma_f32 with the scalar pair as one source
+      }
+      z = __builtin_fmaf(-lik, rdlane(z, k), z);
+      a[k >> 1][k & 1] = lv > k ? lik : a[k >> 1][k & 1];
+      d = lv == k ? dk : d;
+      __builtin_amdgcn_sched_barrier(0);   // keep the steps apart: interleaved, each column becomes one dependent chain
     }
-    z = __builtin_fmaf(-lik, rdlane(z, k), z);
-    a[k >> 1][k & 1] = lv > k ? lik : a[k >> 1][k & 1];
-    d = lv == k ? dk : d;
-    __builtin_amdgcn_sched_barrier(0);   // keep the steps apart: interleaved, each column becomes one dependent chain
   }
   // L^T x = D^-1 y from the last row up: x_j is final in lane j; lanes k < j subtract (d_k l_jk) x_j before their division
   float rd = __builtin_amdgcn_rcpf(d);

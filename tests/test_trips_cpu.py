@@ -68,3 +68,22 @@ def test_wide_stores_written_as_inline_assembly_carry_their_wait_state(src, stor
         lines = [l.strip() for l in b.strip().split("\n") if l.strip()]
         k = [i for i, l in enumerate(lines) if l.startswith(store)]
         assert k and all(i + 1 < len(lines) and lines[i + 1].startswith("s_nop") for i in k), b
+
+
+def test_permlane_swaps_written_as_inline_assembly_carry_their_wait_states(tmp_path):
+    """gfx950 wants two wait states between a VALU write of a VGPR and a v_permlane32_swap that reads it (and before a VALU reads
+    what the swap wrote); the hazard recognizer does not look inside an asm statement and the compiler puts the "+v" copies right
+    in front of it.  Every swap between ;;#ASMSTART and ;;#ASMEND must sit between two s_nop 1 of its own (MFX_SWAP32, als.hip):
+    a round-3 rebuild produced `v_mov v145, v62` directly followed by the bare swap in als_reduce_kernel -- rows with several
+    segments came out 5 % off (scripts/als_reduce_check.py)."""
+    import re
+    text = _device_asm(os.path.join(ROOT, "matfac_amd", "csrc", "als.hip"), tmp_path)
+    blocks = [b for b in re.findall(r";;#ASMSTART\n(.*?);;#ASMEND", text, flags=re.S) if "v_permlane32_swap" in b]
+    assert len(blocks) >= 33
+    for b in blocks:
+        lines = [l.strip() for l in b.strip().split("\n") if l.strip()]
+        k = [i for i, l in enumerate(lines) if l.startswith("v_permlane32_swap")]
+        assert all(i >= 1 and lines[i - 1] == "s_nop 1" and i + 1 < len(lines) and lines[i + 1] == "s_nop 1" for i in k), b
+    # and no swap outside an asm statement (the builtin is not used: the compiler merged most of the 33 calls into three)
+    outside = re.sub(r";;#ASMSTART\n.*?;;#ASMEND", "", text, flags=re.S)
+    assert "v_permlane32_swap" not in outside
