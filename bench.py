@@ -357,7 +357,7 @@ def exact_replay(np, ctx, mfx, tr, U0, V0, lr, ureg, ireg, epochs=3):
 
 def pmc(kernel):
     """Counters of `kernel` from the committed rocprofv3 PMC passes of this same command (scripts/profile_round.sh ->
-    profiles/r02_pmc_summary.json).  rocprofv3 cannot run inside this process: these are per-launch means of THAT run,
+    profiles/r03_pmc_summary.json).  rocprofv3 cannot run inside this process: these are per-launch means of THAT run,
     named as such in the record; None when the summary has no entry for the kernel."""
     path = os.path.join(ROOT, PMC_SUMMARY)
     try:
@@ -587,12 +587,12 @@ def bench_ccd(np, with_cpu):
                         "kernel": "ccd_pass_kernel / ccd_cols pass / resid_update_kernel (whole rank-one step, wall clock)"}}
     # memory-side bytes of one rank-one step from the committed counter passes (scripts/pmc_c4.sh), time from this run
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_c4_pmc.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r03_c4_pmc.json")) as f:
             pmc = json.load(f)
         rec["roofline"]["traffic"] = pmc["hbm_bytes_per_factor"]
         rec["roofline"]["traffic_GBs"] = pmc["hbm_bytes_per_factor"] / per_k / 1e9
         rec["roofline"]["traffic_frac_of_peak"] = pmc["hbm_bytes_per_factor"] / per_k / 1e9 / HBM_PEAK_GBS
-        rec["roofline"]["traffic_source"] = ("profiles/r02_c4_pmc.json: sum over the kernels of a rank-one step of (FETCH_SIZE x2 + WRITE_SIZE) per launch "
+        rec["roofline"]["traffic_source"] = ("profiles/r03_c4_pmc.json: sum over the kernels of a rank-one step of (FETCH_SIZE x2 + WRITE_SIZE) per launch "
                                              "x launches per step, separate --pmc passes of scripts/bench_als_ccd.py; time from this run")
     except (OSError, KeyError, ValueError):
         pass
