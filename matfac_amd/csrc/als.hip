@@ -358,11 +358,11 @@ __global__ __launch_bounds__(64) void als_reduce_kernel(const int32_t* __restric
   }
 }
 // sharded item sweep: solve every item some rank has ratings for, from the accumulators summed over the ranks
-__global__ __launch_bounds__(64) void als_global_solve_kernel(const float* __restrict__ grow, const double* __restrict__ gcol,
+__global__ __launch_bounds__(64) void als_global_solve_kernel(const float* __restrict__ grow, const double* __restrict__ gcol, int32_t row0,
                                                               int32_t nrows, float* __restrict__ X, int K, int ld, float reg) {
   __shared__ __attribute__((aligned(16))) float tr[32 * GT_STRIDE];   // gram_solve's transposition tile
   const int lane = threadIdx.x;
-  for (int64_t r = blockIdx.x; r < nrows; r += gridDim.x) {
+  for (int64_t r = (int64_t)row0 + blockIdx.x; r < nrows; r += gridDim.x) {
     if (gcol[r] == 0.0) continue;
     GramAcc g;
     gram_zero(g);
@@ -507,13 +507,24 @@ extern "C" int mfx_als_half_sweep(mfx_ctx* ctx, int side, float reg) {
   float* X = side == MFX_SIDE_USERS ? ctx->U : ctx->V;
   const int64_t yrows = side == MFX_SIDE_USERS ? ctx->nI : ctx->nU;
   if (side == MFX_SIDE_ITEMS && mfx_sharded(ctx)) {
-    // An item's users live on several ranks (user-block sharding): every rank accumulates (A, b) over ITS users,
-    // the accumulators are summed over the ranks, and every rank solves every item (V stays replicated).
+    // An item's users live on several ranks (user-block sharding): every rank accumulates (A, b) over ITS users.  With RCCL the
+    // accumulators are REDUCE-SCATTERED -- rank r receives the sums of its slice of ceil(nItems / N) items, solves that slice, and
+    // the solved rows are all-gathered ((N - 1) / N of the slab and of V per rank instead of twice the slab, and
+    // every item solved once instead of N times).  On a caller-supplied all-reduce (gloo / MPI callers, the two-process tests)
+    // the whole slab is summed on every rank and every rank solves every item.
     const double* gcol;
     int rc = mfx_comm_global_col_counts(ctx, &gcol);
     if (rc) return rc;
-    const size_t gn = (size_t)m.ncols * SLAB;
-    if (!ctx->als_global && (rc = dev_alloc(ctx, &ctx->als_global, gn))) return rc;
+    const int N = std::max(1, ctx->nranks);
+    const bool scatter = mfx_comm_has_rccl(ctx);
+    const int64_t per = ((int64_t)m.ncols + N - 1) / N;                  // items per slice (the last ones may be short or empty)
+    const size_t gn = scatter ? (size_t)per * N * SLAB : (size_t)m.ncols * SLAB;
+    if (!ctx->als_global || ctx->als_global_cap < gn) {
+      dev_free(ctx->als_global);
+      ctx->als_global_cap = 0;
+      if ((rc = dev_alloc(ctx, &ctx->als_global, gn))) return rc;
+      ctx->als_global_cap = gn;
+    }
     HIPCHK(hipMemsetAsync(ctx->als_global, 0, gn * sizeof(float), ctx->stream));
     if (sd.nseg > 0) {
       ProfScope ps(ctx, MFX_K_ALS_GRAM);
@@ -524,13 +535,39 @@ extern "C" int mfx_als_half_sweep(mfx_ctx* ctx, int side, float reg) {
                          sd.mrow, sd.mrow_first, sd.mrow_n, sd.nmrow, ctx->als_slabs, X, ctx->K, ctx->ld, reg, ctx->als_global);
       HIPCHK(hipGetLastError());
     }
-    if ((rc = mfx_comm_allreduce(ctx, ctx->als_global, gn, 0))) return rc;
-    if (m.ncols > 0) {
+    if (!scatter) {
+      if ((rc = mfx_comm_allreduce(ctx, ctx->als_global, gn, 0))) return rc;
+      if (m.ncols > 0) {
+        ProfScope ps(ctx, MFX_K_ALS_SOLVE);
+        hipLaunchKernelGGL(als_global_solve_kernel, dim3(std::min(m.ncols, 256 * 16)), dim3(64), 0, ctx->stream, ctx->als_global, gcol,
+                           0, m.ncols, X, ctx->K, ctx->ld, reg);
+        HIPCHK(hipGetLastError());
+      }
+      return MFX_OK;
+    }
+    if ((rc = mfx_comm_reduce_scatter(ctx, ctx->als_global, (size_t)per * SLAB))) return rc;
+    const int64_t lo = std::min<int64_t>((int64_t)ctx->rank * per, m.ncols), hi = std::min<int64_t>(lo + per, m.ncols);
+    if (hi > lo) {
       ProfScope ps(ctx, MFX_K_ALS_SOLVE);
-      hipLaunchKernelGGL(als_global_solve_kernel, dim3(std::min(m.ncols, 256 * 16)), dim3(64), 0, ctx->stream, ctx->als_global, gcol,
-                         m.ncols, X, ctx->K, ctx->ld, reg);
+      hipLaunchKernelGGL(als_global_solve_kernel, dim3((unsigned)std::min<int64_t>(hi - lo, 256 * 16)), dim3(64), 0, ctx->stream, ctx->als_global,
+                         gcol, (int32_t)lo, (int32_t)hi, X, ctx->K, ctx->ld, reg);
       HIPCHK(hipGetLastError());
     }
+    // the solved slices (per x ld floats each, the last ones padded) gathered through a slab of their own, then the first ncols rows
+    // go back into V: V itself has nItems + 1 rows, fewer than N slices when the last slice is short
+    const size_t slice = (size_t)per * ctx->ld;
+    if (ctx->comm_tmp_cap < slice * ((size_t)N + 1)) {
+      dev_free(ctx->comm_tmp);
+      ctx->comm_tmp_cap = 0;
+      if ((rc = dev_alloc(ctx, &ctx->comm_tmp, slice * ((size_t)N + 1)))) return rc;
+      ctx->comm_tmp_cap = slice * ((size_t)N + 1);
+    }
+    float* mine = ctx->comm_tmp;
+    float* all = ctx->comm_tmp + slice;
+    HIPCHK(hipMemsetAsync(mine, 0, slice * sizeof(float), ctx->stream));
+    if (hi > lo) HIPCHK(hipMemcpyAsync(mine, X + (size_t)lo * ctx->ld, (size_t)(hi - lo) * ctx->ld * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    if ((rc = mfx_comm_allgather(ctx, mine, all, slice))) return rc;
+    HIPCHK(hipMemcpyAsync(X, all, (size_t)m.ncols * ctx->ld * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
     return MFX_OK;
   }
   if (sd.nseg > 0) {

@@ -150,6 +150,23 @@ int mfx_comm_allreduce(mfx_ctx* ctx, void* dev, size_t count, int dtype) {
   return MFX_OK;
 }
 
+// Reduce-scatter (sum, f32) and all-gather of equal slices, RCCL only: the callers fall back to mfx_comm_allreduce on the
+// caller-supplied reducer.  In place: rank r's slice of `buf` (count floats at r * count) receives the sum over the ranks /
+// is what rank r contributes.
+bool mfx_comm_has_rccl(const mfx_ctx* ctx) { return ctx->comm != nullptr; }
+int mfx_comm_reduce_scatter(mfx_ctx* ctx, float* buf, size_t count) {
+  NEED(ctx->comm, MFX_E_STATE, "reduce-scatter without an RCCL communicator");
+  const int r = g_rccl.reducescatter(buf, buf + (size_t)ctx->rank * count, count, kNcclFloat, kNcclSum, ctx->comm, ctx->stream);
+  NEED(r == 0, MFX_E_COMM, "ncclReduceScatter: %s", rccl_err(r));
+  return MFX_OK;
+}
+int mfx_comm_allgather(mfx_ctx* ctx, const float* mine, float* all, size_t count) {
+  NEED(ctx->comm, MFX_E_STATE, "all-gather without an RCCL communicator");
+  const int r = g_rccl.allgather(mine, all, count, kNcclFloat, ctx->comm, ctx->stream);
+  NEED(r == 0, MFX_E_COMM, "ncclAllGather: %s", rccl_err(r));
+  return MFX_OK;
+}
+
 extern "C" int mfx_comm_unique_id(void* id128) {
   mfx_ctx* ctx = nullptr;
   NEED(id128, MFX_E_ARG, "mfx_comm_unique_id: NULL");
@@ -182,7 +199,7 @@ __global__ void col_count_kernel(const int64_t* __restrict__ colptr, int32_t nco
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < ncols) out[t] = (double)(colptr[t + 1] - colptr[t]);
 }
-void mfx_comm_drop_col_counts(mfx_ctx* ctx) { dev_free(ctx->gcol); dev_free(ctx->als_global); }
+void mfx_comm_drop_col_counts(mfx_ctx* ctx) { dev_free(ctx->gcol); dev_free(ctx->als_global); ctx->als_global_cap = 0; }
 int mfx_comm_global_col_counts(mfx_ctx* ctx, const double** out) {
   const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
   NEED(m.present && m.has_col, MFX_E_STATE, "global item counts: train matrix with column view needed");
@@ -309,8 +326,9 @@ extern "C" int mfx_rotate_item_part(mfx_ctx* ctx, int send_part, int recv_part) 
   if (!ctx) return MFX_E_ARG;
   NEED(ctx->V, MFX_E_STATE, "mfx_rotate_item_part: no model");
   const int N = ctx->nranks;
-  if (N <= 1 || (!ctx->comm && !ctx->ext_reduce)) return MFX_OK;      // one rank: it keeps every part
-  NEED(ctx->item_parts == N, MFX_E_STATE, "mfx_rotate_item_part: mfx_sgd_set_item_parts(%d) must name as many parts as there are ranks (%d)",
+  // one rank keeps every part (MFX_COMM_SELF_TEST=1: the RCCL calls run anyway, rank 0 sending to itself -- tests/test_comm_gpu.py)
+  if ((N <= 1 && !(ctx->comm && getenv("MFX_COMM_SELF_TEST"))) || (!ctx->comm && !ctx->ext_reduce)) return MFX_OK;
+  NEED(ctx->item_parts == N || N == 1, MFX_E_STATE, "mfx_rotate_item_part: mfx_sgd_set_item_parts(%d) must name as many parts as there are ranks (%d)",
        ctx->item_parts, N);
   NEED(send_part >= 0 && send_part < N && recv_part >= 0 && recv_part < N, MFX_E_ARG, "mfx_rotate_item_part: parts %d, %d of %d", send_part, recv_part, N);
   HIPCHK(hipSetDevice(ctx->device));
@@ -350,8 +368,8 @@ extern "C" int mfx_allgather_item_parts(mfx_ctx* ctx, int my_part) {
   if (!ctx) return MFX_E_ARG;
   NEED(ctx->V, MFX_E_STATE, "mfx_allgather_item_parts: no model");
   const int N = ctx->nranks;
-  if (N <= 1 || (!ctx->comm && !ctx->ext_reduce)) return MFX_OK;
-  NEED(ctx->item_parts == N, MFX_E_STATE, "mfx_allgather_item_parts: mfx_sgd_set_item_parts(%d) must name as many parts as there are ranks (%d)",
+  if ((N <= 1 && !(ctx->comm && getenv("MFX_COMM_SELF_TEST"))) || (!ctx->comm && !ctx->ext_reduce)) return MFX_OK;
+  NEED(ctx->item_parts == N || N == 1, MFX_E_STATE, "mfx_allgather_item_parts: mfx_sgd_set_item_parts(%d) must name as many parts as there are ranks (%d)",
        ctx->item_parts, N);
   NEED(my_part >= 0 && my_part < N, MFX_E_ARG, "mfx_allgather_item_parts: part %d of %d", my_part, N);
   HIPCHK(hipSetDevice(ctx->device));

@@ -131,6 +131,7 @@ struct mfx_ctx {
   size_t ext_stage_bytes = 0;
   double* gcol = nullptr;               // sharded runs: ratings per item over ALL ranks [train ncols]
   float* als_global = nullptr;          // sharded ALS: per-item (A, b) summed over ranks
+  size_t als_global_cap = 0;            // floats
 
   bool prof_on = false;
   int prof_period = 1;       // > 1: only every prof_period-th SGD epoch records events
@@ -555,6 +556,9 @@ int mfx_launch_eval2(mfx_ctx* ctx, const DevCSR& ma, int norms_a, const DevCSR& 
                      mfx_eval_out* out_a, mfx_eval_out* out_b);
 int mfx_comm_free_internal(mfx_ctx* ctx);
 int mfx_comm_allreduce(mfx_ctx* ctx, void* dev, size_t count, int dtype);   // sum over ranks, dtype 0 f32 / 1 f64
+bool mfx_comm_has_rccl(const mfx_ctx* ctx);
+int mfx_comm_reduce_scatter(mfx_ctx* ctx, float* buf, size_t count);            // in place, slices of `count` floats (RCCL only)
+int mfx_comm_allgather(mfx_ctx* ctx, const float* mine, float* all, size_t count);
 static inline bool mfx_sharded(const mfx_ctx* ctx);
 // ratings per item summed over the ranks (device, cached until the train matrix changes)
 int mfx_comm_global_col_counts(mfx_ctx* ctx, const double** out);

@@ -33,3 +33,32 @@ def test_single_rank_communicator_roundtrip():
         s = ctx.allreduce_f64([1.5, 2.5])
         assert s.tolist() == [1.5, 2.5]
         ctx.comm_destroy()
+
+
+def test_single_rank_rccl_reduce_scatter_allgather_and_ring_shift(monkeypatch):
+    """The RCCL collectives the N > 1 paths use, on a 1-rank communicator (all this box can run): the sharded ALS item half-sweep
+    -- ncclReduceScatter of the (A, b) slab, solve of the rank's item slice, ncclAllGather of the solved rows -- must equal the
+    unsharded sweep bit for bit; the rotation's ring shift (ncclSend / ncclRecv in one group, rank 0 to itself:
+    MFX_COMM_SELF_TEST=1) and its closing ncclAllGather must hand V back unchanged."""
+    monkeypatch.setenv("MFX_COMM_SELF_TEST", "1")
+    d = small(nU=900, nI=257, nnz=40000, K=64, seed=17)       # 257 items: a last slice that is short
+    K = 64
+    U0, V0 = orc.init_factors(1, d["nUsers"], d["nItems"], K)
+    U0 *= 30
+    V0 *= 30
+    with Ctx(0) as ctx:
+        load_ctx(ctx, d, K, U0, V0)
+        ctx.als_half_sweep(mfx.SIDE_ITEMS, 3.0)
+        _, Vref = ctx.get_factors()
+        uid = Ctx.comm_unique_id()
+        ctx.comm_init(1, 0, uid)
+        ctx.set_factors(U0, V0)
+        ctx.als_half_sweep(mfx.SIDE_ITEMS, 3.0)                # sharded path: reduce-scatter, slice solve, all-gather
+        _, Vsh = ctx.get_factors()
+        assert np.array_equal(Vsh, Vref)
+        assert not np.array_equal(Vref, V0)
+        ctx.rotate_item_part(0, 0)                             # part 0 of 1 = every row: packed, sent round the ring of one, unpacked
+        ctx.allgather_item_parts(0)
+        _, V2 = ctx.get_factors()
+        assert np.array_equal(V2, Vsh)
+        ctx.comm_destroy()
