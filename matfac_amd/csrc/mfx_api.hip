@@ -166,7 +166,7 @@ extern "C" int mfx_set_csr(mfx_ctx* ctx, int which, int32_t nrows, int32_t ncols
   HIPCHK(hipSetDevice(ctx->device));
   DevCSR& m = ctx->mat[which];
   free_csr(m);
-  if (which == MFX_MAT_TRAIN) { mfx_comm_drop_col_counts(ctx); mfx_ccd_free_internal(ctx); mfx_cd_free_internal(ctx); mfx_als_free_internal(ctx); mfx_segs_free_internal(ctx); mfx_slots_free_internal(ctx); }
+  if (which == MFX_MAT_TRAIN) { ctx->train_gen++; mfx_comm_drop_col_counts(ctx); mfx_ccd_free_internal(ctx); mfx_cd_free_internal(ctx); mfx_als_free_internal(ctx); mfx_segs_free_internal(ctx); mfx_slots_free_internal(ctx); }
   int rc;
   if ((rc = dev_alloc(ctx, &m.rowptr, (size_t)nrows + 1))) return rc;
   if ((rc = dev_alloc(ctx, &m.rowind, (size_t)nnz))) return rc;

@@ -77,6 +77,7 @@ struct mfx_ctx {
   // MFX_SGD_TILED: slot lists (sgd_slots.hip owns the type)
   void* slots = nullptr;
   int item_parts = 0;        // mfx_sgd_set_item_parts: > 1 = the multi-GPU rotation runs epochs part by part
+  uint64_t train_gen = 0;    // bumped by every mfx_set_csr(MFX_MAT_TRAIN): what caches keyed on the train matrix compare
   // MFX_SGD_LEVELS: level lists (sgd_levels.hip owns the type)
   void* levels = nullptr;
   bool last_exact_flow = false;   // which schedule the last MFX_SGD_LEVELS epoch ran on

@@ -61,7 +61,13 @@ struct FlowState {
   float* tagbuf = nullptr;
   int64_t tag_cap = 0;                // floats
   std::vector<uint8_t> oslot;
-  bool tagged = false;                // the queues of the last build carry the LDS slot in the top two bits of .w
+  bool tagged = false;                // the queues of the last build carry the LDS slot of the owned row in .y
+  // owner assignment (owned rows -> queues, LDS slots), cached per train matrix: it depends on the rows' chain lengths only for
+  // BALANCE, never for correctness, and the lists replayed over one matrix are permutations of its ratings
+  uint64_t assign_gen = ~0ull;
+  int64_t assign_groups = -1, assign_nU = -1, assign_nI = -1;
+  int assign_own_user = 0;
+  int32_t assign_maxU = 0, assign_maxI = 0;
 };
 FlowState* fl(mfx_ctx* ctx) { return (FlowState*)ctx->flow; }
 
@@ -605,6 +611,7 @@ int build_flow(mfx_ctx* ctx, int64_t first, int64_t count, int64_t groups, bool 
   const int32_t* hoth = own_user ? S->hi.data() : S->hu.data();
   const int64_t nOwn = own_user ? ctx->nU : ctx->nI, nOth = own_user ? ctx->nI : ctx->nU;
   // owned rows -> groups: longest chain first onto the least loaded group
+  S->assign_gen = ~0ull;            // (the device builder's cached assignment lives in the same arrays)
   S->owner.assign((size_t)nOwn, 0);
   {
     std::vector<int32_t> rows;
@@ -725,6 +732,17 @@ __global__ void flow_bounds_kernel(const uint32_t* __restrict__ keys, int64_t n,
     qoff[g] = lo;
   }
 }
+// start[r] = number of sorted keys < r, r = 0 .. nr - 1 (the chain starts of the rows in the sorted order)
+__global__ void flow_bounds32_kernel(const uint32_t* __restrict__ keys, int64_t n, int64_t nr, int64_t* __restrict__ start) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nr; r += (int64_t)gridDim.x * blockDim.x) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if ((int64_t)keys[mid] < r) lo = mid + 1; else hi = mid;
+    }
+    start[r] = lo;
+  }
+}
 static int bits_for(uint64_t n) {
   int b = 1;
   while (b < 32 && ((uint64_t)1 << b) < n) b++;
@@ -765,7 +783,7 @@ int build_flow_device(mfx_ctx* ctx, int64_t first, int64_t count, int64_t groups
   }
   if (S->own_cap < std::max(nU, nI)) {
     dev_free(S->downer); dev_free(S->dstart);
-    S->own_cap = 0;
+    S->own_cap = 0; S->assign_gen = ~0ull;
     if ((rc = dev_alloc(ctx, &S->downer, (size_t)std::max(nU, nI))) || (rc = dev_alloc(ctx, &S->dstart, (size_t)std::max(nU, nI) + 1))) return rc;
     S->own_cap = std::max(nU, nI);
   }
@@ -780,23 +798,26 @@ int build_flow_device(mfx_ctx* ctx, int64_t first, int64_t count, int64_t groups
   const int32_t *eu = ctx->eu + first, *ei = ctx->ei + first;
   const float* er = ctx->er + first;
   const int grid = (int)std::min<int64_t>((count + 255) / 256, 8192);
-  // chain lengths of both sides; the side with the longest chain is owned
-  HIPCHK(hipMemsetAsync(S->degU, 0, sizeof(int32_t) * (size_t)(nU + nI), ctx->stream));
-  hipLaunchKernelGGL(flow_degrees_kernel, dim3(grid), dim3(256), 0, ctx->stream, eu, ei, count, S->degU, S->degI);
-  S->hdeg.resize((size_t)(nU + nI));
-  HIPCHK(hipMemcpyAsync(S->hdeg.data(), S->degU, sizeof(int32_t) * (size_t)(nU + nI), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  const int32_t *hdU = S->hdeg.data(), *hdI = S->hdeg.data() + nU;
-  const int32_t maxU = *std::max_element(hdU, hdU + nU), maxI = *std::max_element(hdI, hdI + nI);
-  const int own_user = maxU > maxI ? 1 : 0;
-  const int32_t* degOwn = own_user ? hdU : hdI;
-  const int32_t* degOth = own_user ? hdI : hdU;
-  const int64_t nOwn = own_user ? nU : nI, nOth = own_user ? nI : nU;
-  // owned rows -> queues: longest chain first onto the least loaded queue (host: a few 10^4..10^6 rows)
-  S->owner.assign((size_t)nOwn, 0);
-  {
+  // Owned rows -> queues (longest chain first onto the least loaded queue) and their LDS slots: ONCE per train matrix and queue
+  // count, from the chain lengths of the first list replayed over it (round 2 recomputed them every epoch: 2.1 ms of global atomics
+  // at C2, a copy back, a host sort and a copy forth -- a third of the queue construction).  The lists replayed over one matrix are
+  // permutations of its ratings (std::shuffle orders, shuffled users, the stratified rounds); for any other list (a sub-range)
+  // the cached assignment is merely less balanced -- ownership, not balance, is what correctness rests on.
+  if (S->assign_gen != ctx->train_gen || S->assign_groups != groups || S->assign_nU != nU || S->assign_nI != nI) {
+    HIPCHK(hipMemsetAsync(S->degU, 0, sizeof(int32_t) * (size_t)(nU + nI), ctx->stream));
+    hipLaunchKernelGGL(flow_degrees_kernel, dim3(grid), dim3(256), 0, ctx->stream, eu, ei, count, S->degU, S->degI);
+    S->hdeg.resize((size_t)(nU + nI));
+    HIPCHK(hipMemcpyAsync(S->hdeg.data(), S->degU, sizeof(int32_t) * (size_t)(nU + nI), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const int32_t *hdU = S->hdeg.data(), *hdI = S->hdeg.data() + nU;
+    S->assign_maxU = *std::max_element(hdU, hdU + nU);
+    S->assign_maxI = *std::max_element(hdI, hdI + nI);
+    S->assign_own_user = S->assign_maxU > S->assign_maxI ? 1 : 0;      // the side with the longest chain is owned
+    const int32_t* degOwn = S->assign_own_user ? hdU : hdI;
+    const int64_t nOwnA = S->assign_own_user ? nU : nI;
+    S->owner.assign((size_t)nOwnA, 0);
     std::vector<int32_t> rows;
-    for (int64_t r = 0; r < nOwn; r++)
+    for (int64_t r = 0; r < nOwnA; r++)
       if (degOwn[r] > 0) rows.push_back((int32_t)r);
     std::sort(rows.begin(), rows.end(), [&](int32_t a, int32_t b) { return degOwn[a] != degOwn[b] ? degOwn[a] > degOwn[b] : a < b; });
     typedef std::pair<int64_t, int32_t> Load;
@@ -811,12 +832,13 @@ int build_flow_device(mfx_ctx* ctx, int64_t first, int64_t count, int64_t groups
       l.first += degOwn[r];
       heap.push(l);
     }
+    HIPCHK(hipMemcpyAsync(S->downer, S->owner.data(), sizeof(int32_t) * (size_t)nOwnA, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));          // S->owner may be reassigned by the host builder
+    S->assign_gen = ctx->train_gen; S->assign_groups = groups; S->assign_nU = nU; S->assign_nI = nI;
   }
-  S->hstart.resize((size_t)nOth + 1);
-  S->hstart[0] = 0;
-  for (int64_t r = 0; r < nOth; r++) S->hstart[(size_t)r + 1] = S->hstart[(size_t)r] + degOth[r];
-  HIPCHK(hipMemcpyAsync(S->downer, S->owner.data(), sizeof(int32_t) * (size_t)nOwn, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(S->dstart, S->hstart.data(), sizeof(int64_t) * ((size_t)nOth + 1), hipMemcpyHostToDevice, ctx->stream));
+  const int own_user = S->assign_own_user;
+  const int32_t maxU = S->assign_maxU, maxI = S->assign_maxI;
+  const int64_t nOth = own_user ? nI : nU;
   if (S->ver_cap < nOth) {
     dev_free(S->ver);
     S->ver_cap = 0;
@@ -831,6 +853,9 @@ int build_flow_device(mfx_ctx* ctx, int64_t first, int64_t count, int64_t groups
   hipLaunchKernelGGL(flow_keys_kernel, dim3(grid), dim3(256), 0, ctx->stream, oth_rows, (const int32_t*)nullptr, count, S->k0, S->v0);
   size_t bytes = S->sort_tmp_bytes;
   HIPCHK(rocprim::radix_sort_pairs(S->sort_tmp, bytes, S->k0, S->k1, S->v0, S->v1, (size_t)count, 0, bits_for((uint64_t)nOth), ctx->stream));
+  // chain starts of the other side in the sorted order: dstart[r] = number of sorted keys < r
+  hipLaunchKernelGGL(flow_bounds32_kernel, dim3((unsigned)std::min<int64_t>((nOth + 256) / 256, 4096)), dim3(256), 0, ctx->stream, S->k1, count,
+                     nOth + 1, S->dstart);
   hipLaunchKernelGGL(flow_rank_kernel, dim3(grid), dim3(256), 0, ctx->stream, S->k1, S->v1, S->dstart, count, S->vert);
   // queue order: stable sort of the list positions by the queue of their owned row
   hipLaunchKernelGGL(flow_keys_kernel, dim3(grid), dim3(256), 0, ctx->stream, own_rows, (const int32_t*)S->downer, count, S->k0, S->v0);
