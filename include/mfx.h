@@ -174,6 +174,9 @@ int mfx_debug_flow_queues(mfx_ctx* ctx, int32_t* records, int64_t cap, int64_t* 
 /* test hook: digest of the slot lists the last MFX_SGD_TILED epoch ran on.  counts = {slots, ratings, row
  * references, rows per slot}; sums = FNV-1a of {rating records, slot_beg, slot_ibeg, slot rows, tile_slot} */
 int mfx_debug_slots_digest(mfx_ctx* ctx, int64_t counts[4], uint64_t sums[5]);
+/* test hook: the user block (0 .. 7) and item block (0 .. 7) of every row in the 8 x 8 tiling the last MFX_SGD_TILED epoch ran on
+ * (balanced over the ratings: rows in descending order of their rating count, each onto the lightest block so far)          */
+int mfx_debug_tile_blocks(mfx_ctx* ctx, uint8_t* user_block, int64_t n_users, uint8_t* item_block, int64_t n_items);
 /* test hook: visits per rating record (slot-list order, as mfx_debug_epoch_list indexes its positions through the
  * per-slot permutation) accumulated by epochs run with MFX_SGD_F_COUNT_VISITS; zeroes the counters.  n receives
  * the number of records; counts may be NULL to query n.                                                         */

@@ -118,12 +118,66 @@ int mfx_build_c2r_map_device(mfx_ctx* ctx, const DevCSR& m, uint32_t** map) {
 // ---------------------------------------------------------------------------
 // slot lists
 // ---------------------------------------------------------------------------
+__global__ void blk_count_kernel(const int32_t* __restrict__ u, const int32_t* __restrict__ i, int64_t n, int32_t* __restrict__ cu,
+                                 int32_t* __restrict__ ci) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    atomicAdd(&cu[u[e]], 1);
+    atomicAdd(&ci[i[e]], 1);
+  }
+}
+// rows by descending count (ties: ascending id), each onto the block with the smallest load so far (ties: the lowest block)
+static void balanced_blocks(const int32_t* cnt, int64_t n, int nb, bool user, bool hash_only, std::vector<uint8_t>& blk) {
+  blk.resize((size_t)n);
+  for (int64_t r = 0; r < n; r++) blk[(size_t)r] = (uint8_t)(user ? slot_user_block((int32_t)r) : mfx_item_block((int32_t)r));
+  if (hash_only) return;
+  std::vector<int32_t> rows;
+  for (int64_t r = 0; r < n; r++)
+    if (cnt[r] > 0) rows.push_back((int32_t)r);
+  std::sort(rows.begin(), rows.end(), [&](int32_t a, int32_t b) { return cnt[a] != cnt[b] ? cnt[a] > cnt[b] : a < b; });
+  std::vector<int64_t> load((size_t)nb, 0);
+  for (int32_t r : rows) {
+    int best = 0;
+    for (int b = 1; b < nb; b++)
+      if (load[(size_t)b] < load[(size_t)best]) best = b;
+    blk[(size_t)r] = (uint8_t)best;
+    load[(size_t)best] += cnt[r];
+  }
+}
+int mfx_slots_block_tables(mfx_ctx* ctx, SlotList* S, const RatingView& view) {
+  const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
+  const int64_t nU = m.nrows, nI = m.ncols;
+  static_assert(NUB <= 256, "block ids are bytes");
+  int rc;
+  Scratch sc;
+  int32_t* cnt;
+  if ((rc = sc.get(ctx, &cnt, (size_t)(nU + nI)))) return rc;
+  const char* e = getenv("MFX_SGD_BLOCKS_HASH");
+  const bool hash_only = e && atoi(e) != 0;
+  std::vector<int32_t> h((size_t)(nU + nI), 0);
+  if (!hash_only && view.n > 0) {
+    HIPCHK(hipMemsetAsync(cnt, 0, sizeof(int32_t) * (size_t)(nU + nI), ctx->stream));
+    hipLaunchKernelGGL(blk_count_kernel, dim3(grid_for(view.n)), dim3(TB), 0, ctx->stream, view.u, view.i, view.n, cnt, cnt + nU);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(h.data(), cnt, sizeof(int32_t) * (size_t)(nU + nI), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  balanced_blocks(h.data(), nU, NUB, true, hash_only, S->h_ublk);
+  balanced_blocks(h.data() + nU, nI, 8, false, hash_only, S->h_iblk);
+  dev_free(S->ublk); dev_free(S->iblk);
+  if ((rc = dev_alloc(ctx, &S->ublk, (size_t)std::max<int64_t>(nU, 1))) || (rc = dev_alloc(ctx, &S->iblk, (size_t)std::max<int64_t>(nI, 1)))) return rc;
+  if (nU) HIPCHK(hipMemcpyAsync(S->ublk, S->h_ublk.data(), (size_t)nU, hipMemcpyHostToDevice, ctx->stream));
+  if (nI) HIPCHK(hipMemcpyAsync(S->iblk, S->h_iblk.data(), (size_t)nI, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return MFX_OK;
+}
+
 // key = tile << ownbits | owned index; value = CSR position
 __global__ void slot_keys_kernel(const int32_t* __restrict__ rowid, const int32_t* __restrict__ rowind, int64_t nnz, int side,
-                                 int ownbits, uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
+                                 int ownbits, const uint8_t* __restrict__ ublk, const uint8_t* __restrict__ iblk,
+                                 uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x) {
     const int32_t u = rowid[e], i = rowind[e];
-    const uint64_t tile = (uint64_t)(slot_user_block(u) * 8 + mfx_item_block(i));
+    const uint64_t tile = (uint64_t)((int)ublk[u] * 8 + (int)iblk[i]);
     key[e] = (tile << ownbits) | (uint64_t)(uint32_t)(side == 0 ? i : u);
     val[e] = (uint32_t)e;
   }
@@ -279,7 +333,8 @@ int mfx_slots_build_device(mfx_ctx* ctx, SlotList* S, int rows, int side, const 
   if ((rc = sc.get(ctx, &k0, (size_t)nnz)) || (rc = sc.get(ctx, &k1, (size_t)nnz)) || (rc = sc.get(ctx, &v0, (size_t)nnz)) ||
       (rc = sc.get(ctx, &v1, (size_t)nnz)))
     return rc;
-  hipLaunchKernelGGL(slot_keys_kernel, dim3(grid_for(nnz)), dim3(TB), 0, st, view.u, view.i, nnz, side, ownbits, k0, v0);
+  if ((rc = mfx_slots_block_tables(ctx, S, view))) return rc;
+  hipLaunchKernelGGL(slot_keys_kernel, dim3(grid_for(nnz)), dim3(TB), 0, st, view.u, view.i, nnz, side, ownbits, S->ublk, S->iblk, k0, v0);
   if ((rc = sort_pairs(ctx, sc, k0, k1, v0, v1, (size_t)nnz, ownbits + tilebits))) return rc;
 
   // 2. runs: (tile, owned row) -> number of ratings; k0 / v0 are free again and hold the unique keys / counts

@@ -29,6 +29,16 @@ struct Rows {
     if (POL == 0) { *(float4v*)(base + elt) = v; return; }
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, v), rs, (uint32_t)(elt * 4), 0, AUXS);
   }
+  // the same through a 32-bit BYTE offset of the row (one v_lshl_or instead of a 64-bit multiply, a narrowing and a shift) plus a
+  // constant that rides in the instruction; buffer policies only
+  __device__ __forceinline__ float4v ldb(uint32_t byte, int konst) const {
+    static_assert(POL != 0, "byte offsets go through the buffer descriptor");
+    return __builtin_bit_cast(float4v, __builtin_amdgcn_raw_buffer_load_b128(rs, byte, konst, AUXL));
+  }
+  __device__ __forceinline__ void stb(uint32_t byte, int konst, float4v v) const {
+    static_assert(POL != 0, "byte offsets go through the buffer descriptor");
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, v), rs, byte, konst, AUXS);
+  }
 };
 
 // All-reduce sum over the L lanes of a group with DPP (no LDS traffic), levels xor 1, 2, 4, 8.  For the

@@ -7,7 +7,22 @@
 
 #include "mfx_internal.h"
 
-constexpr int CAP_R = 1024;   // ratings per slot
+// Slot shape (compile-time; scripts/exp_slots.sh builds variants): ratings per slot, LDS words of owned rows per workgroup and
+// the most rows a slot stages.
+#ifndef MFX_SLOT_CAP
+#define MFX_SLOT_CAP 1024
+#endif
+#ifndef MFX_SLOT_WORDS
+#define MFX_SLOT_WORDS 4096
+#endif
+#ifndef MFX_SLOT_ROWS
+#define MFX_SLOT_ROWS 64
+#endif
+constexpr int CAP_R = MFX_SLOT_CAP;   // ratings per slot
+// owned rows per slot: MFX_SLOT_WORDS * 4 bytes of LDS per workgroup, at most MFX_SLOT_ROWS and at least 8 rows
+constexpr int slot_rows_for(int ld) {
+  return MFX_SLOT_WORDS / ld > MFX_SLOT_ROWS ? MFX_SLOT_ROWS : (MFX_SLOT_WORDS / ld < 8 ? 8 : MFX_SLOT_WORDS / ld);
+}
 // User blocks per XCD (MFX_NUB): 8*SUB user blocks x 8 item blocks = 64*SUB tiles, 8*SUB rounds per epoch.
 #ifndef MFX_SUB
 #define MFX_SUB 1
@@ -24,6 +39,8 @@ struct SlotList {
   int32_t* slot_ibeg = nullptr;    // [nslots+1] range into slot_items
   int32_t* slot_items = nullptr;   // global item ids of every slot
   int32_t* tile_slot = nullptr;    // [NTILE+1] slot range of a tile
+  uint8_t *ublk = nullptr, *iblk = nullptr;   // user block / item block of every row (mfx_slots_block_tables)
+  std::vector<uint8_t> h_ublk, h_iblk;        // their host copies (host builder, mfx_debug_tile_blocks)
   unsigned* ctr = nullptr;         // [NTILE] slot counters + [2] barrier counter and abort flag of the drain
   unsigned* abort_host = nullptr;  // pinned copy of the abort flag of the previous epoch's drain
   unsigned* visit = nullptr;       // [nnz] visits per rating record (MFX_SGD_F_COUNT_VISITS), or NULL
@@ -67,6 +84,13 @@ MFX_SLOTS_DECL(4, 1) MFX_SLOTS_DECL(8, 1) MFX_SLOTS_DECL(16, 1) MFX_SLOTS_DECL(1
 MFX_SLOTS_DECL(16, 5) MFX_SLOTS_DECL(16, 6) MFX_SLOTS_DECL(16, 7) MFX_SLOTS_DECL(16, 8)
 #undef MFX_SLOTS_DECL
 
+// The 8*SUB user blocks and 8 item blocks the tiles are made of, BALANCED over the ratings of `view`: rows in descending order of
+// their rating count, each onto the block with the fewest ratings so far (ties: the lower row id first, the lower block).  The
+// round of an epoch ends when its slowest tile does -- with hashed blocks the 8 tiles of a diagonal differed by +-12 % at C2
+// (the popular items of a block), measured as 11 % of every launch spent waiting for one XCD (scripts/slot_times.py).  Rows the
+// view has no rating of keep the hash.  MFX_SGD_BLOCKS_HASH=1: the hash for every row (the layout of rounds 1 and 2).
+// Fills S->ublk / S->iblk (device) and the host copies (setup.hip).
+int mfx_slots_block_tables(mfx_ctx* ctx, SlotList* S, const RatingView& view);
 // builds S on the device from the ratings of `view` (setup.hip); same lists as the host builder in sgd_slots.hip
 int mfx_slots_build_device(mfx_ctx* ctx, SlotList* S, int rows, int side, const RatingView& view);
 // the train ratings grouped by item part (i % nparts), stable in CSR order: fills st->pu/pi/pv/poff (setup.hip)

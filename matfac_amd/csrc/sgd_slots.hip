@@ -37,7 +37,7 @@ void mfx_slots_free_internal(mfx_ctx* ctx) {
   if (!st) return;
   auto drop = [](SlotList& s) {
     dev_free(s.rec); dev_free(s.slot_beg); dev_free(s.slot_ibeg); dev_free(s.slot_items); dev_free(s.attr); dev_free(s.visit);
-    dev_free(s.tile_slot); dev_free(s.ctr);
+    dev_free(s.tile_slot); dev_free(s.ctr); dev_free(s.ublk); dev_free(s.iblk);
     if (s.abort_host) (void)hipHostFree(s.abort_host);
   };
   for (SlotList& s : st->side) drop(s);
@@ -75,14 +75,19 @@ static int build_slots(mfx_ctx* ctx, SlotList* S, int rows, int side, const Rati
   const std::vector<int32_t>& own = side == 0 ? ri : ru;
   const std::vector<int32_t>& oth = side == 0 ? ru : ri;
   const int32_t nown = side == 0 ? m.ncols : m.nrows;
-  // ratings of each tile (stable in CSR order)
+  // ratings of each tile (stable in CSR order); the blocks are balanced over this view's ratings (mfx_slots_block_tables)
+  {
+    int rc = mfx_slots_block_tables(ctx, S, view);
+    if (rc) return rc;
+  }
+  const std::vector<uint8_t>&ub = S->h_ublk, &ib = S->h_iblk;
   std::vector<int64_t> tstart(NTILE + 1, 0);
-  for (int64_t e = 0; e < nnz; e++) tstart[slot_user_block(ru[e]) * 8 + mfx_item_block(ri[e]) + 1]++;
+  for (int64_t e = 0; e < nnz; e++) tstart[(int)ub[(size_t)ru[e]] * 8 + (int)ib[(size_t)ri[e]] + 1]++;
   for (int t = 0; t < NTILE; t++) tstart[t + 1] += tstart[t];
   std::vector<int64_t> byt((size_t)nnz);
   {
     std::vector<int64_t> pos(tstart.begin(), tstart.end() - 1);
-    for (int64_t e = 0; e < nnz; e++) byt[pos[slot_user_block(ru[e]) * 8 + mfx_item_block(ri[e])]++] = e;
+    for (int64_t e = 0; e < nnz; e++) byt[pos[(int)ub[(size_t)ru[e]] * 8 + (int)ib[(size_t)ri[e]]]++] = e;
   }
   std::vector<int32_t> rec((size_t)nnz * 4), slot_ibeg(1, 0), slot_items, tile_slot(NTILE + 1, 0);
   std::vector<int64_t> slot_beg(1, 0);
@@ -242,7 +247,7 @@ int mfx_launch_sgd_tiled(mfx_ctx* ctx, const mfx_sgd_opts* o) {
     if (st->nparts != ctx->item_parts || !st->pu) {
       for (SlotList& s : st->parts) {
         dev_free(s.rec); dev_free(s.slot_beg); dev_free(s.slot_ibeg); dev_free(s.slot_items); dev_free(s.attr); dev_free(s.visit);
-        dev_free(s.tile_slot); dev_free(s.ctr);
+        dev_free(s.tile_slot); dev_free(s.ctr); dev_free(s.ublk); dev_free(s.iblk);
         if (s.abort_host) (void)hipHostFree(s.abort_host);
       }
       st->parts.clear();
@@ -255,7 +260,7 @@ int mfx_launch_sgd_tiled(mfx_ctx* ctx, const mfx_sgd_opts* o) {
     view.n = st->poff[(size_t)part + 1] - st->poff[(size_t)part];
     if (view.n == 0) return MFX_OK;           // this rank's users hold no rating of the part
   }
-  const int rows = std::min(64, std::max(8, 4096 / ctx->ld));
+  const int rows = slot_rows_for(ctx->ld);
   if (!S->built || S->rows != rows || S->nnz != view.n) {
     int rc = build_slots(ctx, S, rows, side, view);
     if (rc) return rc;
@@ -398,6 +403,17 @@ static int digest_dev(mfx_ctx* ctx, const T* dev, size_t n, uint64_t* out) {
   std::vector<T> h(n);
   if (n) HIPCHK(hipMemcpy(h.data(), dev, sizeof(T) * n, hipMemcpyDeviceToHost));
   *out = fnv1a(h.data(), sizeof(T) * n);
+  return MFX_OK;
+}
+extern "C" int mfx_debug_tile_blocks(mfx_ctx* ctx, uint8_t* user_block, int64_t n_users, uint8_t* item_block, int64_t n_items) {
+  if (!ctx) return MFX_E_ARG;
+  SlotState* st = state(ctx);
+  NEED(st && st->last().built && user_block && item_block, MFX_E_STATE, "mfx_debug_tile_blocks: no tiled epoch has run");
+  const SlotList& S = st->last();
+  NEED(n_users == (int64_t)S.h_ublk.size() && n_items == (int64_t)S.h_iblk.size(), MFX_E_ARG,
+       "mfx_debug_tile_blocks: the tables hold %zu users and %zu items", S.h_ublk.size(), S.h_iblk.size());
+  memcpy(user_block, S.h_ublk.data(), S.h_ublk.size());
+  memcpy(item_block, S.h_iblk.data(), S.h_iblk.size());
   return MFX_OK;
 }
 extern "C" int mfx_debug_slots_digest(mfx_ctx* ctx, int64_t counts[4], uint64_t sums[5]) {

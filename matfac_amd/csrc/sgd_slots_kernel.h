@@ -11,7 +11,9 @@
 
 // Diagnostic builds (scripts/exp_bound.sh; results are WRONG on purpose): what the round time does when one resource is
 // taken out.  1: no user-row stores  2: no LDS atomic adds  3: 16 extra vector multiplies per step  4: user rows are
-// never loaded  5: 32 extra multiplies.  0 (the product): nothing of this is compiled.
+// never loaded  5: 32 extra multiplies.  8: no visit counts -- with MFX_SGD_F_COUNT_VISITS every round workgroup leaves
+// {start, end (100 MHz wall clock), XCD | slots pulled << 8, ratings} in the visit buffer (scripts/slot_times.py).
+// 0 (the product): nothing of this is compiled.
 #ifndef MFX_EXP
 #define MFX_EXP 0
 #endif
@@ -19,9 +21,9 @@
 // ---------------------------------------------------------------------------
 // kernel
 // ---------------------------------------------------------------------------
-// owned rows per slot: 16 KB of LDS per workgroup, at most 64 and at least 8 rows
+// owned rows per slot (sgd_slots.h): 16 KB of LDS per workgroup, at most 64 and at least 8 rows
 template <int LD>
-struct SlotRows { static constexpr int value = 4096 / LD > 64 ? 64 : (4096 / LD < 8 ? 8 : 4096 / LD); };
+struct SlotRows { static constexpr int value = slot_rows_for(LD); };
 
 
 // Item rows of a slot live in LDS as Q = round(q * 2^24) (int32).  A visit reads q = float(Q) * 2^-24,
@@ -60,7 +62,7 @@ struct SlotSteps {
   template <class RowsT>
   static __device__ __forceinline__ void run(const RowsT& Um, int* q_lds, int tx, int ty, int tz, int tw, const float* regk,
                                              int g, int j, int nvalid, float lr, float uReg, float iReg,
-                                             float4v (&pn)[C], int64_t& pen, float4v (&pnn)[C], int64_t& penn) {
+                                             float4v (&pn)[C], uint32_t& pen, float4v (&pnn)[C], uint32_t& penn) {
     constexpr int G = 64 / L;
     constexpr int LD = 4 * L * C;
     const int e = S * G + g;
@@ -75,7 +77,7 @@ struct SlotSteps {
     constexpr bool LEAN = C > 2 && FIX && !OWN_U && ARITH == MFX_ARITH_F32 && VAR == 0;
     constexpr bool DEEP = C <= 2 || LEAN;
     float4v p[C];
-    const int64_t pe = pen;
+    const uint32_t pe = pen;      // byte offset of this step's lock-free row (+ this lane's 16 bytes)
 #pragma unroll
     for (int c = 0; c < C; c++) p[c] = pn[c];
     if constexpr (DEEP) {
@@ -85,17 +87,17 @@ struct SlotSteps {
       if constexpr (S + 2 < L) {
         const int un = slot_take<L, S + 2>(tx, g);
         if (e + 2 * G < nvalid) {
-          penn = (int64_t)un * LD + 4 * j;
+          penn = (uint32_t)un * (uint32_t)(LD * 4) + 16u * (uint32_t)j;
 #pragma unroll
-          for (int c = 0; c < C; c++) pnn[c] = MFX_EXP == 4 ? float4v{0.01f, 0.02f, 0.03f, 0.01f} : Um.ld(penn + c * 4 * L);
+          for (int c = 0; c < C; c++) pnn[c] = MFX_EXP == 4 ? float4v{0.01f, 0.02f, 0.03f, 0.01f} : Um.ldb(penn, c * 16 * L);
         }
       }
     } else if constexpr (S + 1 < L) {
       const int un = slot_take<L, S + 1>(tx, g);
       if (e + G < nvalid) {
-        pen = (int64_t)un * LD + 4 * j;
+        pen = (uint32_t)un * (uint32_t)(LD * 4) + 16u * (uint32_t)j;
 #pragma unroll
-        for (int c = 0; c < C; c++) pn[c] = Um.ld(pen + c * 4 * L);
+        for (int c = 0; c < C; c++) pn[c] = Um.ldb(pen, c * 16 * L);
       }
     }
     if constexpr (LEAN) {
@@ -113,17 +115,17 @@ struct SlotSteps {
         const float est = group_sum<L>(a) * FIX_INV;
         const float c1 = -2.0f * (r - est), cu = 2.0f * uReg;
         const float c1s = c1 * FIX_INV, cis = (2.0f * iReg) * FIX_INV;
+        const float lrs = lr * -FIX_SCALE;     // (see the delta branch below)
 #pragma unroll
         for (int c = 0; c < C; c++) {          // pass 2: both steps of this chunk
           const int4 qi = *(const int4*)(qrow + c * 4 * L);
           const float4v q = float4v{(float)qi.x, (float)qi.y, (float)qi.z, (float)qi.w};
 #pragma unroll
           for (int x = 0; x < 4; x++) p[c][x] = upd_f32(p[c][x], q[x], c1s, cu, lr);
-          Um.st(pe + c * 4 * L, p[c]);
+          Um.stb(pe, c * 16 * L, p[c]);
 #pragma unroll
           for (int x = 0; x < 4; x++) {
-            const float t = lr * (c1 * p[c][x] + cis * q[x]);
-            atomicAdd(qrow + c * 4 * L + x, fix_round(t * -FIX_SCALE));   // ds_add_u32
+            atomicAdd(qrow + c * 4 * L + x, fix_round(lrs * (c1 * p[c][x] + cis * q[x])));   // ds_add_u32
           }
         }
       }
@@ -173,7 +175,7 @@ struct SlotSteps {
           for (int x = 0; x < 4; x++)
             if (c * 4 * L + 4 * j + x < lim) q[c][x] = upd_ref64(q[c][x], p[c][x], m2, VAR == 3 ? 2.0 * (double)rk[x] : ri, lrd);
           if (c * 4 * L + 4 * j < lim) {
-            Um.st(pe + c * 4 * L, p[c]);
+            Um.stb(pe, c * 16 * L, p[c]);
             if (FIX) {
 #pragma unroll
               for (int x = 0; x < 4; x++)
@@ -191,6 +193,9 @@ struct SlotSteps {
         // c1*q_true = (c1 * 2^-24)*q and ci*q_true = (ci * 2^-24)*q bit for bit (powers of two commute with every rounding)
         const float c1 = -2.0f * (r - est * FIX_INV), cu = 2.0f * uReg;
         const float c1s = c1 * FIX_INV, cis = (2.0f * iReg) * FIX_INV;
+        // the delta round(-(lr * X) * 2^24) is taken as round((lr * -2^24) * X): scaling by a power of two commutes with the
+        // rounding of the product, so the integer is the same (where lr * X is subnormal both forms round to 0)
+        const float lrs = lr * -FIX_SCALE;
 #pragma unroll
         for (int c = 0; c < C; c++) {
 #pragma unroll
@@ -202,15 +207,15 @@ struct SlotSteps {
             for (int x = 0; x < 4; x++) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(q[c][x]) : "v"(1.0f));
 #endif
 #if MFX_EXP != 1
-          Um.st(pe + c * 4 * L, p[c]);
+          Um.stb(pe, c * 16 * L, p[c]);
 #endif
 #pragma unroll
           for (int x = 0; x < 4; x++) {
-            const float t = lr * (c1 * p[c][x] + cis * q[c][x]);
+            const float t = lrs * (c1 * p[c][x] + cis * q[c][x]);
 #if MFX_EXP != 2
-            atomicAdd(qrow + c * 4 * L + x, fix_round(t * -FIX_SCALE));   // ds_add_u32
+            atomicAdd(qrow + c * 4 * L + x, fix_round(t));   // ds_add_u32
 #else
-            asm volatile("" ::"v"(fix_round(t * -FIX_SCALE)));
+            asm volatile("" ::"v"(fix_round(t)));
 #endif
           }
         }
@@ -222,7 +227,7 @@ struct SlotSteps {
         else sgd_axpys<C, ARITH>(p, q, r, est, lr, uReg, iReg);
 #pragma unroll
         for (int c = 0; c < C; c++) {
-          Um.st(pe + c * 4 * L, p[c]);
+          Um.stb(pe, c * 16 * L, p[c]);
           if (FIX) {
 #pragma unroll
             for (int x = 0; x < 4; x++)
@@ -280,6 +285,10 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
   const bool onegrp = SWEEP && one != 0;
   const bool drain = SWEEP && tile_only < 0;          // the whole-epoch drain: all diagonals, grid barriers in between
   int4* q4 = (int4*)q_lds;
+#if MFX_EXP == 8
+  const unsigned long long exp_t0 = wall_clock64();
+  unsigned exp_slots = 0, exp_ratings = 0;
+#endif
   if (drain) {
     // anything left anywhere?  (ctr[NTILE], ctr[NTILE + 1]: barrier counter and abort flag, zeroed with the counters)
     if (tid == 0) s_bad = 0;
@@ -316,6 +325,9 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
       const int slot = s0 + sl;
       const int64_t rb = slot_beg[slot], R = slot_beg[slot + 1] - rb;
       const int ib = slot_ibeg[slot], ni = slot_ibeg[slot + 1] - ib;
+#if MFX_EXP == 8
+      exp_slots++; exp_ratings += (unsigned)R;
+#endif
       // stage the slot's item rows (as floats first, to decide the representation)
       bool mybad = false;
       for (int x = tid; x < ni * LD4; x += WG) {
@@ -362,7 +374,9 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
           rc4 = rec[src];
 #endif
           if (VAR == 1 || VAR == 2) tw = attr[src];
+#if MFX_EXP != 8
           if (visit) atomicAdd(&visit[src], 1u);       // MFX_SGD_F_COUNT_VISITS
+#endif
         }
         int nvalid = (int)(R - cb < 64 ? R - cb : 64);
         if (onegrp) nvalid = g == 0 ? (int)(R - cb < L ? R - cb : L) * G : 0;
@@ -376,15 +390,15 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
         }
         // software pipeline: the lock-free rows of steps s+1 and s+2 are requested before step s is computed
         float4v pn[C], pnn[C];
-        int64_t pen = (int64_t)slot_take<L, 0>(tx, g) * LD + 4 * j;
-        int64_t penn = (int64_t)slot_take<L, 1>(tx, g) * LD + 4 * j;
+        uint32_t pen = (uint32_t)slot_take<L, 0>(tx, g) * (uint32_t)(LD * 4) + 16u * (uint32_t)j;
+        uint32_t penn = (uint32_t)slot_take<L, 1>(tx, g) * (uint32_t)(LD * 4) + 16u * (uint32_t)j;
         if (g < nvalid) {
 #pragma unroll
-          for (int c = 0; c < C; c++) pn[c] = MFX_EXP == 4 ? float4v{0.01f, 0.02f, 0.03f, 0.01f} : Um.ld(pen + c * 4 * L);
+          for (int c = 0; c < C; c++) pn[c] = MFX_EXP == 4 ? float4v{0.01f, 0.02f, 0.03f, 0.01f} : Um.ldb(pen, c * 16 * L);
         }
         if ((C <= 2 || (!OWN_U && ARITH == MFX_ARITH_F32 && VAR == 0)) && G + g < nvalid) {   // two-steps-ahead pipelines only
 #pragma unroll
-          for (int c = 0; c < C; c++) pnn[c] = MFX_EXP == 4 ? float4v{0.01f, 0.02f, 0.03f, 0.01f} : Um.ld(penn + c * 4 * L);
+          for (int c = 0; c < C; c++) pnn[c] = MFX_EXP == 4 ? float4v{0.01f, 0.02f, 0.03f, 0.01f} : Um.ldb(penn, c * 16 * L);
         }
         const float* regk = VAR == 3 ? (const float*)attr : nullptr;
         if (fix) SlotSteps<L, C, ARITH, OWN_U, true, VAR, 0>::run(Um, q_lds, tx, ty, tz, tw, regk, g, j, nvalid, lr, uReg, iReg, pn, pen, pnn, penn);
@@ -422,6 +436,12 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
       return;
     }
   }
+#if MFX_EXP == 8
+  if (!SWEEP && visit && tid == 0) {
+    unsigned* o = visit + ((size_t)round * gridDim.x + blockIdx.x) * 4;
+    o[0] = (unsigned)exp_t0; o[1] = (unsigned)wall_clock64(); o[2] = (unsigned)xcc | exp_slots << 8; o[3] = exp_ratings;
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------

@@ -178,6 +178,13 @@ class Ctx:
     def debug_raise_drain_abort(self):
         self._chk(self.lib.mfx_debug_raise_drain_abort(self.h))
 
+    def debug_tile_blocks(self, n_users, n_items):
+        ub = np.empty(n_users, np.uint8)
+        ib = np.empty(n_items, np.uint8)
+        self._chk(self.lib.mfx_debug_tile_blocks(self.h, ub.ctypes.data_as(C.c_void_p), C.c_int64(n_users),
+                                                 ib.ctypes.data_as(C.c_void_p), C.c_int64(n_items)))
+        return ub, ib
+
     def debug_slots_digest(self):
         counts = (C.c_int64 * 4)()
         sums = (C.c_uint64 * 5)()

@@ -218,18 +218,31 @@ def test_tiled_epoch_list_is_tile_grouped_permutation():
             assert np.array_equal(np.sort(k), np.sort(key))
             lists.append((u, i))
         U, V = ctx.get_factors()
+        ub, ib = ctx.debug_tile_blocks(tr.nrows, tr.ncols)
     assert np.array_equal(U, U0) and np.array_equal(V, V0)
     assert not np.array_equal(lists[0][0], lists[1][0])
     # inside the list the (user block, item block) tile id is non-decreasing: 64 contiguous tiles
-    def mix(x):
-        x = x.astype(np.uint64) & 0xffffffff
-        x ^= x >> 16; x = (x * 0x7feb352d) & 0xffffffff; x ^= x >> 15; x = (x * 0x846ca68b) & 0xffffffff; x ^= x >> 16
-        return x
     u, i = lists[0]
-    bu = mix((u.astype(np.uint64) * 0x9e3779b1 + 0x1234567) & 0xffffffff) & 7
-    bi = mix((i.astype(np.uint64) * 0x85ebca6b + 0x89abcde) & 0xffffffff) & 7
-    tile = (bu * 8 + bi).astype(np.int64)
+    assert ub.max() < 8 and ib.max() < 8
+    tile = (ub[u].astype(np.int64) * 8 + ib[i]).astype(np.int64)
     assert np.all(np.diff(tile) >= 0)
+    # the blocks are balanced over the ratings: rows in descending order of their count, each onto the lightest block so far --
+    # restated here; the 8 user blocks and the 8 item blocks then differ by less than the count of ONE of their rows
+    def balanced(cnt):
+        rows = sorted((r for r in range(len(cnt)) if cnt[r] > 0), key=lambda r: (-cnt[r], r))
+        load, blk = [0] * 8, {}
+        for r in rows:
+            b = min(range(8), key=lambda k: (load[k], k))
+            blk[r] = b
+            load[b] += cnt[r]
+        return blk, load
+    cu, ci = np.bincount(tr.rowids(), minlength=tr.nrows), np.bincount(tr.rowind, minlength=tr.ncols)
+    for cnt, blk in ((cu, ub), (ci, ib)):
+        want, load = balanced(cnt.tolist())
+        assert all(blk[r] == b for r, b in want.items())
+        assert max(load) - min(load) <= cnt.max()
+    per_tile = np.bincount(tile, minlength=64)
+    assert per_tile.max() <= 1.25 * per_tile.mean()        # (hashed blocks on this matrix: up to 1.5 x the mean)
 
 
 @pytest.fixture(params=["flow", "flow-ver", "flow-host", "flow-ver-host", "levels"])
