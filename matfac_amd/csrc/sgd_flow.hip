@@ -312,6 +312,10 @@ __device__ __forceinline__ uint4v fl_load(desc4 rs, uint32_t off) {
   else asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v) : "v"(off), "s"(rs) : "memory");
   return v;
 }
+// the load into a LANDING register of the request pipeline: in-out operand (see fw_load2 below)
+__device__ __forceinline__ void fl_land(uint4v& v, desc4 rs, uint32_t off) {
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen sc1" : "+v"(v) : "v"(off), "s"(rs) : "memory");
+}
 template <bool SC1>
 __device__ __forceinline__ void fl_store(desc4 rs, uint32_t off, uint4v v) {
   // (s_nop 1: a store of more than 64 bits needs a wait state before its data registers may be overwritten)
@@ -369,7 +373,7 @@ __global__ __launch_bounds__(FL_WG, (F2<L, C>::WGS)) void sgd_flow_tag_kernel(co
   {                                                                                                                   \
     const uint32_t rb_ = (LIVE) ? (uint32_t)(ROWX) * (uint32_t)(8 * LD) : FL_OOB;                                     \
     _Pragma("unroll") for (int c = 0; c < C; c++) _Pragma("unroll") for (int h = 0; h < 2; h++)                       \
-        Tr[K][2 * c + h] = fl_load<true>(dt, ((LIVE) && act) ? rb_ + (uint32_t)(c * 32 * L + h * 16 * L) + lane_off : FL_OOB); \
+        fl_land(Tr[K][2 * c + h], dt, ((LIVE) && act) ? rb_ + (uint32_t)(c * 32 * L + h * 16 * L) + lane_off : FL_OOB);   \
   }
   // one queue position: S = index in the block (uniform), K = S % LA (static), NWAIT = requests and stores issued behind its poll
 #define FL_STEP(K, S, NWAIT)                                                                                          \
@@ -434,7 +438,7 @@ __global__ __launch_bounds__(FL_WG, (F2<L, C>::WGS)) void sgd_flow_tag_kernel(co
           FL_STAT(2, 1);                                                                                              \
           if ((uint32_t)__builtin_amdgcn_readfirstlane(pr_.y) == exp_) {                                              \
             _Pragma("unroll") for (int c = 0; c < C; c++) _Pragma("unroll") for (int h = 0; h < 2; h++)               \
-                Tr[K][2 * c + h] = fl_load<true>(dt, act ? rb_ + (uint32_t)(c * 32 * L + h * 16 * L) + lane_off : FL_OOB); \
+                fl_land(Tr[K][2 * c + h], dt, act ? rb_ + (uint32_t)(c * 32 * L + h * 16 * L) + lane_off : FL_OOB);       \
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                          \
             _Pragma("unroll") for (int h = 0; h < 2 * C; h++) asm volatile("" : "+v"(Tr[K][h]));                      \
             bool t_ = true;                                                                                           \
@@ -548,6 +552,280 @@ __global__ __launch_bounds__(FL_WG, (F2<L, C>::WGS)) void sgd_flow_tag_kernel(co
     if (have >= 0 && act) {
 #pragma unroll
       for (int c = 0; c < C; c++) *(float4v*)(O + (int64_t)have * LD + c * 4 * L + 4 * j) = qv[(sI * C + c) * L + j];
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The tagged schedule, ONE ELEMENT PER LANE AND CHUNK (rows of 64 C floats, K > 32; round 3).  In the kernel above lanes 0 .. 15
+// hold a row (4 elements per chunk each) and 48 lanes ride along: the wave that works off the longest queue issues ~ 220
+// instructions per visit, 140 of them the reference's double bracket on its 4 C elements -- and a wave issues one vector
+// instruction per ~ 4.5 cycles, so the hottest chain ran at 1 000 cycles per visit.  Here lane l = 4 j + x holds element 4 j + x
+// of every 64-element chunk (the element lane j of the 16-lane layout holds in position x), all 64 lanes work, and the bracket is
+// ONE element per lane and chunk.  The dot product keeps the device order of include/mfx.h bit for bit: the 4 C-long fma chain
+// of "lane j" now hops through the four lanes of quad j (a quad_perm rotate between links), and the xor butterfly over j = 1, 2, 4, 8
+// becomes row_half_mirror, row_mirror (all four lanes of a quad hold the quad's value), v_permlane16_swap and v_permlane32_swap.
+// The granule copy is the one flow_tag_kernel writes for L = 16; a lane reads and writes ITS 8-byte granule {value, tag}.
+// Everything else (queues, records by v_readlane, LA-deep request pipeline with counted waits, owned rows in registers / LDS
+// slots, probe-then-poll) is the kernel above.
+template <int C>
+struct FW {
+  static constexpr int LD = 64 * C;
+  static constexpr int LA = 4;                     // rows of the other side in flight (2 C landing registers each)
+  static constexpr int QR = C <= 2 ? 32 : 16;      // owned rows kept in LDS per queue
+  static constexpr int NB = 64;
+  static constexpr int WS = QR * LD * 4 + QR * 4;
+  static constexpr int LDS = WS * (FL_WG / 64);
+  static constexpr int WGS = C <= 1 ? 4 : 2;
+  static constexpr int NSTEP = 2 * C;              // vector-memory instructions of a step: C tagged stores, C row requests
+  static_assert(LDS * WGS <= 163840 && (LA - 1) * NSTEP <= 63 && NB % LA == 0, "wide tagged dataflow configuration");
+};
+typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+// A landing register is an IN-OUT operand of every load into it and of every wait behind it: one live range from the first
+// request to the last use, so the register allocator has no second definition to connect with a copy.  (With plain outputs the
+// rotation of the unrolled pipeline gave the slot-0 register of the prologue and of the steady state different registers and a
+// v_mov between them IN FRONT of the counted wait -- a copy of a register whose load had not landed: wrong rows, first seen in
+// this kernel.)  tests/test_trips_cpu.py checks the compiled kernels for it.
+__device__ __forceinline__ void fw_load2(unsigned long long& v, desc4 rs, uint32_t off) {          // sc1: past the CU's L1
+  asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen sc1" : "+v"(v) : "v"(off), "s"(rs) : "memory");
+}
+__device__ __forceinline__ void fw_store2(desc4 rs, uint32_t off, uint2v v) {  // sc1: write-through
+  asm volatile("buffer_store_dwordx2 %0, %1, %2, 0 offen sc1" ::"v"(v), "v"(off), "s"(rs) : "memory");
+}
+__device__ __forceinline__ uint32_t fw_load1(desc4 rs, uint32_t off) {
+  uint32_t v;
+  asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(v) : "v"(off), "s"(rs) : "memory");
+  return v;
+}
+__device__ __forceinline__ void fw_store1(desc4 rs, uint32_t off, uint32_t v) {
+  asm volatile("buffer_store_dword %0, %1, %2, 0 offen" ::"v"(v), "v"(off), "s"(rs) : "memory");
+}
+// a quad permutation writes every lane: the form without an "old" operand needs no initialising move
+template <int CTRL>
+__device__ __forceinline__ float fw_dpp(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+// p.q in device order (include/mfx.h) with lane 4 j + x holding element x of "lane j" in every chunk
+template <int C>
+__device__ __forceinline__ float wide_dot(const float (&p)[C], const float (&q)[C]) {
+  float a = 0.0f;
+#pragma unroll
+  for (int c = 0; c < C; c++)
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+      if (c || x) a = fw_dpp<0x93>(a);             // quad_perm [3,0,1,2]: the link of lane x takes the chain from lane x - 1 (x = 0: from 3)
+      a = __builtin_fmaf(p[c], q[c], a);           // (every lane computes; lane x holds the chain)
+    }
+  float s = fw_dpp<0xFF>(a);                       // quad_perm [3,3,3,3]: the finished chain of quad j, in its four lanes
+  s = s + dpp_f<0x141>(s);                         // j xor 1: the partner quad of the 8-lane half   (row_half_mirror)
+  s = s + dpp_f<0x140>(s);                         // j xor 2: the partner half of the 16-lane row   (row_mirror)
+  {                                                // j xor 4: the partner row of the 32-lane half   (odd rows of a <-> even rows of b)
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    s = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  {                                                // j xor 8: the other half of the wave
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    s = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  return s;
+}
+// sgd_axpys on one element per chunk: user row p first, then the item row q with the updated p (modelMF.cpp:94-103)
+template <int C, int ARITH>
+__device__ __forceinline__ void wide_axpys(float (&p)[C], float (&q)[C], float r, float est, float lr, float uReg, float iReg) {
+  if (ARITH == MFX_ARITH_F32) {
+    const float c1 = -2.0f * (r - est);
+    const float cu = 2.0f * uReg, ci = 2.0f * iReg;
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+      p[c] = upd_f32(p[c], q[c], c1, cu, lr);
+      q[c] = upd_f32(q[c], p[c], c1, ci, lr);
+    }
+  } else {
+    double diff;
+    if (ARITH == MFX_ARITH_REF64F) { const float d = r - est; diff = (double)d; }
+    else diff = (double)r - (double)est;
+    const double m2 = -2.0 * diff;
+    const double ru = 2.0 * (double)uReg, ri = 2.0 * (double)iReg, lrd = (double)lr;
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+      p[c] = upd_ref64(p[c], q[c], m2, ru, lrd);
+      q[c] = upd_ref64(q[c], p[c], m2, ri, lrd);
+    }
+  }
+}
+
+template <int C, int ARITH>
+__global__ __launch_bounds__(FL_WG, (FW<C>::WGS)) void sgd_flow_wide_kernel(const int4* __restrict__ q, const int64_t* __restrict__ qoff,
+                                                                           uint32_t qbytes, float* T, uint32_t tbytes, float* O, uint32_t obytes,
+                                                                           int own_user, float lr, float uReg, float iReg, unsigned* flag) {
+  typedef FW<C> P;
+  constexpr int LD = P::LD, LA = P::LA, QR = P::QR, NB = P::NB;
+  extern __shared__ __attribute__((aligned(16))) char fl_smem[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float* qv = (float*)(fl_smem + (size_t)wv * P::WS);              // [QR][C][64]
+  int* qt = (int*)(fl_smem + (size_t)wv * P::WS + QR * LD * 4);    // [QR]
+  const int64_t grp = (int64_t)blockIdx.x * (FL_WG / 64) + __builtin_amdgcn_readfirstlane(wv);
+  uint32_t pos = (uint32_t)qoff[grp];
+  const uint32_t end = (uint32_t)qoff[grp + 1];
+  if (lane < QR) qt[lane] = -1;
+  const desc4 dq = fl_desc(q, qbytes), dt = fl_desc(T, tbytes), dob = fl_desc(O, obytes);
+  // this lane's granule inside a 512-byte chunk of the granule copy, and its float inside a 256-byte chunk of the owned table
+  const uint32_t g_off = (uint32_t)(((lane >> 1) & 1) * 256 + (lane >> 2) * 16 + (lane & 1) * 8), o_off = (uint32_t)lane * 4u;
+  // the landing registers: one 64-bit INTEGER {tag : value} per pipeline slot and chunk.  (As an array of two-element vectors
+  // the compiler promoted the whole array to one register tuple -- 8 registers at C = 1 -- and moved the tuple around between
+  // steps, i.e. copied registers whose loads were still in flight; integers stay separate values.)
+  unsigned long long Tr[LA][C];
+#pragma unroll
+  for (int k = 0; k < LA; k++)
+#pragma unroll
+    for (int c = 0; c < C; c++) Tr[k][c] = 0ull;
+  float ov[C];
+#pragma unroll
+  for (int c = 0; c < C; c++) ov[c] = 0.0f;
+  int cur_row = -1, cur_slot = 0;
+  bool aborted = false;
+
+#define FW_REQUEST(K, ROWX, LIVE)                                                                                     \
+  {                                                                                                                   \
+    const uint32_t rb_ = (LIVE) ? (uint32_t)(ROWX) * (uint32_t)(8 * LD) + g_off : FL_OOB;                             \
+    _Pragma("unroll") for (int c = 0; c < C; c++) fw_load2(Tr[K][c], dt, (LIVE) ? rb_ + (uint32_t)(c * 512) : FL_OOB); \
+  }
+#define FW_STEP(K, S, NWAIT)                                                                                          \
+  {                                                                                                                   \
+    const int s_ = (S);                                                                                               \
+    const bool live_ = s_ < nb;                                                                                       \
+    uint32_t stbase_ = FL_OOB, ntag_ = 0;                                                                             \
+    float tv[C];                                                                                                      \
+    _Pragma("unroll") for (int c = 0; c < C; c++) tv[c] = 0.0f;                                                       \
+    if (live_ && !aborted) {                                                                                          \
+      const int sl_ = s_ & 63;                                                                                        \
+      const int rx_ = __builtin_amdgcn_readlane(rec.x, sl_), ry_ = __builtin_amdgcn_readlane(rec.y, sl_);             \
+      const int rz_ = __builtin_amdgcn_readlane(rec.z, sl_);                                                          \
+      const uint32_t exp_ = (uint32_t)__builtin_amdgcn_readlane(rec.w, sl_);                                          \
+      const int orow_ = ry_ & FL_ROW_MASK, slot_ = (int)((uint32_t)ry_ >> FL_SLOT_SHIFT) & (QR - 1);                  \
+      if (orow_ != cur_row) {               /* another owned row: the held one goes to its LDS slot, this one comes in */ \
+        if (cur_row >= 0) {                                                                                           \
+          _Pragma("unroll") for (int c = 0; c < C; c++) qv[(cur_slot * C + c) * 64 + lane] = ov[c];                   \
+        }                                                                                                             \
+        const int have_ = __builtin_amdgcn_readfirstlane(qt[slot_]);                                                  \
+        if (have_ == orow_) {                                                                                         \
+          _Pragma("unroll") for (int c = 0; c < C; c++) ov[c] = qv[(slot_ * C + c) * 64 + lane];                      \
+        } else {                            /* not in LDS: the slot's row goes back to the table, this one is loaded */ \
+          if (have_ >= 0) {                                                                                           \
+            _Pragma("unroll") for (int c = 0; c < C; c++)                                                             \
+                fw_store1(dob, (uint32_t)have_ * (uint32_t)(4 * LD) + (uint32_t)(c * 256) + o_off,                    \
+                          __float_as_uint(qv[(slot_ * C + c) * 64 + lane]));                                          \
+          }                                                                                                           \
+          uint32_t in_[C];                                                                                            \
+          _Pragma("unroll") for (int c = 0; c < C; c++)                                                               \
+              in_[c] = fw_load1(dob, (uint32_t)orow_ * (uint32_t)(4 * LD) + (uint32_t)(c * 256) + o_off);             \
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                            \
+          _Pragma("unroll") for (int c = 0; c < C; c++) {                                                             \
+            asm volatile("" : "+v"(in_[c]));                                                                          \
+            ov[c] = __uint_as_float(in_[c]);                                                                          \
+          }                                                                                                           \
+          if (lane == 0) qt[slot_] = orow_;                                                                           \
+        }                                                                                                             \
+        cur_row = orow_;                                                                                              \
+        cur_slot = slot_;                                                                                             \
+      }                                                                                                               \
+      /* the row of the other side: requested LA positions ago */                                                     \
+      asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NWAIT) : "memory");                                                    \
+      _Pragma("unroll") for (int c = 0; c < C; c++) asm volatile("" : "+v"(Tr[K][c]));                                \
+      bool ok_ = true;                                                                                                \
+      _Pragma("unroll") for (int c = 0; c < C; c++) ok_ = ok_ && (uint32_t)(Tr[K][c] >> 32) == exp_;                                  \
+      if (__builtin_amdgcn_ballot_w64(ok_) != ~0ull) {       /* not there yet: probe the first granule, then read the row again */ \
+        const uint32_t rb_ = (uint32_t)rx_ * (uint32_t)(8 * LD);                                                      \
+        long long t_last_ = wall_clock64();                                                                           \
+        int spins_ = 0;                                                                                               \
+        for (;;) {                                                                                                    \
+          unsigned long long pr_ = 0ull;                                                                              \
+          fw_load2(pr_, dt, lane == 0 ? rb_ : FL_OOB);                                                                \
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(pr_)::"memory");                                                   \
+          if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(pr_ >> 32)) == exp_) {                                   \
+            _Pragma("unroll") for (int c = 0; c < C; c++) fw_load2(Tr[K][c], dt, rb_ + g_off + (uint32_t)(c * 512));  \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                          \
+            _Pragma("unroll") for (int c = 0; c < C; c++) asm volatile("" : "+v"(Tr[K][c]));                          \
+            bool t_ = true;                                                                                           \
+            _Pragma("unroll") for (int c = 0; c < C; c++) t_ = t_ && (uint32_t)(Tr[K][c] >> 32) == exp_;                              \
+            if (__builtin_amdgcn_ballot_w64(t_) == ~0ull) break;                                                      \
+          }                                                                                                           \
+          if ((++spins_ & 63) == 0) {                                                                                 \
+            if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { aborted = true; break; }       \
+            if (wall_clock64() - t_last_ > 200000000LL) {      /* 100 MHz constant clock: 2 s on one queue head */    \
+              __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                               \
+              aborted = true;                                                                                         \
+              break;                                                                                                  \
+            }                                                                                                         \
+          }                                                                                                           \
+        }                                                                                                             \
+      }                                                                                                               \
+      if (!aborted) {                                                                                                 \
+        _Pragma("unroll") for (int c = 0; c < C; c++) tv[c] = __uint_as_float((uint32_t)Tr[K][c]);                            \
+        if (own_user) {                                                                                               \
+          const float est_ = wide_dot<C>(ov, tv);                                                                     \
+          wide_axpys<C, ARITH>(ov, tv, __int_as_float(rz_), est_, lr, uReg, iReg);                                    \
+        } else {                                                                                                      \
+          const float est_ = wide_dot<C>(tv, ov);                                                                     \
+          wide_axpys<C, ARITH>(tv, ov, __int_as_float(rz_), est_, lr, uReg, iReg);                                    \
+        }                                                                                                             \
+        stbase_ = (uint32_t)rx_ * (uint32_t)(8 * LD) + g_off;                                                         \
+        ntag_ = exp_ + 1u;                                                                                            \
+      }                                                                                                               \
+    }                                                                                                                 \
+    /* the other side's row with its new tag, write-through (always C instructions), then the request for position S + LA */ \
+    _Pragma("unroll") for (int c = 0; c < C; c++)                                                                     \
+        fw_store2(dt, stbase_ == FL_OOB ? FL_OOB : stbase_ + (uint32_t)(c * 512), uint2v{__float_as_uint(tv[c]), ntag_}); \
+    {                                                                                                                 \
+      const int sn_ = s_ + LA;                                                                                        \
+      const bool ln_ = sn_ < nb && !aborted;                                                                          \
+      const int rxn_ = __builtin_amdgcn_readlane(rec.x, sn_ & 63);                                                    \
+      FW_REQUEST(K, rxn_, ln_)                                                                                        \
+    }                                                                                                                 \
+  }
+
+  while (pos < end && !aborted) {
+    const int nb = (int)min((uint32_t)NB, end - pos);
+    uint4v rb = fl_load<false>(dq, lane < nb ? (pos + (uint32_t)lane) * 16u : FL_OOB);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(rb)::"memory");
+    const int4 rec = make_int4((int)rb.x, (int)rb.y, (int)rb.z, (int)rb.w);
+#pragma unroll
+    for (int k = 0; k < LA; k++) {
+      const int rxn = __builtin_amdgcn_readlane(rec.x, k);
+      FW_REQUEST(k, rxn, k < nb)
+    }
+    // the first LA positions: behind the request of position k lie the later requests of the prologue and k full steps
+    FW_STEP(0, 0, 3 * C + 0 * P::NSTEP)
+    FW_STEP(1, 1, 2 * C + 1 * P::NSTEP)
+    FW_STEP(2, 2, 1 * C + 2 * P::NSTEP)
+    FW_STEP(3, 3, 0 * C + 3 * P::NSTEP)
+    for (int s0 = LA; s0 < nb; s0 += LA) {
+      FW_STEP(0, s0, 3 * P::NSTEP)
+      FW_STEP(1, s0 + 1, 3 * P::NSTEP)
+      FW_STEP(2, s0 + 2, 3 * P::NSTEP)
+      FW_STEP(3, s0 + 3, 3 * P::NSTEP)
+    }
+    // nothing may be in flight when the landing registers leave the pipeline (see the kernel above)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < LA; k++)
+#pragma unroll
+      for (int c = 0; c < C; c++) asm volatile("" : "+v"(Tr[k][c]));
+    pos += (uint32_t)nb;
+  }
+#undef FW_STEP
+#undef FW_REQUEST
+  // the owned rows go back to their table: the held one through its LDS slot, then every slot in use
+  if (cur_row >= 0) {
+#pragma unroll
+    for (int c = 0; c < C; c++) qv[(cur_slot * C + c) * 64 + lane] = ov[c];
+  }
+  for (int sI = 0; sI < QR; sI++) {
+    const int have = __builtin_amdgcn_readfirstlane(qt[sI]);
+    if (have >= 0) {
+#pragma unroll
+      for (int c = 0; c < C; c++) O[(int64_t)have * LD + c * 64 + lane] = qv[(sI * C + c) * 64 + lane];
     }
   }
 }
@@ -924,11 +1202,19 @@ int launch_flow_tag_lca(mfx_ctx* ctx, const mfx_sgd_opts* o, int blocks) {
   const int64_t nOth = S->own_user ? ctx->nI : ctx->nU;
   float* X = S->own_user ? ctx->V : ctx->U;          // the other side: read and written through its granule copy
   float* O = S->own_user ? ctx->U : ctx->V;          // the owned side
-  auto kern = sgd_flow_tag_kernel<L, C, ARITH>;
-  static bool attr_done = false;                     // per instantiation
-  if (!attr_done) {
+  // rows of 64 C floats: one element per lane and chunk (sgd_flow_wide_kernel; MFX_FLOW_WIDE=0 keeps the 16-lane kernel, the cross-check)
+  typedef void (*FlowKern)(const int4*, const int64_t*, uint32_t, float*, uint32_t, float*, uint32_t, int, float, float, float, unsigned*);
+  FlowKern kern = sgd_flow_tag_kernel<L, C, ARITH>;
+  int which = 0;
+  if constexpr (L == 16) {
+    static_assert(FW<C>::LDS == P::LDS && FW<C>::WGS == P::WGS && FW<C>::QR == P::QR, "the two tagged kernels share the launch shape");
+    const char* we = getenv("MFX_FLOW_WIDE");
+    if (!(we && we[0] == '0')) { kern = sgd_flow_wide_kernel<C, ARITH>; which = 1; }
+  }
+  static bool attr_done[2] = {false, false};         // per instantiation
+  if (!attr_done[which]) {
     HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, P::LDS));
-    attr_done = true;
+    attr_done[which] = true;
   }
   int per_cu = 0;
   HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, FL_WG, (size_t)P::LDS));

@@ -245,7 +245,7 @@ def test_tiled_epoch_list_is_tile_grouped_permutation():
     assert per_tile.max() <= 1.25 * per_tile.mean()        # (hashed blocks on this matrix: up to 1.5 x the mean)
 
 
-@pytest.fixture(params=["flow", "flow-ver", "flow-host", "flow-ver-host", "levels"])
+@pytest.fixture(params=["flow", "flow-narrow", "flow-ver", "flow-host", "flow-ver-host", "levels"])
 def exact_sched(request, monkeypatch):
     """the schedules behind MFX_SGD_LEVELS: dataflow (default: tagged rows + lookahead window up to K = 256; "ver": the
     version-counter kernel, MFX_FLOW_TAGGED=0; queues built on the device, or by the host statement of the same lists)
@@ -255,6 +255,8 @@ def exact_sched(request, monkeypatch):
         monkeypatch.setenv("MFX_FLOW_HOST", "1")
     if "ver" in request.param:
         monkeypatch.setenv("MFX_FLOW_TAGGED", "0")
+    if "narrow" in request.param:       # rows of 64 C floats: the 16-lane tagged kernel instead of one element per lane
+        monkeypatch.setenv("MFX_FLOW_WIDE", "0")
     return "levels" if request.param == "levels" else "flow"
 
 

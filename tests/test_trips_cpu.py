@@ -45,7 +45,17 @@ def test_trip_lists_cover_every_segment_once(checker, E, n, max_len, nwg, gpw):
     assert wmax - wmin <= 2 * longest + 1          # workgroups are cut at segment ends: within two segments of each other
 
 
+_ASM = {}
+
+
 def _device_asm(src, tmp_path):
+    if src in _ASM:
+        return _ASM[src]
+    _ASM[src] = _compile_asm(src, tmp_path)
+    return _ASM[src]
+
+
+def _compile_asm(src, tmp_path):
     out = str(tmp_path / (os.path.basename(src) + ".s"))
     cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-ffp-contract=off", "--offload-arch=gfx950", "-w", "-I" + os.path.join(ROOT, "include"),
            "-I" + os.path.join(ROOT, "matfac_amd", "csrc"), "-S", "--cuda-device-only", "-o", out, src]
@@ -87,3 +97,43 @@ def test_permlane_swaps_written_as_inline_assembly_carry_their_wait_states(tmp_p
     # and no swap outside an asm statement (the builtin is not used: the compiler merged most of the 33 calls into three)
     outside = re.sub(r";;#ASMSTART\n.*?;;#ASMEND", "", text, flags=re.S)
     assert "v_permlane32_swap" not in outside
+
+
+def test_landing_registers_of_the_tagged_replay_are_never_copied():
+    """sgd_flow_tag_kernel / sgd_flow_wide_kernel request the rows of the next LA queue positions with inline-assembly loads and
+    wait for them with counted s_waitcnt statements the compiler does not understand: for it a landing register holds its value
+    from the load statement on, so any v_mov it schedules between the load and the wait copies a register whose data has not
+    arrived.  The kernels make every landing register ONE live range (in-out operand of every load and wait; 64-bit integers
+    instead of small vectors in the wide kernel, which the compiler promoted to one moving register tuple at C = 1 -- the first GPU
+    run of that kernel computed wrong rows).  Checked on the compiled code: the loads of all steps (prologue, steady state,
+    re-reads) of one pipeline slot target the same registers, i.e. a kernel has LA x (loads per request) landing destinations plus
+    at most two scratch destinations of the probe loop."""
+    import re
+    import tempfile
+    import pathlib
+    with tempfile.TemporaryDirectory() as d:
+        text = _device_asm(os.path.join(ROOT, "matfac_amd", "csrc", "sgd_flow.hip"), pathlib.Path(d))
+    lines = text.split("\n")
+    seen = 0
+    for i, l in enumerate(lines):
+        m = re.match(r"^_ZN12_GLOBAL__N_1\d+sgd_flow_(tag|wide)_kernelILi(\d+)ELi(\d+)E(?:Li(\d+)E)?", l)
+        if not m or ":" not in l:                 # the label line of the kernel ("name:   ; @name")
+            continue
+        if m.group(1) == "tag":
+            L, C = int(m.group(2)), int(m.group(3))
+            la, per = (4 if C <= 2 else 2), 2 * C
+        else:
+            C = int(m.group(2))
+            la, per = 4, C
+        j = i
+        while not lines[j].startswith(".Lfunc_end"):
+            j += 1
+        dst = {}
+        for b in lines[i:j]:
+            k = re.match(r"\s*buffer_load_dwordx[24] (v\[\d+:\d+\]), v\d+, s\[\d+:\d+\], 0 offen sc1", b)
+            if k:
+                dst[k.group(1)] = dst.get(k.group(1), 0) + 1
+        landing = [r for r, n in dst.items() if n >= 5]
+        assert len(landing) >= la * per and len(dst) <= la * per + 2, (l[:60], sorted(dst.items()))
+        seen += 1
+    assert seen >= 30          # 7 rank shapes x 3 arithmetic modes of the 16-lane kernel, 4 x 3 of the wide one
