@@ -66,7 +66,7 @@ struct FlowState {
   // BALANCE, never for correctness, and the lists replayed over one matrix are permutations of its ratings
   uint64_t assign_gen = ~0ull;
   int64_t assign_groups = -1, assign_nU = -1, assign_nI = -1;
-  int assign_own_user = 0;
+  int assign_own_user = 0, assign_want = -2;
   int32_t assign_maxU = 0, assign_maxI = 0;
 };
 FlowState* fl(mfx_ctx* ctx) { return (FlowState*)ctx->flow; }
@@ -883,7 +883,15 @@ int build_flow(mfx_ctx* ctx, int64_t first, int64_t count, int64_t groups, bool 
   std::vector<int32_t> degU((size_t)ctx->nU, 0), degI((size_t)ctx->nI, 0);
   for (int64_t t = 0; t < count; t++) { degU[(size_t)S->hu[(size_t)t]]++; degI[(size_t)S->hi[(size_t)t]]++; }
   const int32_t maxU = *std::max_element(degU.begin(), degU.end()), maxI = *std::max_element(degI.begin(), degI.end());
-  const int own_user = maxU > maxI ? 1 : 0;
+  // owned side: as the device builder chooses it (user rows for a list that keeps a user's ratings together, else the longest chain)
+  int own_user = maxU > maxI ? 1 : 0;
+  if (const char* e = getenv("MFX_FLOW_OWN")) {
+    if (e[0] == 'u') own_user = 1; else if (e[0] == 'i') own_user = 0;
+  } else if (count > 1) {
+    int64_t au = 0, ai = 0;
+    for (int64_t t = 0; t + 1 < count; t++) { au += S->hu[(size_t)t] == S->hu[(size_t)t + 1]; ai += S->hi[(size_t)t] == S->hi[(size_t)t + 1]; }
+    if (2 * au > count) own_user = 1; else if (2 * ai > count) own_user = 0;
+  }
   const std::vector<int32_t>& degOwn = own_user ? degU : degI;
   const int32_t* hown = own_user ? S->hu.data() : S->hi.data();
   const int32_t* hoth = own_user ? S->hi.data() : S->hu.data();
@@ -970,6 +978,35 @@ __global__ void flow_degrees_kernel(const int32_t* __restrict__ eu, const int32_
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
     atomicAdd(degU + eu[t], 1);
     atomicAdd(degI + ei[t], 1);
+  }
+}
+// how often consecutive list positions share their user / their item: out[0], out[1]
+__global__ void flow_adjacent_kernel(const int32_t* __restrict__ eu, const int32_t* __restrict__ ei, int64_t n, unsigned long long* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  unsigned au = 0, ai = 0;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t + 1 < n; t += stride) {
+    au += eu[t] == eu[t + 1];
+    ai += ei[t] == ei[t + 1];
+  }
+  for (int o = 32; o > 0; o >>= 1) { au += __shfl_down(au, o, 64); ai += __shfl_down(ai, o, 64); }
+  if ((threadIdx.x & 63) == 0) { atomicAdd(out, (unsigned long long)au); atomicAdd(out + 1, (unsigned long long)ai); }
+}
+// owned rows of a list that keeps a row's visits together: first list position of every row ...
+__global__ void flow_first_kernel(const int32_t* __restrict__ rows, int64_t n, uint32_t* __restrict__ first) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride)
+    if (t == 0 || rows[t] != rows[t - 1]) atomicMin(first + rows[t], (uint32_t)t);
+}
+__global__ void flow_iota_kernel(uint32_t* __restrict__ v, int64_t n) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) v[r] = (uint32_t)r;
+}
+// ... and, the rows sorted by it, queue = rank mod groups (the rows that are at work at the same time sit in different queues),
+// LDS slot = its place in that queue mod 64; rows the list does not visit (first = ~0, at the end of the order) keep queue 0
+__global__ void flow_deal_kernel(const uint32_t* __restrict__ first_sorted, const uint32_t* __restrict__ row_sorted, int64_t n, int64_t groups,
+                                 int32_t* __restrict__ owner) {
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+    const bool used = first_sorted[k] != 0xffffffffu;
+    owner[row_sorted[k]] = used ? (int32_t)((uint32_t)(k % groups) | (uint32_t)((k / groups) & 63) << FL_SLOT_SHIFT) : 0;
   }
 }
 // key = row of `side` for every list position (or the queue of its owned row), value = the position
@@ -1081,7 +1118,50 @@ int build_flow_device(mfx_ctx* ctx, int64_t first, int64_t count, int64_t groups
   // at C2, a copy back, a host sort and a copy forth -- a third of the queue construction).  The lists replayed over one matrix are
   // permutations of its ratings (std::shuffle orders, shuffled users, the stratified rounds); for any other list (a sub-range)
   // the cached assignment is merely less balanced -- ownership, not balance, is what correctness rests on.
-  if (S->assign_gen != ctx->train_gen || S->assign_groups != groups || S->assign_nU != nU || S->assign_nI != nI) {
+  // Which side is owned.  A list that keeps the ratings of one user together (trainUShuffle's user-ordered epochs, the blocks of
+  // trainSGDPar's rounds) is a chain of back-to-back visits of that user's row: owned by ONE queue they stay in registers; with the
+  // item rows owned every one of them is a hand-off through memory between two queues, and the queues advance like one sequential
+  // sweep (measured: 5.8 s per C2 epoch of trainUShuffle, 3.4 M updates/s).  So: user rows when more than half of the consecutive
+  // list positions share their user; else the side with the longest chain (items, on rating data); MFX_FLOW_OWN=user|item forces.
+  int force_own = -1;
+  if (const char* e = getenv("MFX_FLOW_OWN")) force_own = e[0] == 'u' ? 1 : (e[0] == 'i' ? 0 : -1);
+  int adj_own = -1;
+  if (force_own < 0 && count > 1) {
+    unsigned long long* adj = (unsigned long long*)S->dstart;        // (scratch: dstart is written further down)
+    unsigned long long hadj[2] = {0, 0};
+    HIPCHK(hipMemsetAsync(adj, 0, sizeof hadj, ctx->stream));
+    hipLaunchKernelGGL(flow_adjacent_kernel, dim3(std::min(grid, 1024)), dim3(256), 0, ctx->stream, eu, ei, count, adj);
+    HIPCHK(hipMemcpyAsync(hadj, adj, sizeof hadj, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (2 * hadj[0] > (unsigned long long)count) adj_own = 1;
+    else if (2 * hadj[1] > (unsigned long long)count) adj_own = 0;
+  }
+  const int want_own = force_own >= 0 ? force_own : adj_own;          // -1: by the longest chain
+  // A list that keeps a row's visits together (adj_own >= 0) is worked off like a wave front: the rows at work at any time are
+  // CONSECUTIVE in the order of their first visit (an item's chain passes from one of them to the next).  Dealt round-robin in that
+  // order they sit in different queues; dealt by chain length (below) a queue's next row is often thousands of rows ahead of the
+  // front and its wave waits.  Per call, on the device (the order changes with every epoch); MFX_FLOW_DEAL=0 keeps the dealing by
+  // chain length.
+  const char* dealEnv = getenv("MFX_FLOW_DEAL");
+  const int64_t nOwnD = adj_own == 1 ? nU : nI;
+  const bool deal = adj_own >= 0 && want_own == adj_own && !(dealEnv && dealEnv[0] == '0') && nOwnD <= count;
+  if (deal) {
+    size_t need = 0;
+    HIPCHK(rocprim::radix_sort_pairs(nullptr, need, S->k0, S->k1, S->v0, S->v1, (size_t)nOwnD, 0, 32, ctx->stream));
+    NEED(need <= S->sort_tmp_bytes, MFX_E_STATE, "sgd dataflow: sort workspace for %lld rows exceeds the one for %lld ratings", (long long)nOwnD,
+         (long long)count);
+    const int rgrid = (int)std::min<int64_t>((nOwnD + 255) / 256, 4096);
+    HIPCHK(hipMemsetAsync(S->k0, 0xff, sizeof(uint32_t) * (size_t)nOwnD, ctx->stream));
+    hipLaunchKernelGGL(flow_first_kernel, dim3(grid), dim3(256), 0, ctx->stream, adj_own ? eu : ei, count, S->k0);
+    hipLaunchKernelGGL(flow_iota_kernel, dim3(rgrid), dim3(256), 0, ctx->stream, S->v0, nOwnD);
+    size_t bytes0 = S->sort_tmp_bytes;
+    HIPCHK(rocprim::radix_sort_pairs(S->sort_tmp, bytes0, S->k0, S->k1, S->v0, S->v1, (size_t)nOwnD, 0, 32, ctx->stream));
+    hipLaunchKernelGGL(flow_deal_kernel, dim3(rgrid), dim3(256), 0, ctx->stream, S->k1, S->v1, nOwnD, groups, S->downer);
+    HIPCHK(hipGetLastError());
+    S->assign_gen = ~0ull;                 // the cached dealing by chain length is gone from downer
+    S->assign_own_user = adj_own;
+    S->assign_maxU = S->assign_maxI = 0;   // (not looked at on this path)
+  } else if (S->assign_gen != ctx->train_gen || S->assign_groups != groups || S->assign_nU != nU || S->assign_nI != nI || S->assign_want != want_own) {
     HIPCHK(hipMemsetAsync(S->degU, 0, sizeof(int32_t) * (size_t)(nU + nI), ctx->stream));
     hipLaunchKernelGGL(flow_degrees_kernel, dim3(grid), dim3(256), 0, ctx->stream, eu, ei, count, S->degU, S->degI);
     S->hdeg.resize((size_t)(nU + nI));
@@ -1090,7 +1170,8 @@ int build_flow_device(mfx_ctx* ctx, int64_t first, int64_t count, int64_t groups
     const int32_t *hdU = S->hdeg.data(), *hdI = S->hdeg.data() + nU;
     S->assign_maxU = *std::max_element(hdU, hdU + nU);
     S->assign_maxI = *std::max_element(hdI, hdI + nI);
-    S->assign_own_user = S->assign_maxU > S->assign_maxI ? 1 : 0;      // the side with the longest chain is owned
+    S->assign_own_user = want_own >= 0 ? want_own : (S->assign_maxU > S->assign_maxI ? 1 : 0);
+    S->assign_want = want_own;
     const int32_t* degOwn = S->assign_own_user ? hdU : hdI;
     const int64_t nOwnA = S->assign_own_user ? nU : nI;
     S->owner.assign((size_t)nOwnA, 0);

@@ -1,9 +1,12 @@
 // capi.cpp -- C entry point that drives the host classes on in-memory matrices, so that the
 // parity tests (Python) can run ModelMF::train* exactly as main() would, without text files.
+#include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <numeric>
 #include <string>
 
 #include "mf_model.h"
@@ -230,3 +233,21 @@ extern "C" int mfh_train_bias(int32_t nrows, const int64_t* tr_ptr, const int32_
   return rc;
 }
 
+
+extern "C" int mfh_shuffle_check(int64_t n, uint32_t seed, double* secs) {
+  try {
+    std::vector<size_t> x((size_t)std::max<int64_t>(n, 0)), y;
+    std::iota(x.begin(), x.end(), (size_t)0);
+    y = x;
+    std::mt19937 g1(seed), g2(seed);
+    const auto t0 = std::chrono::steady_clock::now();
+    std::shuffle(x.begin(), x.end(), g1);
+    const auto t1 = std::chrono::steady_clock::now();
+    mfhShuffle(y, g2);
+    const auto t2 = std::chrono::steady_clock::now();
+    if (secs) { secs[0] = std::chrono::duration<double>(t1 - t0).count(); secs[1] = std::chrono::duration<double>(t2 - t1).count(); }
+    return x == y && g1 == g2 ? 1 : 0;
+  } catch (...) {
+    return -1;
+  }
+}

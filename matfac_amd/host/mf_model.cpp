@@ -452,6 +452,51 @@ bool Model::terminateImpl(bool sing, Model& bestModel, const Data& data, int ite
 // ---------------------------------------------------------------------------
 // ModelMF trainers
 // ---------------------------------------------------------------------------
+// ---- std::shuffle of the epoch's index list (modelMF.cpp:76-81), the same permutation in less time -----------------------------
+// The exact replay of ModelMF::train needs the reference's visiting order, i.e. libstdc++'s std::shuffle of the 16 M indices with
+// the model's mt19937 every epoch: 0.4 s on the host at the ML-20M shape, next to 19 ms for the replay itself on the GPU.  For
+// lists longer than 65 536 entries libstdc++ runs the plain loop `for i: swap(a[i], a[d(g, {0, i})])` (bits/stl_algo.h; the
+// two-positions-per-draw path covers shorter lists) and spends its time on the cache misses of a[j].  The positions depend on the
+// generator alone: they are drawn a block ahead -- same distribution object, same calls, same order -- their lines are requested,
+// and the swaps follow in order.  A self-check against std::shuffle on first use (same seed, a list just above the threshold)
+// switches this off for good on a standard library that shuffles differently.
+namespace {
+template <class T>
+void shuffleAhead(std::vector<T>& a, std::mt19937& g) {
+  const size_t n = a.size();
+  const uint64_t urngrange = (uint64_t)g.max() - (uint64_t)g.min();
+  if (n < 2 || urngrange / n >= n) { std::shuffle(a.begin(), a.end(), g); return; }
+  std::uniform_int_distribution<unsigned long> d;
+  typedef std::uniform_int_distribution<unsigned long>::param_type P;
+  constexpr size_t B = 128;
+  size_t j[B];
+  T* p = a.data();
+  for (size_t i0 = 1; i0 < n; i0 += B) {
+    const size_t m = std::min(B, n - i0);
+    for (size_t k = 0; k < m; k++) { j[k] = d(g, P(0, i0 + k)); __builtin_prefetch(p + j[k], 1); }
+    for (size_t k = 0; k < m; k++) std::swap(p[i0 + k], p[j[k]]);
+  }
+}
+bool shuffleAheadIsStd() {
+  static const bool ok = [] {
+    std::vector<size_t> x(70001), y;
+    std::iota(x.begin(), x.end(), (size_t)0);
+    y = x;
+    std::mt19937 g1(12345), g2(12345);
+    std::shuffle(x.begin(), x.end(), g1);
+    shuffleAhead(y, g2);
+    return x == y && g1 == g2;          // the same permutation AND the same generator state afterwards
+  }();
+  return ok;
+}
+}  // namespace
+// std::shuffle(a.begin(), a.end(), g) -- bit for bit, see above (MFX_STD_SHUFFLE=1: the library call itself)
+void mfhShuffle(std::vector<size_t>& a, std::mt19937& g) {
+  static const bool plain = getenv("MFX_STD_SHUFFLE") && atoi(getenv("MFX_STD_SHUFFLE")) != 0;
+  if (!plain && shuffleAheadIsStd()) shuffleAhead(a, g);
+  else std::shuffle(a.begin(), a.end(), g);
+}
+
 // ---- ModelMF::trainSGDPar's stratification (modelMF.cpp:229-265, 273-304; util.cpp:1077-1107) ------------------
 // The reference keeps every part as a std::unordered_set<int> and sweeps a block in that container's iteration order;
 // the sets are rebuilt here by the same insertion sequence (same libstdc++ => same order) and flattened once.
@@ -490,6 +535,7 @@ struct Strata {
     for (int t = 0; t < T; t++) users[(size_t)t].assign(sets[(size_t)t].begin(), sets[(size_t)t].end());
     itemPart.assign((size_t)trainMat->ncols, -1);
     for (size_t i = 0; i < trainItems.size(); i++) itemPart[(size_t)trainItems[i]] = pi[i];
+    blockList.clear();
   }
 
   // sgdUpdateBlockSeq: user parts in shuffled order, each drawing one of the item parts still free
@@ -507,16 +553,29 @@ struct Strata {
     }
   }
 
-  // CSR positions of one epoch's visits: T rounds x T blocks, a block = its users' rows restricted to its item part
+  // CSR positions of one epoch's visits: T rounds x T blocks, a block = its users' rows restricted to its item part.  The
+  // blocks' own lists do not change from epoch to epoch (only the matching does): built once (one pass over the matrix per user
+  // part), an epoch is T x T copies -- the first cut re-filtered every row T times per epoch, 0.3 s at the ML-20M shape.
+  mutable std::vector<std::vector<size_t>> blockList;   // [user part * T + item part]
+  void buildBlocks(const csr_t* trainMat) const {
+    blockList.assign((size_t)T * T, std::vector<size_t>());
+    for (int p = 0; p < T; p++)
+      for (int u : users[(size_t)p])
+        for (int64_t e = trainMat->rowptr[u]; e < trainMat->rowptr[u + 1]; e++) {
+          const int ip = itemPart[(size_t)trainMat->rowind[e]];
+          if (ip >= 0) blockList[(size_t)p * T + ip].push_back((size_t)e);
+        }
+  }
   void epochList(std::mt19937& mt, const csr_t* trainMat, std::vector<size_t>& out) const {
+    if (blockList.size() != (size_t)T * T) buildBlocks(trainMat);
     out.clear();
     std::vector<std::pair<int, int>> seq;
     for (int k = 0; k < T; k++) {
       matching(mt, seq);
-      for (const auto& blk : seq)
-        for (int u : users[(size_t)blk.first])
-          for (int64_t e = trainMat->rowptr[u]; e < trainMat->rowptr[u + 1]; e++)
-            if (itemPart[(size_t)trainMat->rowind[e]] == blk.second) out.push_back((size_t)e);
+      for (const auto& blk : seq) {
+        const std::vector<size_t>& l = blockList[(size_t)blk.first * T + blk.second];
+        out.insert(out.end(), l.begin(), l.end());
+      }
     }
   }
 };
@@ -660,7 +719,7 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
         if (exact) {
           // modelMF.cpp:76-81: std::shuffle every epoch on one thread (parBlockShuffle with one
           // OpenMP thread is a plain std::shuffle; the reference is only reproducible that way)
-          std::shuffle(uiRatingInds.begin(), uiRatingInds.end(), mt);
+          mfhShuffle(uiRatingInds, mt);
           dev->check(mfx_sgd_set_order(dev->ctx, (const uint64_t*)uiRatingInds.data(), nRatings), "set_order");
           o.mode = replayMode; o.order = MFX_ORDER_HOST;
         } else {

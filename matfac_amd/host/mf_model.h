@@ -8,10 +8,15 @@
 #include <stdexcept>
 #include <string>
 #include <unordered_set>
+#include <random>
 #include <vector>
 
 #include "mfx.h"
 #include "params_data.h"
+
+// std::shuffle(a.begin(), a.end(), g) bit for bit (same permutation, same generator state), with the swap positions drawn a block
+// ahead so that their cache lines are on the way when the swaps follow (mf_model.cpp)
+void mfhShuffle(std::vector<size_t>& a, std::mt19937& g);
 
 // constants of const.h:4-12 / modelMF.h:16-17
 #define MF_OBJ_ITER 1

@@ -48,6 +48,10 @@ int mfh_data_shape(const char* train, const char* test, const char* val, int32_t
 int mfh_mat_write(const char* path, const float* data, int32_t n, int32_t k, int32_t bin);
 int mfh_mat_read(const char* path, float* data, int32_t n, int32_t k);
 
+/* test hook: 1 when mfhShuffle (the block-ahead form of the epoch shuffle, mf_model.cpp) and std::shuffle turn the list 0 .. n-1 into
+ * the same permutation with mt19937(seed) and leave the generator in the same state; secs (may be NULL) = {std::shuffle, mfhShuffle} */
+int mfh_shuffle_check(int64_t n, uint32_t seed, double* secs);
+
 #ifdef __cplusplus
 }
 #endif

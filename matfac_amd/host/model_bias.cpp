@@ -129,7 +129,7 @@ void ModelMFBias::train(const Data& data, Model& bestModel, IntSet& invalidUsers
   o.order = MFX_ORDER_HOST;
   const auto loopStart = std::chrono::steady_clock::now();
   for (iter = 0; iter < maxIter; iter++) {
-    std::shuffle(inds.begin(), inds.end(), mt);
+    mfhShuffle(inds, mt);              // std::shuffle, bit for bit (mf_model.cpp)
     dev->check(mfx_sgd_set_order(dev->ctx, (const uint64_t*)inds.data(), nRatings), "set_order");
     o.learnRate = learnRate;
     o.epoch = iter;

@@ -234,3 +234,15 @@ def test_host_classes_report_a_missing_device_instead_of_exiting():
                        C.c_int32(1), C.c_float(0.01), C.c_float(0.01), C.c_float(0.01), None, P(bufs[0]), P(bufs[1]), None, None, None, None, None)
     assert rc == -6                      # MFX_E_NODEVICE
 
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 999, 65535, 65536, 65537, 70001, 300007, 2000003])
+def test_epoch_shuffle_is_std_shuffle_bit_for_bit(n):
+    """ModelMF::train's per-epoch std::shuffle of the index list (modelMF.cpp:76-81) is the host's largest cost next to the replay
+    on the GPU; mfhShuffle draws the swap positions a block ahead (same distribution object, same calls) and requests their cache
+    lines before the swaps follow.  Same permutation and same mt19937 state afterwards as the library call, on both of
+    libstdc++'s paths (two positions per draw up to 65 536 entries, the plain loop beyond)."""
+    lib = synth._host()
+    lib.mfh_shuffle_check.argtypes = [C.c_int64, C.c_uint32, C.POINTER(C.c_double)]
+    for seed in (1, 12345):
+        assert lib.mfh_shuffle_check(n, seed, None) == 1
