@@ -246,6 +246,7 @@ extern "C" int mfh_shuffle_check(int64_t n, uint32_t seed, double* secs) {
     mfhShuffle(y, g2);
     const auto t2 = std::chrono::steady_clock::now();
     if (secs) { secs[0] = std::chrono::duration<double>(t1 - t0).count(); secs[1] = std::chrono::duration<double>(t2 - t1).count(); }
+    if (secs) secs[2] = (double)mfhShuffleForm();
     return x == y && g1 == g2 ? 1 : 0;
   } catch (...) {
     return -1;

@@ -7,14 +7,18 @@
 #include "mf_model.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <future>
 #include <iostream>
 #include <numeric>
 #include <omp.h>
 #include <random>
+#include <sstream>
+#include <thread>
 #include <unordered_set>
 
 // ---------------------------------------------------------------------------
@@ -477,24 +481,180 @@ void shuffleAhead(std::vector<T>& a, std::mt19937& g) {
     for (size_t k = 0; k < m; k++) std::swap(p[i0 + k], p[j[k]]);
   }
 }
+// mt19937 and libstdc++'s uniform_int_distribution, restated for speed: the generator's state leaves and re-enters the std::mt19937
+// through its stream operators (libstdc++ writes the 624 words and the position), a twist tempers all 624 outputs in one
+// vectorisable loop, and the position of entry i is Lemire's multiply-shift with its rare rejection, as bits/uniform_int_dist.h
+// has it for a 32-bit generator since GCC 11 (`_S_nd`).  Only ever used behind shuffleAheadIsStd(): another library version
+// (GCC 10 divides) fails that check and the library's own calls are used.
+struct MtBulk {
+  uint32_t x[624], out[624];
+  size_t p = 624;
+  bool load(const std::mt19937& g) {
+    std::stringstream ss;
+    ss << g;
+    for (int k = 0; k < 624; k++) { unsigned long v; if (!(ss >> v)) return false; x[k] = (uint32_t)v; }
+    unsigned long pp;
+    if (!(ss >> pp) || pp > 624) return false;
+    p = pp;
+    temperAll();
+    return true;
+  }
+  bool store(std::mt19937& g) const {
+    std::stringstream ss;
+    for (int k = 0; k < 624; k++) ss << x[k] << ' ';
+    ss << p;
+    return (bool)(ss >> g);
+  }
+  void temperAll() {
+    for (int k = 0; k < 624; k++) {
+      uint32_t y = x[k];
+      y ^= y >> 11;
+      y ^= (y << 7) & 0x9d2c5680u;
+      y ^= (y << 15) & 0xefc60000u;
+      y ^= y >> 18;
+      out[k] = y;
+    }
+  }
+  void twist() {
+    constexpr uint32_t UP = 0x80000000u, LO = 0x7fffffffu, A = 0x9908b0dfu;
+    for (int k = 0; k < 624 - 397; k++) {
+      const uint32_t y = (x[k] & UP) | (x[k + 1] & LO);
+      x[k] = x[k + 397] ^ (y >> 1) ^ ((y & 1u) ? A : 0u);
+    }
+    for (int k = 624 - 397; k < 623; k++) {
+      const uint32_t y = (x[k] & UP) | (x[k + 1] & LO);
+      x[k] = x[k + (397 - 624)] ^ (y >> 1) ^ ((y & 1u) ? A : 0u);
+    }
+    const uint32_t y = (x[623] & UP) | (x[0] & LO);
+    x[623] = x[396] ^ (y >> 1) ^ ((y & 1u) ? A : 0u);
+    p = 0;
+    temperAll();
+  }
+  inline uint32_t next() {
+    if (p >= 624) twist();
+    return out[p++];
+  }
+  // d(g, param_type(0, range - 1)) of std::uniform_int_distribution<unsigned long> on std::mt19937, 1 <= range < 2^32
+  inline size_t below(uint32_t range) {
+    uint64_t product = (uint64_t)next() * (uint64_t)range;
+    uint32_t low = (uint32_t)product;
+    if (low < range) {
+      const uint32_t threshold = (0u - range) % range;
+      while (low < threshold) {
+        product = (uint64_t)next() * (uint64_t)range;
+        low = (uint32_t)product;
+      }
+    }
+    return (size_t)(product >> 32);
+  }
+};
+
+// The same on two threads for long lists: this thread draws the positions (the generator and the distribution are about half of the
+// time), a helper requests their lines and swaps -- in order, block by block, through a ring of position blocks.  fast: the
+// positions come from MtBulk instead of the library's generator and distribution objects.
+template <class T>
+void shuffleAheadPair(std::vector<T>& a, std::mt19937& g, size_t block, bool fast = false) {
+  const size_t n = a.size();
+  const uint64_t urngrange = (uint64_t)g.max() - (uint64_t)g.min();
+  if (n < 2 || urngrange / n >= n) { std::shuffle(a.begin(), a.end(), g); return; }
+  constexpr size_t RING = 8;
+  std::vector<size_t> ring(RING * block);
+  std::atomic<size_t> produced(0), consumed(0);
+  const size_t nblocks = (n - 1 + block - 1) / block;
+  T* p = a.data();
+  std::thread helper([&] {
+    for (size_t b = 0; b < nblocks; b++) {
+      while (produced.load(std::memory_order_acquire) <= b) std::this_thread::yield();
+      const size_t* j = ring.data() + (b % RING) * block;
+      const size_t i0 = 1 + b * block, m = std::min(block, n - i0);
+      constexpr size_t AHEAD = 64;
+      for (size_t k = 0; k < std::min(AHEAD, m); k++) __builtin_prefetch(p + j[k], 1);
+      for (size_t k = 0; k < m; k++) {
+        if (k + AHEAD < m) __builtin_prefetch(p + j[k + AHEAD], 1);
+        std::swap(p[i0 + k], p[j[k]]);
+      }
+      consumed.store(b + 1, std::memory_order_release);
+    }
+  });
+  std::uniform_int_distribution<unsigned long> d;
+  typedef std::uniform_int_distribution<unsigned long>::param_type P;
+  std::unique_ptr<MtBulk> bulk;
+  if (fast && n < ((size_t)1 << 32)) {
+    bulk.reset(new MtBulk);
+    if (!bulk->load(g)) bulk.reset();
+  }
+  for (size_t b = 0; b < nblocks; b++) {
+    while (b - consumed.load(std::memory_order_acquire) >= RING) std::this_thread::yield();
+    size_t* j = ring.data() + (b % RING) * block;
+    const size_t i0 = 1 + b * block, m = std::min(block, n - i0);
+    if (bulk) for (size_t k = 0; k < m; k++) j[k] = bulk->below((uint32_t)(i0 + k + 1));
+    else for (size_t k = 0; k < m; k++) j[k] = d(g, P(0, i0 + k));
+    produced.store(b + 1, std::memory_order_release);
+  }
+  helper.join();
+  if (bulk && !bulk->store(g)) throw std::runtime_error("mfhShuffle: the generator state could not be handed back");
+}
 bool shuffleAheadIsStd() {
   static const bool ok = [] {
-    std::vector<size_t> x(70001), y;
+    std::vector<size_t> x(70001), y, z;
     std::iota(x.begin(), x.end(), (size_t)0);
     y = x;
-    std::mt19937 g1(12345), g2(12345);
+    z = x;
+    std::mt19937 g1(12345), g2(12345), g3(12345);
+    g1.discard(1000); g2.discard(1000); g3.discard(1000);      // (a generator in the middle of its block of 624)
     std::shuffle(x.begin(), x.end(), g1);
     shuffleAhead(y, g2);
-    return x == y && g1 == g2;          // the same permutation AND the same generator state afterwards
+    shuffleAheadPair(z, g3, 1000);
+    return x == y && g1 == g2 && x == z && g1 == g3;          // the same permutation AND the same generator state afterwards
+  }();
+  return ok;
+}
+// ... and whether the restated generator + distribution (MtBulk) are this library's: the same, and over a range of list lengths whose
+// position ranges reject often enough to exercise the rejection loop
+bool shuffleFastIsStd() {
+  static const bool ok = [] {
+    for (size_t n : {(size_t)70001, (size_t)300007}) {
+      std::vector<size_t> x(n), z;
+      std::iota(x.begin(), x.end(), (size_t)0);
+      z = x;
+      std::mt19937 g1(777), g3(777);
+      g1.discard(n % 1000); g3.discard(n % 1000);
+      std::shuffle(x.begin(), x.end(), g1);
+      shuffleAheadPair(z, g3, 4096, true);
+      if (!(x == z && g1 == g3)) return false;
+    }
+    // the rejection path proper: ranges just above 2^31 reject half of the draws
+    std::mt19937 g1(99), g2(99);
+    MtBulk b;
+    if (!b.load(g2)) return false;
+    std::uniform_int_distribution<unsigned long> d;
+    typedef std::uniform_int_distribution<unsigned long>::param_type P;
+    for (int k = 0; k < 20000; k++) {
+      const uint32_t range = k % 3 == 0 ? 0x80000001u + (uint32_t)k : (k % 3 == 1 ? 3u + (uint32_t)k : 0xfffffff0u);
+      if (d(g1, P(0, (unsigned long)range - 1)) != b.below(range)) return false;
+    }
+    return b.store(g2) && g1 == g2;
   }();
   return ok;
 }
 }  // namespace
+// which form mfhShuffle takes for a long list: 0 std::shuffle, 1 block-ahead with the library's generator and distribution,
+// 2 block-ahead with the restated ones
+int mfhShuffleForm() {
+  if (!shuffleAheadIsStd()) return 0;
+  return shuffleFastIsStd() ? 2 : 1;
+}
 // std::shuffle(a.begin(), a.end(), g) -- bit for bit, see above (MFX_STD_SHUFFLE=1: the library call itself)
 void mfhShuffle(std::vector<size_t>& a, std::mt19937& g) {
   static const bool plain = getenv("MFX_STD_SHUFFLE") && atoi(getenv("MFX_STD_SHUFFLE")) != 0;
-  if (!plain && shuffleAheadIsStd()) shuffleAhead(a, g);
-  else std::shuffle(a.begin(), a.end(), g);
+  static const bool single = getenv("MFX_SHUFFLE_THREADS") && atoi(getenv("MFX_SHUFFLE_THREADS")) == 1;
+  if (!plain && shuffleAheadIsStd()) {
+    static const bool slowGen = getenv("MFX_SHUFFLE_LIBGEN") && atoi(getenv("MFX_SHUFFLE_LIBGEN")) != 0;
+    if (a.size() >= (size_t)1 << 20 && !single) shuffleAheadPair(a, g, 8192, !slowGen && shuffleFastIsStd());
+    else shuffleAhead(a, g);
+  } else {
+    std::shuffle(a.begin(), a.end(), g);
+  }
 }
 
 // ---- ModelMF::trainSGDPar's stratification (modelMF.cpp:229-265, 273-304; util.cpp:1077-1107) ------------------
@@ -707,6 +867,7 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
   if (!exact && (kind == K_SGD || kind == K_SGDPAR)) o.arith = MFX_ARITH_F32;
 
   double subIterDuration = 0;
+  std::future<void> nextOrder;          // K_SGD / K_HOG / K_IFW, exact replay: the shuffle of the following epoch (joins on destruction)
   const auto loopStart = std::chrono::steady_clock::now();
   for (iter = 0; iter < maxIter; iter++) {
     auto start = std::chrono::system_clock::now();
@@ -719,9 +880,15 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
         if (exact) {
           // modelMF.cpp:76-81: std::shuffle every epoch on one thread (parBlockShuffle with one
           // OpenMP thread is a plain std::shuffle; the reference is only reproducible that way)
-          mfhShuffle(uiRatingInds, mt);
-          dev->check(mfx_sgd_set_order(dev->ctx, (const uint64_t*)uiRatingInds.data(), nRatings), "set_order");
+          if (nextOrder.valid()) nextOrder.get();       // drawn while the previous epoch ran (below)
+          else mfhShuffle(uiRatingInds, mt);
+          dev->check(mfx_sgd_set_order(dev->ctx, (const uint64_t*)uiRatingInds.data(), nRatings), "set_order");   // (copied when it returns)
           o.mode = replayMode; o.order = MFX_ORDER_HOST;
+          // The next epoch's order depends on the generator alone (nothing else in this loop draws from mt): it is shuffled on a
+          // second host thread while the device replays this epoch and the objective is taken -- the shuffle is the larger of
+          // the two.  An iteration that ends the loop leaves one shuffle unused; mt is local to this function.
+          if (iter + 1 < maxIter && !getenv("MFX_NO_SHUFFLE_AHEAD"))
+            nextOrder = std::async(std::launch::async, [&uiRatingInds, &mt] { mfhShuffle(uiRatingInds, mt); });
         } else {
           o.mode = MFX_SGD_TILED; o.order = MFX_ORDER_DEVICE;   // (K_IFW: the tiled kernel's weighted variant)
         }

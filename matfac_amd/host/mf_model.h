@@ -17,6 +17,7 @@
 // std::shuffle(a.begin(), a.end(), g) bit for bit (same permutation, same generator state), with the swap positions drawn a block
 // ahead so that their cache lines are on the way when the swaps follow (mf_model.cpp)
 void mfhShuffle(std::vector<size_t>& a, std::mt19937& g);
+int mfhShuffleForm();      // 0: the library call, 1: block-ahead, 2: block-ahead with the restated generator (self-checks passed)
 
 // constants of const.h:4-12 / modelMF.h:16-17
 #define MF_OBJ_ITER 1

@@ -49,7 +49,8 @@ int mfh_mat_write(const char* path, const float* data, int32_t n, int32_t k, int
 int mfh_mat_read(const char* path, float* data, int32_t n, int32_t k);
 
 /* test hook: 1 when mfhShuffle (the block-ahead form of the epoch shuffle, mf_model.cpp) and std::shuffle turn the list 0 .. n-1 into
- * the same permutation with mt19937(seed) and leave the generator in the same state; secs (may be NULL) = {std::shuffle, mfhShuffle} */
+ * the same permutation with mt19937(seed) and leave the generator in the same state; secs (may be NULL) = {seconds of std::shuffle, of mfhShuffle,
+ * the form mfhShuffle takes: 0 library call, 1 block-ahead, 2 block-ahead with the restated generator and distribution} */
 int mfh_shuffle_check(int64_t n, uint32_t seed, double* secs);
 
 #ifdef __cplusplus

@@ -236,13 +236,18 @@ def test_host_classes_report_a_missing_device_instead_of_exiting():
 
 
 
-@pytest.mark.parametrize("n", [0, 1, 2, 999, 65535, 65536, 65537, 70001, 300007, 2000003])
+@pytest.mark.parametrize("n", [0, 1, 2, 999, 65535, 65536, 65537, 70001, 300007, 1048576, 2000003])
 def test_epoch_shuffle_is_std_shuffle_bit_for_bit(n):
     """ModelMF::train's per-epoch std::shuffle of the index list (modelMF.cpp:76-81) is the host's largest cost next to the replay
-    on the GPU; mfhShuffle draws the swap positions a block ahead (same distribution object, same calls) and requests their cache
-    lines before the swaps follow.  Same permutation and same mt19937 state afterwards as the library call, on both of
+    on the GPU; mfhShuffle draws the swap positions a block ahead (same distribution object, same calls; for long lists on a
+    second thread, from a restated mt19937 + Lemire multiply-shift that a self-check holds to the library's) and requests their
+    cache lines before the swaps follow.  Same permutation and same mt19937 state afterwards as the library call, on both of
     libstdc++'s paths (two positions per draw up to 65 536 entries, the plain loop beyond)."""
     lib = synth._host()
     lib.mfh_shuffle_check.argtypes = [C.c_int64, C.c_uint32, C.POINTER(C.c_double)]
     for seed in (1, 12345):
-        assert lib.mfh_shuffle_check(n, seed, None) == 1
+        secs = (C.c_double * 3)()
+        assert lib.mfh_shuffle_check(n, seed, secs) == 1
+    # this image's libstdc++ (GCC 11) is the one the restated generator + distribution were written against: from 2^20 entries on a
+    # second thread swaps while the first draws with them (form 2); another library would fail the self-check and report 0 or 1
+    assert secs[2] == 2.0
