@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <functional>
 #include <future>
 #include <iostream>
 #include <numeric>
@@ -734,7 +735,7 @@ struct Strata {
       matching(mt, seq);
       for (const auto& blk : seq) {
         const std::vector<size_t>& l = blockList[(size_t)blk.first * T + blk.second];
-        out.insert(out.end(), l.begin(), l.end());
+        out.insert(out.end(), l.begin(), l.end());       // (filled by an OpenMP loop instead: slower, 96 -> 159 ms per iteration)
       }
     }
   }
@@ -867,7 +868,21 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
   if (!exact && (kind == K_SGD || kind == K_SGDPAR)) o.arith = MFX_ARITH_F32;
 
   double subIterDuration = 0;
-  std::future<void> nextOrder;          // K_SGD / K_HOG / K_IFW, exact replay: the shuffle of the following epoch (joins on destruction)
+  // Exact replay: the order of an epoch depends on the generator alone (nothing else in this loop draws from mt), so the order of
+  // epoch e + 1 is made on a second host thread while the device replays epoch e and the objective is taken -- for train the
+  // shuffle is the larger of the two.  orderOfEpoch(make) leaves this epoch's order in uiRatingInds (made ahead, or now);
+  // orderAhead(), called once mfx_sgd_set_order has copied it, starts the next one.  An iteration that ends the loop leaves one
+  // order unused; mt is local to this function.  MFX_NO_SHUFFLE_AHEAD=1: everything on the calling thread.
+  std::future<void> nextOrder;          // (joins on destruction)
+  std::function<void()> makeOrder;
+  auto orderOfEpoch = [&](std::function<void()> make) {
+    makeOrder = std::move(make);
+    if (nextOrder.valid()) nextOrder.get();
+    else makeOrder();
+  };
+  auto orderAhead = [&] {
+    if (iter + 1 < maxIter && !getenv("MFX_NO_SHUFFLE_AHEAD")) nextOrder = std::async(std::launch::async, makeOrder);
+  };
   const auto loopStart = std::chrono::steady_clock::now();
   for (iter = 0; iter < maxIter; iter++) {
     auto start = std::chrono::system_clock::now();
@@ -880,15 +895,10 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
         if (exact) {
           // modelMF.cpp:76-81: std::shuffle every epoch on one thread (parBlockShuffle with one
           // OpenMP thread is a plain std::shuffle; the reference is only reproducible that way)
-          if (nextOrder.valid()) nextOrder.get();       // drawn while the previous epoch ran (below)
-          else mfhShuffle(uiRatingInds, mt);
+          orderOfEpoch([&uiRatingInds, &mt] { mfhShuffle(uiRatingInds, mt); });
           dev->check(mfx_sgd_set_order(dev->ctx, (const uint64_t*)uiRatingInds.data(), nRatings), "set_order");   // (copied when it returns)
           o.mode = replayMode; o.order = MFX_ORDER_HOST;
-          // The next epoch's order depends on the generator alone (nothing else in this loop draws from mt): it is shuffled on a
-          // second host thread while the device replays this epoch and the objective is taken -- the shuffle is the larger of
-          // the two.  An iteration that ends the loop leaves one shuffle unused; mt is local to this function.
-          if (iter + 1 < maxIter && !getenv("MFX_NO_SHUFFLE_AHEAD"))
-            nextOrder = std::async(std::launch::async, [&uiRatingInds, &mt] { mfhShuffle(uiRatingInds, mt); });
+          orderAhead();
         } else {
           o.mode = MFX_SGD_TILED; o.order = MFX_ORDER_DEVICE;   // (K_IFW: the tiled kernel's weighted variant)
         }
@@ -899,11 +909,14 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
           // modelMF.cpp:273-304: T rounds, each a fresh random matching user part -> item part; the blocks of a round
           // share no rows, so their sequential sweeps commute and ONE list (round by round, block by block) replayed in
           // order is the reference's parallel-for.  float diff, double bracket (:289-299).
-          strata.epochList(mt, trainMat, uiRatingInds);
+          orderOfEpoch([&strata, &mt, trainMat, &uiRatingInds] { strata.epochList(mt, trainMat, uiRatingInds); });
           if (!uiRatingInds.empty()) {
             dev->check(mfx_sgd_set_order(dev->ctx, (const uint64_t*)uiRatingInds.data(), (int64_t)uiRatingInds.size()), "set_order");
+            orderAhead();
             o.mode = replayMode; o.order = MFX_ORDER_HOST;
             dev->check(mfx_sgd_epoch(dev->ctx, &o), "mfx_sgd_epoch");
+          } else {
+            orderAhead();
           }
         } else {
           // default: the stratification mapped onto the chip's own strata -- user-block x item-block tiles, one L2 domain per tile
@@ -924,22 +937,27 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
         dev->check(mfx_sgd_epoch(dev->ctx, &o), "mfx_sgd_epoch");
         break;
       case K_SGDU: {
-        std::shuffle(validUsers.begin(), validUsers.end(), mt);   // modelMF.cpp:635
         if (exact) {
-          uiRatingInds.clear();
-          for (size_t u : validUsers)
-            for (int64_t e = trainMat->rowptr[u]; e < trainMat->rowptr[u + 1]; e++) uiRatingInds.push_back((size_t)e);
+          orderOfEpoch([&validUsers, &mt, trainMat, &uiRatingInds] {
+            std::shuffle(validUsers.begin(), validUsers.end(), mt);   // modelMF.cpp:635
+            uiRatingInds.clear();
+            for (size_t u : validUsers)
+              for (int64_t e = trainMat->rowptr[u]; e < trainMat->rowptr[u + 1]; e++) uiRatingInds.push_back((size_t)e);
+          });
           dev->check(mfx_sgd_set_order(dev->ctx, (const uint64_t*)uiRatingInds.data(), (int64_t)uiRatingInds.size()),
                      "set_order");
+          orderAhead();
           o.mode = replayMode; o.order = MFX_ORDER_HOST;
         } else if (getenv("MFX_SGDU_USERS_KERNEL")) {
           // one group per user, the user row kept in registers over the user's ratings (closest to the reference's
           // order; 12x slower than the tiled schedule at the ML-20M shape)
+          std::shuffle(validUsers.begin(), validUsers.end(), mt);   // modelMF.cpp:635
           dev->check(mfx_sgd_set_order(dev->ctx, (const uint64_t*)validUsers.data(), (int64_t)validUsers.size()),
                      "set_order");
           o.mode = MFX_SGD_USERS; o.order = MFX_ORDER_HOST;
         } else {
           // like train / hogTrain: the lock-free tiled schedule (the order of the users is then the kernel's business)
+          std::shuffle(validUsers.begin(), validUsers.end(), mt);   // modelMF.cpp:635 (keeps mt where the reference has it)
           o.mode = MFX_SGD_TILED; o.order = MFX_ORDER_DEVICE; o.arith = MFX_ARITH_F32;
         }
         dev->check(mfx_sgd_epoch(dev->ctx, &o), "mfx_sgd_epoch");
