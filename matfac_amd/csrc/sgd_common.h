@@ -30,14 +30,17 @@ struct Rows {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, v), rs, (uint32_t)(elt * 4), 0, AUXS);
   }
   // the same through a 32-bit BYTE offset of the row (one v_lshl_or instead of a 64-bit multiply, a narrowing and a shift) plus a
-  // constant that rides in the instruction; buffer policies only
+  // constant that the compiler folds into the instruction's 12-bit immediate offset; buffer policies only.  (The constant was first
+  // handed over as the instruction's SGPR offset: correct on every matrix of the test suite, and half-zeroed user rows on a
+  // 1.25 M x 1 M matrix at every rank above 64 -- seen as NaN in bench.py's C5 record; tests/test_fullsize_gpu.py now runs a
+  // tall matrix with learning rate 0 and wants the factors back bit for bit.)
   __device__ __forceinline__ float4v ldb(uint32_t byte, int konst) const {
     static_assert(POL != 0, "byte offsets go through the buffer descriptor");
-    return __builtin_bit_cast(float4v, __builtin_amdgcn_raw_buffer_load_b128(rs, byte, konst, AUXL));
+    return __builtin_bit_cast(float4v, __builtin_amdgcn_raw_buffer_load_b128(rs, byte + (uint32_t)konst, 0, AUXL));
   }
   __device__ __forceinline__ void stb(uint32_t byte, int konst, float4v v) const {
     static_assert(POL != 0, "byte offsets go through the buffer descriptor");
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, v), rs, byte, konst, AUXS);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, v), rs, byte + (uint32_t)konst, 0, AUXS);
   }
 };
 

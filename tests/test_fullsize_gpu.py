@@ -277,3 +277,22 @@ def test_c5_shard_shape_visits_every_rating_once_stays_finite_and_learns():
     # finite everywhere: the norms of the evaluation pass run over every row of both tables (a NaN or Inf anywhere would show)
     assert np.isfinite(ctx.objective(0.01, 0.01))
     ctx.close()
+
+
+@pytest.mark.parametrize("K", [128, 192])
+def test_tiled_epoch_with_rate_zero_leaves_a_tall_model_untouched(K):
+    """1.25 M users x 1 M items, 5 M train ratings, learning rate 0: every visit reads its rows, computes with them and writes them
+    back, so both tables must come back bit for bit.  Round 3 handed the chunk offset of a wide row (ranks above 64) to the buffer
+    instructions as their SGPR offset: right on every matrix of the suite, and on this shape a fifth of the rated users came back
+    with the second chunk of their row zeroed or garbage (NaN in bench.py's C5 record).  The constant is an immediate offset now."""
+    shape = dict(nU=1_250_000, nI=1_000_000, nnz=6_000_000, K=K)
+    d = synth.make(shape, seed=1, r0_i=0.002)
+    d["nItems"] = shape["nI"]
+    ctx, U0, V0 = _ctx(d, K)
+    ctx.sgd_epoch(0.0, 0.01, 0.01, mode=mfx.SGD_TILED, seed=1, epoch=0)
+    U, V = ctx.get_factors()
+    assert np.array_equal(U, U0) and np.array_equal(V, V0)
+    ctx.sgd_epoch(0.0025, 0.01, 0.01, mode=mfx.SGD_TILED, seed=1, epoch=1)
+    U, V = ctx.get_factors()
+    assert np.isfinite(U).all() and np.isfinite(V).all() and np.abs(U).max() < 0.1 and np.abs(V).max() < 0.5
+    ctx.close()
