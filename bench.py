@@ -303,6 +303,11 @@ def main():
     ctx.close()
     if rank == 0 and solo:
         if exact is not None:
+            if "error" not in exact:
+                try:        # (after ctx.close(): the host class opens its own context on the device)
+                    exact["host_class_loop"] = host_loop_ms(np, d, K, lr, ureg, ireg)
+                except Exception as e:              # noqa: BLE001
+                    exact["host_class_loop"] = {"error": str(e)}
             out["exact_replay"] = exact
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(np, tr, nU, nI, K, lr, ureg, ireg, args.cpu_sample)
@@ -717,7 +722,34 @@ def rmse_parity(np):
     return recs
 
 
+def host_loop_ms(np, d, K, lr, ureg, ireg):
+    """ModelMF::train end to end through the host class (libmfhost.so): what one iteration of the reference's loop costs a caller --
+    the epoch's std::shuffle order drawn on the host (bit-identical to the library's, mf_model.cpp), its upload, the replay on the
+    device and Model::isTerminateModel.  Steady state = (9 iterations - 3 iterations) / 6."""
+    import ctypes as C
+    from matfac_amd import synth
+    if not all(k in d for k in ("train", "val", "test")):
+        return {"error": "the workload has no val / test split"}
+    cfg = {"K": K, "lr": lr, "ureg": ureg, "ireg": ireg}
+    t = {}
+    for iters in (3, 9):
+        cfg["maxIter"] = iters
+        stats = host_train_stats(C, np, synth, d, cfg, {})
+        t[iters] = (float(stats[6]), int(stats[7]))
+    if t[9][1] <= t[3][1]:
+        return {"error": "the loops ended after %d and %d iterations" % (t[3][1], t[9][1])}
+    ms = (t[9][0] - t[3][0]) / (t[9][1] - t[3][1]) * 1e3
+    nnz = d["train"].nnz
+    return {"trainer": "ModelMF::train (order replay, the default up to 32 M train ratings)", "ms_per_iteration": ms,
+            "updates_per_s": nnz / (ms * 1e-3), "includes": "host shuffle of the epoch's order (a thread ahead), upload of the order, "
+            "replay, objective + validation RMSE and the termination rule of every iteration"}
+
+
 def host_train_rmse(C, np, synth, d, cfg, env):
+    return float(host_train_stats(C, np, synth, d, cfg, env)[1])
+
+
+def host_train_stats(C, np, synth, d, cfg, env):
     """ModelMF::train through libmfhost.so (mfh_train): best-validation model's test RMSE.  (The class prints the reference's
     per-iteration lines on stdout; bench.py has already pointed stdout at stderr.)"""
     lib = synth._host()
@@ -744,7 +776,7 @@ def host_train_rmse(C, np, synth, d, cfg, env):
                 os.environ[k] = v
     if rc != 0:
         raise RuntimeError("mfh_train returned %d" % rc)
-    return float(stats[1])
+    return stats
 
 
 if __name__ == "__main__":
