@@ -425,8 +425,8 @@ int mfx_slots_build_device(mfx_ctx* ctx, SlotList* S, int rows, int side, const 
       (rc = dev_alloc(ctx, &S->slot_ibeg, (size_t)nslots + 1)) || (rc = dev_alloc(ctx, &S->tile_slot, (size_t)NTILE + 1)))
     return rc;
   if (!S->ctr) {     // [NTILE] slot counters, barrier counter, abort flag, and the STICKY abort flag (zeroed here, cleared only when reported)
-    if ((rc = dev_alloc(ctx, &S->ctr, (size_t)NTILE + 3))) return rc;
-    HIPCHK(hipMemsetAsync(S->ctr, 0, (NTILE + 3) * sizeof(unsigned), ctx->stream));
+    if ((rc = dev_alloc(ctx, &S->ctr, (size_t)CTR_WORDS))) return rc;
+    HIPCHK(hipMemsetAsync(S->ctr, 0, CTR_WORDS * sizeof(unsigned), ctx->stream));
   }
   static_assert(NTILE + 1 <= TB, "tile_slot is written by the first workgroup");
   hipLaunchKernelGGL(slot_heads_kernel, dim3(grid_for(R)), dim3(TB), 0, st, head, hs, dst, R, nslots, nnz, trun, NTILE,

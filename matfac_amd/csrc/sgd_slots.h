@@ -32,6 +32,9 @@ __host__ __device__ static inline int slot_user_block(int32_t u) {
   return (int)(mfx_mix32((uint32_t)u * 0x9e3779b1U + 0x1234567U) & (uint32_t)(NUB - 1));
 }
 constexpr int WG = 1024;      // threads per workgroup: 16 waves = 64 ratings in flight on one slot
+// SlotList::ctr: [0, NTILE) slots pulled per tile | [NTILE] barrier counter of the drain | [NTILE + 1] abort flag | [NTILE + 2] the
+// STICKY abort flag (not cleared per epoch) | [CTR_DONE, CTR_DONE + NTILE) slots FINISHED per tile (the one-launch epoch's hand-off)
+constexpr int CTR_DONE = NTILE + 4, CTR_WORDS = CTR_DONE + NTILE;
 
 struct SlotList {
   int32_t* rec = nullptr;          // int4 per rating: other-side index, local owned index, rating bits, owned index
@@ -60,6 +63,8 @@ struct SlotState {
   SlotList side[2];
   uint32_t last_k0 = 0, last_k1 = 0;
   int last_side = 0, last_part = -1;       // last_part >= 0: the last epoch ran on parts[last_part]
+  int xcc_probe_blocks = -1;               // mfx_xcc_ids_populated: the grid size probed last and what it found
+  bool xcc_probe_ok = false;
   // item parts: the train ratings grouped by part (COO copy, part p = [poff[p], poff[p+1])) and one slot list per part
   int nparts = 0;
   int32_t *pu = nullptr, *pi = nullptr;
@@ -77,6 +82,10 @@ __device__ __forceinline__ int64_t slot_perm(int64_t t, int64_t R, uint32_t k0, 
   return mfx_perm_index(t, R, ab, bits - ab, k0, k1);
 }
 
+// Does a grid of `blocks` 1024-thread workgroups put at least 8 workgroups on each of the eight XCC ids (HW_REG_XCC_ID)?  Probed once per
+// context and grid size with a kernel that does nothing else; the one-launch epoch needs it (a partition mode that reports one
+// id would leave seven neighbours that never finish).
+bool mfx_xcc_ids_populated(mfx_ctx* ctx, int blocks, int* rc);
 // the kernel launchers, one per rank shape (sgd_slots_inst_<L>x<C>.hip)
 #define MFX_SLOTS_DECL(LL, CC) \
   int mfx_slots_launch_##LL##x##CC(mfx_ctx* ctx, SlotList* S, int side, const mfx_sgd_opts* o, int blocks, uint32_t k0, uint32_t k1);

@@ -47,6 +47,34 @@ void mfx_slots_free_internal(mfx_ctx* ctx) {
   ctx->slots = nullptr;
 }
 
+__global__ __launch_bounds__(WG) void xcc_probe_kernel(unsigned* __restrict__ count) {
+  if (threadIdx.x == 0) atomicAdd(&count[__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7], 1u);   // HW_REG_XCC_ID[3:0]
+}
+bool mfx_xcc_ids_populated(mfx_ctx* ctx, int blocks, int* rc) {
+  *rc = MFX_OK;
+  SlotState* st = state(ctx);
+  if (st->xcc_probe_blocks == blocks) return st->xcc_probe_ok;
+  unsigned* d = nullptr;
+  unsigned h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if ((*rc = dev_alloc(ctx, &d, (size_t)8))) return false;
+  auto fail = [&](hipError_t e) { if (e != hipSuccess) { *rc = mfx_fail(ctx, MFX_E_HIP, "XCC probe: %s", hipGetErrorString(e)); } return e != hipSuccess; };
+  if (fail(hipMemsetAsync(d, 0, sizeof h, ctx->stream))) { dev_free(d); return false; }
+  hipLaunchKernelGGL(xcc_probe_kernel, dim3(blocks), dim3(WG), 0, ctx->stream, d);
+  if (fail(hipGetLastError()) || fail(hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, ctx->stream)) || fail(hipStreamSynchronize(ctx->stream))) {
+    dev_free(d);
+    return false;
+  }
+  dev_free(d);
+  bool ok = true;
+  for (int x = 0; x < 8; x++) ok = ok && h[x] >= 8;
+  if (getenv("MFX_DEBUG"))
+    fprintf(stderr, "[mfx] XCC ids of a %d-workgroup grid: %u %u %u %u %u %u %u %u -> one-launch epoch %s\n", blocks, h[0], h[1], h[2], h[3], h[4],
+            h[5], h[6], h[7], ok ? "on" : "off");
+  st->xcc_probe_blocks = blocks;
+  st->xcc_probe_ok = ok;
+  return ok;
+}
+
 // ---------------------------------------------------------------------------
 // slot lists (once per train matrix and rank shape)
 // ---------------------------------------------------------------------------
@@ -164,8 +192,8 @@ static int build_slots(mfx_ctx* ctx, SlotList* S, int rows, int side, const Rati
   if ((rc = up(ctx, &S->slot_items, slot_items))) return rc;
   if ((rc = up(ctx, &S->tile_slot, tile_slot))) return rc;
   if (!S->ctr) {
-    if ((rc = dev_alloc(ctx, &S->ctr, (size_t)NTILE + 3))) return rc;
-    HIPCHK(hipMemsetAsync(S->ctr, 0, (NTILE + 3) * sizeof(unsigned), ctx->stream));      // [NTILE + 2]: the sticky abort flag
+    if ((rc = dev_alloc(ctx, &S->ctr, (size_t)CTR_WORDS))) return rc;
+    HIPCHK(hipMemsetAsync(S->ctr, 0, CTR_WORDS * sizeof(unsigned), ctx->stream));      // [NTILE + 2]: the sticky abort flag
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (getenv("MFX_DEBUG")) {

@@ -259,7 +259,20 @@ struct SlotSteps {
 constexpr int DRAIN_WGS = 128;        // at most; the launch takes what is resident on THIS device (launch_slots)
 // ALLW: every wave of the workgroup takes part (compile-time chunk stride; a run-time stride cost 3.6 % at C2 -- measured A/B on one
 // box: 19.2 vs 19.9 G updates/s); otherwise `aw` waves do (small tiles, see mfx_launch_sgd_tiled).
-template <int L, int C, int ARITH, bool SWEEP, bool OWN_U, int VAR, bool ALLW = false>
+//
+// PERSIST (round 3, an experiment that did not pay: MFX_SGD_PERSIST=1): the eight rounds in ONE launch.  A round only needs its NEIGHBOUR: in round r XCD x owns item block (x + r) mod 8,
+// which XCD x + 1 owned in round r - 1, and user block x, which is its own throughout.  So the workgroups on XCD x walk the rounds
+// by themselves and wait, before round r, until every slot of XCD x + 1's round r - 1 tile is FINISHED (ctr[CTR_DONE + tile] ==
+// slots of the tile; a finished slot = its item rows written through and acknowledged).  No kernel boundary between rounds (nine
+// boundaries were 4-5 % of an epoch), and an XCD that is slower in one round (the tiles of a diagonal differ by a few per cent, and
+// so do the XCDs) no longer holds the other seven back: only its neighbour, and only if it runs out of slack.  The item rows change
+// XCD between rounds, so their staging loads and write-backs go through memory (sc1: L1-bypass loads, write-through stores -- 2 x
+// 7 MB per round at C2); the user rows stay in the XCD's L2 as before.  Needs every workgroup resident and all eight XCC ids
+// populated (launch_slots checks both, else the eight launches); a waiter that sees no progress for 2 s raises the abort flags.
+// Measured at C2: 19.2 G updates/s against 20.9 for the eight launches, with the acknowledgements waited for per slot or per tile
+// alike -- an XCD still waits for ALL of its neighbour's previous tile (the same tail as a kernel boundary), and staging the item rows
+// through memory costs more than the nine boundaries did.  What would pay is a hand-off per item row, not per tile.
+template <int L, int C, int ARITH, bool SWEEP, bool OWN_U, int VAR, bool ALLW = false, bool PERSIST = false>
 __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kernel(const int4* __restrict__ rec,
                                                            const int64_t* __restrict__ slot_beg,
                                                            const int32_t* __restrict__ slot_ibeg,
@@ -268,7 +281,9 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
                                                            int round, float* Oth, float* Own, uint32_t obytes,
                                                            float lr, float uReg, float iReg, uint32_t k0,
                                                            uint32_t k1, const int32_t* __restrict__ attr,
-                                                           unsigned* __restrict__ visit, int tile_only, int one, int aw) {
+                                                           unsigned* __restrict__ visit, int tile_only, int one, int aw,
+                                                           uint32_t ownbytes) {
+  static_assert(!PERSIST || (!SWEEP && SUB == 1), "the one-launch epoch walks the eight XCD rounds");
   constexpr int G = 64 / L;
   constexpr int LD = 4 * L * C;
   constexpr int LD4 = LD / 4;
@@ -277,6 +292,7 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
   __shared__ int s_slot, s_bad;
   // Oth: the lock-free side (user rows when item rows are owned, and vice versa); Own: staged in LDS
   const Rows<SWEEP ? 1 : 3> Um(Oth, obytes);
+  const Rows<PERSIST ? 1 : 0> Om(Own, ownbytes);     // the owned rows' table: staging loads and write-backs of a slot
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane / L, j = lane % L;
   const int xcc = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7);  // HW_REG_XCC_ID[3:0]
@@ -305,17 +321,42 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
     }
     if (!left) return;
   }
-  const int r_end = drain ? NUB : round + 1;
-  for (int rr = drain ? 0 : round; rr < r_end; rr++) {
+  const int r_end = (drain || PERSIST) ? NUB : round + 1;
+  for (int rr = (drain || PERSIST) ? 0 : round; rr < r_end; rr++) {
     const int tile = (SWEEP && tile_only >= 0) ? tile_only : (x * SUB + rr % SUB) * 8 + ((x + rr / SUB) & 7);
     const int s0 = tile_slot[tile], ns = tile_slot[tile + 1] - s0;
     bool skip = false;
+    if (PERSIST && rr > 0) {
+      // this round's item block was XCD x + 1's in the round before: wait until all of that tile's slots are finished
+      const int dep = ((x + 1) & 7) * 8 + ((x + rr) & 7);
+      const unsigned need = (unsigned)(tile_slot[dep + 1] - tile_slot[dep]);
+      if (tid == 0) {
+        int ab = 0;
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(&ctr[CTR_DONE + dep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+          __builtin_amdgcn_s_sleep(2);
+          if (__hip_atomic_load(&ctr[NTILE + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ab = 1; break; }
+          if (wall_clock64() - t0 > 200000000LL) {           // 100 MHz constant clock: 2 s
+            __hip_atomic_store(&ctr[NTILE + 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctr[NTILE + 2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ab = 1;
+            break;
+          }
+        }
+        s_bad = ab;
+      }
+      __syncthreads();
+      const bool ab = s_bad != 0;
+      __syncthreads();
+      if (ab) return;
+    }
     if (SWEEP) {  // nothing left in this tile: do not queue on its counter
       if (tid == 0) s_slot = (int)__hip_atomic_load(&ctr[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __syncthreads();
       skip = s_slot >= ns;
       __syncthreads();
     }
+    unsigned mine = 0;          // PERSIST: slots of this tile this workgroup has worked off
     while (!skip) {
       if (tid == 0) { s_slot = (int)atomicAdd(&ctr[tile], 1u); s_bad = 0; }
       __syncthreads();
@@ -335,7 +376,7 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
 #if MFX_EXP == 7
         const float4v v = __builtin_nontemporal_load((const float4v*)(Own + (int64_t)slot_items[ib + row] * LD + 4 * c4));
 #else
-        const float4v v = *(const float4v*)(Own + (int64_t)slot_items[ib + row] * LD + 4 * c4);
+        const float4v v = Om.ld((int64_t)slot_items[ib + row] * LD + 4 * c4);
 #endif
 #pragma unroll
         for (int e = 0; e < 4; e++) mybad |= !(__builtin_fabsf(v[e]) <= FIX_MAX);   // also true for NaN
@@ -409,12 +450,12 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
       for (int x = tid; x < ni * LD4; x += WG) {
         const int row = x / LD4, c4 = x % LD4;
         const int4 qi = q4[x];
-        float* vrow = Own + (int64_t)slot_items[ib + row] * LD + 4 * c4;
+        const int64_t vrow = (int64_t)slot_items[ib + row] * LD + 4 * c4;
         float4v v;
         if (fix) {
           // new row = staged fp32 row + the accumulated fixed-point delta: an untouched row is
           // written back bit for bit, a touched one carries only the rounding of its updates
-          const float4v v0 = *(const float4v*)vrow;
+          const float4v v0 = Om.ld(vrow);
           const int lim = 0x7f000000;   // |q| beyond ~127: the row left the fixed-point range => diverged
           const float nanv = __builtin_nanf("");
           const int qa[4] = {qi.x, qi.y, qi.z, qi.w};
@@ -426,9 +467,17 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
         } else {
           v = __builtin_bit_cast(float4v, qi);
         }
-        *(float4v*)vrow = v;
+        Om.st(vrow, v);
       }
       __syncthreads();
+      if (PERSIST) mine++;
+    }
+    if (PERSIST && mine) {
+      // the slots this workgroup took from the tile are FINISHED when every wave's write-through stores are acknowledged (their rows
+      // may change XCD then); waited for once per tile, not per slot -- the acknowledgements of a slot arrive while the next is at work
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(&ctr[CTR_DONE + tile], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // the next diagonal re-owns these item rows from other workgroups (other XCDs): L2 write-back, barrier, invalidate
     if (drain && rr + 1 < r_end && grid_barrier<0>(ctr + NTILE, (unsigned)(rr + 2) * gridDim.x)) {
@@ -459,20 +508,48 @@ static int launch_slots(mfx_ctx* ctx, SlotList* S, const mfx_sgd_opts* o, int bl
     for (int tile = 0; tile < NTILE; tile++)
       hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, true, OWN_U, VAR>), dim3(1), dim3(WG), 0, ctx->stream,
                          (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->tile_slot, S->ctr, 0,
-                         oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1, at, visit, tile, 1, 1);
+                         oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1, at, visit, tile, 1, 1, 0u);
     HIPCHK(hipGetLastError());
     return MFX_OK;
   }
-  for (int round = 0; round < NUB && !(o->flags & MFX_SGD_F_DRAIN_ONLY); round++) {
+  // the eight rounds in one launch (PERSIST, see the kernel) -- an EXPERIMENT, MFX_SGD_PERSIST=1: measured 8 % slower than the eight
+  // launches at C2 (19.2 vs 20.9 G updates/s on one box).  Needs the plain update with all waves at work, every workgroup resident,
+  // all eight XCC ids populated by this grid, the owned table within a buffer descriptor's reach.
+  bool persist = false;
+  if constexpr (VAR == 0 && SUB == 1) {
+    const uint64_t ownb = (uint64_t)(OWN_U ? ctx->nU : ctx->nI) * ctx->ld * 4;
+    const char* pe = getenv("MFX_SGD_PERSIST");
+    if (S->active_waves == WG / 64 && ownb < (1ull << 32) && pe && pe[0] == '1' && !(o->flags & MFX_SGD_F_DRAIN_ONLY)) {
+      static int resident = -1;                          // per instantiation: workgroups of the persistent kernel the device holds
+      if (resident < 0) {
+        int per_cu = 0, dev = 0, cus = 0;
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sgd_slots_kernel<L, C, ARITH, false, OWN_U, VAR, true, true>, WG, 0));
+        HIPCHK(hipGetDevice(&dev));
+        HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        resident = std::max(0, per_cu) * std::max(0, cus);
+      }
+      int rc = 0;
+      persist = blocks <= resident && mfx_xcc_ids_populated(ctx, blocks, &rc);
+      if (rc) return rc;
+    }
+    if (persist) {
+      HIPCHK(hipMemsetAsync(S->ctr + CTR_DONE, 0, NTILE * sizeof(unsigned), ctx->stream));
+      ProfScope ps(ctx, MFX_K_SGD);
+      hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, false, OWN_U, VAR, true, true>), dim3(blocks), dim3(WG), 0, ctx->stream,
+                         (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->tile_slot, S->ctr, 0,
+                         oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1, at, visit, -1, 0, S->active_waves, (uint32_t)ownb);
+    }
+  }
+  for (int round = 0; round < NUB && !persist && !(o->flags & MFX_SGD_F_DRAIN_ONLY); round++) {
     ProfScope ps(ctx, MFX_K_SGD);
     if (S->active_waves == WG / 64)
       hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, false, OWN_U, VAR, true>), dim3(blocks), dim3(WG), 0, ctx->stream,
                          (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->tile_slot, S->ctr, round,
-                         oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1, at, visit, -1, 0, S->active_waves);
+                         oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1, at, visit, -1, 0, S->active_waves, 0u);
     else
       hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, false, OWN_U, VAR, false>), dim3(blocks), dim3(WG), 0, ctx->stream,
                          (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->tile_slot, S->ctr, round,
-                         oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1, at, visit, -1, 0, S->active_waves);
+                         oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1, at, visit, -1, 0, S->active_waves, 0u);
   }
   {
     // the drain: one launch; the same diagonals keyed on the workgroup index (an item row keeps a single owner).  Its grid
@@ -492,7 +569,7 @@ static int launch_slots(mfx_ctx* ctx, SlotList* S, const mfx_sgd_opts* o, int bl
     ProfScope ps(ctx, MFX_K_SGD_SWEEP);
     hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, true, OWN_U, VAR>), dim3(drain_wgs), dim3(WG), 0, ctx->stream,
                        (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->tile_slot, S->ctr, 0,
-                       oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1, at, visit, -1, 0, S->active_waves);
+                       oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1, at, visit, -1, 0, S->active_waves, 0u);
   }
   HIPCHK(hipGetLastError());
   // a drain whose barrier gave up (2 s without progress: the device is shared with another resident kernel) leaves a STICKY

@@ -83,6 +83,36 @@ def test_tiled_conflict_free_batch_matches_oracle(K, arith, n):
     assert visits.size == n and np.all(visits == 1)                        # as counted by the update loop itself
 
 
+@pytest.mark.parametrize("K", [64, 128])
+def test_tiled_one_launch_epoch_visits_every_rating_once_and_matches_the_oracle(K, monkeypatch):
+    """MFX_SGD_PERSIST=1 (an experiment, slower than the eight launches): the eight XCD rounds in one launch, an XCD waiting for
+    its neighbour's previous tile through per-tile counters of finished slots, item rows staged through memory.  Same bar as the
+    default path: every rating once (as counted by the update loop), the oracle's factors on a conflict-free batch."""
+    monkeypatch.setenv("MFX_SGD_PERSIST", "1")
+    n = 2048 * 4 + 808
+    tr = _conflict_free_matrix(n, K, seed=K + 5)
+    rng = np.random.default_rng(300 + K)
+    U0 = rng.normal(0, 0.3, (n, K)).astype(np.float32)
+    V0 = rng.normal(0, 0.3, (n, K)).astype(np.float32)
+    with Ctx(0) as ctx:
+        ctx.set_csr(mfx.MAT_TRAIN, n, n, tr.rowptr, tr.rowind, tr.rowval)
+        ctx.set_model(n, n, K)
+        ctx.set_factors(U0, V0)
+        for ep in range(2):
+            ctx.sgd_epoch(0.0, 0.05, 0.02, mode=mfx.SGD_TILED, order=mfx.ORDER_DEVICE, arith=mfx.ARITH_F32, seed=3, epoch=ep,
+                          flags=mfx.SGD_F_COUNT_VISITS)
+            visits = ctx.debug_visit_counts()
+            assert visits.size == n and np.all(visits == 1)
+        U, V = ctx.get_factors()
+        assert np.array_equal(U, U0) and np.array_equal(V, V0)          # rate 0, twice: both tables untouched
+        ctx.sgd_epoch(0.01, 0.05, 0.02, mode=mfx.SGD_TILED, order=mfx.ORDER_DEVICE, arith=mfx.ARITH_F32, seed=3, epoch=2)
+        U, V = ctx.get_factors()
+    Uo, Vo = U0.copy(), V0.copy()
+    orc.sgd_pass(Uo, Vo, tr.rowids(), tr.rowind, tr.rowval, None, 0.01, 0.05, 0.02, orc.ARITH_F32, orc.DOT_TREE)
+    assert np.abs(V - Vo).max() <= 2.0e-7 and np.abs(U - Uo).max() <= 2.0e-7
+    assert np.abs(V - V0).max() > 1e-3
+
+
 @pytest.mark.parametrize("K", [10, 64, 256])
 def test_tiled_drain_launch_alone_runs_a_whole_epoch(K):
     """MFX_SGD_F_DRAIN_ONLY: no XCD-scheduled rounds, the drain launch (diagonals keyed on the workgroup index, grid
