@@ -257,6 +257,13 @@ struct SlotSteps {
 // It also carries the two test hooks of include/mfx.h: `tile_only` >= 0 restricts a launch to that tile and `one`
 // makes ONE lane group visit a slot's ratings one at a time (MFX_SGD_F_ONE_GROUP).
 constexpr int DRAIN_WGS = 128;        // at most; the launch takes what is resident on THIS device (launch_slots)
+// one wave: did the rounds leave a slot anywhere?  -> ctr[NTILE + 3]
+static __global__ void slots_left_kernel(const int32_t* __restrict__ tile_slot, unsigned* __restrict__ ctr) {
+  const int t = threadIdx.x;
+  const bool left = t < NTILE && ctr[t] < (unsigned)(tile_slot[t + 1] - tile_slot[t]);
+  const unsigned long long any = __builtin_amdgcn_ballot_w64(left);
+  if (t == 0) ctr[NTILE + 3] = any != 0ull ? 1u : 0u;
+}
 // ALLW: every wave of the workgroup takes part (compile-time chunk stride; a run-time stride cost 3.6 % at C2 -- measured A/B on one
 // box: 19.2 vs 19.9 G updates/s); otherwise `aw` waves do (small tiles, see mfx_launch_sgd_tiled).
 //
@@ -306,7 +313,10 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
   unsigned exp_slots = 0, exp_ratings = 0;
 #endif
   if (drain) {
-    // anything left anywhere?  (ctr[NTILE], ctr[NTILE + 1]: barrier counter and abort flag, zeroed with the counters)
+    // anything left anywhere?  slots_left_kernel has looked (ctr[NTILE + 3], written behind the rounds and in front of this launch):
+    // normally nothing is, and the drain costs a launch without a grid barrier (with the barrier: 18 us of a 950 us epoch at C2)
+    if (__hip_atomic_load(&ctr[NTILE + 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+    // (ctr[NTILE], ctr[NTILE + 1]: barrier counter and abort flag, zeroed with the counters)
     if (tid == 0) s_bad = 0;
     __syncthreads();
     if (tid < NTILE && __hip_atomic_load(&ctr[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(tile_slot[tid + 1] - tile_slot[tid]))
@@ -567,6 +577,8 @@ static int launch_slots(mfx_ctx* ctx, SlotList* S, const mfx_sgd_opts* o, int bl
       else drain_wgs = fit;
     }
     ProfScope ps(ctx, MFX_K_SGD_SWEEP);
+    static_assert(NTILE <= 64, "slots_left_kernel looks at the tiles with one wave");
+    hipLaunchKernelGGL(slots_left_kernel, dim3(1), dim3(64), 0, ctx->stream, (const int32_t*)S->tile_slot, S->ctr);
     hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, true, OWN_U, VAR>), dim3(drain_wgs), dim3(WG), 0, ctx->stream,
                        (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->tile_slot, S->ctr, 0,
                        oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1, at, visit, -1, 0, S->active_waves, 0u);
