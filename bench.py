@@ -319,6 +319,10 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     sys.stdout.flush()
+    try:
+        os.write(2, b"\n")          # (the host classes end their last line without a newline: keep the JSON at a line start for 2>&1 readers)
+    except OSError:
+        pass
     os.dup2(saved_stdout, 1)
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -38,7 +38,7 @@ for k, cs in vals.items():
     summary[k] = e
 # updates one launch of the round kernel processed in the profiled command (its JSON line is the last line of trace.log)
 try:
-    line = [l for l in open(os.path.join(out, "trace.log")) if l.startswith("{")][-1]
+    line = [l[l.index('{"metric"'):] for l in open(os.path.join(out, "trace.log")) if '{"metric"' in l][-1]
     upl = json.loads(line)["roofline"]["updates_per_launch"]
     for k in ("sgd_slots_kernel", "sgd_hogwild_kernel"):
         if k in summary:
