@@ -667,11 +667,11 @@ def bench_c5_shard(np):
                                     "user row serves several ratings of a tile from L2: fewer bytes cross the memory side than the model counts"},
             "compulsory_bytes_per_step": compulsory}
     try:   # bytes that really crossed the L2's memory side, from the committed PMC passes of scripts/c5_shard.py (scripts/pmc_c5.sh)
-        c = json.load(open(os.path.join(ROOT, "profiles", "r02_c5_pmc.json")))
+        c = json.load(open(os.path.join(ROOT, "profiles", "r03_c5_pmc.json")))
         traffic = c["hbm_bytes_per_launch"] * (tr.nnz / 8.0) / c["updates_per_launch"]
         ach = traffic / (launch_ms * 1e-3) / 1e9
         roof.update({"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                     "traffic_source": "profiles/r02_c5_pmc.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per round launch, separate "
+                     "traffic_source": "profiles/r03_c5_pmc.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per round launch, separate "
                                        "--pmc passes of the same workload; launch time from this run's HIP events",
                      "l2_hit_rate": c.get("l2_hit_rate")})
     except Exception:                             # noqa: BLE001 -- no committed counters: only the model line

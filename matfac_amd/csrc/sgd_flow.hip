@@ -48,7 +48,8 @@ struct FlowState {
   std::vector<uint32_t> hpos, hver;
   std::vector<int64_t> hoff;
   // device-side construction (build_flow_device): sort buffers, per-row tables
-  uint32_t *k0 = nullptr, *k1 = nullptr, *v0 = nullptr, *v1 = nullptr, *vert = nullptr;
+  uint32_t *k0 = nullptr, *k1 = nullptr, *v0 = nullptr, *v1 = nullptr;
+  int4* pack = nullptr;               // device builder: the queue record of every list position, in list order
   char* sort_tmp = nullptr;
   size_t sort_tmp_bytes = 0;
   int64_t dcap = 0;
@@ -1018,23 +1019,29 @@ __global__ void flow_keys_kernel(const int32_t* __restrict__ rows, const int32_t
     val[t] = (uint32_t)t;
   }
 }
-// sorted by other-side row (stable: list order inside a row): rank of position v1[k] in its row's chain = k - start[row]
-__global__ void flow_rank_kernel(const uint32_t* __restrict__ k1, const uint32_t* __restrict__ v1, const int64_t* __restrict__ start, int64_t n,
-                                 uint32_t* __restrict__ vert) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) vert[v1[k]] = (uint32_t)(k - start[k1[k]]);
-}
-// owner != NULL (tagged schedule): the LDS slot of the owned row rides in the top six bits of .y
-__global__ void flow_gather2_kernel(const uint32_t* __restrict__ lpos, const uint32_t* __restrict__ vert, int64_t n, const int32_t* __restrict__ eu,
-                                    const int32_t* __restrict__ ei, const float* __restrict__ er, int own_user, const int32_t* __restrict__ owner,
-                                    int4* __restrict__ q) {
+// the queue record of every list position, in LIST order (sequential reads and writes): {other-side row, owned row | LDS slot << 26,
+// rating bits, 0}; owner != NULL (tagged schedule): the LDS slot of the owned row rides in the top six bits of .y
+__global__ void flow_pack_kernel(const int32_t* __restrict__ eu, const int32_t* __restrict__ ei, const float* __restrict__ er, int64_t n, int own_user,
+                                 const int32_t* __restrict__ owner, int4* __restrict__ pack) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
-    const uint32_t s = lpos[t];
-    const int u = eu[s], i = ei[s];
+    const int u = eu[t], i = ei[t];
     const uint32_t slot = owner ? (uint32_t)owner[own_user ? u : i] >> FL_SLOT_SHIFT : 0u;
-    q[t] = make_int4(own_user ? i : u, (int)((uint32_t)(own_user ? u : i) | slot << FL_SLOT_SHIFT), __float_as_int(er[s]), (int)vert[s]);
+    pack[t] = make_int4(own_user ? i : u, (int)((uint32_t)(own_user ? u : i) | slot << FL_SLOT_SHIFT), __float_as_int(er[t]), 0);
   }
+}
+// sorted by other-side row (stable: list order inside a row): rank of position v1[k] in its row's chain = k - start[row], written
+// into the record of that position (.w: the version the visit expects)
+__global__ void flow_rank_kernel(const uint32_t* __restrict__ k1, const uint32_t* __restrict__ v1, const int64_t* __restrict__ start, int64_t n,
+                                 int4* __restrict__ pack) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) pack[v1[k]].w = (int)(uint32_t)(k - start[k1[k]]);
+}
+// queue order: ONE 16-byte record per position (round 3 first gathered user, item, rating and rank from four arrays: 1.4 ms of the
+// 4 ms a C2 call spends building its queues)
+__global__ void flow_gather2_kernel(const uint32_t* __restrict__ lpos, const int4* __restrict__ pack, int64_t n, int4* __restrict__ q) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) q[t] = pack[lpos[t]];
 }
 // qoff[g] = number of sorted queue keys < g
 __global__ void flow_bounds_kernel(const uint32_t* __restrict__ keys, int64_t n, int64_t ng1, int64_t* __restrict__ qoff) {
@@ -1078,10 +1085,10 @@ int build_flow_device(mfx_ctx* ctx, int64_t first, int64_t count, int64_t groups
     S->cap = count;
   }
   if (S->dcap < count) {
-    dev_free(S->k0); dev_free(S->k1); dev_free(S->v0); dev_free(S->v1); dev_free(S->vert); dev_free(S->sort_tmp);
+    dev_free(S->k0); dev_free(S->k1); dev_free(S->v0); dev_free(S->v1); dev_free(S->pack); dev_free(S->sort_tmp);
     S->dcap = 0;
     if ((rc = dev_alloc(ctx, &S->k0, (size_t)count)) || (rc = dev_alloc(ctx, &S->k1, (size_t)count)) || (rc = dev_alloc(ctx, &S->v0, (size_t)count)) ||
-        (rc = dev_alloc(ctx, &S->v1, (size_t)count)) || (rc = dev_alloc(ctx, &S->vert, (size_t)count)))
+        (rc = dev_alloc(ctx, &S->v1, (size_t)count)) || (rc = dev_alloc(ctx, &S->pack, (size_t)count)))
       return rc;
     size_t bytes = 0;
     HIPCHK(rocprim::radix_sort_pairs(nullptr, bytes, S->k0, S->k1, S->v0, S->v1, (size_t)count, 0, 32, ctx->stream));
@@ -1215,15 +1222,16 @@ int build_flow_device(mfx_ctx* ctx, int64_t first, int64_t count, int64_t groups
   // chain starts of the other side in the sorted order: dstart[r] = number of sorted keys < r
   hipLaunchKernelGGL(flow_bounds32_kernel, dim3((unsigned)std::min<int64_t>((nOth + 256) / 256, 4096)), dim3(256), 0, ctx->stream, S->k1, count,
                      nOth + 1, S->dstart);
-  hipLaunchKernelGGL(flow_rank_kernel, dim3(grid), dim3(256), 0, ctx->stream, S->k1, S->v1, S->dstart, count, S->vert);
+  hipLaunchKernelGGL(flow_pack_kernel, dim3(grid), dim3(256), 0, ctx->stream, eu, ei, er, count, own_user,
+                     tagged ? (const int32_t*)S->downer : (const int32_t*)nullptr, S->pack);
+  hipLaunchKernelGGL(flow_rank_kernel, dim3(grid), dim3(256), 0, ctx->stream, S->k1, S->v1, S->dstart, count, S->pack);
   // queue order: stable sort of the list positions by the queue of their owned row
   hipLaunchKernelGGL(flow_keys_kernel, dim3(grid), dim3(256), 0, ctx->stream, own_rows, (const int32_t*)S->downer, count, S->k0, S->v0);
   bytes = S->sort_tmp_bytes;
   HIPCHK(rocprim::radix_sort_pairs(S->sort_tmp, bytes, S->k0, S->k1, S->v0, S->lpos, (size_t)count, 0, bits_for((uint64_t)groups), ctx->stream));
   hipLaunchKernelGGL(flow_bounds_kernel, dim3((unsigned)std::min<int64_t>((groups + 256) / 256, 4096)), dim3(256), 0, ctx->stream, S->k1, count,
                      groups + 1, S->qoff);
-  hipLaunchKernelGGL(flow_gather2_kernel, dim3(grid), dim3(256), 0, ctx->stream, S->lpos, S->vert, count, eu, ei, er, own_user,
-                     tagged ? (const int32_t*)S->downer : (const int32_t*)nullptr, S->q);
+  hipLaunchKernelGGL(flow_gather2_kernel, dim3(grid), dim3(256), 0, ctx->stream, S->lpos, (const int4*)S->pack, count, S->q);
   HIPCHK(hipGetLastError());
   S->hoff.resize((size_t)groups + 1);
   HIPCHK(hipMemcpyAsync(S->hoff.data(), S->qoff, sizeof(int64_t) * ((size_t)groups + 1), hipMemcpyDeviceToHost, ctx->stream));
@@ -1355,7 +1363,7 @@ void mfx_flow_free_internal(mfx_ctx* ctx) {
   FlowState* S = fl(ctx);
   if (!S) return;
   dev_free(S->q); dev_free(S->qoff); dev_free(S->lpos); dev_free(S->vexp); dev_free(S->ver); dev_free(S->flag);
-  dev_free(S->k0); dev_free(S->k1); dev_free(S->v0); dev_free(S->v1); dev_free(S->vert); dev_free(S->sort_tmp);
+  dev_free(S->k0); dev_free(S->k1); dev_free(S->v0); dev_free(S->v1); dev_free(S->pack); dev_free(S->sort_tmp);
   dev_free(S->degU); dev_free(S->downer); dev_free(S->dstart); dev_free(S->tagbuf);
   delete S;
   ctx->flow = nullptr;

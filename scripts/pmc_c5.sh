@@ -1,9 +1,9 @@
 #!/bin/bash
 # HBM-side traffic of the tiled SGD round at one GPU's share of config 5 (scripts/c5_shard.py: 1.25 M x 1 M, 125 M train
 # ratings, rank 256) -- separate --pmc passes (FETCH_SIZE takes 3 TCC slots, WRITE_SIZE 2), never combined with tracing:
-#   bash scripts/pmc_c5.sh r02      ->  profiles/r02_c5_pmc.json
+#   bash scripts/pmc_c5.sh r03      ->  profiles/r03_c5_pmc.json
 set -e
-R=${1:-r02}
+R=${1:-r03}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/pmc_c5_$R
 rm -rf "$OUT"; mkdir -p "$OUT"
