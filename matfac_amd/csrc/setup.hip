@@ -419,6 +419,7 @@ int mfx_slots_build_device(mfx_ctx* ctx, SlotList* S, int rows, int side, const 
   }
   const int64_t nslots = (int64_t)hns;
 
+  dev_free(S->slot_need); dev_free(S->rowver); S->rowver_n = 0;      // (of the lists that go)
   dev_free(S->visit); dev_free(S->attr); dev_free(S->rec); dev_free(S->slot_beg); dev_free(S->slot_ibeg); dev_free(S->slot_items); dev_free(S->tile_slot);
   S->slot_items = own2;
   if ((rc = dev_alloc(ctx, &S->rec, (size_t)nnz * 4)) || (rc = dev_alloc(ctx, &S->slot_beg, (size_t)nslots + 1)) ||

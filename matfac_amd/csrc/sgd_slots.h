@@ -33,8 +33,8 @@ __host__ __device__ static inline int slot_user_block(int32_t u) {
 }
 constexpr int WG = 1024;      // threads per workgroup: 16 waves = 64 ratings in flight on one slot
 // SlotList::ctr: [0, NTILE) slots pulled per tile | [NTILE] barrier counter of the drain | [NTILE + 1] abort flag | [NTILE + 2] the
-// STICKY abort flag (not cleared per epoch) | [CTR_DONE, CTR_DONE + NTILE) slots FINISHED per tile (the one-launch epoch's hand-off)
-constexpr int CTR_DONE = NTILE + 4, CTR_WORDS = CTR_DONE + NTILE;
+// STICKY abort flag (not cleared per epoch) | [NTILE + 3] "the rounds left something" (slots_left_kernel)
+constexpr int CTR_WORDS = NTILE + 4;
 
 struct SlotList {
   int32_t* rec = nullptr;          // int4 per rating: other-side index, local owned index, rating bits, owned index
@@ -47,6 +47,11 @@ struct SlotList {
   unsigned* ctr = nullptr;         // [NTILE] slot counters + [2] barrier counter and abort flag of the drain
   unsigned* abort_host = nullptr;  // pinned copy of the abort flag of the previous epoch's drain
   unsigned* visit = nullptr;       // [nnz] visits per rating record (MFX_SGD_F_COUNT_VISITS), or NULL
+  // the one-launch epoch (PERSIST): finished visits of every owned row in this epoch, and for every (slot, row) entry of
+  // slot_items the number of visits that precede this slot's in round order (mfx_slots_build_needs)
+  unsigned* rowver = nullptr;
+  uint8_t* slot_need = nullptr;
+  int64_t rowver_n = 0;
   int32_t* attr = nullptr;         // sibling models: per rating (slot order) weight bits (var 1) or rank (var 2)
   int var = 0;                     // which of them attr holds (0: none)
   uint64_t attr_gen = 0;           // ctx->var_gen it was computed for
@@ -86,6 +91,9 @@ __device__ __forceinline__ int64_t slot_perm(int64_t t, int64_t R, uint32_t k0, 
 // context and grid size with a kernel that does nothing else; the one-launch epoch needs it (a partition mode that reports one
 // id would leave seven neighbours that never finish).
 bool mfx_xcc_ids_populated(mfx_ctx* ctx, int blocks, int* rc);
+// S->slot_need and S->rowver for the one-launch epoch: an owned row is visited by one slot in every tile of its block's column of
+// tiles in which it has ratings, in round order r = (item block - user block) mod 8; slot_need = how many of them come before.
+int mfx_slots_build_needs(mfx_ctx* ctx, SlotList* S, int64_t nown);
 // the kernel launchers, one per rank shape (sgd_slots_inst_<L>x<C>.hip)
 #define MFX_SLOTS_DECL(LL, CC) \
   int mfx_slots_launch_##LL##x##CC(mfx_ctx* ctx, SlotList* S, int side, const mfx_sgd_opts* o, int blocks, uint32_t k0, uint32_t k1);

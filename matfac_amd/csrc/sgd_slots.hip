@@ -37,7 +37,7 @@ void mfx_slots_free_internal(mfx_ctx* ctx) {
   if (!st) return;
   auto drop = [](SlotList& s) {
     dev_free(s.rec); dev_free(s.slot_beg); dev_free(s.slot_ibeg); dev_free(s.slot_items); dev_free(s.attr); dev_free(s.visit);
-    dev_free(s.tile_slot); dev_free(s.ctr); dev_free(s.ublk); dev_free(s.iblk);
+    dev_free(s.tile_slot); dev_free(s.ctr); dev_free(s.ublk); dev_free(s.iblk); dev_free(s.rowver); dev_free(s.slot_need);
     if (s.abort_host) (void)hipHostFree(s.abort_host);
   };
   for (SlotList& s : st->side) drop(s);
@@ -73,6 +73,52 @@ bool mfx_xcc_ids_populated(mfx_ctx* ctx, int blocks, int* rc) {
   st->xcc_probe_blocks = blocks;
   st->xcc_probe_ok = ok;
   return ok;
+}
+
+// one thread per slot: the user block of its tile into the presence mask of every owned row it stages ...
+__global__ void need_presence_kernel(const int32_t* __restrict__ tile_slot, const int32_t* __restrict__ slot_ibeg, const int32_t* __restrict__ slot_items,
+                                     int64_t nslots, unsigned* __restrict__ pres) {
+  for (int64_t sl = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; sl < nslots; sl += (int64_t)gridDim.x * blockDim.x) {
+    int t = 0;
+    while (t + 1 < NTILE && tile_slot[t + 1] <= sl) t++;
+    const unsigned bit = 1u << (t / 8);
+    for (int e = slot_ibeg[sl]; e < slot_ibeg[sl + 1]; e++) atomicOr(&pres[slot_items[e]], bit);
+  }
+}
+// ... and, per (slot, row) entry, how many tiles with that row come earlier in round order (round of tile (ub, ib) = (ib - ub) mod 8)
+__global__ void need_count_kernel(const int32_t* __restrict__ tile_slot, const int32_t* __restrict__ slot_ibeg, const int32_t* __restrict__ slot_items,
+                                  int64_t nslots, const unsigned* __restrict__ pres, uint8_t* __restrict__ need) {
+  for (int64_t sl = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; sl < nslots; sl += (int64_t)gridDim.x * blockDim.x) {
+    int t = 0;
+    while (t + 1 < NTILE && tile_slot[t + 1] <= sl) t++;
+    const int ub = t / 8, ib = t % 8, r = (ib - ub) & 7;
+    for (int e = slot_ibeg[sl]; e < slot_ibeg[sl + 1]; e++) {
+      const unsigned p = pres[slot_items[e]];
+      int n = 0;
+      for (int u2 = 0; u2 < 8; u2++) n += ((p >> u2) & 1u) && ((ib - u2) & 7) < r;
+      need[e] = (uint8_t)n;
+    }
+  }
+}
+int mfx_slots_build_needs(mfx_ctx* ctx, SlotList* S, int64_t nown) {
+  static_assert(SUB == 1 && NUB == 8, "round of a tile = (item block - user block) mod 8");
+  int rc;
+  if (S->slot_need && S->rowver && S->rowver_n == nown) return MFX_OK;
+  dev_free(S->slot_need); dev_free(S->rowver);
+  S->rowver_n = 0;
+  int32_t refs = 0;
+  HIPCHK(hipMemcpyAsync(&refs, S->slot_ibeg + S->nslots, sizeof refs, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if ((rc = dev_alloc(ctx, &S->slot_need, (size_t)std::max(refs, 1))) || (rc = dev_alloc(ctx, &S->rowver, (size_t)std::max<int64_t>(nown, 1)))) return rc;
+  HIPCHK(hipMemsetAsync(S->rowver, 0, sizeof(unsigned) * (size_t)std::max<int64_t>(nown, 1), ctx->stream));      // (the presence masks, for now)
+  const int grid = (int)std::min<int64_t>(std::max<int64_t>((S->nslots + 255) / 256, 1), 4096);
+  hipLaunchKernelGGL(need_presence_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const int32_t*)S->tile_slot, (const int32_t*)S->slot_ibeg,
+                     (const int32_t*)S->slot_items, S->nslots, S->rowver);
+  hipLaunchKernelGGL(need_count_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const int32_t*)S->tile_slot, (const int32_t*)S->slot_ibeg,
+                     (const int32_t*)S->slot_items, S->nslots, (const unsigned*)S->rowver, S->slot_need);
+  HIPCHK(hipGetLastError());
+  S->rowver_n = nown;
+  return MFX_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -183,6 +229,7 @@ static int build_slots(mfx_ctx* ctx, SlotList* S, int rows, int side, const Rati
     for (int32_t it : items) cnt[it] = 0;
   }
   tile_slot[NTILE] = nslots;
+  dev_free(S->slot_need); dev_free(S->rowver); S->rowver_n = 0;      // (of the lists that go)
   dev_free(S->visit); dev_free(S->attr); dev_free(S->rec); dev_free(S->slot_beg); dev_free(S->slot_ibeg); dev_free(S->slot_items);
   dev_free(S->tile_slot);
   int rc;
@@ -275,7 +322,7 @@ int mfx_launch_sgd_tiled(mfx_ctx* ctx, const mfx_sgd_opts* o) {
     if (st->nparts != ctx->item_parts || !st->pu) {
       for (SlotList& s : st->parts) {
         dev_free(s.rec); dev_free(s.slot_beg); dev_free(s.slot_ibeg); dev_free(s.slot_items); dev_free(s.attr); dev_free(s.visit);
-        dev_free(s.tile_slot); dev_free(s.ctr); dev_free(s.ublk); dev_free(s.iblk);
+        dev_free(s.tile_slot); dev_free(s.ctr); dev_free(s.ublk); dev_free(s.iblk); dev_free(s.rowver); dev_free(s.slot_need);
         if (s.abort_host) (void)hipHostFree(s.abort_host);
       }
       st->parts.clear();

@@ -17,6 +17,10 @@
 #ifndef MFX_EXP
 #define MFX_EXP 0
 #endif
+// slots from this many ratings on run at raised wave priority (a build-time knob: scripts/exp_slots.sh)
+#ifndef MFX_POLE_PRIO
+#define MFX_POLE_PRIO 2048
+#endif
 
 // ---------------------------------------------------------------------------
 // kernel
@@ -267,18 +271,15 @@ static __global__ void slots_left_kernel(const int32_t* __restrict__ tile_slot, 
 // ALLW: every wave of the workgroup takes part (compile-time chunk stride; a run-time stride cost 3.6 % at C2 -- measured A/B on one
 // box: 19.2 vs 19.9 G updates/s); otherwise `aw` waves do (small tiles, see mfx_launch_sgd_tiled).
 //
-// PERSIST (round 3, an experiment that did not pay: MFX_SGD_PERSIST=1): the eight rounds in ONE launch.  A round only needs its NEIGHBOUR: in round r XCD x owns item block (x + r) mod 8,
-// which XCD x + 1 owned in round r - 1, and user block x, which is its own throughout.  So the workgroups on XCD x walk the rounds
-// by themselves and wait, before round r, until every slot of XCD x + 1's round r - 1 tile is FINISHED (ctr[CTR_DONE + tile] ==
-// slots of the tile; a finished slot = its item rows written through and acknowledged).  No kernel boundary between rounds (nine
-// boundaries were 4-5 % of an epoch), and an XCD that is slower in one round (the tiles of a diagonal differ by a few per cent, and
-// so do the XCDs) no longer holds the other seven back: only its neighbour, and only if it runs out of slack.  The item rows change
-// XCD between rounds, so their staging loads and write-backs go through memory (sc1: L1-bypass loads, write-through stores -- 2 x
-// 7 MB per round at C2); the user rows stay in the XCD's L2 as before.  Needs every workgroup resident and all eight XCC ids
-// populated (launch_slots checks both, else the eight launches); a waiter that sees no progress for 2 s raises the abort flags.
-// Measured at C2: 19.2 G updates/s against 20.9 for the eight launches, with the acknowledgements waited for per slot or per tile
-// alike -- an XCD still waits for ALL of its neighbour's previous tile (the same tail as a kernel boundary), and staging the item rows
-// through memory costs more than the nine boundaries did.  What would pay is a hand-off per item row, not per tile.
+// PERSIST (round 3, an experiment that did not pay: MFX_SGD_PERSIST=1): the eight rounds in ONE launch.  A round only needs its
+// NEIGHBOUR: in round r XCD x owns item block (x + r) mod 8, which XCD x + 1 owned in round r - 1, and user block x, which is its own
+// throughout.  So the workgroups on XCD x walk the rounds by themselves; a slot starts when each of its <= 64 item rows has received
+// the visits that precede this slot's in round order (rowver[row] >= slot_need[entry]; a visit is finished when the row's
+// write-through stores are acknowledged).  The item rows change XCD between rounds, so their staging loads and write-backs go
+// through memory (sc1: L1-bypass loads, write-through stores -- 2 x 7 MB per round at C2); the user rows stay in the XCD's L2 as
+// before.  Needs every workgroup resident and all eight XCC ids populated (launch_slots checks both, else the eight launches); a
+// waiter that sees no progress for 2 s raises the abort flags.  Measured at C2: with no waits at all (wrong on
+// purpose) 23.0 G updates/s; with a hand-off per tile 19.2, per row 21.0 - 21.2, against 21.6 - 21.9 for the eight launches.
 template <int L, int C, int ARITH, bool SWEEP, bool OWN_U, int VAR, bool ALLW = false, bool PERSIST = false>
 __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kernel(const int4* __restrict__ rec,
                                                            const int64_t* __restrict__ slot_beg,
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
                                                            float lr, float uReg, float iReg, uint32_t k0,
                                                            uint32_t k1, const int32_t* __restrict__ attr,
                                                            unsigned* __restrict__ visit, int tile_only, int one, int aw,
-                                                           uint32_t ownbytes) {
+                                                           uint32_t ownbytes, unsigned* rowver, const uint8_t* __restrict__ slot_need) {
   static_assert(!PERSIST || (!SWEEP && SUB == 1), "the one-launch epoch walks the eight XCD rounds");
   constexpr int G = 64 / L;
   constexpr int LD = 4 * L * C;
@@ -336,46 +337,70 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
     const int tile = (SWEEP && tile_only >= 0) ? tile_only : (x * SUB + rr % SUB) * 8 + ((x + rr / SUB) & 7);
     const int s0 = tile_slot[tile], ns = tile_slot[tile + 1] - s0;
     bool skip = false;
-    if (PERSIST && rr > 0) {
-      // this round's item block was XCD x + 1's in the round before: wait until all of that tile's slots are finished
-      const int dep = ((x + 1) & 7) * 8 + ((x + rr) & 7);
-      const unsigned need = (unsigned)(tile_slot[dep + 1] - tile_slot[dep]);
-      if (tid == 0) {
-        int ab = 0;
-        const long long t0 = wall_clock64();
-        while (__hip_atomic_load(&ctr[CTR_DONE + dep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-          __builtin_amdgcn_s_sleep(2);
-          if (__hip_atomic_load(&ctr[NTILE + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ab = 1; break; }
-          if (wall_clock64() - t0 > 200000000LL) {           // 100 MHz constant clock: 2 s
-            __hip_atomic_store(&ctr[NTILE + 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&ctr[NTILE + 2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ab = 1;
-            break;
-          }
-        }
-        s_bad = ab;
-      }
-      __syncthreads();
-      const bool ab = s_bad != 0;
-      __syncthreads();
-      if (ab) return;
-    }
     if (SWEEP) {  // nothing left in this tile: do not queue on its counter
       if (tid == 0) s_slot = (int)__hip_atomic_load(&ctr[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __syncthreads();
       skip = s_slot >= ns;
       __syncthreads();
     }
-    unsigned mine = 0;          // PERSIST: slots of this tile this workgroup has worked off
+    // PERSIST: the next slot is pulled when the ratings of the one at work are done, and the finished-visit counts of its rows are
+    // requested then, in front of the write-back -- a check at the moment of use is a dependent round trip to memory in front of
+    // every staging (2-3 us of a 25 us slot: measured as the whole loss of the first cut); here it travels while the write-back's
+    // stores are acknowledged.  A count that was not there yet is polled when the slot's turn comes.  (Pulling a whole slot ahead
+    // was tried: with five slots per workgroup and tile, a slot held back is a fifth of the tile's balance -- 17.5 G updates/s.)
+    int ahead = 0;                       // PERSIST: the slot pulled ahead (index in the tile)
+    unsigned pre_ver = 0, pre_need = 0;  // ... and this thread's row of it: finished visits as of the request, visits it needs
+    int pre_row = -1;
+    int pub_row = -1;                    // PERSIST: the row of the slot just written back that this thread still has to publish
+    if (PERSIST && !skip) {
+      if (tid == 0) s_slot = (int)atomicAdd(&ctr[tile], 1u);
+      __syncthreads();
+      ahead = s_slot;
+      __syncthreads();
+      if (ahead < ns) {
+        const int ib0 = slot_ibeg[s0 + ahead], ni0 = slot_ibeg[s0 + ahead + 1] - ib0;
+        if (tid < ni0) { pre_row = slot_items[ib0 + tid]; pre_need = (unsigned)slot_need[ib0 + tid]; pre_ver = __hip_atomic_load(&rowver[pre_row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      }
+    }
     while (!skip) {
-      if (tid == 0) { s_slot = (int)atomicAdd(&ctr[tile], 1u); s_bad = 0; }
-      __syncthreads();
-      const int sl = s_slot;
-      __syncthreads();
+      int sl;
+      if (PERSIST) {
+        sl = ahead;
+        if (tid == 0) s_bad = 0;           // (the wait below holds a barrier in front of the staging)
+      } else {
+        if (tid == 0) { s_slot = (int)atomicAdd(&ctr[tile], 1u); s_bad = 0; }
+        __syncthreads();
+        sl = s_slot;
+        __syncthreads();
+      }
       if (sl >= ns) break;
       const int slot = s0 + sl;
       const int64_t rb = slot_beg[slot], R = slot_beg[slot + 1] - rb;
       const int ib = slot_ibeg[slot], ni = slot_ibeg[slot + 1] - ib;
+      const int my_row = PERSIST ? pre_row : -1;
+      if (PERSIST && tile_only != -2) {      // (tile_only == -2: MFX_PERSIST_NOWAIT=1, a timing diagnostic with wrong results)
+        // every owned row of the slot must have received its visits of the EARLIER rounds (their owners sit on other XCDs and run
+        // on their own): row i carries a count of finished visits, the slot list says how many precede this one (slot_need)
+        const bool wait_mine = tid < ni;
+        unsigned ver = pre_ver;
+        const long long t0 = wall_clock64();
+        for (;;) {
+          const bool ok = !wait_mine || ver >= pre_need;
+          if (__syncthreads_and(ok)) break;
+          __builtin_amdgcn_s_sleep(2);
+          if (wait_mine) ver = __hip_atomic_load(&rowver[my_row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          bool ab = false;
+          if (tid == 0) {
+            ab = __hip_atomic_load(&ctr[NTILE + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+            if (!ab && wall_clock64() - t0 > 200000000LL) {         // 100 MHz constant clock: 2 s without the rows
+              __hip_atomic_store(&ctr[NTILE + 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(&ctr[NTILE + 2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              ab = true;
+            }
+          }
+          if (__syncthreads_or(ab)) return;
+        }
+      }
 #if MFX_EXP == 8
       exp_slots++; exp_ratings += (unsigned)R;
 #endif
@@ -393,7 +418,11 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
         q4[row * LD4 + c4] = __builtin_bit_cast(int4, v);
       }
       if (mybad) s_bad = 1;
+      // PERSIST: the rows of the slot written back before this one are published HERE, one staging later: their write-through stores
+      // have been acknowledged by now without anybody waiting for it (a wait at the end of every slot cost 6 %)
+      if (PERSIST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      if (PERSIST && pub_row >= 0) __hip_atomic_fetch_add(&rowver[pub_row], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const bool fix = s_bad == 0;
       if (fix) {
         for (int x = tid; x < ni * LD4; x += WG) {
@@ -404,6 +433,12 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
       }
       __syncthreads();
       const uint32_t ks0 = k0 + (uint32_t)slot * 0x632be5abU, ks1 = k1 ^ mfx_mix32((uint32_t)slot + 77U);
+      // A popular row's slot is a POLE: one owner, however many ratings (C2: 6 200 of the most popular item per tile), worked off 64 at
+      // a time -- with two workgroups per CU it gets half of the CU and ends when the round does: the eight poles of that item are the
+      // critical path of the epoch (an epoch whose rounds do not wait for each other, wrong on purpose, ran 6.5 % faster).  Its waves
+      // issue first (s_setprio 3) while the workgroup next to it, which is not on that path, fills the gaps.
+      const bool pole = !SWEEP && R >= MFX_POLE_PRIO;
+      if (pole) __builtin_amdgcn_s_setprio(3);
       // one group (test hook): wave 0 alone, L ratings per chunk, rating cb+s in entry s*G (group 0's entry of step s)
       // aw = waves of the workgroup that take part (16 unless the tile has few lock-free rows: mfx_launch_sgd_tiled)
       const int64_t cb0 = onegrp ? (wave == 0 ? 0 : R) : ALLW ? (int64_t)wave * 64 : (wave < aw ? (int64_t)wave * 64 : R);
@@ -455,7 +490,17 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
         if (fix) SlotSteps<L, C, ARITH, OWN_U, true, VAR, 0>::run(Um, q_lds, tx, ty, tz, tw, regk, g, j, nvalid, lr, uReg, iReg, pn, pen, pnn, penn);
         else SlotSteps<L, C, ARITH, OWN_U, false, VAR, 0>::run(Um, q_lds, tx, ty, tz, tw, regk, g, j, nvalid, lr, uReg, iReg, pn, pen, pnn, penn);
       }
+      if (pole) __builtin_amdgcn_s_setprio(0);
+      if (PERSIST && tid == 0) s_slot = (int)atomicAdd(&ctr[tile], 1u);
       __syncthreads();
+      if (PERSIST) {
+        ahead = s_slot;
+        pre_row = -1; pre_ver = 0; pre_need = 0;
+        if (ahead < ns) {
+          const int ibn = slot_ibeg[s0 + ahead], nin = slot_ibeg[s0 + ahead + 1] - ibn;
+          if (tid < nin) { pre_row = slot_items[ibn + tid]; pre_need = (unsigned)slot_need[ibn + tid]; pre_ver = __hip_atomic_load(&rowver[pre_row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        }
+      }
       // write the item rows back (this workgroup is their only owner during the round)
       for (int x = tid; x < ni * LD4; x += WG) {
         const int row = x / LD4, c4 = x % LD4;
@@ -480,14 +525,12 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
         Om.st(vrow, v);
       }
       __syncthreads();
-      if (PERSIST) mine++;
+      if (PERSIST) pub_row = tid < ni ? my_row : -1;
     }
-    if (PERSIST && mine) {
-      // the slots this workgroup took from the tile are FINISHED when every wave's write-through stores are acknowledged (their rows
-      // may change XCD then); waited for once per tile, not per slot -- the acknowledgements of a slot arrive while the next is at work
+    if (PERSIST) {       // the last slot this workgroup worked off in the tile: its rows may change XCD when every wave's stores are acknowledged
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (tid == 0) __hip_atomic_fetch_add(&ctr[CTR_DONE + tile], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (pub_row >= 0) __hip_atomic_fetch_add(&rowver[pub_row], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // the next diagonal re-owns these item rows from other workgroups (other XCDs): L2 write-back, barrier, invalidate
     if (drain && rr + 1 < r_end && grid_barrier<0>(ctr + NTILE, (unsigned)(rr + 2) * gridDim.x)) {
@@ -518,7 +561,7 @@ static int launch_slots(mfx_ctx* ctx, SlotList* S, const mfx_sgd_opts* o, int bl
     for (int tile = 0; tile < NTILE; tile++)
       hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, true, OWN_U, VAR>), dim3(1), dim3(WG), 0, ctx->stream,
                          (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->tile_slot, S->ctr, 0,
-                         oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1, at, visit, tile, 1, 1, 0u);
+                         oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1, at, visit, tile, 1, 1, 0u, nullptr, nullptr);
     HIPCHK(hipGetLastError());
     return MFX_OK;
   }
@@ -526,7 +569,7 @@ static int launch_slots(mfx_ctx* ctx, SlotList* S, const mfx_sgd_opts* o, int bl
   // launches at C2 (19.2 vs 20.9 G updates/s on one box).  Needs the plain update with all waves at work, every workgroup resident,
   // all eight XCC ids populated by this grid, the owned table within a buffer descriptor's reach.
   bool persist = false;
-  if constexpr (VAR == 0 && SUB == 1) {
+  if constexpr (VAR == 0 && SUB == 1 && !OWN_U) {       // (user rows owned: it is the LOCK-FREE rows that would change XCD between rounds)
     const uint64_t ownb = (uint64_t)(OWN_U ? ctx->nU : ctx->nI) * ctx->ld * 4;
     const char* pe = getenv("MFX_SGD_PERSIST");
     if (S->active_waves == WG / 64 && ownb < (1ull << 32) && pe && pe[0] == '1' && !(o->flags & MFX_SGD_F_DRAIN_ONLY)) {
@@ -543,11 +586,15 @@ static int launch_slots(mfx_ctx* ctx, SlotList* S, const mfx_sgd_opts* o, int bl
       if (rc) return rc;
     }
     if (persist) {
-      HIPCHK(hipMemsetAsync(S->ctr + CTR_DONE, 0, NTILE * sizeof(unsigned), ctx->stream));
+      const int64_t nown = OWN_U ? ctx->nU : ctx->nI;
+      int rc = mfx_slots_build_needs(ctx, S, nown);
+      if (rc) return rc;
+      HIPCHK(hipMemsetAsync(S->rowver, 0, sizeof(unsigned) * (size_t)nown, ctx->stream));
       ProfScope ps(ctx, MFX_K_SGD);
       hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, false, OWN_U, VAR, true, true>), dim3(blocks), dim3(WG), 0, ctx->stream,
                          (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->tile_slot, S->ctr, 0,
-                         oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1, at, visit, -1, 0, S->active_waves, (uint32_t)ownb);
+                         oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1, at, visit, getenv("MFX_PERSIST_NOWAIT") ? -2 : -1, 0,
+                         S->active_waves, (uint32_t)ownb, S->rowver, (const uint8_t*)S->slot_need);
     }
   }
   for (int round = 0; round < NUB && !persist && !(o->flags & MFX_SGD_F_DRAIN_ONLY); round++) {
@@ -555,11 +602,11 @@ static int launch_slots(mfx_ctx* ctx, SlotList* S, const mfx_sgd_opts* o, int bl
     if (S->active_waves == WG / 64)
       hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, false, OWN_U, VAR, true>), dim3(blocks), dim3(WG), 0, ctx->stream,
                          (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->tile_slot, S->ctr, round,
-                         oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1, at, visit, -1, 0, S->active_waves, 0u);
+                         oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1, at, visit, -1, 0, S->active_waves, 0u, nullptr, nullptr);
     else
       hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, false, OWN_U, VAR, false>), dim3(blocks), dim3(WG), 0, ctx->stream,
                          (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->tile_slot, S->ctr, round,
-                         oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1, at, visit, -1, 0, S->active_waves, 0u);
+                         oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1, at, visit, -1, 0, S->active_waves, 0u, nullptr, nullptr);
   }
   {
     // the drain: one launch; the same diagonals keyed on the workgroup index (an item row keeps a single owner).  Its grid
@@ -581,7 +628,7 @@ static int launch_slots(mfx_ctx* ctx, SlotList* S, const mfx_sgd_opts* o, int bl
     hipLaunchKernelGGL(slots_left_kernel, dim3(1), dim3(64), 0, ctx->stream, (const int32_t*)S->tile_slot, S->ctr);
     hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, true, OWN_U, VAR>), dim3(drain_wgs), dim3(WG), 0, ctx->stream,
                        (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->tile_slot, S->ctr, 0,
-                       oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1, at, visit, -1, 0, S->active_waves, 0u);
+                       oth, own, (uint32_t)ob, o->learnRate, o->uReg, o->iReg, k0, k1, at, visit, -1, 0, S->active_waves, 0u, nullptr, nullptr);
   }
   HIPCHK(hipGetLastError());
   // a drain whose barrier gave up (2 s without progress: the device is shared with another resident kernel) leaves a STICKY
