@@ -563,6 +563,11 @@ void shuffleAheadPair(std::vector<T>& a, std::mt19937& g, size_t block, bool fas
   std::atomic<size_t> produced(0), consumed(0);
   const size_t nblocks = (n - 1 + block - 1) / block;
   T* p = a.data();
+  std::unique_ptr<MtBulk> bulk;          // (everything that allocates happens before the helper starts: nothing below throws while it runs)
+  if (fast && n < ((size_t)1 << 32)) {
+    bulk.reset(new MtBulk);
+    if (!bulk->load(g)) bulk.reset();
+  }
   std::thread helper([&] {
     for (size_t b = 0; b < nblocks; b++) {
       while (produced.load(std::memory_order_acquire) <= b) std::this_thread::yield();
@@ -579,11 +584,6 @@ void shuffleAheadPair(std::vector<T>& a, std::mt19937& g, size_t block, bool fas
   });
   std::uniform_int_distribution<unsigned long> d;
   typedef std::uniform_int_distribution<unsigned long>::param_type P;
-  std::unique_ptr<MtBulk> bulk;
-  if (fast && n < ((size_t)1 << 32)) {
-    bulk.reset(new MtBulk);
-    if (!bulk->load(g)) bulk.reset();
-  }
   for (size_t b = 0; b < nblocks; b++) {
     while (b - consumed.load(std::memory_order_acquire) >= RING) std::this_thread::yield();
     size_t* j = ring.data() + (b % RING) * block;

@@ -106,8 +106,8 @@ def test_landing_registers_of_the_tagged_replay_are_never_copied():
     arrived.  The kernels make every landing register ONE live range (in-out operand of every load and wait; 64-bit integers
     instead of small vectors in the wide kernel, which the compiler promoted to one moving register tuple at C = 1 -- the first GPU
     run of that kernel computed wrong rows).  Checked on the compiled code: the loads of all steps (prologue, steady state,
-    re-reads) of one pipeline slot target the same registers, i.e. a kernel has LA x (loads per request) landing destinations plus
-    at most two scratch destinations of the probe loop."""
+    re-reads) of one pipeline slot target the same registers, i.e. a kernel has exactly LA x (loads per request) destinations that
+    are loaded five times or more, plus the few scratch destinations of the probe loop."""
     import re
     import tempfile
     import pathlib
@@ -128,12 +128,16 @@ def test_landing_registers_of_the_tagged_replay_are_never_copied():
         j = i
         while not lines[j].startswith(".Lfunc_end"):
             j += 1
+        # destinations of the L1-bypass row loads.  A landing register is loaded by the prologue, the first steps, the steady state and
+        # the two re-reads of a stalled head: five statements, all into the same registers -- a slot whose loads were split over two
+        # registers (with a copy in between) shows up as two destinations with fewer loads each.  What else appears are the probe's
+        # scratch registers.
         dst = {}
         for b in lines[i:j]:
             k = re.match(r"\s*buffer_load_dwordx[24] (v\[\d+:\d+\]), v\d+, s\[\d+:\d+\], 0 offen sc1", b)
             if k:
                 dst[k.group(1)] = dst.get(k.group(1), 0) + 1
         landing = [r for r, n in dst.items() if n >= 5]
-        assert len(landing) >= la * per and len(dst) <= la * per + 2, (l[:60], sorted(dst.items()))
+        assert la * per <= len(landing) <= la * per + 2 and len(dst) <= la * per + 6, (l[:60], sorted(dst.items()))
         seen += 1
     assert seen >= 30          # 7 rank shapes x 3 arithmetic modes of the 16-lane kernel, 4 x 3 of the wide one
