@@ -506,7 +506,9 @@ struct MtBulk {
     ss << p;
     return (bool)(ss >> g);
   }
-  void temperAll() {
+  // (twist and tempering are plain integer loops over 624 words: cloned for AVX2 where the CPU has it -- the drawing thread is the
+  //  slower of the two, 3 ns per position with the baseline SSE2 code)
+  __attribute__((target_clones("avx2", "default"))) void temperAll() {
     for (int k = 0; k < 624; k++) {
       uint32_t y = x[k];
       y ^= y >> 11;
@@ -516,7 +518,7 @@ struct MtBulk {
       out[k] = y;
     }
   }
-  void twist() {
+  __attribute__((target_clones("avx2", "default"))) void twist() {
     constexpr uint32_t UP = 0x80000000u, LO = 0x7fffffffu, A = 0x9908b0dfu;
     for (int k = 0; k < 624 - 397; k++) {
       const uint32_t y = (x[k] & UP) | (x[k + 1] & LO);
@@ -568,8 +570,15 @@ void shuffleAheadPair(std::vector<T>& a, std::mt19937& g, size_t block, bool fas
     bulk.reset(new MtBulk);
     if (!bulk->load(g)) bulk.reset();
   }
+  double waitSwap = 0, waitDraw = 0;          // MFX_TIME_LOOP=1: which of the two threads waits for the other
+  static const bool timeIt = getenv("MFX_TIME_LOOP") && atoi(getenv("MFX_TIME_LOOP")) != 0;
   std::thread helper([&] {
     for (size_t b = 0; b < nblocks; b++) {
+      if (timeIt && produced.load(std::memory_order_acquire) <= b) {
+        const auto w0 = std::chrono::steady_clock::now();
+        while (produced.load(std::memory_order_acquire) <= b) std::this_thread::yield();
+        waitSwap += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+      }
       while (produced.load(std::memory_order_acquire) <= b) std::this_thread::yield();
       const size_t* j = ring.data() + (b % RING) * block;
       const size_t i0 = 1 + b * block, m = std::min(block, n - i0);
@@ -585,6 +594,11 @@ void shuffleAheadPair(std::vector<T>& a, std::mt19937& g, size_t block, bool fas
   std::uniform_int_distribution<unsigned long> d;
   typedef std::uniform_int_distribution<unsigned long>::param_type P;
   for (size_t b = 0; b < nblocks; b++) {
+    if (timeIt && b - consumed.load(std::memory_order_acquire) >= RING) {
+      const auto w0 = std::chrono::steady_clock::now();
+      while (b - consumed.load(std::memory_order_acquire) >= RING) std::this_thread::yield();
+      waitDraw += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+    }
     while (b - consumed.load(std::memory_order_acquire) >= RING) std::this_thread::yield();
     size_t* j = ring.data() + (b % RING) * block;
     const size_t i0 = 1 + b * block, m = std::min(block, n - i0);
@@ -593,6 +607,7 @@ void shuffleAheadPair(std::vector<T>& a, std::mt19937& g, size_t block, bool fas
     produced.store(b + 1, std::memory_order_release);
   }
   helper.join();
+  if (timeIt) fprintf(stderr, "[mfh] shuffle of %zu entries: the drawing thread waited %.1f ms for the swapping one, the swapping thread %.1f ms for draws\n", n, waitDraw, waitSwap);
   if (bulk && !bulk->store(g)) throw std::runtime_error("mfhShuffle: the generator state could not be handed back");
 }
 bool shuffleAheadIsStd() {
@@ -875,10 +890,20 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
   // order unused; mt is local to this function.  MFX_NO_SHUFFLE_AHEAD=1: everything on the calling thread.
   std::future<void> nextOrder;          // (joins on destruction)
   std::function<void()> makeOrder;
+  // MFX_TIME_LOOP=1: where an iteration of an exact trainer goes (stderr): waiting for the order, its upload, the rest
+  static const bool timeLoop = getenv("MFX_TIME_LOOP") && atoi(getenv("MFX_TIME_LOOP")) != 0;
+  double tOrder = 0, tMake = 0;
   auto orderOfEpoch = [&](std::function<void()> make) {
-    makeOrder = std::move(make);
+    const auto t0 = std::chrono::steady_clock::now();
+    makeOrder = [make, &tMake] {
+      const auto m0 = std::chrono::steady_clock::now();
+      make();
+      tMake = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - m0).count();
+    };
     if (nextOrder.valid()) nextOrder.get();
     else makeOrder();
+    tOrder = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (timeLoop) fprintf(stderr, "[mfh] iteration %d: waited %.1f ms for the order (made in %.1f ms)\n", iter, tOrder, tMake);
   };
   auto orderAhead = [&] {
     if (iter + 1 < maxIter && !getenv("MFX_NO_SHUFFLE_AHEAD")) nextOrder = std::async(std::launch::async, makeOrder);
@@ -896,9 +921,17 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
           // modelMF.cpp:76-81: std::shuffle every epoch on one thread (parBlockShuffle with one
           // OpenMP thread is a plain std::shuffle; the reference is only reproducible that way)
           orderOfEpoch([&uiRatingInds, &mt] { mfhShuffle(uiRatingInds, mt); });
+          const auto u0 = std::chrono::steady_clock::now();
           dev->check(mfx_sgd_set_order(dev->ctx, (const uint64_t*)uiRatingInds.data(), nRatings), "set_order");   // (copied when it returns)
+          const auto u1 = std::chrono::steady_clock::now();
           o.mode = replayMode; o.order = MFX_ORDER_HOST;
           orderAhead();
+          dev->check(mfx_sgd_epoch(dev->ctx, &o), "mfx_sgd_epoch");
+          if (timeLoop)
+            fprintf(stderr, "[mfh] iteration %d: order upload %.1f ms, replay call %.1f ms\n", iter,
+                    std::chrono::duration<double, std::milli>(u1 - u0).count(),
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - u1).count());
+          break;
         } else {
           o.mode = MFX_SGD_TILED; o.order = MFX_ORDER_DEVICE;   // (K_IFW: the tiled kernel's weighted variant)
         }
