@@ -888,11 +888,11 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
   // shuffle is the larger of the two.  orderOfEpoch(make) leaves this epoch's order in uiRatingInds (made ahead, or now);
   // orderAhead(), called once mfx_sgd_set_order has copied it, starts the next one.  An iteration that ends the loop leaves one
   // order unused; mt is local to this function.  MFX_NO_SHUFFLE_AHEAD=1: everything on the calling thread.
+  double tOrder = 0, tMake = 0;         // (declared in front of nextOrder: the thread it joins on destruction writes tMake)
   std::future<void> nextOrder;          // (joins on destruction)
   std::function<void()> makeOrder;
   // MFX_TIME_LOOP=1: where an iteration of an exact trainer goes (stderr): waiting for the order, its upload, the rest
   static const bool timeLoop = getenv("MFX_TIME_LOOP") && atoi(getenv("MFX_TIME_LOOP")) != 0;
-  double tOrder = 0, tMake = 0;
   auto orderOfEpoch = [&](std::function<void()> make) {
     const auto t0 = std::chrono::steady_clock::now();
     makeOrder = [make, &tMake] {
