@@ -160,6 +160,9 @@ enum { MFX_SGD_F_ONE_GROUP = 1, MFX_SGD_F_COUNT_VISITS = 2, MFX_SGD_F_DRAIN_ONLY
  * std::vector<size_t> uiRatingInds in modelMF.cpp:67-68; for MFX_SGD_USERS the
  * list is the shuffled valid-user list (modelMF.cpp:620-635).                   */
 int mfx_sgd_set_order(mfx_ctx* ctx, const uint64_t* perm, int64_t n);
+/* the same list as 32-bit indices (half the bytes to shuffle on the host and to upload; the host classes use it for lists below
+ * 2^32 entries)                                                                  */
+int mfx_sgd_set_order32(mfx_ctx* ctx, const uint32_t* perm, int64_t n);
 int mfx_sgd_epoch(mfx_ctx* ctx, const mfx_sgd_opts* opts);
 /* test hook: the (u,i,r) list the last epoch visited, in visiting order */
 int mfx_debug_epoch_list(mfx_ctx* ctx, int32_t* u, int32_t* i, float* r, int64_t cap,

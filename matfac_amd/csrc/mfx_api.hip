@@ -110,7 +110,7 @@ void mfx_destroy(mfx_ctx* ctx) {
   mfx_segs_free_internal(ctx);
   for (auto& m : ctx->mat) free_csr(m);
   free_model(ctx);
-  dev_free(ctx->eu); dev_free(ctx->ei); dev_free(ctx->er); dev_free(ctx->order);
+  dev_free(ctx->eu); dev_free(ctx->ei); dev_free(ctx->er); dev_free(ctx->order); dev_free(ctx->order32);
   mfx_slots_free_internal(ctx);
   mfx_levels_free_internal(ctx);
   mfx_flow_free_internal(ctx);
@@ -459,6 +459,37 @@ extern "C" int mfx_sgd_set_order(mfx_ctx* ctx, const uint64_t* perm, int64_t n) 
   }
   if (n) HIPCHK(hipMemcpyAsync(ctx->order, perm, sizeof(uint64_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->order_n = n;
+  return MFX_OK;
+}
+
+__global__ void widen_order_kernel(const uint32_t* __restrict__ in, int64_t n, uint64_t* __restrict__ out) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) out[t] = in[t];
+}
+extern "C" int mfx_sgd_set_order32(mfx_ctx* ctx, const uint32_t* perm, int64_t n) {
+  if (!ctx) return MFX_E_ARG;
+  NEED(perm && n >= 0, MFX_E_ARG, "mfx_sgd_set_order32: perm NULL or n<0");
+  HIPCHK(hipSetDevice(ctx->device));
+  int rc;
+  if (ctx->order_cap < n || !ctx->order) {
+    dev_free(ctx->order);
+    ctx->order_cap = 0;
+    if ((rc = dev_alloc(ctx, &ctx->order, (size_t)n))) return rc;
+    ctx->order_cap = n;
+  }
+  if (ctx->order32_cap < n || !ctx->order32) {
+    dev_free(ctx->order32);
+    ctx->order32_cap = 0;
+    if ((rc = dev_alloc(ctx, &ctx->order32, (size_t)n))) return rc;
+    ctx->order32_cap = n;
+  }
+  if (n) {
+    HIPCHK(hipMemcpyAsync(ctx->order32, perm, sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(widen_order_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, ctx->stream,
+                       (const uint32_t*)ctx->order32, n, ctx->order);
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));        // (the caller's buffer is free when this returns)
   ctx->order_n = n;
   return MFX_OK;
 }

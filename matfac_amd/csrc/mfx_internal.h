@@ -72,6 +72,8 @@ struct mfx_ctx {
   int64_t elist_n = 0, elist_cap = 0;
   uint64_t* order = nullptr;
   int64_t order_n = 0, order_cap = 0;
+  uint32_t* order32 = nullptr;   // staging of mfx_sgd_set_order32
+  int64_t order32_cap = 0;
   int32_t* ulist = nullptr;  // user list for MFX_SGD_USERS
   int64_t ulist_cap = 0;
   // MFX_SGD_TILED: slot lists (sgd_slots.hip owns the type)

@@ -252,3 +252,26 @@ extern "C" int mfh_shuffle_check(int64_t n, uint32_t seed, double* secs) {
     return -1;
   }
 }
+
+extern "C" int mfh_shuffle_check32(int64_t n, uint32_t seed, double* secs) {
+  try {
+    if (n < 0 || n >= ((int64_t)1 << 32)) return -1;
+    std::vector<size_t> x((size_t)n);
+    std::vector<uint32_t> y((size_t)n);
+    std::iota(x.begin(), x.end(), (size_t)0);
+    std::iota(y.begin(), y.end(), 0u);
+    std::mt19937 g1(seed), g2(seed);
+    const auto t0 = std::chrono::steady_clock::now();
+    std::shuffle(x.begin(), x.end(), g1);
+    const auto t1 = std::chrono::steady_clock::now();
+    mfhShuffle(y, g2);
+    const auto t2 = std::chrono::steady_clock::now();
+    if (secs) { secs[0] = std::chrono::duration<double>(t1 - t0).count(); secs[1] = std::chrono::duration<double>(t2 - t1).count(); secs[2] = (double)mfhShuffleForm(); }
+    if (!(g1 == g2)) return 0;
+    for (size_t k = 0; k < x.size(); k++)
+      if (x[k] != (size_t)y[k]) return 0;
+    return 1;
+  } catch (...) {
+    return -1;
+  }
+}

@@ -11,6 +11,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <functional>
 #include <future>
@@ -552,11 +553,10 @@ struct MtBulk {
   }
 };
 
-// The same on two threads for long lists: this thread draws the positions (the generator and the distribution are about half of the
-// time), a helper requests their lines and swaps -- in order, block by block, through a ring of position blocks.  fast: the
-// positions come from MtBulk instead of the library's generator and distribution objects.
+// The same on two threads for long lists: this thread draws the positions with the library's generator and distribution objects
+// (about half of the time), a helper requests their lines and swaps -- in order, block by block, through a ring of position blocks.
 template <class T>
-void shuffleAheadPair(std::vector<T>& a, std::mt19937& g, size_t block, bool fast = false) {
+void shuffleAheadPair(std::vector<T>& a, std::mt19937& g, size_t block) {
   const size_t n = a.size();
   const uint64_t urngrange = (uint64_t)g.max() - (uint64_t)g.min();
   if (n < 2 || urngrange / n >= n) { std::shuffle(a.begin(), a.end(), g); return; }
@@ -565,11 +565,6 @@ void shuffleAheadPair(std::vector<T>& a, std::mt19937& g, size_t block, bool fas
   std::atomic<size_t> produced(0), consumed(0);
   const size_t nblocks = (n - 1 + block - 1) / block;
   T* p = a.data();
-  std::unique_ptr<MtBulk> bulk;          // (everything that allocates happens before the helper starts: nothing below throws while it runs)
-  if (fast && n < ((size_t)1 << 32)) {
-    bulk.reset(new MtBulk);
-    if (!bulk->load(g)) bulk.reset();
-  }
   double waitSwap = 0, waitDraw = 0;          // MFX_TIME_LOOP=1: which of the two threads waits for the other
   static const bool timeIt = getenv("MFX_TIME_LOOP") && atoi(getenv("MFX_TIME_LOOP")) != 0;
   std::thread helper([&] {
@@ -602,13 +597,96 @@ void shuffleAheadPair(std::vector<T>& a, std::mt19937& g, size_t block, bool fas
     while (b - consumed.load(std::memory_order_acquire) >= RING) std::this_thread::yield();
     size_t* j = ring.data() + (b % RING) * block;
     const size_t i0 = 1 + b * block, m = std::min(block, n - i0);
-    if (bulk) for (size_t k = 0; k < m; k++) j[k] = bulk->below((uint32_t)(i0 + k + 1));
-    else for (size_t k = 0; k < m; k++) j[k] = d(g, P(0, i0 + k));
+    for (size_t k = 0; k < m; k++) j[k] = d(g, P(0, i0 + k));
     produced.store(b + 1, std::memory_order_release);
   }
   helper.join();
   if (timeIt) fprintf(stderr, "[mfh] shuffle of %zu entries: the drawing thread waited %.1f ms for the swapping one, the swapping thread %.1f ms for draws\n", n, waitDraw, waitSwap);
-  if (bulk && !bulk->store(g)) throw std::runtime_error("mfhShuffle: the generator state could not be handed back");
+}
+
+// Three threads, with the restated generator and distribution (behind shuffleFastIsStd() only): one twists and tempers the
+// generator's blocks of 624 words a few blocks ahead, this one turns them into swap positions (Lemire's multiply-shift, the rare
+// rejection drawing again from the same stream), a third requests the positions' lines and swaps.  On the GPU box's host the two
+// threads of shuffleAheadPair were level at 2.5 ns per entry each -- drawing = generating + scaling; split, and with 32-bit lists
+// to swap, every stage has less to do.  The generator's state afterwards is the state of the block the last draw came from.
+template <class T>
+bool shuffleAheadTriple(std::vector<T>& a, std::mt19937& g, size_t block) {
+  const size_t n = a.size();
+  const uint64_t urngrange = (uint64_t)g.max() - (uint64_t)g.min();
+  if (n < 2 || urngrange / n >= n || n >= ((size_t)1 << 32)) return false;
+  constexpr size_t RAWS = 8, RING = 8;
+  std::vector<MtBulk> raw(RAWS);                       // (everything that allocates happens before the helpers start)
+  std::vector<uint32_t> ring(RING * block);
+  if (!raw[0].load(g)) return false;
+  std::atomic<size_t> rawProduced(1), rawReleased(0), produced(0), consumed(0);
+  std::atomic<bool> stop(false);
+  const size_t nblocks = (n - 1 + block - 1) / block;
+  T* p = a.data();
+  std::thread gen([&] {
+    for (size_t b = 1;; b++) {                         // block b of the raw stream = block b - 1 twisted
+      while (b - rawReleased.load(std::memory_order_acquire) >= RAWS) {
+        if (stop.load(std::memory_order_acquire)) return;
+        std::this_thread::yield();
+      }
+      if (stop.load(std::memory_order_acquire)) return;
+      MtBulk& nx = raw[b % RAWS];
+      std::memcpy(nx.x, raw[(b - 1) % RAWS].x, sizeof nx.x);
+      nx.twist();
+      rawProduced.store(b + 1, std::memory_order_release);
+    }
+  });
+  std::thread swp([&] {
+    for (size_t b = 0; b < nblocks; b++) {
+      while (produced.load(std::memory_order_acquire) <= b) std::this_thread::yield();
+      const uint32_t* j = ring.data() + (b % RING) * block;
+      const size_t i0 = 1 + b * block, m = std::min(block, n - i0);
+      constexpr size_t AHEAD = 64;
+      for (size_t k = 0; k < std::min(AHEAD, m); k++) __builtin_prefetch(p + j[k], 1);
+      for (size_t k = 0; k < m; k++) {
+        if (k + AHEAD < m) __builtin_prefetch(p + j[k + AHEAD], 1);
+        std::swap(p[i0 + k], p[j[k]]);
+      }
+      consumed.store(b + 1, std::memory_order_release);
+    }
+  });
+  size_t rb = 0, idx = raw[0].p;                       // the next raw number: block rb, word idx
+  const uint32_t* out = raw[0].out;
+  auto nextRaw = [&]() -> uint32_t {
+    if (idx >= 624) {                                  // block rb is used up: release it, take the next one
+      rawReleased.store(rb + 1, std::memory_order_release);
+      rb++;
+      while (rawProduced.load(std::memory_order_acquire) <= rb) std::this_thread::yield();
+      out = raw[rb % RAWS].out;
+      idx = 0;
+    }
+    return out[idx++];
+  };
+  for (size_t b = 0; b < nblocks; b++) {
+    while (b - consumed.load(std::memory_order_acquire) >= RING) std::this_thread::yield();
+    uint32_t* j = ring.data() + (b % RING) * block;
+    const size_t i0 = 1 + b * block, m = std::min(block, n - i0);
+    for (size_t k = 0; k < m; k++) {
+      const uint32_t range = (uint32_t)(i0 + k + 1);   // d(g, param_type(0, i)) of bits/uniform_int_dist.h, see MtBulk::below
+      uint64_t product = (uint64_t)nextRaw() * (uint64_t)range;
+      uint32_t low = (uint32_t)product;
+      if (low < range) {
+        const uint32_t threshold = (0u - range) % range;
+        while (low < threshold) {
+          product = (uint64_t)nextRaw() * (uint64_t)range;
+          low = (uint32_t)product;
+        }
+      }
+      j[k] = (uint32_t)(product >> 32);
+    }
+    produced.store(b + 1, std::memory_order_release);
+  }
+  stop.store(true, std::memory_order_release);
+  swp.join();
+  gen.join();
+  MtBulk& last = raw[rb % RAWS];                       // (never released: the generating thread has not touched it again)
+  last.p = idx;
+  if (!last.store(g)) throw std::runtime_error("mfhShuffle: the generator state could not be handed back");
+  return true;
 }
 bool shuffleAheadIsStd() {
   static const bool ok = [] {
@@ -636,8 +714,14 @@ bool shuffleFastIsStd() {
       std::mt19937 g1(777), g3(777);
       g1.discard(n % 1000); g3.discard(n % 1000);
       std::shuffle(x.begin(), x.end(), g1);
-      shuffleAheadPair(z, g3, 4096, true);
-      if (!(x == z && g1 == g3)) return false;
+      if (!shuffleAheadTriple(z, g3, 4096) || !(x == z && g1 == g3)) return false;
+      std::vector<uint32_t> w(n);                         // ... and a 32-bit list through the same draws
+      std::iota(w.begin(), w.end(), 0u);
+      std::mt19937 g4(777);
+      g4.discard(n % 1000);
+      if (!shuffleAheadTriple(w, g4, 1000) || !(g1 == g4)) return false;
+      for (size_t k = 0; k < n; k++)
+        if ((size_t)w[k] != x[k]) return false;
     }
     // the rejection path proper: ranges just above 2^31 reject half of the draws
     std::mt19937 g1(99), g2(99);
@@ -661,17 +745,23 @@ int mfhShuffleForm() {
   return shuffleFastIsStd() ? 2 : 1;
 }
 // std::shuffle(a.begin(), a.end(), g) -- bit for bit, see above (MFX_STD_SHUFFLE=1: the library call itself)
-void mfhShuffle(std::vector<size_t>& a, std::mt19937& g) {
+namespace {
+template <class T>
+void mfhShuffleT(std::vector<T>& a, std::mt19937& g) {
   static const bool plain = getenv("MFX_STD_SHUFFLE") && atoi(getenv("MFX_STD_SHUFFLE")) != 0;
   static const bool single = getenv("MFX_SHUFFLE_THREADS") && atoi(getenv("MFX_SHUFFLE_THREADS")) == 1;
-  if (!plain && shuffleAheadIsStd()) {
-    static const bool slowGen = getenv("MFX_SHUFFLE_LIBGEN") && atoi(getenv("MFX_SHUFFLE_LIBGEN")) != 0;
-    if (a.size() >= (size_t)1 << 20 && !single) shuffleAheadPair(a, g, 8192, !slowGen && shuffleFastIsStd());
-    else shuffleAhead(a, g);
+  static const bool slowGen = getenv("MFX_SHUFFLE_LIBGEN") && atoi(getenv("MFX_SHUFFLE_LIBGEN")) != 0;
+  if (plain || !shuffleAheadIsStd()) { std::shuffle(a.begin(), a.end(), g); return; }
+  if (a.size() >= (size_t)1 << 20 && !single) {
+    if (!slowGen && shuffleFastIsStd() && shuffleAheadTriple(a, g, 8192)) return;
+    shuffleAheadPair(a, g, 8192);
   } else {
-    std::shuffle(a.begin(), a.end(), g);
+    shuffleAhead(a, g);
   }
 }
+}  // namespace
+void mfhShuffle(std::vector<size_t>& a, std::mt19937& g) { mfhShuffleT(a, g); }
+void mfhShuffle(std::vector<uint32_t>& a, std::mt19937& g) { mfhShuffleT(a, g); }
 
 // ---- ModelMF::trainSGDPar's stratification (modelMF.cpp:229-265, 273-304; util.cpp:1077-1107) ------------------
 // The reference keeps every part as a std::unordered_set<int> and sweeps a block in that container's iteration order;
@@ -851,7 +941,14 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
   std::vector<size_t> uiRatingInds;
   std::vector<uint64_t> userPerm;
   std::vector<size_t> validUsers;
-  if ((kind == K_SGD || kind == K_HOG || kind == K_IFW) && exact) {
+  // (the reference's uiRatingInds is a vector<size_t>; below 2^32 ratings the same list is kept in 32 bits -- the same swaps, half the
+  //  bytes for the host's shuffle and for the upload -- unless MFX_ORDER64=1)
+  std::vector<uint32_t> ratingInds32;
+  const bool order32 = nRatings < ((int64_t)1 << 32) && !(getenv("MFX_ORDER64") && atoi(getenv("MFX_ORDER64")) != 0);
+  if ((kind == K_SGD || kind == K_HOG || kind == K_IFW) && exact && order32) {
+    ratingInds32.resize((size_t)nRatings);
+    std::iota(ratingInds32.begin(), ratingInds32.end(), 0u);
+  } else if ((kind == K_SGD || kind == K_HOG || kind == K_IFW) && exact) {
     uiRatingInds.resize((size_t)nRatings);
     std::iota(uiRatingInds.begin(), uiRatingInds.end(), 0);
   }
@@ -920,9 +1017,11 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
         if (exact) {
           // modelMF.cpp:76-81: std::shuffle every epoch on one thread (parBlockShuffle with one
           // OpenMP thread is a plain std::shuffle; the reference is only reproducible that way)
-          orderOfEpoch([&uiRatingInds, &mt] { mfhShuffle(uiRatingInds, mt); });
+          if (order32) orderOfEpoch([&ratingInds32, &mt] { mfhShuffle(ratingInds32, mt); });
+          else orderOfEpoch([&uiRatingInds, &mt] { mfhShuffle(uiRatingInds, mt); });
           const auto u0 = std::chrono::steady_clock::now();
-          dev->check(mfx_sgd_set_order(dev->ctx, (const uint64_t*)uiRatingInds.data(), nRatings), "set_order");   // (copied when it returns)
+          if (order32) dev->check(mfx_sgd_set_order32(dev->ctx, ratingInds32.data(), nRatings), "set_order32");   // (copied when it returns)
+          else dev->check(mfx_sgd_set_order(dev->ctx, (const uint64_t*)uiRatingInds.data(), nRatings), "set_order");
           const auto u1 = std::chrono::steady_clock::now();
           o.mode = replayMode; o.order = MFX_ORDER_HOST;
           orderAhead();

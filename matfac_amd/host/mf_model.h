@@ -4,6 +4,7 @@
 #ifndef MFHOST_MF_MODEL_H_
 #define MFHOST_MF_MODEL_H_
 #include <cmath>
+#include <cstdint>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -17,6 +18,7 @@
 // std::shuffle(a.begin(), a.end(), g) bit for bit (same permutation, same generator state), with the swap positions drawn a block
 // ahead so that their cache lines are on the way when the swaps follow (mf_model.cpp)
 void mfhShuffle(std::vector<size_t>& a, std::mt19937& g);
+void mfhShuffle(std::vector<uint32_t>& a, std::mt19937& g);      // the same swaps on a list of 32-bit entries (half the bytes)
 int mfhShuffleForm();      // 0: the library call, 1: block-ahead, 2: block-ahead with the restated generator (self-checks passed)
 
 // constants of const.h:4-12 / modelMF.h:16-17

@@ -52,6 +52,8 @@ int mfh_mat_read(const char* path, float* data, int32_t n, int32_t k);
  * the same permutation with mt19937(seed) and leave the generator in the same state; secs (may be NULL) = {seconds of std::shuffle, of mfhShuffle,
  * the form mfhShuffle takes: 0 library call, 1 block-ahead, 2 block-ahead with the restated generator and distribution} */
 int mfh_shuffle_check(int64_t n, uint32_t seed, double* secs);
+/* the same with mfhShuffle working on a list of 32-bit entries (what ModelMF::train shuffles below 2^32 ratings) */
+int mfh_shuffle_check32(int64_t n, uint32_t seed, double* secs);
 
 #ifdef __cplusplus
 }

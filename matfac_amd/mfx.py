@@ -138,6 +138,10 @@ class Ctx:
         k = _p(perm, np.uint64)
         self._chk(self.lib.mfx_sgd_set_order(self.h, k[1], C.c_int64(k[0].size)))
 
+    def sgd_set_order32(self, perm):
+        k = _p(perm, np.uint32)
+        self._chk(self.lib.mfx_sgd_set_order32(self.h, k[1], C.c_int64(k[0].size)))
+
     def sgd_epoch(self, lr, uReg, iReg, mode=SGD_HOGWILD, order=ORDER_DEVICE, arith=ARITH_F32, seed=1,
                   epoch=0, first=0, count=0, blocks=0, own=0, flags=0, item_part=0):
         o = SgdOpts(mode, order, arith, lr, uReg, iReg, seed, epoch, blocks, own, first, count, flags, item_part)

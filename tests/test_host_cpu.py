@@ -245,9 +245,11 @@ def test_epoch_shuffle_is_std_shuffle_bit_for_bit(n):
     libstdc++'s paths (two positions per draw up to 65 536 entries, the plain loop beyond)."""
     lib = synth._host()
     lib.mfh_shuffle_check.argtypes = [C.c_int64, C.c_uint32, C.POINTER(C.c_double)]
+    lib.mfh_shuffle_check32.argtypes = [C.c_int64, C.c_uint32, C.POINTER(C.c_double)]
     for seed in (1, 12345):
         secs = (C.c_double * 3)()
         assert lib.mfh_shuffle_check(n, seed, secs) == 1
+        assert lib.mfh_shuffle_check32(n, seed, secs) == 1          # a list of 32-bit entries: the same swaps, the same state
     # this image's libstdc++ (GCC 11) is the one the restated generator + distribution were written against: from 2^20 entries on a
     # second thread swaps while the first draws with them (form 2); another library would fail the self-check and report 0 or 1
     assert secs[2] == 2.0
