@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -16,6 +17,7 @@
 #include <functional>
 #include <future>
 #include <iostream>
+#include <mutex>
 #include <numeric>
 #include <omp.h>
 #include <random>
@@ -847,6 +849,59 @@ struct Strata {
 };
 }  // namespace
 
+namespace {
+// One host thread that makes the epoch orders of an exact trainer, for the whole loop; the list it shuffles is first touched (and
+// so placed) by it.  (Inside the loop a shuffle takes 51 - 59 ms where it takes 41 - 48 alone; a thread per epoch or this one, the
+// list touched here or by the caller: the same -- not the placement, then.)
+class OrderThread {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::function<void()> job;
+  bool busy = false, quit = false;
+  std::exception_ptr err;
+
+ public:
+  OrderThread() {
+    th = std::thread([this] {
+      std::unique_lock<std::mutex> lk(mu);
+      for (;;) {
+        cv.wait(lk, [this] { return quit || (busy && job); });
+        if (quit) return;
+        std::function<void()> j = std::move(job);
+        job = nullptr;
+        lk.unlock();
+        try { j(); } catch (...) { err = std::current_exception(); }
+        lk.lock();
+        busy = false;
+        cv.notify_all();
+      }
+    });
+  }
+  ~OrderThread() {
+    { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [this] { return !busy; }); quit = true; }
+    cv.notify_all();
+    th.join();
+  }
+  bool pending() { std::lock_guard<std::mutex> lk(mu); return busy; }
+  void start(std::function<void()> j) {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [this] { return !busy; });
+    job = std::move(j);
+    busy = true;
+    started = true;
+    cv.notify_all();
+  }
+  void wait() {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [this] { return !busy; });
+    started = false;
+    if (err) { std::exception_ptr e = err; err = nullptr; std::rethrow_exception(e); }
+  }
+  bool started = false;      // a job was started and not yet waited for
+};
+}  // namespace
+
 void ModelMF::train(const Data& d, Model& b, IntSet& iu, IntSet& ii) { run(K_SGD, "train", d, b, iu, ii); }
 void ModelMF::hogTrain(const Data& d, Model& b, IntSet& iu, IntSet& ii) { run(K_HOG, "hogTrain", d, b, iu, ii); }
 void ModelMF::trainSGDPar(const Data& d, Model& b, IntSet& iu, IntSet& ii) { run(K_SGDPAR, "trainSGDPar", d, b, iu, ii); }
@@ -945,13 +1000,8 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
   //  bytes for the host's shuffle and for the upload -- unless MFX_ORDER64=1)
   std::vector<uint32_t> ratingInds32;
   const bool order32 = nRatings < ((int64_t)1 << 32) && !(getenv("MFX_ORDER64") && atoi(getenv("MFX_ORDER64")) != 0);
-  if ((kind == K_SGD || kind == K_HOG || kind == K_IFW) && exact && order32) {
-    ratingInds32.resize((size_t)nRatings);
-    std::iota(ratingInds32.begin(), ratingInds32.end(), 0u);
-  } else if ((kind == K_SGD || kind == K_HOG || kind == K_IFW) && exact) {
-    uiRatingInds.resize((size_t)nRatings);
-    std::iota(uiRatingInds.begin(), uiRatingInds.end(), 0);
-  }
+  // (the list of K_SGD / K_HOG / K_IFW is allocated and numbered by the thread that shuffles it: orderThread, below)
+  const bool listOfAll = (kind == K_SGD || kind == K_HOG || kind == K_IFW) && exact;
   Strata strata;
   if (kind == K_SGDPAR && exact) {
     // modelMF.cpp:191-265: valid users / items shuffled with mt and dealt into T = omp_get_max_threads() parts
@@ -981,13 +1031,20 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
 
   double subIterDuration = 0;
   // Exact replay: the order of an epoch depends on the generator alone (nothing else in this loop draws from mt), so the order of
-  // epoch e + 1 is made on a second host thread while the device replays epoch e and the objective is taken -- for train the
+  // epoch e + 1 is made on a second host thread (orderThread) while the device replays epoch e and the objective is taken -- for train the
   // shuffle is the larger of the two.  orderOfEpoch(make) leaves this epoch's order in uiRatingInds (made ahead, or now);
   // orderAhead(), called once mfx_sgd_set_order has copied it, starts the next one.  An iteration that ends the loop leaves one
   // order unused; mt is local to this function.  MFX_NO_SHUFFLE_AHEAD=1: everything on the calling thread.
   double tOrder = 0, tMake = 0;         // (declared in front of nextOrder: the thread it joins on destruction writes tMake)
-  std::future<void> nextOrder;          // (joins on destruction)
+  OrderThread orderThread;               // (waits for its job on destruction)
   std::function<void()> makeOrder;
+  if (listOfAll) {
+    orderThread.start([&] {
+      if (order32) { ratingInds32.resize((size_t)nRatings); std::iota(ratingInds32.begin(), ratingInds32.end(), 0u); }
+      else { uiRatingInds.resize((size_t)nRatings); std::iota(uiRatingInds.begin(), uiRatingInds.end(), (size_t)0); }
+    });
+    orderThread.wait();
+  }
   // MFX_TIME_LOOP=1: where an iteration of an exact trainer goes (stderr): waiting for the order, its upload, the rest
   static const bool timeLoop = getenv("MFX_TIME_LOOP") && atoi(getenv("MFX_TIME_LOOP")) != 0;
   auto orderOfEpoch = [&](std::function<void()> make) {
@@ -997,13 +1054,13 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
       make();
       tMake = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - m0).count();
     };
-    if (nextOrder.valid()) nextOrder.get();
+    if (orderThread.started) orderThread.wait();
     else makeOrder();
     tOrder = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (timeLoop) fprintf(stderr, "[mfh] iteration %d: waited %.1f ms for the order (made in %.1f ms)\n", iter, tOrder, tMake);
   };
   auto orderAhead = [&] {
-    if (iter + 1 < maxIter && !getenv("MFX_NO_SHUFFLE_AHEAD")) nextOrder = std::async(std::launch::async, makeOrder);
+    if (iter + 1 < maxIter && !getenv("MFX_NO_SHUFFLE_AHEAD")) orderThread.start(makeOrder);
   };
   const auto loopStart = std::chrono::steady_clock::now();
   for (iter = 0; iter < maxIter; iter++) {
