@@ -311,7 +311,10 @@ def test_level_schedule_is_the_sequential_loop_bit_for_bit(K, arith, exact_sched
         load_ctx(ctx, d, K, U0, V0)
         for ep in range(3):
             mt.shuffle_u64(order)
-            ctx.sgd_set_order(order)
+            if ep == 1:
+                ctx.sgd_set_order32(order.astype(np.uint32))      # the 32-bit form of the same list (what the host classes upload)
+            else:
+                ctx.sgd_set_order(order)
             ctx.sgd_epoch(0.005, 0.01, 0.01, mode=mfx.SGD_LEVELS, order=mfx.ORDER_HOST, arith=arith[0])
             orc.sgd_pass(Uo, Vo, ru, tr.rowind, tr.rowval, order, 0.005, 0.01, 0.01, arith[1], orc.DOT_TREE)
             info, prep_ms = ctx.debug_levels_info()
