@@ -924,8 +924,9 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
   // unset: every trainer keeps ITS OWN semantics.
   //   * ModelMF::train, trainUShuffle, trainSGDPar are sequential / deterministic in the reference (modelMF.cpp:83-105, 637-659,
   //     273-304): they replay the reference's order -- the numbers ARE the reference's -- up to MFX_EXACT_SEQ_BELOW train ratings
-  //     (default 32 M: the ML-20M shape replays at 0.96 G updates/s, 21 ms per epoch, next to the reference's own std::shuffle
-  //     of the index list on the host, 0.4 s); larger matrices take the lock-free tiled schedule unless MFX_EXACT=1;
+  //     (default 32 M: the ML-20M shape replays at 1.38 G updates/s, 18 ms per call, next to the reference's own std::shuffle
+  //     of the index list on the host -- 0.37 s as the library call, 0.05 s as mfhShuffle above, a thread ahead); larger matrices take
+  //     the lock-free tiled schedule unless MFX_EXACT=1;
   //   * hogTrain is lock-free in the reference (:1747-1763) and the sibling models' loops sit in OpenMP-parallel block loops: they
   //     take the lock-free tiled schedule, except on small matrices (up to MFX_EXACT_BELOW = 2 M ratings), where >= 64 ratings of
   //     a workgroup in flight collide on the few hundred rows of a tile and the one-thread replay is both exact and cheap.
