@@ -17,10 +17,6 @@
 #ifndef MFX_EXP
 #define MFX_EXP 0
 #endif
-// slots from this many ratings on run at raised wave priority (a build-time knob: scripts/exp_slots.sh)
-#ifndef MFX_POLE_PRIO
-#define MFX_POLE_PRIO 2048
-#endif
 
 // ---------------------------------------------------------------------------
 // kernel
@@ -433,12 +429,9 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
       }
       __syncthreads();
       const uint32_t ks0 = k0 + (uint32_t)slot * 0x632be5abU, ks1 = k1 ^ mfx_mix32((uint32_t)slot + 77U);
-      // A popular row's slot is a POLE: one owner, however many ratings (C2: 6 200 of the most popular item per tile), worked off 64 at
-      // a time -- with two workgroups per CU it gets half of the CU and ends when the round does: the eight poles of that item are the
-      // critical path of the epoch (an epoch whose rounds do not wait for each other, wrong on purpose, ran 6.5 % faster).  Its waves
-      // issue first (s_setprio 3) while the workgroup next to it, which is not on that path, fills the gaps.
-      const bool pole = !SWEEP && R >= MFX_POLE_PRIO;
-      if (pole) __builtin_amdgcn_s_setprio(3);
+      // (A popular row's slot is a POLE: one owner, however many ratings -- C2: 6 200 of the most popular item per tile, ended about when
+      //  its round does.  Raised wave priority for such slots, s_setprio 3 from 512 ... 4 096 ratings on, was measured on one box:
+      //  21.12 - 21.29 G updates/s against 21.16 - 21.25 without: nothing.)
       // one group (test hook): wave 0 alone, L ratings per chunk, rating cb+s in entry s*G (group 0's entry of step s)
       // aw = waves of the workgroup that take part (16 unless the tile has few lock-free rows: mfx_launch_sgd_tiled)
       const int64_t cb0 = onegrp ? (wave == 0 ? 0 : R) : ALLW ? (int64_t)wave * 64 : (wave < aw ? (int64_t)wave * 64 : R);
@@ -490,7 +483,6 @@ __global__ __launch_bounds__(WG, (4 * L * C <= 64 ? 8 : 4)) void sgd_slots_kerne
         if (fix) SlotSteps<L, C, ARITH, OWN_U, true, VAR, 0>::run(Um, q_lds, tx, ty, tz, tw, regk, g, j, nvalid, lr, uReg, iReg, pn, pen, pnn, penn);
         else SlotSteps<L, C, ARITH, OWN_U, false, VAR, 0>::run(Um, q_lds, tx, ty, tz, tw, regk, g, j, nvalid, lr, uReg, iReg, pn, pen, pnn, penn);
       }
-      if (pole) __builtin_amdgcn_s_setprio(0);
       if (PERSIST && tid == 0) s_slot = (int)atomicAdd(&ctr[tile], 1u);
       __syncthreads();
       if (PERSIST) {
