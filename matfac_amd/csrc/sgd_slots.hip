@@ -101,7 +101,7 @@ __global__ void need_count_kernel(const int32_t* __restrict__ tile_slot, const i
   }
 }
 int mfx_slots_build_needs(mfx_ctx* ctx, SlotList* S, int64_t nown) {
-  static_assert(SUB == 1 && NUB == 8, "round of a tile = (item block - user block) mod 8");
+  NEED(SUB == 1 && NUB == 8, MFX_E_STATE, "the one-launch epoch: round of a tile = (item block - user block) mod 8 needs 8 user blocks");
   int rc;
   if (S->slot_need && S->rowver && S->rowver_n == nown) return MFX_OK;
   dev_free(S->slot_need); dev_free(S->rowver);

@@ -259,9 +259,10 @@ struct SlotSteps {
 constexpr int DRAIN_WGS = 128;        // at most; the launch takes what is resident on THIS device (launch_slots)
 // one wave: did the rounds leave a slot anywhere?  -> ctr[NTILE + 3]
 static __global__ void slots_left_kernel(const int32_t* __restrict__ tile_slot, unsigned* __restrict__ ctr) {
-  const int t = threadIdx.x;
-  const bool left = t < NTILE && ctr[t] < (unsigned)(tile_slot[t + 1] - tile_slot[t]);
+  bool left = false;
+  for (int t = threadIdx.x; t < NTILE; t += 64) left = left || ctr[t] < (unsigned)(tile_slot[t + 1] - tile_slot[t]);
   const unsigned long long any = __builtin_amdgcn_ballot_w64(left);
+  const int t = threadIdx.x;
   if (t == 0) ctr[NTILE + 3] = any != 0ull ? 1u : 0u;
 }
 // ALLW: every wave of the workgroup takes part (compile-time chunk stride; a run-time stride cost 3.6 % at C2 -- measured A/B on one
@@ -616,7 +617,6 @@ static int launch_slots(mfx_ctx* ctx, SlotList* S, const mfx_sgd_opts* o, int bl
       else drain_wgs = fit;
     }
     ProfScope ps(ctx, MFX_K_SGD_SWEEP);
-    static_assert(NTILE <= 64, "slots_left_kernel looks at the tiles with one wave");
     hipLaunchKernelGGL(slots_left_kernel, dim3(1), dim3(64), 0, ctx->stream, (const int32_t*)S->tile_slot, S->ctr);
     hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, true, OWN_U, VAR>), dim3(drain_wgs), dim3(WG), 0, ctx->stream,
                        (const int4*)S->rec, S->slot_beg, S->slot_ibeg, S->slot_items, S->tile_slot, S->ctr, 0,
