@@ -126,14 +126,28 @@ __global__ void blk_count_kernel(const int32_t* __restrict__ u, const int32_t* _
   }
 }
 // rows by descending count (ties: ascending id), each onto the block with the smallest load so far (ties: the lowest block)
-static void balanced_blocks(const int32_t* cnt, int64_t n, int nb, bool user, bool hash_only, std::vector<uint8_t>& blk) {
+// Tiling t > 0 (sgd_slots.h): the same dealing over a JITTERED order -- every count scaled by a factor in [1, 1.25) drawn from a hash
+// of (row, tiling) -- so that rows of similar weight change places (ties, i.e. most rows, are shuffled outright) and end up in
+// different company, while every block still fills up longest-first.
+static void balanced_blocks(const int32_t* cnt, int64_t n, int nb, bool user, bool hash_only, int tiling, std::vector<uint8_t>& blk) {
   blk.resize((size_t)n);
-  for (int64_t r = 0; r < n; r++) blk[(size_t)r] = (uint8_t)(user ? slot_user_block((int32_t)r) : mfx_item_block((int32_t)r));
+  for (int64_t r = 0; r < n; r++) {
+    const int32_t rr = tiling == 0 ? (int32_t)r : (int32_t)mfx_mix32((uint32_t)r + 0x9e3779b9U * (uint32_t)tiling);
+    blk[(size_t)r] = (uint8_t)(user ? slot_user_block(rr) : mfx_item_block(rr));
+  }
   if (hash_only) return;
   std::vector<int32_t> rows;
   for (int64_t r = 0; r < n; r++)
     if (cnt[r] > 0) rows.push_back((int32_t)r);
-  std::sort(rows.begin(), rows.end(), [&](int32_t a, int32_t b) { return cnt[a] != cnt[b] ? cnt[a] > cnt[b] : a < b; });
+  if (tiling == 0) {
+    std::sort(rows.begin(), rows.end(), [&](int32_t a, int32_t b) { return cnt[a] != cnt[b] ? cnt[a] > cnt[b] : a < b; });
+  } else {
+    std::vector<double> key((size_t)n, 0.0);
+    const uint32_t salt = mfx_mix32(0x51ed270bU * (uint32_t)tiling + (user ? 0x68bc21ebU : 0x02e5be93U));
+    for (int32_t r : rows)
+      key[(size_t)r] = (double)cnt[r] * (1.0 + 0.25 * ((double)mfx_mix32((uint32_t)r ^ salt) * (1.0 / 4294967296.0)));
+    std::sort(rows.begin(), rows.end(), [&](int32_t a, int32_t b) { return key[(size_t)a] != key[(size_t)b] ? key[(size_t)a] > key[(size_t)b] : a < b; });
+  }
   std::vector<int64_t> load((size_t)nb, 0);
   for (int32_t r : rows) {
     int best = 0;
@@ -161,8 +175,8 @@ int mfx_slots_block_tables(mfx_ctx* ctx, SlotList* S, const RatingView& view) {
     HIPCHK(hipMemcpyAsync(h.data(), cnt, sizeof(int32_t) * (size_t)(nU + nI), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
   }
-  balanced_blocks(h.data(), nU, NUB, true, hash_only, S->h_ublk);
-  balanced_blocks(h.data() + nU, nI, 8, false, hash_only, S->h_iblk);
+  balanced_blocks(h.data(), nU, NUB, true, hash_only, S->tiling, S->h_ublk);
+  balanced_blocks(h.data() + nU, nI, 8, false, hash_only, S->tiling, S->h_iblk);
   dev_free(S->ublk); dev_free(S->iblk);
   if ((rc = dev_alloc(ctx, &S->ublk, (size_t)std::max<int64_t>(nU, 1))) || (rc = dev_alloc(ctx, &S->iblk, (size_t)std::max<int64_t>(nI, 1)))) return rc;
   if (nU) HIPCHK(hipMemcpyAsync(S->ublk, S->h_ublk.data(), (size_t)nU, hipMemcpyHostToDevice, ctx->stream));

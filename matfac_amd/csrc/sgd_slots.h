@@ -58,16 +58,30 @@ struct SlotList {
   int64_t nslots = 0, nnz = 0;
   int rows = 0;                    // owned rows per slot the lists were built for
   int active_waves = WG / 64;      // waves of a workgroup that work on a slot (fewer when a tile has few lock-free rows)
+  int tiling = 0;                  // which dealing of the rows into blocks this list was built on (mfx_slots_block_tables)
+  bool shared_ctr = false;         // ctr / abort_host are tiling 0's (ONE sticky abort flag per side, whichever tiling ran)
   bool built = false;
 };
+// Tilings.  ONE dealing of the users and items into blocks, used epoch after epoch, is a structure the shuffled loops of the
+// reference do not have: a user's ratings always arrive grouped by the same 8 item blocks, in the same cyclic order, and the
+// model that is evaluated at the end of an epoch has just been fitted to the last round's pairing.  Measured with the oracle's
+// SEQUENTIAL pass over such lists (tests/tools/order_effect.py, the 2.4 M-rating fixture, lr 0.005, no concurrency at all): test
+// RMSE at the best validation epoch 0.62303 for uniformly shuffled epochs, 0.62500 for one static 8 x 8 tiling (+2e-3: what
+// round 3 called "the block order"), 0.62395 with the rounds of an epoch in a fresh random order, 0.62338 / 0.62303 / 0.62305
+// with 2 / 4 / 8 different tilings taken in turn (and rounds in random order), 0.62319 with a fresh tiling every epoch.  So the
+// epochs cycle through MFX_SGD_TILINGS (default 4) independently dealt tilings -- each balanced over the ratings like the
+// first -- and walk their rounds in a per-epoch random order; tiling 0 is the deterministic dealing of round 3.
+constexpr int MAX_TILINGS = 8;
 // The ratings a slot list is built from: the whole train matrix (CSR arrays) or one ITEM PART of it (mfx_sgd_set_item_parts:
 // the multi-GPU rotation runs an epoch as nparts sub-epochs, each on the ratings whose item i has i % nparts == part).
 struct RatingView { const int32_t* u = nullptr; const int32_t* i = nullptr; const float* r = nullptr; int64_t n = 0; };
 // side 0: item rows owned (slots item-major), side 1: user rows owned (slots user-major)
 struct SlotState {
-  SlotList side[2];
+  SlotList side[2][MAX_TILINGS];
   uint32_t last_k0 = 0, last_k1 = 0;
   int last_side = 0, last_part = -1;       // last_part >= 0: the last epoch ran on parts[last_part]
+  int last_tiling = 0;
+  SlotList* visit_list = nullptr;          // the list of the last epoch run with MFX_SGD_F_COUNT_VISITS (mfx_debug_visit_counts)
   int xcc_probe_blocks = -1;               // mfx_xcc_ids_populated: the grid size probed last and what it found
   bool xcc_probe_ok = false;
   // item parts: the train ratings grouped by part (COO copy, part p = [poff[p], poff[p+1])) and one slot list per part
@@ -76,7 +90,7 @@ struct SlotState {
   float* pv = nullptr;
   std::vector<int64_t> poff;
   std::vector<SlotList> parts;
-  SlotList& last() { return last_part >= 0 ? parts[(size_t)last_part] : side[last_side]; }
+  SlotList& last() { return last_part >= 0 ? parts[(size_t)last_part] : side[last_side][last_tiling]; }
 };
 
 // position t of a slot's visiting order (Feistel permutation of [0, R) keyed per epoch and slot)

@@ -37,10 +37,14 @@ void mfx_slots_free_internal(mfx_ctx* ctx) {
   if (!st) return;
   auto drop = [](SlotList& s) {
     dev_free(s.rec); dev_free(s.slot_beg); dev_free(s.slot_ibeg); dev_free(s.slot_items); dev_free(s.attr); dev_free(s.visit);
-    dev_free(s.tile_slot); dev_free(s.ctr); dev_free(s.ublk); dev_free(s.iblk); dev_free(s.rowver); dev_free(s.slot_need);
-    if (s.abort_host) (void)hipHostFree(s.abort_host);
+    dev_free(s.tile_slot); dev_free(s.ublk); dev_free(s.iblk); dev_free(s.rowver); dev_free(s.slot_need);
+    if (!s.shared_ctr) {
+      dev_free(s.ctr);
+      if (s.abort_host) (void)hipHostFree(s.abort_host);
+    }
   };
-  for (SlotList& s : st->side) drop(s);
+  for (auto& sd : st->side)
+    for (SlotList& s : sd) drop(s);
   for (SlotList& s : st->parts) drop(s);
   dev_free(st->pu); dev_free(st->pi); dev_free(st->pv);
   delete st;
@@ -312,7 +316,30 @@ int mfx_launch_sgd_tiled(mfx_ctx* ctx, const mfx_sgd_opts* o) {
   const DevCSR& tm = ctx->mat[MFX_MAT_TRAIN];
   RatingView view;
   view.u = tm.rowid; view.i = tm.rowind; view.r = tm.rowval; view.n = tm.nnz;
-  SlotList* S = &st->side[side];
+  // which tiling this epoch runs on (sgd_slots.h): epochs take the tilings in turn; the test hooks that compare with a restated
+  // order (ONE_GROUP) and the item parts of the multi-GPU rotation stay on tiling 0
+  static const int n_tilings = [] {
+    const char* e = getenv("MFX_SGD_TILINGS");
+    return std::max(1, std::min(MAX_TILINGS, e ? atoi(e) : 4));
+  }();
+  const int tiling = (o->item_part != 0 || (o->flags & MFX_SGD_F_ONE_GROUP)) ? 0 : (int)((uint32_t)o->epoch % (uint32_t)n_tilings);
+  SlotList* S = &st->side[side][tiling];
+  S->tiling = tiling;
+  {
+    // one set of slot counters and ONE sticky abort flag per side: the tilings are used one epoch at a time on one stream, and a
+    // drain that gave up must be reported by the next epoch whichever tiling that runs on
+    SlotList* S0 = &st->side[side][0];
+    if (!S0->ctr) {
+      int rc;
+      if ((rc = dev_alloc(ctx, &S0->ctr, (size_t)CTR_WORDS))) return rc;
+      HIPCHK(hipMemsetAsync(S0->ctr, 0, CTR_WORDS * sizeof(unsigned), ctx->stream));
+    }
+    if (!S0->abort_host) {
+      HIPCHK(hipHostMalloc((void**)&S0->abort_host, sizeof(unsigned), hipHostMallocDefault));
+      *S0->abort_host = 0;
+    }
+    if (S != S0) { S->ctr = S0->ctr; S->abort_host = S0->abort_host; S->shared_ctr = true; }
+  }
   const int part = o->item_part - 1;
   if (o->item_part != 0) {
     // one item part of the train matrix (the multi-GPU rotation): its ratings come from the part-grouped copy
@@ -326,6 +353,7 @@ int mfx_launch_sgd_tiled(mfx_ctx* ctx, const mfx_sgd_opts* o) {
         if (s.abort_host) (void)hipHostFree(s.abort_host);
       }
       st->parts.clear();
+      st->visit_list = nullptr;
       int rc = mfx_slots_group_by_part(ctx, st, ctx->item_parts);
       if (rc) return rc;
       st->parts.resize((size_t)ctx->item_parts);
@@ -379,9 +407,11 @@ int mfx_launch_sgd_tiled(mfx_ctx* ctx, const mfx_sgd_opts* o) {
     if ((rc = dev_alloc(ctx, &S->visit, (size_t)S->nnz))) return rc;
     HIPCHK(hipMemsetAsync(S->visit, 0, sizeof(unsigned) * (size_t)S->nnz, ctx->stream));
   }
+  if (o->flags & MFX_SGD_F_COUNT_VISITS) st->visit_list = S;
   const uint32_t k0 = mfx_mix32(o->seed ^ 0x3c6ef372U) + (uint32_t)o->epoch * 0x9e3779b9U;
   const uint32_t k1 = mfx_mix32(o->seed * 0x85ebca6bU + 0xdaa66d2bU) ^ mfx_mix32((uint32_t)o->epoch + 0x1b873593U);
   st->last_k0 = k0; st->last_k1 = k1; st->last_side = side; st->last_part = o->item_part != 0 ? part : -1;
+  st->last_tiling = tiling;
   int blocks = env_blocks();
   // `blocks` counts 256-thread workgroups (include/mfx.h); this kernel runs WG-thread ones
   if (blocks <= 0) blocks = o->blocks > 0 ? std::min(o->blocks, 8192) : std::max(8, std::min(2048, ctx->nU / 64));
@@ -409,11 +439,16 @@ int mfx_launch_sgd_tiled(mfx_ctx* ctx, const mfx_sgd_opts* o) {
 int mfx_slots_check_abort(mfx_ctx* ctx) {
   SlotState* st = state(ctx);
   if (!st) return MFX_OK;
-  for (size_t k = 0; k < 2 + st->parts.size(); k++) {
-    SlotList& S = k < 2 ? st->side[k] : st->parts[k - 2];
+  for (size_t k = 0; k < 2 * MAX_TILINGS + st->parts.size(); k++) {
+    SlotList& S = k < 2 * MAX_TILINGS ? st->side[k / MAX_TILINGS][k % MAX_TILINGS] : st->parts[k - 2 * MAX_TILINGS];
     if (!S.abort_host || !*(volatile unsigned*)S.abort_host) continue;
-    *S.abort_host = 0;
+    // reported ONCE: copies of the sticky flag queued by epochs that are still in flight would set the host word again behind
+    // this point (the start-of-epoch check does not synchronise), so the stream is drained first -- an error path, taken once --
+    // and both words are cleared behind everything that could still write them
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     if (S.ctr) HIPCHK(hipMemsetAsync(S.ctr + NTILE + 2, 0, sizeof(unsigned), ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *S.abort_host = 0;
     return mfx_fail(ctx, MFX_E_HIP, "MFX_SGD_TILED: the drain of an epoch gave up at its grid barrier (no progress for 2 s; is the device "
                     "shared with another resident kernel?) -- that epoch may have left ratings unvisited");
   }
@@ -455,9 +490,9 @@ extern "C" int mfx_debug_visit_counts(mfx_ctx* ctx, uint32_t* counts, int64_t ca
   if (!ctx) return MFX_E_ARG;
   SlotState* st = state(ctx);
   NEED(n, MFX_E_ARG, "mfx_debug_visit_counts: n NULL");
-  NEED(st && st->last().built && st->last().visit, MFX_E_STATE,
+  NEED(st && st->visit_list && st->visit_list->built && st->visit_list->visit, MFX_E_STATE,
        "mfx_debug_visit_counts: no tiled epoch has run with MFX_SGD_F_COUNT_VISITS");
-  SlotList& S = st->last();
+  SlotList& S = *st->visit_list;
   *n = S.nnz;
   if (!counts) return MFX_OK;
   NEED(cap >= S.nnz, MFX_E_ARG, "mfx_debug_visit_counts: cap too small");

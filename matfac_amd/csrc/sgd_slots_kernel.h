@@ -590,7 +590,20 @@ static int launch_slots(mfx_ctx* ctx, SlotList* S, const mfx_sgd_opts* o, int bl
                          S->active_waves, (uint32_t)ownb, S->rowver, (const uint8_t*)S->slot_need);
     }
   }
-  for (int round = 0; round < NUB && !persist && !(o->flags & MFX_SGD_F_DRAIN_ONLY); round++) {
+  // the rounds of an epoch in a fresh random order (sgd_slots.h, "Tilings": the same cyclic order of pairings epoch after epoch is
+  // half of what a static tiling costs); any order of the diagonals visits every tile once.  MFX_SGD_ROUND_PERM=0: 0, 1, 2, ...
+  int rorder[NUB];
+  for (int r = 0; r < NUB; r++) rorder[r] = r;
+  {
+    static const bool perm_on = [] { const char* e = getenv("MFX_SGD_ROUND_PERM"); return !e || atoi(e) != 0; }();
+    uint32_t h = mfx_mix32(k0 ^ 0x7f4a7c15U) ^ k1;
+    for (int r = NUB - 1; r > 0 && perm_on; r--) {
+      h = mfx_mix32(h + 0x9e3779b9U);
+      std::swap(rorder[r], rorder[(int)(h % (uint32_t)(r + 1))]);
+    }
+  }
+  for (int rix = 0; rix < NUB && !persist && !(o->flags & MFX_SGD_F_DRAIN_ONLY); rix++) {
+    const int round = rorder[rix];
     ProfScope ps(ctx, MFX_K_SGD);
     if (S->active_waves == WG / 64)
       hipLaunchKernelGGL((sgd_slots_kernel<L, C, ARITH, false, OWN_U, VAR, true>), dim3(blocks), dim3(WG), 0, ctx->stream,

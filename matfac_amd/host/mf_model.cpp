@@ -402,6 +402,7 @@ bool Model::terminateImpl(bool sing, Model& bestModel, const Data& data, int ite
                           double& prevObj, double& bestValRMSE, double& prevValRMSE, IntSet& invalidUsers,
                           IntSet& invalidItems) {
   bool ret = false;
+  rolledBack = false;
   double currObj, currValRMSE = -1;
   const int wt = dev ? dev->which(data.trainMat) : -1, wv = dev && data.valMat ? dev->which(data.valMat) : -1;
   if (!sing && baseObjective() && wt >= 0 && wv >= 0) {
@@ -427,6 +428,7 @@ bool Model::terminateImpl(bool sing, Model& bestModel, const Data& data, int ite
       copyScalarsFrom(bestModel);
       hostStale = true;
       learnRate = learnRate / 2;
+      rolledBack = true;
       return false;
     }
     return true;
@@ -1030,6 +1032,32 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
   o.arith = kind == K_HOG ? MFX_ARITH_F32 : kind == K_SGDPAR ? MFX_ARITH_REF64F : MFX_ARITH_REF64;
   if (!exact && (kind == K_SGD || kind == K_SGDPAR)) o.arith = MFX_ARITH_F32;
 
+  // Lock-free tiled schedule, first epochs (MFX_TILED_WARM = "<n>" | "hog:<n>" | "flow:<n>", n epochs; default below).  While the
+  // factors are still at their +-0.01 initialisation the tiled schedule's block order is what makes it diverge where the
+  // reference's shuffled loops train: an item's ratings of a tile are visited as one burst, every user of the burst is fresh
+  // (p ~ 0, so the error stays at r however large q has grown) and each of them pushes q by (2 lr e)^2 q along itself
+  // (tests/test_block_order.py shows the reference's own trainSGDPar order doing it).  In a uniformly shuffled
+  // list the same item meets users that other items have already moved.  So the epochs that start from the initialisation run
+  // in a uniformly shuffled device order -- lock-free over the whole list like hogTrain (modelMF.cpp:1747-1763: "hog"), or as
+  // the sequential replay of that list ("flow") -- and the tiles take over from there; a NaN rollback to the initial model
+  // (model.cpp:1486-1498) starts the count again.
+  // Default flow:1 -- measured on the 2.4 M-rating fixture at the reference's rate 0.005 (scripts/warm_epochs.py, three seeds): tiles
+  // from epoch 0: NaN, rollback, half the rate for the rest of the run, test RMSE 0.6141 (hogTrain's own: 0.62281); hog:1 0.6174
+  // (the flat lock-free epoch on this chip loses most updates of the popular rows: a gentler start, a better model, but not the
+  // reference's); flow:1 0.6225 ... 0.6233 (with the four tilings of sgd_slots.h; 0.6241 ... 0.6252 on one static tiling).
+  int warmN = 1, warmMode = MFX_SGD_LEVELS;
+  if (const char* e = getenv("MFX_TILED_WARM")) {
+    const char* c = strchr(e, ':');
+    if (c && !strncmp(e, "hog", 3)) warmMode = MFX_SGD_HOGWILD;
+    warmN = std::max(0, atoi(c ? c + 1 : e));
+  }
+  if (kind == K_SGDPARSVD) warmN = 0;    // starts from the singular vectors, not from +-0.01
+  int freshEpochs = 0;                   // epochs run since the factors were last at their initialisation
+  auto tiledOrWarm = [&](mfx_sgd_opts& so) {
+    so.order = MFX_ORDER_DEVICE;
+    so.mode = freshEpochs < warmN ? warmMode : MFX_SGD_TILED;
+  };
+
   double subIterDuration = 0;
   // Exact replay: the order of an epoch depends on the generator alone (nothing else in this loop draws from mt), so the order of
   // epoch e + 1 is made on a second host thread (orderThread) while the device replays epoch e and the objective is taken -- for train the
@@ -1090,7 +1118,7 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - u1).count());
           break;
         } else {
-          o.mode = MFX_SGD_TILED; o.order = MFX_ORDER_DEVICE;   // (K_IFW: the tiled kernel's weighted variant)
+          tiledOrWarm(o);                                        // (K_IFW: the tiled kernel's weighted variant)
         }
         dev->check(mfx_sgd_epoch(dev->ctx, &o), "mfx_sgd_epoch");
         break;
@@ -1110,15 +1138,15 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
           }
         } else {
           // default: the stratification mapped onto the chip's own strata -- user-block x item-block tiles, one L2 domain per tile
-          o.mode = MFX_SGD_TILED; o.order = MFX_ORDER_DEVICE;
+          tiledOrWarm(o);
           dev->check(mfx_sgd_epoch(dev->ctx, &o), "mfx_sgd_epoch");
         }
         break;
       case K_TMFD:        // modelPoissonDropout.cpp:170-224: K_TMF with the draws mfx_set_tmf_dropout installed
       case K_TMF:         // modelDropoutSigmoid.cpp:140-192 with the rank table beforeLoop() installed; float diff
         o.arith = MFX_ARITH_REF64F;
-        o.mode = exact ? replayMode : MFX_SGD_TILED;           // the tiled kernel's truncated-rank variant
-        o.order = exact ? MFX_ORDER_NATURAL : MFX_ORDER_DEVICE;
+        if (exact) { o.mode = replayMode; o.order = MFX_ORDER_NATURAL; }
+        else tiledOrWarm(o);                                    // the tiled kernel's truncated-rank variant
         dev->check(mfx_sgd_epoch(dev->ctx, &o), "mfx_sgd_epoch");
         break;
       case K_SGDPARSVD:   // modelMF.cpp:474-512 with the per-dimension regulariser set above; lock-free, coherent rows
@@ -1148,7 +1176,7 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
         } else {
           // like train / hogTrain: the lock-free tiled schedule (the order of the users is then the kernel's business)
           std::shuffle(validUsers.begin(), validUsers.end(), mt);   // modelMF.cpp:635 (keeps mt where the reference has it)
-          o.mode = MFX_SGD_TILED; o.order = MFX_ORDER_DEVICE; o.arith = MFX_ARITH_F32;
+          tiledOrWarm(o); o.arith = MFX_ARITH_F32;
         }
         dev->check(mfx_sgd_epoch(dev->ctx, &o), "mfx_sgd_epoch");
         break;
@@ -1201,6 +1229,7 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
                               : isTerminateModel(bestModel, data, iter, bestIter, bestObj, prevObj, bestValRMSE, prevValRMSE,
                                                  invalidUsers, invalidItems))
         break;
+      freshEpochs = (rolledBack && bestIter < 0) ? 0 : freshEpochs + 1;
       if (iter % MF_DISP_ITER == 0) {
         std::cout << "ModelMF::" << name << " trainSeed: " << trainSeed << " Iter: " << iter
                   << " Objective: " << std::scientific << prevObj

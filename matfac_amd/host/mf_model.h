@@ -128,6 +128,7 @@ class Model {
   bool hostStale = false;            // device copy is newer than uFac/iFac
   double lastLoopSeconds = 0;        // wall time of the last trainer's iteration loop (updates + termination checks)
   int lastIters = 0;
+  bool rolledBack = false;           // the last isTerminateModel call found NaN and restored bestModel (model.cpp:1486-1498)
   virtual void syncHost();           // download uFac/iFac if hostStale
   virtual void pushToDevice();       // upload uFac/iFac to the CURRENT snapshot
   // scalar fields of `*this = other` without touching the factor storage

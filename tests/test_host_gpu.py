@@ -16,7 +16,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def host_train(method, d, K, maxIter, seed, lr, ureg, ireg, prefix=None, env=None):
+def host_train(method, d, K, maxIter, seed, lr, ureg, ireg, prefix=None, env=None, capture=False):
+    """capture=True: the trainer's own stdout (the reference's log lines, "Found nan" among them) comes back as h["log"]"""
     lib = synth._host()
     tr, va, te = d["train"], d["val"], d["test"]
     nU, nI = d["nUsers"], d["nItems"]
@@ -29,6 +30,13 @@ def host_train(method, d, K, maxIter, seed, lr, ureg, ireg, prefix=None, env=Non
     for k, v in (env or {}).items():
         old[k] = os.environ.get(k)
         os.environ[k] = v
+    tmp = saved = None
+    if capture:
+        import sys, tempfile
+        sys.stdout.flush()
+        tmp = tempfile.TemporaryFile(mode="w+b")
+        saved = os.dup(1)
+        os.dup2(tmp.fileno(), 1)
     try:
         rc = lib.mfh_train(method.encode(), C.c_int32(tr.nrows), P(tr.rowptr), P(tr.rowind), P(tr.rowval),
                            C.c_int32(tr.ncols), P(va.rowptr), P(va.rowind), P(va.rowval), C.c_int32(va.ncols),
@@ -36,14 +44,23 @@ def host_train(method, d, K, maxIter, seed, lr, ureg, ireg, prefix=None, env=Non
                            C.c_int32(maxIter), C.c_int32(seed), C.c_float(lr), C.c_float(ureg), C.c_float(ireg),
                            prefix.encode() if prefix else None, P(Ul), P(Vl), P(Ub), P(Vb), P(stats), P(invU), P(invI))
     finally:
+        if capture:
+            C.CDLL(None).fflush(None)
+            os.dup2(saved, 1)
+            os.close(saved)
         for k, v in old.items():
             if v is None:
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
     assert rc == 0
+    log = None
+    if capture:
+        tmp.seek(0)
+        log = tmp.read().decode(errors="replace")
+        tmp.close()
     return dict(U=Ul, V=Vl, Ubest=Ub, Vbest=Vb, train=stats[0], test=stats[1], val=stats[2], lr=stats[3],
-                invU=invU, invI=invI, nItems=int(stats[5]), loop_s=stats[6], iters=int(stats[7]))
+                invU=invU, invI=invI, nItems=int(stats[5]), loop_s=stats[6], iters=int(stats[7]), log=log)
 
 
 def oracle_train(method, d, K, maxIter, seed, lr, ureg, ireg, dot_mode=orc.DOT_SEQ, nthreads=1):
