@@ -29,7 +29,43 @@ HBM_PEAK_GBS = 8000.0
 MFMA_F32_PEAK_TF = 157.3
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0      # G wave-instructions/s
 L2_GATHER_PEAK_GBS = 17800.0               # rows gathered out of the XCDs' L2s: 16.8 - 18.8 TB/s chip-wide (MI355X_MICROARCH.md, 'Indexed rows')
-PMC_SUMMARY = os.path.join("profiles", "r03_pmc_summary.json")
+PMC_SUMMARY = os.path.join("profiles", "r04_pmc_summary.json")
+PMC_C4 = os.path.join("profiles", "r04_c4_pmc.json")
+PMC_C5 = os.path.join("profiles", "r04_c5_pmc.json")
+
+
+def _first_existing(path):
+    """the committed counter summary of this round, or the newest earlier one (named in traffic_source either way)"""
+    if os.path.exists(os.path.join(ROOT, path)):
+        return path
+    for r in ("r03", "r02", "r01"):
+        q = path.replace("r04", r)
+        if os.path.exists(os.path.join(ROOT, q)):
+            return q
+    return path
+
+
+def host_cores():
+    """(threads the OpenMP baselines run on, physical cores of the box): SURVEY 8(d) wants the core count stated"""
+    from oracle import binding as orc
+    threads = orc.max_threads()
+    phys = set()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                pid = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":")[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+        if pid is not None and cid is not None:
+            phys.add((pid, cid))
+    except OSError:
+        pass
+    return threads, (len(phys) if phys else None)
 
 
 def self_launch(args):
@@ -49,7 +85,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=8)   # (two turns through the four tilings of the tiled schedule; their lists are built in the first)
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--rank-k", type=int, default=64, dest="K")
     ap.add_argument("--scale", type=float, default=1.0, help="scale nnz (debug only)")
@@ -274,8 +310,9 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %s synthetic CSR, %s, train nnz=%d %s, rank=%d, %s LOCK-FREE SGD epoch (hogTrain analogue: device "
-                                   "reshuffle + update kernel%s); a lock-free variant: test RMSE within 1e-2 of the sequential reference, "
-                                   "two-sided (rmse_parity.*.gpu_lock_free_tiled_*); the path that reproduces ModelMF::train to 1e-6 is exact_replay"
+                                   "reshuffle + update kernel%s; epochs take four tilings in turn, rounds in a fresh order); a lock-free trainer: whole loops land "
+                                   "within 2e-3 of the reference hogTrain's mean test RMSE (rmse_parity.*.gpu_lock_free_tiled_hogtrain_*); "
+                                   "the path that reproduces ModelMF::train to 1e-6 is exact_replay"
                                    % (args.workload, {"C1": "ML-100K-shape", "C2": "ML-20M-shape", "C4": "Netflix-shape", "C5": "10Mx1M (BASELINE config 5)"}.get(args.workload, ""),
                                       ("%dx%d per GPU (weak scaling: one such user block per GPU over the same items)" % (nU, nI)) if args.scaling == "weak" or N == 1
                                       else ("ONE %dx%d matrix cut into %d nnz-balanced user blocks (strong scaling)" % (shape["nU"], nI, N)),
@@ -315,6 +352,11 @@ def main():
             out["secondary"] = secondary(np, args, d, K, with_cpu=not args.no_cpu_baseline)
         if not args.no_parity:
             out["rmse_parity"] = rmse_parity(np)
+        if not args.no_secondary and args.workload == "C2" and args.scale == 1.0:
+            try:
+                out["secondary"].append(default_rate_record(np, d, K, ureg, ireg))
+            except Exception as e:              # noqa: BLE001
+                out["secondary"].append({"config": "C2 at the default learning rate", "error": str(e)})
     if multi:
         dist.barrier()
         dist.destroy_process_group()
@@ -364,11 +406,11 @@ def exact_replay(np, ctx, mfx, tr, U0, V0, lr, ureg, ireg, epochs=3):
             "test_rmse_vs_reference": "rmse_parity.*.gpu_default_path_* (whole training loops against the fixture's seed-1 row)"}
 
 
-def pmc(kernel):
+def pmc(kernel, src=None):
     """Counters of `kernel` from the committed rocprofv3 PMC passes of this same command (scripts/profile_round.sh ->
-    profiles/r03_pmc_summary.json).  rocprofv3 cannot run inside this process: these are per-launch means of THAT run,
+    profiles/r04_pmc_summary.json).  rocprofv3 cannot run inside this process: these are per-launch means of THAT run,
     named as such in the record; None when the summary has no entry for the kernel."""
-    path = os.path.join(ROOT, PMC_SUMMARY)
+    path = os.path.join(ROOT, src or _first_existing(PMC_SUMMARY))
     try:
         return json.load(open(path))[kernel]
     except Exception:
@@ -376,17 +418,19 @@ def pmc(kernel):
 
 
 def sgd_roofline(K, nnz, launches_per_step, avg_ms, launches, kernel):
-    """What bounds the dominant kernel, with fractions that cannot exceed 1.
+    """SURVEY 8(d)'s fraction for the dominant kernel, counter-backed.
 
-    SURVEY 8(d)'s algorithmic figure (16K+12 bytes per update) assumes both rows of every update come from and go back to HBM.
-    At C2 they do not: the item rows of a slot live in LDS and the 42 MB of factors stay in L2 / Infinity Cache, so that figure
-    exceeds the HBM peak and bounds nothing (kept as `algorithmic`).  Three candidates are priced instead, `bound` names the
-    largest fraction:
-      l2-memory-side  bytes that cross the L2's memory side (FETCH_SIZE x2 + WRITE_SIZE: fabric requests, Infinity-Cache hits
-                      INCLUDED -- not HBM traffic at this working set) against the 8 TB/s HBM peak as the conservative ceiling;
-      l2-rows         the lock-free rows every update moves through its XCD's L2 (one 4K-byte row read, one written) against the
-                      16.8 - 18.8 TB/s the guide measured for row gathers served by L2 (MI355X_MICROARCH.md, 'Indexed rows');
-      valu-issue      vector instructions per update at the issue costs measured on this chip (scripts/valu_probe.hip)."""
+    `frac` = bytes that crossed the L2s' memory side per launch (FETCH_SIZE x 2 + WRITE_SIZE from the committed separate --pmc
+    passes of this same command, profiles/r04_pmc_summary.json) / this run's average launch time (HIP events) / the 8 TB/s HBM peak:
+    one division on two committed numbers.  At C2 those bytes are fabric requests, Infinity-Cache hits included (the 42 MB of
+    factors never leave the MALL), so it is an upper bound on real HBM use -- `bound` says "l2-memory-side", not "hbm".
+    Named secondaries, none of them `frac`:
+      algorithmic  SURVEY 8(d)'s model line, (16K+12) bytes per update as if every row came from and went back to HBM; above 1 at
+                   this working set (item rows owned in LDS, user rows served by L2) -- not a bound here, the work IS done
+                   (device visit counter all ones at C2, tests/test_fullsize_gpu.py);
+      l2_rows      the lock-free rows through the XCDs' L2s (one row read + one written per update) against the 16.8 - 18.8 TB/s the
+                   guide measured for L2-served row gathers;
+      valu_issue   SQ_INSTS_VALU per update at the guide's 2 cycles per wave64 instruction (no kernel-specific derating)."""
     avg_s = avg_ms * 1e-3
     per_launch = nnz / launches_per_step
     alg_bytes = (16 * K + 12) * per_launch
@@ -395,24 +439,12 @@ def sgd_roofline(K, nnz, launches_per_step, avg_ms, launches, kernel):
          "algorithmic": {"bytes_per_launch": alg_bytes, "achieved": alg_bytes / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": alg_bytes / avg_s / 1e9 / HBM_PEAK_GBS,
                          "note": "SURVEY 8(d) model: every row read and written in HBM; exceeds 1 when the rows are "
-                                 "served from LDS / L2 / Infinity Cache (C2: 42 MB of factors) -- not a bound there"}}
-    c = pmc(kernel)
-    cands = []
-    if c and "hbm_bytes_per_launch" in c:
-        traffic = c["hbm_bytes_per_launch"] * (per_launch / c.get("updates_per_launch", per_launch))
-        fr = traffic / avg_s / 1e9 / HBM_PEAK_GBS
-        cands.append(("l2-memory-side", traffic / avg_s / 1e9, HBM_PEAK_GBS, "GB/s", fr))
-        r["traffic"] = traffic
-        r["traffic_source"] = ("%s: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per launch (fabric requests of the L2s, Infinity-Cache hits "
-                               "included), separate --pmc passes of this command; time from this run's HIP events" % PMC_SUMMARY)
-        r["l2_hit_rate"] = c.get("l2_hit_rate")
-        r["l2_memory_side"] = {"achieved": traffic / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fr}
-    else:
-        r["traffic"] = None
+                                 "served from LDS / L2 / Infinity Cache (C2: 42 MB of factors) -- not a bound at this working set"}}
+    src = _first_existing(PMC_SUMMARY)
+    c = pmc(kernel, src)
     ld = (K + 63) // 64 * 64 if K > 32 else (32 if K > 16 else 16)
     row_bytes = 2 * 4 * ld * per_launch            # the lock-free row of every update: read once, written once, through one L2
     l2_ach = row_bytes / avg_s / 1e9
-    cands.append(("l2-rows", l2_ach, L2_GATHER_PEAK_GBS, "GB/s", l2_ach / L2_GATHER_PEAK_GBS))
     r["l2_rows"] = {"bytes_per_update": 2 * 4 * ld, "achieved": l2_ach, "peak": L2_GATHER_PEAK_GBS, "unit": "GB/s", "frac": l2_ach / L2_GATHER_PEAK_GBS,
                     "note": "user rows through the XCD's L2 (sc1 loads, plain stores); peak = middle of the 16.8 - 18.8 TB/s measured for "
                             "L2-served row gathers (MI355X_MICROARCH.md)"}
@@ -420,17 +452,23 @@ def sgd_roofline(K, nnz, launches_per_step, avg_ms, launches, kernel):
         valu = c["counters_mean_per_launch"]["SQ_INSTS_VALU"]
         per_update = valu / c.get("updates_per_launch", per_launch)
         ach = per_update * per_launch / avg_s / 1e9
-        # priced at the issue costs scripts/valu_probe.hip measured on this chip (v_mul/add/logic 2.44, v_fma 3.9, conversions and DPP
-        # 4.3, packed f32 4.67 cycles per SIMD) over the mix of the round kernel's step (49 / 7.5 / 21 / 27 %): 3.65 cycles on average
-        fr = ach * 3.65 / (256 * 4 * 2.4)
-        cands.append(("valu-issue", ach, 256 * 4 * 2.4 / 3.65, "G wave-instr/s", fr))
-        r["valu_issue"] = {"wave_instructions_per_update": per_update, "achieved": ach, "peak": 256 * 4 * 2.4 / 3.65,
-                           "unit": "G wave-instr/s", "frac": fr, "cycles_per_instruction": 3.65,
-                           "note": "SQ_INSTS_VALU per launch from %s / updates of that launch; peak = 256 CUs x 4 SIMD-32 x 2.4 GHz / the "
-                                   "3.65 cycles a wave64 instruction of this mix takes to issue (measured); at the nominal 2 cycles: frac %.3f"
-                                   % (PMC_SUMMARY, ach / VALU_PEAK_GINST)}
-    b = max(cands, key=lambda x: x[4])
-    r.update({"bound": b[0], "achieved": b[1], "peak": b[2], "unit": b[3], "frac": b[4]})
+        r["valu_issue"] = {"wave_instructions_per_update": per_update, "achieved": ach, "peak": VALU_PEAK_GINST,
+                           "unit": "G wave-instr/s", "frac": ach / VALU_PEAK_GINST,
+                           "note": "SQ_INSTS_VALU per launch from %s / updates of that launch; peak = 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per "
+                                   "wave64 instruction (MI355X_MICROARCH.md)" % src}
+    if c and "hbm_bytes_per_launch" in c:
+        traffic = c["hbm_bytes_per_launch"] * (per_launch / c.get("updates_per_launch", per_launch))
+        ach = traffic / avg_s / 1e9
+        r.update({"bound": "l2-memory-side", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                  "traffic": traffic, "l2_hit_rate": c.get("l2_hit_rate"),
+                  "traffic_over_algorithmic": traffic / alg_bytes,
+                  "traffic_source": "%s: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per launch (fabric requests of the L2s, Infinity-Cache hits "
+                                    "included: an upper bound on HBM bytes), separate --pmc passes of this command; time from this run's HIP "
+                                    "events; frac = traffic / avg_launch_ms / 8 TB/s" % src})
+    else:
+        a = r["algorithmic"]
+        r.update({"bound": "hbm (model line: no committed counters for this kernel)", "achieved": a["achieved"], "peak": a["peak"],
+                  "unit": "GB/s", "frac": a["frac"], "traffic": None})
     return r
 
 
@@ -440,7 +478,7 @@ def cpu_baseline(np, tr, nU, nI, K, lr, ureg, ireg, epochs):
     of the same train list (Hogwild) / the first users of the same matrix (stratified)."""
     from oracle import binding as orc
     from matfac_amd import synth
-    threads = orc.max_threads()
+    threads, phys = host_cores()
     n = int(tr.nnz * min(1.0, epochs))
     rng = np.random.default_rng(1)
     sel = rng.permutation(tr.nnz)[:n]
@@ -455,7 +493,7 @@ def cpu_baseline(np, tr, nU, nI, K, lr, ureg, ireg, epochs):
         orc.time_hogwild(Uc, Vc, u[: n // 20], i[: n // 20], r[: n // 20], nU, nI, K, lr, ureg, ireg, threads, colmajor)
         s = orc.time_hogwild(Uc, Vc, u, i, r, nU, nI, K, lr, ureg, ireg, threads, colmajor)
         res[name] = n / s
-    out = {"value": res["rowmajor"], "unit": "updates/s", "cores": threads, "kind": "port",
+    out = {"value": res["rowmajor"], "unit": "updates/s", "cores": threads, "physical_cores": phys, "kind": "port",
            "sample": "%d shuffled train ratings (%.2f epoch) of the same workload, OpenMP Hogwild "
                      "(modelMF.cpp:1746-1767 restated), row-major factors" % (n, n / tr.nnz),
            "value_colmajor_reference_layout": res["colmajor"]}
@@ -469,7 +507,7 @@ def cpu_baseline(np, tr, nU, nI, K, lr, ureg, ireg, epochs):
         invI = np.zeros(nI, np.uint8)
         Us, Vs = U[:m].copy(), V.copy()
         s = orc.time_strat(Us, Vs, sub_ptr, tr.rowind[:sub_n], tr.rowval[:sub_n], m, nI, invU, invI, threads, lr, ureg, ireg)
-        out["stratified"] = {"value": sub_n / s, "unit": "updates/s (ratings of the matrix per epoch time)", "cores": threads,
+        out["stratified"] = {"value": sub_n / s, "unit": "updates/s (ratings of the matrix per epoch time)", "cores": threads, "physical_cores": phys,
                              "sample": "first %d users, %d ratings, one epoch of trainSGDPar (modelMF.cpp:271-309 restated), "
                                        "T = %d parts" % (m, sub_n, threads)}
     except Exception as e:                      # noqa: BLE001 -- the baseline is optional, the bench line is not
@@ -540,14 +578,14 @@ def bench_als(np, d, K, with_cpu):
                         "note": "flop count of the reference (both triangles); the kernels form 3 of the 4 32x32 tiles"}}
     if with_cpu:
         from oracle import binding as orc
-        threads = orc.max_threads()
+        threads, phys = host_cores()
         m = int(np.searchsorted(tr.rowptr, 1_000_000))           # users holding the first ~1 M ratings
         X = U0[:m].copy()
         t0 = time.perf_counter()
         orc.als_half(0, X, V0, m, tr.rowptr[: m + 1], tr.rowind, tr.rowval, np.zeros(m, np.uint8), reg, nthreads=threads)
         s = time.perf_counter() - t0
         n = int(tr.rowptr[m])
-        rec["cpu_baseline"] = {"value": n / s / 2, "unit": "rating-iterations/sec", "cores": threads, "kind": "port",
+        rec["cpu_baseline"] = {"value": n / s / 2, "unit": "rating-iterations/sec", "cores": threads, "physical_cores": phys, "kind": "port",
                                "sample": "user half-sweep over the first %d users (%d ratings), modelMF.cpp:805-841 restated; "
                                          "an iteration is two half-sweeps, so ratings / seconds / 2" % (m, n)}
     return rec
@@ -596,18 +634,19 @@ def bench_ccd(np, with_cpu):
                         "kernel": "ccd_pass_kernel / ccd_cols pass / resid_update_kernel (whole rank-one step, wall clock)"}}
     # memory-side bytes of one rank-one step from the committed counter passes (scripts/pmc_c4.sh), time from this run
     try:
-        with open(os.path.join(ROOT, "profiles", "r03_c4_pmc.json")) as f:
+        c4src = _first_existing(PMC_C4)
+        with open(os.path.join(ROOT, c4src)) as f:
             pmc = json.load(f)
         rec["roofline"]["traffic"] = pmc["hbm_bytes_per_factor"]
         rec["roofline"]["traffic_GBs"] = pmc["hbm_bytes_per_factor"] / per_k / 1e9
         rec["roofline"]["traffic_frac_of_peak"] = pmc["hbm_bytes_per_factor"] / per_k / 1e9 / HBM_PEAK_GBS
-        rec["roofline"]["traffic_source"] = ("profiles/r03_c4_pmc.json: sum over the kernels of a rank-one step of (FETCH_SIZE x2 + WRITE_SIZE) per launch "
+        rec["roofline"]["traffic_source"] = (c4src + ": sum over the kernels of a rank-one step of (FETCH_SIZE x2 + WRITE_SIZE) per launch "
                                              "x launches per step, separate --pmc passes of scripts/bench_als_ccd.py; time from this run")
     except (OSError, KeyError, ValueError):
         pass
     if with_cpu:
         from oracle import binding as orc
-        threads = orc.max_threads()
+        threads, phys = host_cores()
         m = int(np.searchsorted(tr.rowptr, 4_000_000))           # first users holding ~4 M ratings
         n = int(tr.rowptr[m])
         rp, ri, rv = tr.rowptr[: m + 1], tr.rowind[:n], tr.rowval[:n]
@@ -621,7 +660,7 @@ def bench_ccd(np, with_cpu):
         for k in (1, 2):
             orc.ccdpp_rank1(k, Us, Vs, m, nI, nI, rp, ri, rr, cp, ci, rc, invU, invI, reg, reg, True, nthreads=threads)
         s = (time.perf_counter() - t0) / 2
-        rec["cpu_baseline"] = {"value": n / s, "unit": "rating-factor updates/sec", "cores": threads, "kind": "port",
+        rec["cpu_baseline"] = {"value": n / s, "unit": "rating-factor updates/sec", "cores": threads, "physical_cores": phys, "kind": "port",
                                "sample": "first %d users (%d ratings), two rank-one steps with add-back, modelMF.cpp:1027-1121 restated" % (m, n)}
     return rec
 
@@ -645,12 +684,13 @@ def bench_c5_shard(np):
         ctx.set_factors(U0, V0)
         ctx.compute_invalid()
         v0 = ctx.rmse(mfx.MAT_VAL)
-        ctx.sgd_epoch(0.0025, 0.01, 0.01, mode=mfx.SGD_TILED, seed=1, epoch=0)
+        for ep in range(4):                    # (one epoch on each of the four tilings: their slot lists are built here)
+            ctx.sgd_epoch(0.0025, 0.01, 0.01, mode=mfx.SGD_TILED, seed=1, epoch=ep)
         ctx.synchronize()
         ctx.prof_enable(True)
         ctx.prof_reset()
         t0 = time.perf_counter()
-        for ep in range(1, 1 + n):
+        for ep in range(4, 4 + n):
             ctx.sgd_epoch(0.0025, 0.01, 0.01, mode=mfx.SGD_TILED, seed=1, epoch=ep)
         ctx.synchronize()
         wall = (time.perf_counter() - t0) / n
@@ -667,11 +707,12 @@ def bench_c5_shard(np):
                                     "user row serves several ratings of a tile from L2: fewer bytes cross the memory side than the model counts"},
             "compulsory_bytes_per_step": compulsory}
     try:   # bytes that really crossed the L2's memory side, from the committed PMC passes of scripts/c5_shard.py (scripts/pmc_c5.sh)
-        c = json.load(open(os.path.join(ROOT, "profiles", "r03_c5_pmc.json")))
+        c5src = _first_existing(PMC_C5)
+        c = json.load(open(os.path.join(ROOT, c5src)))
         traffic = c["hbm_bytes_per_launch"] * (tr.nnz / 8.0) / c["updates_per_launch"]
         ach = traffic / (launch_ms * 1e-3) / 1e9
         roof.update({"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                     "traffic_source": "profiles/r03_c5_pmc.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per round launch, separate "
+                     "traffic_source": c5src + ": FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per round launch, separate "
                                        "--pmc passes of the same workload; launch time from this run's HIP events",
                      "l2_hit_rate": c.get("l2_hit_rate")})
     except Exception:                             # noqa: BLE001 -- no committed counters: only the model line
@@ -722,8 +763,45 @@ def rmse_parity(np):
                     rec[label + "_sigmas_from_trainSGDPar_mean"] = (t - float(par.mean())) / float(par.std(ddof=1))
             except Exception as e:              # noqa: BLE001
                 rec[label + "_error"] = str(e)
+        # the trainer the lock-free tiled schedule stands in for: the reference's hogTrain (modelMF.cpp:1747-1763), the fixture's
+        # `hogwild` rows, at the reference's default rate -- test RMSE, distance from the hogwild mean, NaN rollbacks of the run
+        try:
+            log = []
+            st = host_train_stats(C, np, synth, d, cfg, {"MFX_EXACT": "0"}, method=b"hogsgd", log=log)
+            t = float(st[1])
+            rec.update({"reference_hogwild_test_rmse_mean": float(hog.mean()), "reference_hogwild_test_rmse_std": float(hog.std(ddof=1)),
+                        "reference_hogwild_draws": int(hog.size), "reference_hogwild_best_iter": [int(x["best_iter"]) for x in f["hogwild"]],
+                        "gpu_lock_free_tiled_hogtrain_test_rmse": t, "gpu_lock_free_tiled_hogtrain_iterations": int(st[7]),
+                        "gpu_lock_free_tiled_hogtrain_found_nan": log[0].count("Found nan"),
+                        "gpu_lock_free_tiled_hogtrain_delta_from_hogwild_mean": t - float(hog.mean()),
+                        "gpu_lock_free_tiled_hogtrain_sigmas_from_hogwild_mean": (t - float(hog.mean())) / float(hog.std(ddof=1)),
+                        "gpu_lock_free_tiled_hogtrain_delta_in_sequential_sigmas": (t - float(hog.mean())) / float(seq.std(ddof=1)),
+                        "gpu_lock_free_tiled_hogtrain_inside_hogwild_envelope": bool(hog.min() <= t <= hog.max()),
+                        "gpu_lock_free_tiled_hogtrain_gate": "|delta| <= 2e-3 (mid) / inside the hogwild envelope +- one sequential sigma (c1): tests/test_parity_spread_gpu.py"})
+        except Exception as e:                  # noqa: BLE001
+            rec["gpu_lock_free_tiled_hogtrain_error"] = str(e)
         recs[name] = rec
     return recs
+
+
+def default_rate_record(np, d, K, ureg, ireg, iters=12):
+    """What the reference's DEFAULT learning rate (main.cpp:29: 0.005) does on the headline workload: hogTrain through the host
+    class on the C2 matrix (20 M ratings > MFX_EXACT_BELOW: the lock-free tiled schedule, first epoch as the sequential replay of a
+    shuffled device order), `iters` iterations with the reference's NaN guard.  The reference's own sequential loop leaves its
+    first epoch with NaN at this rate on this matrix (tests/test_fullsize_gpu.py::test_reference_loop_needs_the_halved_rate_at_c2),
+    and so does an exact replay of it: `found_nan` counts the rollbacks, `final_learnrate` shows the halvings."""
+    import ctypes as C
+    from matfac_amd import synth
+    cfg = {"K": K, "lr": 0.005, "ureg": ureg, "ireg": ireg, "maxIter": iters}
+    rec = {"config": "C2 at the reference's default learning rate 0.005: ModelMF::hogTrain through libmfhost.so, %d iterations" % iters}
+    for lr in (0.005, 0.0025):
+        cfg["lr"] = lr
+        log = []
+        st = host_train_stats(C, np, synth, d, cfg, {}, method=b"hogsgd", log=log)
+        rec["learnrate_%g" % lr] = {"found_nan": log[0].count("Found nan"), "final_learnrate": float(st[3]), "iterations": int(st[7]),
+                                     "best_val_rmse": float(st[2]), "test_rmse_of_best": float(st[1]), "loop_s": float(st[6]),
+                                     "schedule": "lock-free tiled" if "lock-free tiled schedule" in log[0] else "order replay"}
+    return rec
 
 
 def host_loop_ms(np, d, K, lr, ureg, ireg):
@@ -753,9 +831,11 @@ def host_train_rmse(C, np, synth, d, cfg, env):
     return float(host_train_stats(C, np, synth, d, cfg, env)[1])
 
 
-def host_train_stats(C, np, synth, d, cfg, env):
-    """ModelMF::train through libmfhost.so (mfh_train): best-validation model's test RMSE.  (The class prints the reference's
-    per-iteration lines on stdout; bench.py has already pointed stdout at stderr.)"""
+def host_train_stats(C, np, synth, d, cfg, env, method=b"sgd", log=None):
+    """A trainer of the host class through libmfhost.so (mfh_train): best-validation model's test RMSE.  (The class prints the
+    reference's per-iteration lines on stdout; bench.py has already pointed stdout at stderr.)  log = a list: the trainer's
+    output is also appended to it as one string (for counting its "Found nan" lines)."""
+    import tempfile
     lib = synth._host()
     tr, va, te = d["train"], d["val"], d["test"]
     nU, nI, K = d["nUsers"], d["nItems"], cfg["K"]
@@ -766,13 +846,28 @@ def host_train_stats(C, np, synth, d, cfg, env):
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     os.environ["MFX_NO_SAVE"] = "1"
+    tmp = saved = None
+    if log is not None:
+        sys.stdout.flush()
+        tmp = tempfile.TemporaryFile(mode="w+b")
+        saved = os.dup(1)
+        os.dup2(tmp.fileno(), 1)
     try:
-        rc = lib.mfh_train(b"sgd", C.c_int32(tr.nrows), P(tr.rowptr), P(tr.rowind), P(tr.rowval), C.c_int32(tr.ncols),
+        rc = lib.mfh_train(method, C.c_int32(tr.nrows), P(tr.rowptr), P(tr.rowind), P(tr.rowval), C.c_int32(tr.ncols),
                            P(va.rowptr), P(va.rowind), P(va.rowval), C.c_int32(va.ncols), P(te.rowptr), P(te.rowind), P(te.rowval),
                            C.c_int32(te.ncols), C.c_int32(K), C.c_int32(cfg["maxIter"]), C.c_int32(1), C.c_float(cfg["lr"]),
                            C.c_float(cfg["ureg"]), C.c_float(cfg["ireg"]), None, P(bufs[0]), P(bufs[1]), P(bufs[2]), P(bufs[3]),
                            P(stats), P(invU), P(invI))
     finally:
+        if log is not None:
+            C.CDLL(None).fflush(None)
+            os.dup2(saved, 1)
+            os.close(saved)
+            tmp.seek(0)
+            text = tmp.read()
+            tmp.close()
+            os.write(1, text)                   # (still shown where the rest of the trainer output goes)
+            log.append(text.decode(errors="replace"))
         for k, v in old.items():
             if v is None:
                 os.environ.pop(k, None)

@@ -3,7 +3,7 @@
 # ratings, rank 256) -- separate --pmc passes (FETCH_SIZE takes 3 TCC slots, WRITE_SIZE 2), never combined with tracing:
 #   bash scripts/pmc_c5.sh r03      ->  profiles/r03_c5_pmc.json
 set -e
-R=${1:-r03}
+R=${1:-r04}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/pmc_c5_$R
 rm -rf "$OUT"; mkdir -p "$OUT"

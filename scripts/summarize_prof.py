@@ -11,7 +11,7 @@ if stats:
 
 
 def short(name):
-    for k in ("sgd_slots_kernel", "eval_sse_kernel", "eval_norm_kernel", "sgd_hogwild_kernel", "sgd_flow_tag_kernel"):
+    for k in ("sgd_slots_kernel", "eval_sse_kernel", "eval_norm_kernel", "sgd_hogwild_kernel", "sgd_flow_wide_kernel", "sgd_flow_tag_kernel"):
         if k in name:
             if k == "sgd_slots_kernel":      # <L, C, ARITH, SWEEP, OWN_U>: the leftover sweep launch is reported apart
                 args = [a.strip() for a in name.split("<", 1)[1].split(">", 1)[0].split(",")]
