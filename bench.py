@@ -624,6 +624,16 @@ def bench_ccd(np, with_cpu):
         c_ms, c_n = ctx.prof_get(mfx.K_CCD_COL)
         x_ms, x_n = ctx.prof_get(mfx.K_CCD_RESID)
         ctx.ccdpp_end()
+        # the order replay of ModelMF::train at THIS size (100 M ratings, rank 128): above MFX_EXACT_SEQ_BELOW the host class takes the
+        # lock-free schedule unless MFX_EXACT=1; this is what the replay itself costs here
+        replay = None
+        try:
+            ctx.prof_enable(False)
+            ctx.set_factors(U0, V0)
+            replay = exact_replay(np, ctx, mfx, tr, U0, V0, 0.0025, 0.01, 0.01, epochs=2)
+            replay.pop("test_rmse_vs_reference", None)
+        except Exception as e:                  # noqa: BLE001
+            replay = {"error": str(e)}
     bytes_per_k = 128 * tr.nnz                    # 128 B per (rating, factor) per outer iteration, T = 5
     rec = {"config": "C4: Netflix-shape %dx%d, train nnz=%d, rank=%d, CCD++ (5 inner sweeps per factor), reg=%.1f" % (nU, nI, tr.nnz, K, reg),
            "metric": "rating-factor updates/sec", "value": tr.nnz / per_k, "ms_per_factor": per_k * 1e3,
@@ -632,6 +642,7 @@ def bench_ccd(np, with_cpu):
            "roofline": {"bound": "hbm", "achieved": bytes_per_k / per_k / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": bytes_per_k / per_k / 1e9 / HBM_PEAK_GBS, "bytes_per_factor": bytes_per_k, "traffic": None,
                         "kernel": "ccd_pass_kernel / ccd_cols pass / resid_update_kernel (whole rank-one step, wall clock)"}}
+    rec["exact_replay_of_ModelMF_train_at_this_size"] = replay
     # memory-side bytes of one rank-one step from the committed counter passes (scripts/pmc_c4.sh), time from this run
     try:
         c4src = _first_existing(PMC_C4)

@@ -324,6 +324,17 @@ __device__ __forceinline__ void fl_store(desc4 rs, uint32_t off, uint4v v) {
   else asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(off), "s"(rs) : "memory");
 }
 
+// The launch ends with its longest queue (C2: the most popular item's 49 777 visits, ten times the average queue), and that queue's wave
+// shares its SIMD with three others: its ~ 70 instructions per visit then issue at ~ 10 cycles each.  Waves whose queue is more than twice
+// the average raise their priority (own_flags bit 1; MFX_FLOW_PRIO=0 is the A/B): they are few, and whenever one is ready it issues.
+__device__ __forceinline__ void fl_prio(int own_flags, uint32_t mine, const int64_t* __restrict__ qoff) {
+  if (own_flags & 2) {
+    const uint32_t ng = gridDim.x * (uint32_t)(FL_WG / 64);
+    const uint64_t total = (uint64_t)qoff[ng];
+    if ((uint64_t)mine * ng > 2ull * total) __builtin_amdgcn_s_setprio(3);
+  }
+}
+
 template <int L, int C>
 struct F2 {
   static constexpr int LD = 4 * L * C;
@@ -340,8 +351,9 @@ struct F2 {
 template <int L, int C, int ARITH>
 __global__ __launch_bounds__(FL_WG, (F2<L, C>::WGS)) void sgd_flow_tag_kernel(const int4* __restrict__ q, const int64_t* __restrict__ qoff,
                                                                               uint32_t qbytes, float* T, uint32_t tbytes, float* O, uint32_t obytes,
-                                                                              int own_user, float lr, float uReg, float iReg, unsigned* flag) {
+                                                                              int own_flags, float lr, float uReg, float iReg, unsigned* flag) {
   typedef F2<L, C> P;
+  const int own_user = own_flags & 1;
   constexpr int LD = P::LD, LA = P::LA, QR = P::QR, NB = P::NB;
   extern __shared__ __attribute__((aligned(16))) char fl_smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane % L;
@@ -351,6 +363,7 @@ __global__ __launch_bounds__(FL_WG, (F2<L, C>::WGS)) void sgd_flow_tag_kernel(co
   const int64_t grp = (int64_t)blockIdx.x * (FL_WG / 64) + __builtin_amdgcn_readfirstlane(wv);
   uint32_t pos = (uint32_t)qoff[grp];
   const uint32_t end = (uint32_t)qoff[grp + 1];
+  fl_prio(own_flags, end - pos, qoff);
   if (lane < QR) qt[lane] = -1;
   const desc4 dq = fl_desc(q, qbytes), dt = fl_desc(T, tbytes), dob = fl_desc(O, obytes);
   const uint32_t lane_off = act ? (uint32_t)(j * 16) : FL_OOB;       // this lane's 16 bytes inside a 16 L-byte piece
@@ -659,7 +672,7 @@ __device__ __forceinline__ void wide_axpys(float (&p)[C], float (&q)[C], float r
 template <int C, int ARITH>
 __global__ __launch_bounds__(FL_WG, (FW<C>::WGS)) void sgd_flow_wide_kernel(const int4* __restrict__ q, const int64_t* __restrict__ qoff,
                                                                            uint32_t qbytes, float* T, uint32_t tbytes, float* O, uint32_t obytes,
-                                                                           int own_user, float lr, float uReg, float iReg, unsigned* flag) {
+                                                                           int own_flags, float lr, float uReg, float iReg, unsigned* flag) {
   typedef FW<C> P;
   constexpr int LD = P::LD, LA = P::LA, QR = P::QR, NB = P::NB;
   extern __shared__ __attribute__((aligned(16))) char fl_smem[];
@@ -669,6 +682,8 @@ __global__ __launch_bounds__(FL_WG, (FW<C>::WGS)) void sgd_flow_wide_kernel(cons
   const int64_t grp = (int64_t)blockIdx.x * (FL_WG / 64) + __builtin_amdgcn_readfirstlane(wv);
   uint32_t pos = (uint32_t)qoff[grp];
   const uint32_t end = (uint32_t)qoff[grp + 1];
+  const int own_user = own_flags & 1;
+  fl_prio(own_flags, end - pos, qoff);
   if (lane < QR) qt[lane] = -1;
   const desc4 dq = fl_desc(q, qbytes), dt = fl_desc(T, tbytes), dob = fl_desc(O, obytes);
   // this lane's granule inside a 512-byte chunk of the granule copy, and its float inside a 256-byte chunk of the owned table
@@ -1312,12 +1327,14 @@ int launch_flow_tag_lca(mfx_ctx* ctx, const mfx_sgd_opts* o, int blocks) {
   HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   NEED((int64_t)per_cu * cus >= blocks, MFX_E_STATE, "sgd dataflow (tagged): %d workgroups do not fit the device (%d per CU x %d CUs)", blocks,
        per_cu, cus);
+  static const bool prio = [] { const char* e = getenv("MFX_FLOW_PRIO"); return !e || atoi(e) != 0; }();
   const int64_t total = nOth * L * C;
   const int tgrid = (int)std::min<int64_t>((total + 255) / 256, 8192);
   hipLaunchKernelGGL(flow_tag_kernel, dim3(tgrid), dim3(256), 0, ctx->stream, (const float*)X, nOth, L, C, S->tagbuf);
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(FL_WG), (size_t)P::LDS, ctx->stream, (const int4*)S->q, S->qoff,
                      (uint32_t)((uint64_t)S->hoff.back() * 16u), S->tagbuf, (uint32_t)((uint64_t)nOth * 8u * P::LD), O,
-                     (uint32_t)((uint64_t)(S->own_user ? ctx->nU : ctx->nI) * 4u * P::LD), S->own_user, o->learnRate, o->uReg, o->iReg, S->flag);
+                     (uint32_t)((uint64_t)(S->own_user ? ctx->nU : ctx->nI) * 4u * P::LD), (S->own_user ? 1 : 0) | (prio ? 2 : 0), o->learnRate, o->uReg, o->iReg,
+                     S->flag);
   hipLaunchKernelGGL(flow_untag_kernel, dim3(tgrid), dim3(256), 0, ctx->stream, (const float*)S->tagbuf, nOth, L, C, X);
   HIPCHK(hipGetLastError());
   return MFX_OK;

@@ -926,7 +926,7 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
   // unset: every trainer keeps ITS OWN semantics.
   //   * ModelMF::train, trainUShuffle, trainSGDPar are sequential / deterministic in the reference (modelMF.cpp:83-105, 637-659,
   //     273-304): they replay the reference's order -- the numbers ARE the reference's -- up to MFX_EXACT_SEQ_BELOW train ratings
-  //     (default 32 M: the ML-20M shape replays at 1.38 G updates/s, 18 ms per call, next to the reference's own std::shuffle
+  //     (default 128 M -- the Netflix shape, 100 M ratings at rank 128, replays in 114 ms per epoch, bench.py secondary[C4]; the ML-20M shape replays at 1.38 G updates/s, 18 ms per call, next to the reference's own std::shuffle
   //     of the index list on the host -- 0.37 s as the library call, 0.05 s as mfhShuffle above, a thread ahead); larger matrices take
   //     the lock-free tiled schedule unless MFX_EXACT=1;
   //   * hogTrain is lock-free in the reference (:1747-1763) and the sibling models' loops sit in OpenMP-parallel block loops: they
@@ -939,11 +939,15 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
   const char* belowEnv = getenv("MFX_EXACT_BELOW");
   const char* seqBelowEnv = getenv("MFX_EXACT_SEQ_BELOW");
   const int64_t exactBelow = belowEnv ? atoll(belowEnv) : 2000000;
-  const int64_t exactSeqBelow = seqBelowEnv ? atoll(seqBelowEnv) : (belowEnv ? std::max<int64_t>(exactBelow, 0) : 32000000);
+  const int64_t exactSeqBelow = seqBelowEnv ? atoll(seqBelowEnv) : (belowEnv ? std::max<int64_t>(exactBelow, 0) : 128000000);
   const bool exact = exactEnv ? atoi(exactEnv) != 0
                               : (plainSgd && data.trainMat->nnz() <= (sequentialSgd ? exactSeqBelow : exactBelow));
   const int replayMode = (exactEnv && atoi(exactEnv) == 2) ? MFX_SGD_SERIAL : MFX_SGD_LEVELS;
   if (plainSgd) std::cout << " [" << (exact ? (replayMode == MFX_SGD_SERIAL ? "order replay, serial" : "order replay, dataflow schedule") : "lock-free tiled schedule") << "]";
+  if (sequentialSgd && !exact && !exactEnv)
+    std::cout << "\n[mfx] " << name << ": " << data.trainMat->nnz() << " train ratings exceed MFX_EXACT_SEQ_BELOW = " << exactSeqBelow
+              << ": this run takes the lock-free tiled schedule (hogTrain's semantics), not the reference's sequential order; "
+                 "MFX_EXACT=1 replays the order at any size";
   const csr_t* trainMat = data.trainMat;
 
   // bestModel starts as its own initialisation (main.cpp:1326-1327); it becomes the BEST snapshot
