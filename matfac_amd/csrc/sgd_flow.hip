@@ -669,6 +669,116 @@ __device__ __forceinline__ void wide_axpys(float (&p)[C], float (&q)[C], float r
   }
 }
 
+// ---- POLE BLOCKS (round 4).  The launch lasts as long as its longest queue, and that queue is one popular row's visits back to back
+// (C2: 49 777 of them): a dependent chain.  scripts/chain_probe.hip measured what one wave pays per LINK of such a chain on this chip:
+// 8.5 - 9 cycles for any dependent VALU instruction (f32 or f64 alike), 16 with a DPP read of a register just written, 36 for
+// mov + v_permlane32_swap + add, and 26 cycles for a scalar compare + branch even when it is NOT taken.  The generic step above spends
+// ~ 690 cycles per visit: nine branches (owned-row switch, live / abort / tag checks, own_user), ~ 48 vector instructions, a dot chain of
+// 4 fma + 4 DPP moves and two swap levels.  A block of 64 records that all visit ONE owned row runs the step below instead:
+//   * one branch per visit -- "the NEXT position's row had not arrived with its tags": checked early, taken (to the probe loop) only
+//     AFTER this visit's store, so nothing of ours that another queue may wait for is held back;
+//   * the dot chain of "lane j" (include/mfx.h) without moves: every lane of quad j runs all four links, reading the owned element of
+//     link x through the DPP source of v_fmac (quad_perm:[x,x,x,x]) and the other side's from four registers gathered off the chain:
+//     the same products in the same order, so the same bits, and the quad broadcast of the finished chain falls away;
+//   * the levels j ^ 4 and j ^ 8 as v_add_f32 row_bcast:15 (rows 1, 3) and row_bcast:31 (row 3): lane 63 ends with
+//     (R3 + R2) + (R1 + R0) -- the butterfly's (R0 + R1) + (R2 + R3) up to commutations, i.e. the same float -- read with one v_readlane;
+//   * the reference's  m2*y + reg2*x  (modelMF.cpp:96 / :102 in double) as fma(reg2, x, m2*y): reg2 and x are floats widened to double,
+//     their product has <= 48 significant bits and is EXACT, so the fused form rounds once where the unfused one rounds once -- same bits,
+//     one multiplication fewer per side.
+// Everything else (queues, landing registers, counted waits, tags, probe-then-poll) is the kernel's.  MFX_FLOW_POLE=0: generic steps only.
+template <int X>
+__device__ __forceinline__ void fwp_link(float& a, float own, float oth, bool first) {
+  // (s_nop 1: `own` may have been written by the previous visit's last conversion; a DPP read wants two wait states and the hazard
+  //  recognizer does not look inside an asm statement)
+  (void)first;
+  if (X == 0) asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(own), "v"(oth));
+  if (X == 1) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(own), "v"(oth));
+  if (X == 2) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(own), "v"(oth));
+  if (X == 3) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(own), "v"(oth));
+}
+// LANDING REGISTERS OF THE POLE PATH ARE ACCUMULATION REGISTERS (a0 .. a31), named in the asm text.  The generic steps keep theirs as
+// C++ values that are in-out operands of every request and wait, and rely on the register allocator never copying one (checked on
+// the compiled code, tests/test_trips_cpu.py).  The first build of the pole path did it the same way and that property was gone for
+// the whole kernel: SROA turned the array into one <4 x i64> value (an 8-register tuple, copied as a whole behind every re-read, the
+// slot in flight included), and as sixteen separate variables the allocator still moved slots between registers on the edges of the
+// step loop -- with their loads in flight.  A register the compiler never sees cannot be copied: slot K, chunk c lands in
+// a[8 K + 2 c : 8 K + 2 c + 1] = {value, tag}; a request is `buffer_load_dwordx2 a[..]`, a step reads the pair out with
+// v_accvgpr_read_b32 BEHIND its counted wait, inside the same asm statement.  The kernel uses no other accumulation registers (no
+// MFMA, no spills: checked in tests/test_trips_cpu.py).
+#define FWA_CLOBBER "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", \
+                    "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31"
+template <int IDX>
+__device__ __forceinline__ void fwa_load(desc4 rs, uint32_t off) {
+  static_assert(IDX >= 0 && IDX < 16, "landing pairs a[2 IDX : 2 IDX + 1] of a0 .. a31");
+  asm volatile("buffer_load_dwordx2 a[%2:%3], %0, %1, 0 offen sc1" ::"v"(off), "s"(rs), "i"(2 * IDX), "i"(2 * IDX + 1) : "memory", FWA_CLOBBER);
+}
+template <int IDX>
+__device__ __forceinline__ void fwa_read(uint32_t& val, uint32_t& tag) {
+  static_assert(IDX >= 0 && IDX < 16, "landing pairs a[2 IDX : 2 IDX + 1] of a0 .. a31");
+  asm volatile("v_accvgpr_read_b32 %0, a%2\n\tv_accvgpr_read_b32 %1, a%3" : "=v"(val), "=v"(tag) : "i"(2 * IDX), "i"(2 * IDX + 1) : "memory");
+}
+// the C requests of one row into slot K (row byte offset rb, or behind the buffer), and the C {value, tag} pairs of slot K;
+// slot K, chunk c = pair K C + c
+template <int K, int C>
+__device__ __forceinline__ void fwa_request(desc4 rs, uint32_t rb) {
+  fwa_load<K * C + 0>(rs, rb);
+  if constexpr (C > 1) fwa_load<K * C + 1>(rs, rb == FL_OOB ? FL_OOB : rb + 512u);
+  if constexpr (C > 2) fwa_load<K * C + 2>(rs, rb == FL_OOB ? FL_OOB : rb + 1024u);
+  if constexpr (C > 3) fwa_load<K * C + 3>(rs, rb == FL_OOB ? FL_OOB : rb + 1536u);
+}
+template <int K, int C>
+__device__ __forceinline__ void fwa_take(uint32_t (&val)[C], uint32_t (&tag)[C]) {
+  fwa_read<K * C + 0>(val[0], tag[0]);
+  if constexpr (C > 1) fwa_read<K * C + 1>(val[1], tag[1]);
+  if constexpr (C > 2) fwa_read<K * C + 2>(val[2], tag[2]);
+  if constexpr (C > 3) fwa_read<K * C + 3>(val[3], tag[3]);
+}
+// the requests of queue positions K .. N - 1 of a block (row ids in lane k of recx)
+template <int K, int N, int C>
+__device__ __forceinline__ void fwp_prologue(desc4 rs, int recx, uint32_t rowbytes, uint32_t g_off) {
+  if constexpr (K < N) {
+    fwa_request<K, C>(rs, (uint32_t)__builtin_amdgcn_readlane(recx, K) * rowbytes + g_off);
+    fwp_prologue<K + 1, N, C>(rs, recx, rowbytes, g_off);
+  }
+}
+// p.q in device order, uniform result (see above); own = the owned row (one element per lane and chunk), g = the other side's
+// elements of this lane's quad, g[c][x] = element x
+template <int C>
+__device__ __forceinline__ float pole_dot(const float (&own)[C], const float (&g)[C][4]) {
+  float a = 0.0f;
+#pragma unroll
+  for (int c = 0; c < C; c++) {
+    fwp_link<0>(a, own[c], g[c][0], c == 0);
+    fwp_link<1>(a, own[c], g[c][1], false);
+    fwp_link<2>(a, own[c], g[c][2], false);
+    fwp_link<3>(a, own[c], g[c][3], false);
+  }
+  asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(a));
+  asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(a));
+  asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(a));
+  asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(a));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), 63));
+}
+// sgd_axpys on one element per chunk with the exact-product fma (see above); bit for bit wide_axpys
+template <int C, int ARITH>
+__device__ __forceinline__ void pole_axpys(float (&p)[C], float (&q)[C], float r, float est, float lr, float uReg, float iReg) {
+  if (ARITH == MFX_ARITH_F32) {
+    wide_axpys<C, ARITH>(p, q, r, est, lr, uReg, iReg);
+  } else {
+    double diff;
+    if (ARITH == MFX_ARITH_REF64F) { const float d = r - est; diff = (double)d; }
+    else diff = (double)r - (double)est;
+    const double m2 = -2.0 * diff;
+    const double ru = 2.0 * (double)uReg, ri = 2.0 * (double)iReg, lrd = (double)lr;
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+      const double p64 = (double)p[c], q64 = (double)q[c];
+      p[c] = (float)(p64 - lrd * __builtin_fma(ru, p64, m2 * q64));
+      q[c] = (float)(q64 - lrd * __builtin_fma(ri, q64, m2 * (double)p[c]));
+    }
+  }
+}
+
 template <int C, int ARITH>
 __global__ __launch_bounds__(FL_WG, (FW<C>::WGS)) void sgd_flow_wide_kernel(const int4* __restrict__ q, const int64_t* __restrict__ qoff,
                                                                            uint32_t qbytes, float* T, uint32_t tbytes, float* O, uint32_t obytes,
@@ -683,6 +793,7 @@ __global__ __launch_bounds__(FL_WG, (FW<C>::WGS)) void sgd_flow_wide_kernel(cons
   uint32_t pos = (uint32_t)qoff[grp];
   const uint32_t end = (uint32_t)qoff[grp + 1];
   const int own_user = own_flags & 1;
+  const int pollfull = (own_flags >> 8) & 0xffff;      // pole path: tries of a stalled head that read the whole row (MFX_FLOW_POLLFULL)
   fl_prio(own_flags, end - pos, qoff);
   if (lane < QR) qt[lane] = -1;
   const desc4 dq = fl_desc(q, qbytes), dt = fl_desc(T, tbytes), dob = fl_desc(O, obytes);
@@ -778,6 +889,7 @@ __global__ __launch_bounds__(FL_WG, (FW<C>::WGS)) void sgd_flow_wide_kernel(cons
         }                                                                                                             \
       }                                                                                                               \
       if (!aborted) {                                                                                                 \
+        FL_STAT(2, 1);                                                                                                \
         _Pragma("unroll") for (int c = 0; c < C; c++) tv[c] = __uint_as_float((uint32_t)Tr[K][c]);                            \
         if (own_user) {                                                                                               \
           const float est_ = wide_dot<C>(ov, tv);                                                                     \
@@ -801,11 +913,190 @@ __global__ __launch_bounds__(FL_WG, (FW<C>::WGS)) void sgd_flow_wide_kernel(cons
     }                                                                                                                 \
   }
 
+#ifdef MFX_FLOW_STATS
+  // per queue: {pole visits, polls, generic visits, pole blocks, -, cycles in the kernel, cycles in polls, cycles in counted waits + block starts}
+  unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
+#define FLW_T0 const unsigned long long st_w = __builtin_amdgcn_s_memtime();
+#define FLW_T1(i) st_[i] += __builtin_amdgcn_s_memtime() - st_w;
+#else
+#define FLW_T0
+#define FLW_T1(i)
+#endif
+  // ---- pole blocks (see fwp_link above; landing registers a0 .. a31, see fwa_load) ------------------------------------------------
+  // the probe-then-poll of FW_STEP for landing slot K, row RX, tags EXP: until the row carries its tags (or the launch is aborted);
+  // leaves the row's values in VAL
+#define FWP_POLL(K, RX, EXP, VAL)                                                                                     \
+  {                                                                                                                   \
+    const uint32_t rb_ = (uint32_t)(RX) * (uint32_t)(8 * LD);                                                         \
+    long long t_last_ = wall_clock64();                                                                               \
+    int spins_ = 0;                                                                                                   \
+    for (;;) {                                                                                                        \
+      bool hit_ = spins_ < pollfull;           /* the first `pollfull` tries read the whole row: one round trip, not two */ \
+      if (!hit_) {                                                                                                    \
+        unsigned long long pr_ = 0ull;                                                                                \
+        fw_load2(pr_, dt, lane == 0 ? rb_ : FL_OOB);                                                                  \
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pr_)::"memory");                                                     \
+        hit_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pr_ >> 32)) == (EXP);                                   \
+      }                                                                                                               \
+      if (hit_) {                                                                                                     \
+        fwa_request<K, C>(dt, rb_ + g_off);                                                                           \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                              \
+        uint32_t tg_[C];                                                                                              \
+        fwa_take<K, C>(VAL, tg_);                                                                                     \
+        bool t_ = true;                                                                                               \
+        _Pragma("unroll") for (int c = 0; c < C; c++) t_ = t_ && tg_[c] == (EXP);                                     \
+        if (__builtin_amdgcn_ballot_w64(t_) == ~0ull) break;                                                          \
+      }                                                                                                               \
+      if ((++spins_ & 63) == 0) {                                                                                     \
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { aborted = true; break; }           \
+        if (wall_clock64() - t_last_ > 200000000LL) {        /* 100 MHz constant clock: 2 s on one queue head */      \
+          __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                                   \
+          aborted = true;                                                                                             \
+          break;                                                                                                      \
+        }                                                                                                             \
+      }                                                                                                               \
+    }                                                                                                                 \
+  }
+  // One visit of a pole block.  K = landing slot of position S (verified: its values are in tvc, its record in rx_c / rz_c / exp_c),
+  // K1 = slot of position S + 1, NW = vector-memory instructions issued behind the request of position S + 1 (2 C, 3 C, then 4 C).
+  // Order: (1) wait for the row of S + 1 to have LANDED, read it out and compare its tags -- no branch yet; (2) this visit; (3) its
+  // tagged store; (4) the request of position S + 4 into slot K; (5) only now, if S + 1 did not carry its tags: probe and poll
+  // (another queue may be waiting for the store of (3)).
+#define FWP_STEP(K, K1, S, NW)                                                                                        \
+  {                                                                                                                   \
+    const int s1_ = ((S) + 1) & 63;                                                                                   \
+    FL_STAT(0, 1);                                                                                                    \
+    { FLW_T0 asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NW) : "memory"); FLW_T1(7) }                                    \
+    uint32_t vn_[C], tn_[C];                                                                                          \
+    fwa_take<K1, C>(vn_, tn_);                                                                                        \
+    const int rx_n = __builtin_amdgcn_readlane(rec.x, s1_), rz_n = __builtin_amdgcn_readlane(rec.z, s1_);             \
+    const uint32_t exp_n = (uint32_t)__builtin_amdgcn_readlane(rec.w, s1_);                                           \
+    bool okn_ = true;                                                                                                 \
+    _Pragma("unroll") for (int c = 0; c < C; c++) okn_ = okn_ && tn_[c] == exp_n;                                     \
+    const bool needn_ = (S) + 1 < NB && __builtin_amdgcn_ballot_w64(okn_) != ~0ull;                                   \
+    /* (2) the visit: other side's row gathered per quad, the chain, the reference's bracket */                      \
+    float g_[C][4];                                                                                                   \
+    _Pragma("unroll") for (int c = 0; c < C; c++) {                                                                   \
+      g_[c][0] = fw_dpp<0x00>(tvc[c]); g_[c][1] = fw_dpp<0x55>(tvc[c]);                                               \
+      g_[c][2] = fw_dpp<0xAA>(tvc[c]); g_[c][3] = fw_dpp<0xFF>(tvc[c]);                                               \
+    }                                                                                                                 \
+    const float est_ = pole_dot<C>(ov, g_);                                                                           \
+    if (OWN_U) pole_axpys<C, ARITH>(ov, tvc, __int_as_float(rz_c), est_, lr, uReg, iReg);                             \
+    else pole_axpys<C, ARITH>(tvc, ov, __int_as_float(rz_c), est_, lr, uReg, iReg);                                   \
+    /* (3) + (4) */                                                                                                   \
+    {                                                                                                                 \
+      const uint32_t stb_ = (uint32_t)rx_c * (uint32_t)(8 * LD) + g_off;                                              \
+      _Pragma("unroll") for (int c = 0; c < C; c++)                                                                   \
+          fw_store2(dt, stb_ + (uint32_t)(c * 512), uint2v{__float_as_uint(tvc[c]), exp_c + 1u});                     \
+      const int sn_ = (S) + LAP;                                                                                      \
+      const int rxq_ = __builtin_amdgcn_readlane(rec.x, sn_ & 63);                                                    \
+      fwa_request<K, C>(dt, sn_ < NB ? (uint32_t)rxq_ * (uint32_t)(8 * LD) + g_off : FL_OOB);                         \
+    }                                                                                                                 \
+    /* (5) */                                                                                                         \
+    if (needn_ && !aborted) { FL_STAT(1, 1); FLW_T0 FWP_POLL(K1, rx_n, exp_n, vn_) FLW_T1(6) }                        \
+    _Pragma("unroll") for (int c = 0; c < C; c++) tvc[c] = __uint_as_float(vn_[c]);                                   \
+    rx_c = rx_n; rz_c = rz_n; exp_c = exp_n;                                                                          \
+  }
+  // LAP = rows of the other side in flight in a pole block.  The landing pairs cost nothing but accumulation registers: 16 rows in
+  // flight at C = 1, 8 at C = 2, 4 beyond (a0 .. a31; LAP divides the 64 positions of a block).  (Measured at C2, rank 64: 4 or 16 in
+  // flight, float or double bracket, probes or whole-row polls -- the epoch takes 14.2 - 14.5 ms all the same, because the launch no longer
+  // ends with the most popular item's queue but with the chain of the busiest USER's row: 10 717 visits in 10 717 different queues, each a
+  // hand-off through memory at ~ 1.3 us (MI355X_MICROARCH.md, handoff-1to1: 0.8 - 1.0 us on an idle chip).  scripts/flow_model.py
+  // reproduces it: makespan = max(49 777 x step, 10 717 x (step + hand-off)).  Ranks 128 / 256, where the step was the larger term:
+  // 18.6 -> 16.4 ms, 27.7 -> 24.1 ms.)
+  constexpr int LAP = C == 1 ? 16 : C == 2 ? 8 : 4;
+  static_assert(LAP * C <= 16 && (LAP - 2) * 2 * C <= 63 && LAP <= 16 && NB % LAP == 0, "pole path: landing pairs and the counted waits");
+  // vector-memory instructions issued behind the request of position S + 1 when step S waits for it: the rest of the prologue's
+  // requests and 2 C per earlier step -- (LAP - 2 + S) C in the first steps of a block, (LAP - 2) 2 C from step LAP - 2 on
+#define FWP_NW(PEEL_, S_) (((PEEL_) && (S_) <= LAP - 2) ? (LAP - 2 + (S_)) * C : (LAP - 2) * 2 * C)
+#define FWP_ROUND(S0_, PEEL_)                                                                                         \
+  {                                                                                                                   \
+    if constexpr (LAP > 0) { FWP_STEP(0, (1 % LAP), (S0_) + 0, FWP_NW(PEEL_, 0)) }   \
+    if constexpr (LAP > 1) { FWP_STEP(1, (2 % LAP), (S0_) + 1, FWP_NW(PEEL_, 1)) }   \
+    if constexpr (LAP > 2) { FWP_STEP(2, (3 % LAP), (S0_) + 2, FWP_NW(PEEL_, 2)) }   \
+    if constexpr (LAP > 3) { FWP_STEP(3, (4 % LAP), (S0_) + 3, FWP_NW(PEEL_, 3)) }   \
+    if constexpr (LAP > 4) { FWP_STEP(4, (5 % LAP), (S0_) + 4, FWP_NW(PEEL_, 4)) }   \
+    if constexpr (LAP > 5) { FWP_STEP(5, (6 % LAP), (S0_) + 5, FWP_NW(PEEL_, 5)) }   \
+    if constexpr (LAP > 6) { FWP_STEP(6, (7 % LAP), (S0_) + 6, FWP_NW(PEEL_, 6)) }   \
+    if constexpr (LAP > 7) { FWP_STEP(7, (8 % LAP), (S0_) + 7, FWP_NW(PEEL_, 7)) }   \
+    if constexpr (LAP > 8) { FWP_STEP(8, (9 % LAP), (S0_) + 8, FWP_NW(PEEL_, 8)) }   \
+    if constexpr (LAP > 9) { FWP_STEP(9, (10 % LAP), (S0_) + 9, FWP_NW(PEEL_, 9)) }   \
+    if constexpr (LAP > 10) { FWP_STEP(10, (11 % LAP), (S0_) + 10, FWP_NW(PEEL_, 10)) }   \
+    if constexpr (LAP > 11) { FWP_STEP(11, (12 % LAP), (S0_) + 11, FWP_NW(PEEL_, 11)) }   \
+    if constexpr (LAP > 12) { FWP_STEP(12, (13 % LAP), (S0_) + 12, FWP_NW(PEEL_, 12)) }   \
+    if constexpr (LAP > 13) { FWP_STEP(13, (14 % LAP), (S0_) + 13, FWP_NW(PEEL_, 13)) }   \
+    if constexpr (LAP > 14) { FWP_STEP(14, (15 % LAP), (S0_) + 14, FWP_NW(PEEL_, 14)) }   \
+    if constexpr (LAP > 15) { FWP_STEP(15, (16 % LAP), (S0_) + 15, FWP_NW(PEEL_, 15)) }   \
+  }
+#define FWP_BLOCK(OWN_U_)                                                                                             \
+  {                                                                                                                   \
+    constexpr bool OWN_U = OWN_U_;                                                                                    \
+    float tvc[C];                                                                                                     \
+    int rx_c = __builtin_amdgcn_readlane(rec.x, 0), rz_c = __builtin_amdgcn_readlane(rec.z, 0);                       \
+    uint32_t exp_c = (uint32_t)__builtin_amdgcn_readlane(rec.w, 0);                                                   \
+    /* the requests of positions 0 .. LAP - 1; position 0: behind its request lie the LAP - 1 others */              \
+    FL_STAT(3, 1);                                                                                                    \
+    fwp_prologue<0, LAP, C>(dt, rec.x, (uint32_t)(8 * LD), g_off);                                                    \
+    { FLW_T0 asm volatile("s_waitcnt vmcnt(%0)" ::"i"((LAP - 1) * C) : "memory"); FLW_T1(7) }                         \
+    {                                                                                                                 \
+      uint32_t v0_[C], t0_[C];                                                                                        \
+      fwa_take<0, C>(v0_, t0_);                                                                                       \
+      bool ok0_ = true;                                                                                               \
+      _Pragma("unroll") for (int c = 0; c < C; c++) ok0_ = ok0_ && t0_[c] == exp_c;                                   \
+      if (__builtin_amdgcn_ballot_w64(ok0_) != ~0ull) { FL_STAT(1, 1); FLW_T0 FWP_POLL(0, rx_c, exp_c, v0_) FLW_T1(6) }   \
+      _Pragma("unroll") for (int c = 0; c < C; c++) tvc[c] = __uint_as_float(v0_[c]);                                 \
+    }                                                                                                                 \
+    if (!aborted) {                                                                                                   \
+      FWP_ROUND(0, true)                                                                                              \
+      _Pragma("clang loop unroll(disable)")                                                                           \
+      for (int s0 = LAP; s0 < NB && !aborted; s0 += LAP) FWP_ROUND(s0, false)                                         \
+    }                                                                                                                 \
+    { FLW_T0 asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); FLW_T1(7) }   /* nothing in flight into a0 .. a31 when the block is left */ \
+  }
+
   while (pos < end && !aborted) {
     const int nb = (int)min((uint32_t)NB, end - pos);
     uint4v rb = fl_load<false>(dq, lane < nb ? (pos + (uint32_t)lane) * 16u : FL_OOB);
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(rb)::"memory");
+    { FLW_T0 asm volatile("s_waitcnt vmcnt(0)" : "+v"(rb)::"memory"); FLW_T1(4) }
     const int4 rec = make_int4((int)rb.x, (int)rb.y, (int)rb.z, (int)rb.w);
+    // a pole block: 64 records, one owned row (nothing of it touches the landing registers Tr of the generic steps)
+    const int ry0 = __builtin_amdgcn_readfirstlane(rec.y);
+    if ((own_flags & 4) && nb == NB && __builtin_amdgcn_ballot_w64(rec.y == ry0) == ~0ull) {
+      const int orow_ = ry0 & FL_ROW_MASK, slot_ = (int)((uint32_t)ry0 >> FL_SLOT_SHIFT) & (QR - 1);
+      if (orow_ != cur_row) {               // the owned-row switch of FW_STEP, once for the block
+        if (cur_row >= 0) {
+#pragma unroll
+          for (int c = 0; c < C; c++) qv[(cur_slot * C + c) * 64 + lane] = ov[c];
+        }
+        const int have_ = __builtin_amdgcn_readfirstlane(qt[slot_]);
+        if (have_ == orow_) {
+#pragma unroll
+          for (int c = 0; c < C; c++) ov[c] = qv[(slot_ * C + c) * 64 + lane];
+        } else {
+          if (have_ >= 0) {
+#pragma unroll
+            for (int c = 0; c < C; c++)
+              fw_store1(dob, (uint32_t)have_ * (uint32_t)(4 * LD) + (uint32_t)(c * 256) + o_off, __float_as_uint(qv[(slot_ * C + c) * 64 + lane]));
+          }
+          uint32_t in_[C];
+#pragma unroll
+          for (int c = 0; c < C; c++) in_[c] = fw_load1(dob, (uint32_t)orow_ * (uint32_t)(4 * LD) + (uint32_t)(c * 256) + o_off);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int c = 0; c < C; c++) {
+            asm volatile("" : "+v"(in_[c]));
+            ov[c] = __uint_as_float(in_[c]);
+          }
+          if (lane == 0) qt[slot_] = orow_;
+        }
+        cur_row = orow_;
+        cur_slot = slot_;
+      }
+      if (own_user) FWP_BLOCK(true) else FWP_BLOCK(false)
+      pos += (uint32_t)nb;
+      continue;
+    }
 #pragma unroll
     for (int k = 0; k < LA; k++) {
       const int rxn = __builtin_amdgcn_readlane(rec.x, k);
@@ -832,6 +1123,16 @@ __global__ __launch_bounds__(FL_WG, (FW<C>::WGS)) void sgd_flow_wide_kernel(cons
   }
 #undef FW_STEP
 #undef FW_REQUEST
+#undef FWP_STEP
+#undef FWP_BLOCK
+#undef FWP_POLL
+#undef FWP_ROUND
+#undef FWP_NW
+#ifdef MFX_FLOW_STATS
+  st_[5] = __builtin_amdgcn_s_memtime() - st_t0;
+  if (lane == 0)
+    for (int i = 0; i < 8; i++) fl_stats[grp * 8 + i] = st_[i];
+#endif
   // the owned rows go back to their table: the held one through its LDS slot, then every slot in use
   if (cur_row >= 0) {
 #pragma unroll
@@ -1327,13 +1628,17 @@ int launch_flow_tag_lca(mfx_ctx* ctx, const mfx_sgd_opts* o, int blocks) {
   HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   NEED((int64_t)per_cu * cus >= blocks, MFX_E_STATE, "sgd dataflow (tagged): %d workgroups do not fit the device (%d per CU x %d CUs)", blocks,
        per_cu, cus);
-  static const bool prio = [] { const char* e = getenv("MFX_FLOW_PRIO"); return !e || atoi(e) != 0; }();
+  static const bool prio = [] { const char* e = getenv("MFX_FLOW_PRIO"); return e && atoi(e) != 0; }();   // (measured: no effect; off)
+  const char* pe_ = getenv("MFX_FLOW_POLE");                                                                // (read per call: tests switch it)
+  const bool pole = !pe_ || atoi(pe_) != 0;
+  const char* pf_ = getenv("MFX_FLOW_POLLFULL");
+  const int pollfull = pf_ ? std::max(0, std::min(65535, atoi(pf_))) : 0;
   const int64_t total = nOth * L * C;
   const int tgrid = (int)std::min<int64_t>((total + 255) / 256, 8192);
   hipLaunchKernelGGL(flow_tag_kernel, dim3(tgrid), dim3(256), 0, ctx->stream, (const float*)X, nOth, L, C, S->tagbuf);
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(FL_WG), (size_t)P::LDS, ctx->stream, (const int4*)S->q, S->qoff,
                      (uint32_t)((uint64_t)S->hoff.back() * 16u), S->tagbuf, (uint32_t)((uint64_t)nOth * 8u * P::LD), O,
-                     (uint32_t)((uint64_t)(S->own_user ? ctx->nU : ctx->nI) * 4u * P::LD), (S->own_user ? 1 : 0) | (prio ? 2 : 0), o->learnRate, o->uReg, o->iReg,
+                     (uint32_t)((uint64_t)(S->own_user ? ctx->nU : ctx->nI) * 4u * P::LD), (S->own_user ? 1 : 0) | (prio ? 2 : 0) | (pole ? 4 : 0) | (pollfull << 8), o->learnRate, o->uReg, o->iReg,
                      S->flag);
   hipLaunchKernelGGL(flow_untag_kernel, dim3(tgrid), dim3(256), 0, ctx->stream, (const float*)S->tagbuf, nOth, L, C, X);
   HIPCHK(hipGetLastError());

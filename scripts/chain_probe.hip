@@ -31,33 +31,22 @@ __global__ void probe(float* out, unsigned long long* cyc, float seed) {
     if (WHICH == 12) { REP16(asm volatile("v_add_f32 %0, %0, %1" : "+v"(a) : "v"(c));) }
     if (WHICH == 13) { REP16(asm volatile("v_mul_f64 %0, %0, %2\n\tv_add_f32 %1, %1, %3" : "+v"(d), "+v"(a) : "v"(e), "v"(c));) }      // f64 chain + independent f32 chain
     if (WHICH == 14) { REP16(asm volatile("v_cmp_eq_u32 vcc, %0, %0\n\ts_cmp_eq_u64 vcc, -1\n\ts_cbranch_scc0 1f\n1:" :: "v"(a) : "vcc", "scc");) }  // VALU compare -> scalar branch
-    if (WHICH == 15) { REP16(asm volatile("v_readlane_b32 s20, %0, 3\n\ts_lshl_b32 s21, s20, 9\n\tv_or_b32 %1, s21, %1" :: "v"(a), "v"(b) : "s20", "s21");) }
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1));
   out[threadIdx.x] = a + (float)d + b;
   if (threadIdx.x == 0) cyc[0] = t1 - t0;
 }
 
-__global__ void calib(unsigned long long* o, float* out) {
-  unsigned long long a0, a1, b0, b1;
-  float a = threadIdx.x;
-  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(a0), "=s"(b0));
-  for (int i = 0; i < 200000; i++) asm volatile("v_add_f32 %0, %0, %0" : "+v"(a));
-  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(a1), "=s"(b1));
-  out[threadIdx.x] = a;
-  if (threadIdx.x == 0) { o[0] = a1 - a0; o[1] = b1 - b0; }
-}
-
 int main() {
   float* out; unsigned long long* cyc;
-  hipMalloc(&out, 64 * 4); hipMalloc(&cyc, 16);
+  hipMalloc(&out, 64 * 4); hipMalloc(&cyc, 16);   // (a sixteenth probe, v_readlane -> s_lshl -> v_or without wait states, and a 200 000-iteration calibration loop were removed: one of them did not return)
   const char* names[] = {"v_fma_f32 chain", "v_fmac_f32_dpp chain", "nop1 + v_mov_dpp chain", "v_mul_f64 chain", "v_add_f64 chain", "v_fma_f64 chain",
                          "cvt f32->f64->f32 (2 links)", "mov+swap32+add (xor-32 level)", "readlane -> nop3 -> v_add (sgpr)", "nop1 + v_add_dpp row_mirror",
                          "s_cmp + branch not taken", "s_cmp + branch taken over 4 nops", "v_add_f32 chain", "mul_f64 chain + add_f32 chain (2 instr)",
-                         "v_cmp -> s_cmp vcc -> branch", "readlane -> s_lshl -> v_or"};
+                         "v_cmp -> s_cmp vcc -> branch"};
   void (*k[])(float*, unsigned long long*, float) = {probe<0>, probe<1>, probe<2>, probe<3>, probe<4>, probe<5>, probe<6>, probe<7>, probe<8>, probe<9>,
-                                                      probe<10>, probe<11>, probe<12>, probe<13>, probe<14>, probe<15>};
-  for (int w = 0; w < 16; w++) {
+                                                      probe<10>, probe<11>, probe<12>, probe<13>, probe<14>};
+  for (int w = 0; w < 15; w++) {
     fprintf(stderr, "probe %d\n", w);
     unsigned long long best = ~0ull;
     for (int rep = 0; rep < 5; rep++) {
@@ -67,9 +56,5 @@ int main() {
     }
     printf("%-42s %8.2f s_memtime ticks per group of the 16 x %d\n", names[w], (double)best / (16.0 * N_IT), N_IT); fflush(stdout);
   }
-  // calibration: s_memtime ticks per s_memrealtime tick (100 MHz)
-  hipLaunchKernelGGL(calib, dim3(1), dim3(64), 0, 0, cyc, out);
-  unsigned long long h[2]; hipMemcpy(h, cyc, 16, hipMemcpyDeviceToHost);
-  printf("s_memtime ticks per microsecond: %.1f\n", (double)h[0] / ((double)h[1] / 100.0));
   return 0;
 }

@@ -46,7 +46,14 @@ with Ctx(0) as ctx:
             st = np.zeros((ng, 8), dtype=np.uint64)
             _lib.load().mfx_debug_flow_stats(st.ctypes.data_as(C.c_void_p), C.c_int64(ng))
             st = st.astype(np.float64)
-            hot = int(np.argmax(st[:, 0]))
+            hot = int(np.argmax(st[:, 0] + (st[:, 2] if os.environ.get("FLOW_STATS") == "wide" else 0)))
+            if os.environ.get("FLOW_STATS") == "wide":
+                for nm, row in (("hottest queue", st[hot]), ("mean over queues", st.mean(axis=0))):
+                    v = max(row[0] + row[2], 1)
+                    print("   %s: pole visits %.0f in %.0f blocks, generic visits %.0f, polls %.0f; kernel cycles %.3g = %.0f per visit: in counted waits "
+                          "%.0f, in polls %.0f, waiting for the block's records %.0f per visit" % (nm, row[0], row[3], row[2], row[1], row[5], row[5] / v, row[7] / v, row[6] / v, row[4] / v))
+                print("   queues by kernel cycles: max %.3g, median %.3g, min %.3g" % (st[:, 5].max(), np.median(st[:, 5]), st[:, 5].min()))
+                continue
             for nm, row in (("hottest queue", st[hot]), ("mean over queues", st.mean(axis=0))):
                 v = max(row[0], 1)
                 print("   %s: visits %.0f, waited for their row %.0f (probes %.0f), owned-row switches %.0f (table loads %.0f), "

@@ -343,6 +343,71 @@ def test_level_schedule_is_the_sequential_loop_bit_for_bit(K, arith, exact_sched
     assert np.array_equal(V, Vo)
 
 
+def _pole_matrix(n_heavy, n_light, seed, transpose):
+    """A few rows of one side with thousands of ratings each (5 000, 3 000, 700, 130 -- whole 64-record blocks of ONE owned row in
+    their queues, and tails) over a background of light rows; transpose=True makes the heavy rows users."""
+    rng = np.random.default_rng(seed)
+    pairs = set()
+    for h, cnt in enumerate((5000, 3000, 700, 130)[:n_heavy]):
+        for o in rng.choice(n_light, cnt, replace=False):
+            pairs.add((int(o), h))
+    for _ in range(20000):
+        pairs.add((int(rng.integers(n_light)), int(rng.integers(n_heavy, n_heavy + 200))))
+    a = np.array(sorted(pairs), dtype=np.int64)            # (light row, heavy-side row)
+    if transpose:
+        a = a[:, ::-1]
+        a = a[np.lexsort((a[:, 1], a[:, 0]))]
+    nr, nc = int(a[:, 0].max()) + 1, int(a[:, 1].max()) + 1
+    rowptr = np.zeros(nr + 1, np.int64)
+    np.add.at(rowptr, a[:, 0] + 1, 1)
+    rowptr = np.cumsum(rowptr)
+    vals = (rng.integers(1, 11, len(a)) * 0.5).astype(np.float32)
+    return synth.CSR(nr, nc, rowptr, a[:, 1].astype(np.int32), vals)
+
+
+@pytest.mark.parametrize("K", [40, 64, 128, 200, 256])
+@pytest.mark.parametrize("arith", ARITHS)
+@pytest.mark.parametrize("own", ["item", "user"])
+def test_pole_blocks_of_the_tagged_replay_are_the_sequential_loop_bit_for_bit(K, arith, own, monkeypatch):
+    """sgd_flow_wide_kernel's pole path (sgd_flow.hip, round 4): blocks of 64 queue records that visit ONE owned row run a
+    branch-light step with its landing registers in a0 .. a31, the dot chain through the DPP source of v_fmac, row_bcast levels
+    and the exact-product fma in the double bracket.  Same bits as the oracle's sequential pass and as the generic steps
+    (MFX_FLOW_POLE=0), with item rows owned (a shuffled list) and with user rows owned (a user-ordered list), over two epochs."""
+    tr = _pole_matrix(4, 6000, seed=K, transpose=(own == "user"))
+    nU, nI = tr.nrows, tr.ncols
+    rng = np.random.default_rng(5 + K)
+    U0 = rng.normal(0, 0.25 * np.sqrt(40.0 / K), (nU, K)).astype(np.float32)     # (|p.q| ~ 2.5 at every rank: the pass stays finite)
+    V0 = rng.normal(0, 0.25 * np.sqrt(40.0 / K), (nI, K)).astype(np.float32)
+    ru = tr.rowids()
+    orders = []
+    for ep in range(2):
+        if own == "item":
+            orders.append(rng.permutation(tr.nnz).astype(np.uint64))
+        else:                                              # users in a fresh order, each user's ratings together (trainUShuffle's list)
+            up = rng.permutation(nU)
+            orders.append(np.concatenate([np.arange(tr.rowptr[u], tr.rowptr[u + 1]) for u in up]).astype(np.uint64))
+    Uo, Vo = U0.copy(), V0.copy()
+    for o in orders:
+        orc.sgd_pass(Uo, Vo, ru, tr.rowind, tr.rowval, o, 0.004, 0.01, 0.02, arith[1], orc.DOT_TREE)
+    got = {}
+    for pole in ("1", "0"):
+        monkeypatch.setenv("MFX_FLOW_POLE", pole)
+        with Ctx(0) as ctx:
+            ctx.set_csr(mfx.MAT_TRAIN, nU, nI, tr.rowptr, tr.rowind, tr.rowval)
+            ctx.set_model(nU, nI, K)
+            ctx.set_factors(U0, V0)
+            for o in orders:
+                ctx.sgd_set_order(o)
+                ctx.sgd_epoch(0.004, 0.01, 0.02, mode=mfx.SGD_LEVELS, order=mfx.ORDER_HOST, arith=arith[0])
+                info, _ = ctx.debug_levels_info()
+                assert info[0] == 1 and info[3] == (1 if own == "user" else 0)      # dataflow schedule, the expected owned side
+                assert info[1] >= 5000
+            got[pole] = ctx.get_factors()
+    assert np.isfinite(Uo).all() and np.isfinite(Vo).all() and np.abs(Uo - U0).max() > 1e-3 and np.abs(Vo - V0).max() > 1e-2
+    for pole in ("1", "0"):
+        assert np.array_equal(got[pole][0], Uo) and np.array_equal(got[pole][1], Vo), pole
+
+
 @pytest.mark.parametrize("K", [10, 64, 128, 200])
 @pytest.mark.parametrize("tagged", ["1", "0"])
 def test_dataflow_with_many_owned_rows_per_queue(K, tagged, monkeypatch):

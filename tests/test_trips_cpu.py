@@ -100,14 +100,18 @@ def test_permlane_swaps_written_as_inline_assembly_carry_their_wait_states(tmp_p
 
 
 def test_landing_registers_of_the_tagged_replay_are_never_copied():
-    """sgd_flow_tag_kernel / sgd_flow_wide_kernel request the rows of the next LA queue positions with inline-assembly loads and
+    """sgd_flow_tag_kernel / sgd_flow_wide_kernel request the rows of the next queue positions with inline-assembly loads and
     wait for them with counted s_waitcnt statements the compiler does not understand: for it a landing register holds its value
     from the load statement on, so any v_mov it schedules between the load and the wait copies a register whose data has not
-    arrived.  The kernels make every landing register ONE live range (in-out operand of every load and wait; 64-bit integers
-    instead of small vectors in the wide kernel, which the compiler promoted to one moving register tuple at C = 1 -- the first GPU
-    run of that kernel computed wrong rows).  Checked on the compiled code: the loads of all steps (prologue, steady state,
-    re-reads) of one pipeline slot target the same registers, i.e. a kernel has exactly LA x (loads per request) destinations that
-    are loaded five times or more, plus the few scratch destinations of the probe loop."""
+    arrived (the first GPU run of the wide kernel computed wrong rows that way).  Checked on the compiled code:
+      * 16-lane kernel: the loads of all steps of one pipeline slot target the same registers -- exactly LA x (loads per request)
+        destinations that are loaded five times or more, plus the few scratch destinations of the probe loop;
+      * wide kernel, generic steps: every move that reads or writes a register an `sc1` row load lands in sits behind an
+        `s_waitcnt vmcnt(0)` with no such load in between (round 4: with the pole path in the kernel the allocator parks the four slots
+        in other registers across a pole block -- moves at block boundaries, where nothing is in flight, are what is allowed);
+      * wide kernel, pole blocks: the landing registers are accumulation registers named in the asm text (a0 .. a31), which the compiler
+        never allocates: no accumulation register appears outside an asm statement, the loads into them are LAP x C distinct pairs,
+        and nothing spills."""
     import re
     import tempfile
     import pathlib
@@ -115,29 +119,62 @@ def test_landing_registers_of_the_tagged_replay_are_never_copied():
         text = _device_asm(os.path.join(ROOT, "matfac_amd", "csrc", "sgd_flow.hip"), pathlib.Path(d))
     lines = text.split("\n")
     seen = 0
+
+    def regs(tok):                                # "v[14:15]" / "v7" -> set of register numbers
+        m = re.match(r"v\[(\d+):(\d+)\]", tok)
+        if m:
+            return set(range(int(m.group(1)), int(m.group(2)) + 1))
+        m = re.match(r"v(\d+)$", tok)
+        return {int(m.group(1))} if m else set()
+
     for i, l in enumerate(lines):
         m = re.match(r"^_ZN12_GLOBAL__N_1\d+sgd_flow_(tag|wide)_kernelILi(\d+)ELi(\d+)E(?:Li(\d+)E)?", l)
         if not m or ":" not in l:                 # the label line of the kernel ("name:   ; @name")
             continue
-        if m.group(1) == "tag":
-            L, C = int(m.group(2)), int(m.group(3))
-            la, per = (4 if C <= 2 else 2), 2 * C
-        else:
-            C = int(m.group(2))
-            la, per = 4, C
         j = i
         while not lines[j].startswith(".Lfunc_end"):
             j += 1
-        # destinations of the L1-bypass row loads.  A landing register is loaded by the prologue, the first steps, the steady state and
-        # the two re-reads of a stalled head: five statements, all into the same registers -- a slot whose loads were split over two
-        # registers (with a copy in between) shows up as two destinations with fewer loads each.  What else appears are the probe's
-        # scratch registers.
-        dst = {}
-        for b in lines[i:j]:
-            k = re.match(r"\s*buffer_load_dwordx[24] (v\[\d+:\d+\]), v\d+, s\[\d+:\d+\], 0 offen sc1", b)
-            if k:
-                dst[k.group(1)] = dst.get(k.group(1), 0) + 1
-        landing = [r for r, n in dst.items() if n >= 5]
-        assert la * per <= len(landing) <= la * per + 2 and len(dst) <= la * per + 6, (l[:60], sorted(dst.items()))
+        body = lines[i:j]
+        if m.group(1) == "tag":
+            L, C = int(m.group(2)), int(m.group(3))
+            la, per = (4 if C <= 2 else 2), 2 * C
+            dst = {}
+            for b in body:
+                k = re.match(r"\s*buffer_load_dwordx[24] (v\[\d+:\d+\]), v\d+, s\[\d+:\d+\], 0 offen sc1", b)
+                if k:
+                    dst[k.group(1)] = dst.get(k.group(1), 0) + 1
+            landing = [r for r, n in dst.items() if n >= 5]
+            assert la * per <= len(landing) <= la * per + 2 and len(dst) <= la * per + 6, (l[:60], sorted(dst.items()))
+        else:
+            C = int(m.group(2))
+            lap = 16 if C == 1 else 8 if C == 2 else 4
+            land = set()
+            for b in body:
+                k = re.match(r"\s*buffer_load_dwordx2 (v\[\d+:\d+\]), v\d+, s\[\d+:\d+\], 0 offen sc1", b)
+                if k:
+                    land |= regs(k.group(1))
+            for n, b in enumerate(body):
+                k = re.match(r"\s*v_mov_b(?:32|64)(?:_e32|_e64)? (v\[\d+:\d+\]|v\d+), (v\[\d+:\d+\]|v\d+)\s*$", b)
+                if not k or not ((regs(k.group(1)) | regs(k.group(2))) & land):
+                    continue
+                touched = regs(k.group(1)) | regs(k.group(2))
+                ok = None
+                for t in range(n - 1, -1, -1):
+                    x = body[t].strip()
+                    if x.startswith("s_waitcnt vmcnt(0)"):
+                        ok = True
+                        break
+                    q = re.match(r"buffer_load_dwordx2 (v\[\d+:\d+\]), v\d+, s\[\d+:\d+\], 0 offen sc1", x)
+                    if q and regs(q.group(1)) & touched:
+                        ok = False
+                        break
+                assert ok, (l[:70], n, b.strip())
+            # the pole path: accumulation registers only inside asm statements, LAP x C landing pairs, no scratch
+            joined = "\n".join(body)
+            outside = re.sub(r";;#ASMSTART\n.*?;;#ASMEND", "", joined, flags=re.S)
+            assert not [x for x in outside.split("\n") if re.search(r"\ba\d+\b|\ba\[\d+", x) and not x.strip().startswith(";")], l[:70]
+            pairs = set(re.findall(r"buffer_load_dwordx2 (a\[\d+:\d+\])", joined))
+            assert len(pairs) == lap * C, (l[:70], sorted(pairs))
+            assert "scratch_" not in joined
         seen += 1
     assert seen >= 30          # 7 rank shapes x 3 arithmetic modes of the 16-lane kernel, 4 x 3 of the wide one
