@@ -177,11 +177,13 @@ def main():
     ctx.set_factors(U0, V0)
     ctx.compute_invalid()
     exchange = "RCCL over xGMI"
+    ext_reducer = None           # the host-staged all-reduce the contexts use when the library's RCCL communicator is not (rehearsal / fallback)
     if multi:
         import torch
         if use_gloo:
             exchange = "gloo, staged through the host (rehearsal)"
-            ctx.comm_init_external(N, rank, lambda a: dist.all_reduce(torch.from_numpy(a), op=dist.ReduceOp.SUM))
+            ext_reducer = lambda a: dist.all_reduce(torch.from_numpy(a), op=dist.ReduceOp.SUM)   # noqa: E731
+            ctx.comm_init_external(N, rank, ext_reducer)
         else:
             # the library's own RCCL communicator (device buffers, on its stream).  Every rank reports whether it came
             # up; if any did not, all of them fall back to the host-staged external reducer over torch's communicator,
@@ -214,6 +216,7 @@ def main():
                     t = torch.from_numpy(a).cuda()
                     dist.all_reduce(t, op=dist.ReduceOp.SUM)
                     a[...] = t.cpu().numpy()
+                ext_reducer = staged
                 ctx.comm_init_external(N, rank, staged)
         ctx.comm_mark_synced()
 
@@ -287,6 +290,89 @@ def main():
             step(ep, exch=False)
         val_rmse_solo = global_rmse(mfx.MAT_VAL)
 
+    # ---- N > 1 sub-records (round 4): the OTHER exchange on the same data, and the strong-scaling split of the ONE named matrix next to
+    # the weak-scaling default -- so that a scaling run measures what north_star names (one matrix, an item-factor all-reduce) as well as
+    # the headline (rotation, one block per GPU).  Every rank takes the same path through this block (collectives inside).
+    sub = {}
+
+    def run_epochs(c, stepfn, warm, n_ep):
+        """max over ranks of the wall time of n_ep epochs of stepfn on context c (after `warm` untimed ones)"""
+        import torch
+        for ep in range(warm):
+            stepfn(ep)
+        c.synchronize(); dist.barrier()
+        t0_ = time.perf_counter()
+        for ep in range(warm, warm + n_ep):
+            stepfn(ep)
+        c.synchronize(); dist.barrier()
+        tt = torch.tensor([time.perf_counter() - t0_], dtype=torch.float64, device="cpu" if use_gloo else "cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt[0])
+
+    if multi and mode == mfx.SGD_TILED and os.environ.get("BENCH_NO_SUBRECORDS") != "1":
+        n_ep = max(2, min(args.steps, 8))
+        other = "allreduce" if rotate else "rotate"
+        ctx.set_factors(U0, V0)
+        ctx.comm_mark_synced()
+        if other == "rotate":
+            ctx.set_item_parts(N)
+
+        def step_other(ep):
+            if other == "rotate":
+                mdist.rotating_epoch(ctx, rank, N, lr, ureg, ireg, mode=mode, order=mfx.ORDER_DEVICE, arith=arith, seed=1, epoch=ep, blocks=args.blocks)
+            else:
+                ctx.sgd_epoch(lr, ureg, ireg, mode=mode, order=mfx.ORDER_DEVICE, arith=arith, seed=1, epoch=ep, blocks=args.blocks)
+                ctx.allreduce_item_factors(mfx.REDUCE_AVERAGE)
+        el = run_epochs(ctx, step_other, 4, n_ep)
+        # what one exchange costs on its own: the all-reduce of V / the ring shifts and the all-gather, timed without the epochs
+        def exch_only(ep):
+            if other == "rotate":
+                steps_, held_ = mdist.rotation_schedule(rank, N)
+                for part_, send_, recv_ in steps_:
+                    if send_ is not None:
+                        ctx.rotate_item_part(send_, recv_)
+                ctx.allgather_item_parts(held_)
+            else:
+                ctx.allreduce_item_factors(mfx.REDUCE_AVERAGE)
+        ex = run_epochs(ctx, exch_only, 1, 4)
+        sub["exchange_" + other] = {"exchange": other, "epochs": n_ep, "ms_per_step": el / n_ep * 1e3,
+                                    "ms_per_exchange_alone": ex / 4 * 1e3, "val_rmse_after_%d_epochs" % (4 + n_ep + 5): global_rmse(mfx.MAT_VAL),
+                                    "note": "same data and schedule as the headline, the other exchange (rotate = item parts round a ring, every update "
+                                            "applied once; allreduce = north_star's item-factor all-reduce, replicas averaged); the RMSE is after the 4 warm-up, "
+                                            "the timed and the 5 exchange-only epochs of THIS sub-record"}
+        if args.scaling == "weak" and args.workload != "C5":
+            # strong scaling: ONE matrix of the named shape cut into N nnz-balanced user blocks, its own context and communicator
+            full = synth.make(shape, seed=1, shard=0)
+            bb = mdist.user_blocks(full["train"].rowptr, N)
+            tr2 = mdist.take_rows(full["train"], bb[rank], bb[rank + 1])
+            nU2 = int(bb[rank + 1] - bb[rank])
+            full_nnz = int(full["train"].nnz)
+            del full
+            ctx2 = Ctx(local_rank)
+            ctx2.set_csr(mfx.MAT_TRAIN, tr2.nrows, nI, tr2.rowptr, tr2.rowind, tr2.rowval)
+            ctx2.set_model(nU2, nI, K)
+            U2, _ = synth.init_factors(1 + rank, nU2, nI, K, want_v=False)
+            ctx2.set_factors(U2, V0)
+            ctx2.compute_invalid()
+            import torch
+            if ext_reducer is not None:
+                ctx2.comm_init_external(N, rank, ext_reducer)
+            else:
+                uid2 = [Ctx.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid2, src=0)
+                ctx2.comm_init(N, rank, uid2[0])
+            ctx2.comm_mark_synced()
+            ctx2.set_item_parts(N)
+
+            def step_strong(ep):
+                mdist.rotating_epoch(ctx2, rank, N, lr, ureg, ireg, mode=mode, order=mfx.ORDER_DEVICE, arith=arith, seed=1, epoch=ep, blocks=args.blocks)
+            el2 = run_epochs(ctx2, step_strong, 4, n_ep)
+            sub["strong_scaling"] = {"workload": "ONE %dx%d matrix, %d train ratings in total, cut into %d nnz-balanced user blocks" % (shape["nU"], nI, full_nnz, N),
+                                     "exchange": "rotate", "epochs": n_ep, "ms_per_step": el2 / n_ep * 1e3, "value": full_nnz * n_ep / el2,
+                                     "unit": "updates/s", "train_nnz_this_rank": int(tr2.nnz)}
+            ctx2.comm_destroy()
+            ctx2.close()
+
     total_nnz = nnz
     if multi:
         import torch
@@ -327,6 +413,9 @@ def main():
         }
         if multi:
             out["val_rmse_after_same_epochs_without_exchange"] = val_rmse_solo
+            out["sub_records"] = sub
+            out["config"]["sub_records"] = ("exchange_%s: the other exchange on the same blocks; strong_scaling: one %s matrix cut into %d user blocks (rotate)"
+                                            % ("allreduce" if rotate else "rotate", args.workload, N)) if sub else None
     solo = N == 1 and not force_dist
     exact = None
     if rank == 0 and solo and not args.no_exact:

@@ -516,7 +516,9 @@ extern "C" int mfx_als_half_sweep(mfx_ctx* ctx, int side, float reg) {
     int rc = mfx_comm_global_col_counts(ctx, &gcol);
     if (rc) return rc;
     const int N = std::max(1, ctx->nranks);
-    const bool scatter = mfx_comm_has_rccl(ctx);
+    // (MFX_ALS_ALLREDUCE=1: the whole slab all-reduced and every item solved on every rank, also over RCCL)
+    static const bool force_allreduce = [] { const char* e = getenv("MFX_ALS_ALLREDUCE"); return e && atoi(e) != 0; }();
+    const bool scatter = mfx_comm_has_rccl(ctx) && !force_allreduce;
     const int64_t per = ((int64_t)m.ncols + N - 1) / N;                  // items per slice (the last ones may be short or empty)
     const size_t gn = scatter ? (size_t)per * N * SLAB : (size_t)m.ncols * SLAB;
     if (!ctx->als_global || ctx->als_global_cap < gn) {
@@ -568,6 +570,10 @@ extern "C" int mfx_als_half_sweep(mfx_ctx* ctx, int side, float reg) {
     if (hi > lo) HIPCHK(hipMemcpyAsync(mine, X + (size_t)lo * ctx->ld, (size_t)(hi - lo) * ctx->ld * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
     if ((rc = mfx_comm_allgather(ctx, mine, all, slice))) return rc;
     HIPCHK(hipMemcpyAsync(X, all, (size_t)m.ncols * ctx->ld * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    if (!ctx->comm_checked_als) {            // once per communicator: the slices of ceil(ncols / N) items and their offsets are rank arithmetic
+      ctx->comm_checked_als = true;
+      if ((rc = mfx_comm_check_replicas(ctx, X, (size_t)m.ncols * ctx->ld, "sharded ALS item sweep (reduce-scatter, slice solve, all-gather)"))) return rc;
+    }
     return MFX_OK;
   }
   if (sd.nseg > 0) {

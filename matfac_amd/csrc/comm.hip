@@ -167,6 +167,42 @@ int mfx_comm_allgather(mfx_ctx* ctx, const float* mine, float* all, size_t count
   return MFX_OK;
 }
 
+__global__ void bits_checksum_kernel(const uint32_t* __restrict__ x, size_t n, unsigned* __restrict__ out) {
+  unsigned s = 0;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x)
+    s += x[t] * (unsigned)(2 * (t % 65521) + 1);                    // position-weighted: rows that changed places do not cancel
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+int mfx_comm_check_replicas(mfx_ctx* ctx, const float* buf, size_t n, const char* what) {
+  if (ctx->nranks <= 1 || (!ctx->comm && !ctx->ext_reduce) || n == 0) return MFX_OK;
+  double v[2] = {0.0, 1.0};
+  {
+    unsigned* d = nullptr;
+    int rc = dev_alloc(ctx, &d, (size_t)1);
+    if (rc) return rc;
+    unsigned h = 0;
+    hipError_t e = hipMemsetAsync(d, 0, sizeof(unsigned), ctx->stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(bits_checksum_kernel, dim3(1024), dim3(256), 0, ctx->stream, (const uint32_t*)buf, n, d);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&h, d, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    dev_free(d);
+    if (e != hipSuccess) return mfx_fail(ctx, MFX_E_HIP, "replica check: %s", hipGetErrorString(e));
+    v[0] = (double)(h & 0x7fffffffu);                               // exact in a double, and so is the sum over <= 2^20 ranks
+  }
+  const double own = v[0];
+  int rc = mfx_allreduce_f64(ctx, v, 2);
+  if (rc) return rc;
+  if (v[1] != (double)ctx->nranks || v[0] != own * (double)ctx->nranks)
+    return mfx_fail(ctx, MFX_E_COMM, "%s: the ranks do not hold the same bytes afterwards (checksum of this rank %.0f, sum over %d ranks %.0f, "
+                    "%.0f ranks answered) -- the exchange is broken on this communicator; MFX_ALS_ALLREDUCE=1 / --exchange allreduce take the "
+                    "all-reduce paths", what, own, ctx->nranks, v[0], v[1]);
+  return MFX_OK;
+}
+
 extern "C" int mfx_comm_unique_id(void* id128) {
   mfx_ctx* ctx = nullptr;
   NEED(id128, MFX_E_ARG, "mfx_comm_unique_id: NULL");
@@ -179,6 +215,7 @@ extern "C" int mfx_comm_unique_id(void* id128) {
 }
 
 extern "C" int mfx_comm_init(mfx_ctx* ctx, int nranks, int rank, const void* id128) {
+  if (ctx) ctx->comm_checked_parts = ctx->comm_checked_als = false;
   if (!ctx) return MFX_E_ARG;
   NEED(nranks >= 1 && rank >= 0 && rank < nranks && id128, MFX_E_ARG, "mfx_comm_init: nranks=%d rank=%d", nranks, rank);
   NEED(load_rccl(), MFX_E_COMM, "mfx_comm_init: %s", g_rccl.err.c_str());
@@ -217,6 +254,7 @@ int mfx_comm_global_col_counts(mfx_ctx* ctx, const double** out) {
 }
 
 extern "C" int mfx_comm_init_external(mfx_ctx* ctx, int nranks, int rank, mfx_reduce_fn fn, void* user) {
+  if (ctx) ctx->comm_checked_parts = ctx->comm_checked_als = false;
   if (!ctx) return MFX_E_ARG;
   NEED(nranks >= 1 && rank >= 0 && rank < nranks && fn, MFX_E_ARG, "mfx_comm_init_external: nranks=%d rank=%d", nranks, rank);
   HIPCHK(hipSetDevice(ctx->device));
@@ -397,6 +435,10 @@ extern "C" int mfx_allgather_item_parts(mfx_ctx* ctx, int my_part) {
   }
   HIPCHK(hipGetLastError());
   if (ctx->Vsync) HIPCHK(hipMemcpyAsync(ctx->Vsync, ctx->V, sizeof(float) * (size_t)ctx->nI * ctx->ld, hipMemcpyDeviceToDevice, ctx->stream));
+  if (!ctx->comm_checked_parts) {            // once per communicator: prev / next, the receive offsets and the unpacked parts are rank arithmetic
+    ctx->comm_checked_parts = true;
+    if ((rc = mfx_comm_check_replicas(ctx, ctx->V, (size_t)ctx->nI * ctx->ld, "mfx_allgather_item_parts (item-part rotation)"))) return rc;
+  }
   return MFX_OK;
 }
 

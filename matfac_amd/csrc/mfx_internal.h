@@ -126,6 +126,7 @@ struct mfx_ctx {
   // comm
   void* comm = nullptr;      // ncclComm_t
   int nranks = 1, rank = 0;
+  bool comm_checked_parts = false, comm_checked_als = false;   // mfx_comm_check_replicas ran for the rotation / the sharded ALS sweep
   float* comm_tmp = nullptr;
   size_t comm_tmp_cap = 0;              // floats
   mfx_reduce_fn ext_reduce = nullptr;   // caller-supplied all-reduce on a host copy (mfx_comm_init_external)
@@ -558,6 +559,10 @@ int mfx_launch_eval(mfx_ctx* ctx, const DevCSR& m, const float* U, const float* 
 int mfx_launch_eval2(mfx_ctx* ctx, const DevCSR& ma, int norms_a, const DevCSR& mb, int norms_b, const float* U, const float* V,
                      mfx_eval_out* out_a, mfx_eval_out* out_b);
 int mfx_comm_free_internal(mfx_ctx* ctx);
+// Every rank holds the same bytes in buf[0 .. n)?  A 31-bit checksum of the buffer, all-reduced: N x own == sum on every rank.
+// MFX_E_COMM with `what` in the message otherwise (comm.hip; the first all-gather of item parts and the first sharded ALS item
+// sweep of a communicator run it: their rank-dependent indexing is invisible on one rank).
+int mfx_comm_check_replicas(mfx_ctx* ctx, const float* buf, size_t n, const char* what);
 int mfx_comm_allreduce(mfx_ctx* ctx, void* dev, size_t count, int dtype);   // sum over ranks, dtype 0 f32 / 1 f64
 bool mfx_comm_has_rccl(const mfx_ctx* ctx);
 int mfx_comm_reduce_scatter(mfx_ctx* ctx, float* buf, size_t count);            // in place, slices of `count` floats (RCCL only)

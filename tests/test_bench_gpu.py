@@ -49,3 +49,10 @@ def test_two_ranks_on_one_gpu_through_gloo(scaling, exchange):
     assert ("strong" in d["config"]["workload"]) == (scaling == "strong")
     assert d["value"] > 1e8 and d["val_rmse_after"] > 0 and d["val_rmse_after_same_epochs_without_exchange"] > 0
     assert "cpu_baseline" not in d and "secondary" not in d
+    # round 4: the line carries the OTHER exchange and (weak-scaling runs) the strong-scaling split of the one named matrix
+    other = "allreduce" if exchange == "rotate" else "rotate"
+    sr = d["sub_records"]
+    assert sr["exchange_" + other]["ms_per_step"] > 0 and sr["exchange_" + other]["ms_per_exchange_alone"] > 0
+    assert ("strong_scaling" in sr) == (scaling == "weak")
+    if scaling == "weak":
+        assert sr["strong_scaling"]["value"] > 1e8 and "ONE" in sr["strong_scaling"]["workload"]

@@ -1,6 +1,11 @@
 """The N > 1 path on the device: two processes, each with its own context and its block of user rows, the
 exchanges carried by gloo through mfx_comm_init_external (the same library code runs over RCCL when
-mfx_comm_init made the communicator).  Sharded CCD++ / ALS / SGD against the one-context run of the same work."""
+mfx_comm_init made the communicator).  Sharded CCD++ / ALS / SGD against the one-context run of the same work.
+
+Round 4: every test here also exists in an RCCL form -- one process per GPU, mfx_comm_init with a broadcast unique id, the
+library's own ncclAllReduce / ncclReduceScatter / ncclAllGather / ncclSend + ncclRecv -- that SKIPS unless mfx_device_count()
+reports two devices: the first box with two GPUs exercises comm.hip beyond a one-rank communicator (tests/test_comm_gpu.py),
+with the same expectations as the gloo forms."""
 import os
 import socket
 
@@ -13,6 +18,28 @@ from oracle import binding as orc
 
 pytestmark = pytest.mark.gpu
 K = 16
+
+
+def _n_devices():
+    import ctypes as C
+    from matfac_amd import _lib
+    n = C.c_int(0)
+    return int(n.value) if _lib.load().mfx_device_count(C.byref(n)) == 0 else 0
+
+
+def _open(rank, world, transport):
+    """(context, torch.distributed) of one rank: gloo + mfx_comm_init_external on device 0, or the library's RCCL communicator on
+    device `rank` (gloo only carries the unique id and the closing barrier)."""
+    import torch
+    import torch.distributed as dist
+    ctx = Ctx(rank if transport == "rccl" else 0)
+    if transport == "rccl":
+        uid = [Ctx.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(world, rank, uid[0])
+    else:
+        ctx.comm_init_external(world, rank, lambda a: dist.all_reduce(torch.from_numpy(a), op=dist.ReduceOp.SUM))
+    return ctx
 
 
 def _problem():
@@ -56,8 +83,7 @@ def _run(ctx, nI, tr, U0, V0, exchange):
     return out
 
 
-def _worker(rank, world, port, out_dir):
-    import torch
+def _worker(rank, world, port, out_dir, transport="gloo"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -66,8 +92,7 @@ def _worker(rank, world, port, out_dir):
     b = mdist.user_blocks(tr.rowptr, world)
     lo, hi = int(b[rank]), int(b[rank + 1])
     sh = mdist.take_rows(tr, lo, hi)
-    with Ctx(0) as ctx:
-        ctx.comm_init_external(world, rank, lambda a: dist.all_reduce(torch.from_numpy(a), op=dist.ReduceOp.SUM))
+    with _open(rank, world, transport) as ctx:
 
         def exchange(what):
             if what == "mark":
@@ -81,7 +106,10 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_shards_equal_one_context(tmp_path):
+@pytest.mark.parametrize("transport", ["gloo", "rccl"])
+def test_two_shards_equal_one_context(tmp_path, transport):
+    if transport == "rccl" and _n_devices() < 2:
+        pytest.skip("the RCCL form needs two GPUs (mfx_device_count() = %d)" % _n_devices())
     # stdlib multiprocessing: torch (and the HIP/RCCL copies it bundles) is loaded in the two workers only, never
     # into this process, which already holds libmfx.so and possibly the system RCCL from other tests
     import multiprocessing as mp
@@ -90,7 +118,7 @@ def test_two_shards_equal_one_context(tmp_path):
     port = s.getsockname()[1]
     s.close()
     cx = mp.get_context("spawn")
-    procs = [cx.Process(target=_worker, args=(g, 2, port, str(tmp_path))) for g in range(2)]
+    procs = [cx.Process(target=_worker, args=(g, 2, port, str(tmp_path), transport)) for g in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -141,8 +169,7 @@ def _rot_problem():
     return tr, nI, U0, V0
 
 
-def _rot_worker(rank, world, port, out_dir, one_group):
-    import torch
+def _rot_worker(rank, world, port, out_dir, one_group, transport="gloo"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -152,8 +179,7 @@ def _rot_worker(rank, world, port, out_dir, one_group):
     lo, hi = int(b[rank]), int(b[rank + 1])
     sh = mdist.take_rows(tr, lo, hi)
     lists = {}
-    with Ctx(0) as ctx:
-        ctx.comm_init_external(world, rank, lambda a: dist.all_reduce(torch.from_numpy(a), op=dist.ReduceOp.SUM))
+    with _open(rank, world, transport) as ctx:
         ctx.set_csr(mfx.MAT_TRAIN, sh.nrows, nI, sh.rowptr, sh.rowind, sh.rowval)
         ctx.set_model(sh.nrows, nI, K)
         ctx.set_factors(U0[lo:hi], V0)
@@ -182,20 +208,23 @@ def _rot_worker(rank, world, port, out_dir, one_group):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("transport", ["gloo", "rccl"])
 @pytest.mark.parametrize("one_group", [True, False])
-def test_two_ranks_rotating_item_parts_through_the_library(tmp_path, one_group):
+def test_two_ranks_rotating_item_parts_through_the_library(tmp_path, one_group, transport):
     """Two processes, one GPU, gloo behind mfx_comm_init_external: an epoch = 2 part-restricted tiled epochs with a ring shift in
     between and the closing all-gather.  Every rating is visited exactly once per epoch (counted by the kernel), a sub-epoch
     touches only its part's items, both replicas of V agree bit for bit afterwards -- and with ONE lane group per slot (the
     deterministic test mode: the list mfx_debug_epoch_list returns IS the visiting order) the factors are the oracle's
     sequential replay of the recorded lists, sub-epoch by sub-epoch, rank by rank."""
+    if transport == "rccl" and _n_devices() < 2:
+        pytest.skip("the RCCL form (ncclSend / ncclRecv ring shift, ncclAllGather) needs two GPUs (mfx_device_count() = %d)" % _n_devices())
     import multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     cx = mp.get_context("spawn")
-    procs = [cx.Process(target=_rot_worker, args=(g, 2, port, str(tmp_path), one_group)) for g in range(2)]
+    procs = [cx.Process(target=_rot_worker, args=(g, 2, port, str(tmp_path), one_group, transport)) for g in range(2)]
     for p in procs:
         p.start()
     for p in procs:
