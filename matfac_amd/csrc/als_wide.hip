@@ -417,6 +417,10 @@ namespace {
 // One buffer descriptor per wave-uniform base pointer: the lane offset sits in ONE vector register and everything else in the
 // scalar / immediate offset of the instruction.  (Plain pointer arithmetic made the compiler keep ~64 64-bit addresses per
 // block alive and spill them: 1.2 KB of scratch per lane and a third of the kernel's time.)
+// (The scalar-offset operand is used here with offsets of a few hundred KB at most: the descriptor's base is the wave's own workspace or
+//  slab.  The tiled SGD kernel lost half-rows when it handed a chunk constant to the SGPR offset of accesses whose VECTOR offset was a
+//  row's byte offset in a 1.28 GB table -- sgd_common.h: the rows that failed were those at byte offsets >= 2^30.  Nothing here comes
+//  near that; the launcher checks the extents.)
 struct BufF {
   __amdgpu_buffer_rsrc_t rs;
   __device__ __forceinline__ BufF(const float* base) { rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7ffffffc, 0x00020000); }
@@ -714,6 +718,9 @@ int mfx_als_wide_half_sweep(mfx_ctx* ctx, int side, float reg) {
       const int dbgb = dbe ? atoi(dbe) : 0;
       const int64_t ws_stride = ((int64_t)C * (C - 1) / 2 * 2 + C) * BLK + 3 * C * 64;
       const size_t needw = (size_t)blocksb * 4 * (size_t)ws_stride;
+      NEED((size_t)ws_stride * 4 < ((size_t)1 << 30) && (size_t)stride * 4 < ((size_t)1 << 30), MFX_E_ARG,
+           "wide ALS solve: a wave's workspace / slab (%lld / %lld floats) must stay below 2^30 bytes (buffer offsets, see BufF)", (long long)ws_stride,
+           (long long)stride);
       if (needw > st->bws_floats) {
         dev_free(st->bws);
         st->bws_floats = 0;

@@ -33,7 +33,13 @@ struct Rows {
   // constant that the compiler folds into the instruction's 12-bit immediate offset; buffer policies only.  (The constant was first
   // handed over as the instruction's SGPR offset: correct on every matrix of the test suite, and half-zeroed user rows on a
   // 1.25 M x 1 M matrix at every rank above 64 -- seen as NaN in bench.py's C5 record; tests/test_fullsize_gpu.py now runs a
-  // tall matrix with learning rate 0 and wants the factors back bit for bit.)
+  // tall matrix with learning rate 0 and wants the factors back bit for bit.  Round 4, from the evidence in hand: what failed were
+  // the rows whose byte offset in the table is >= 2^30 -- a 1.25 M-row table of 1 KB rows has 201 424 of them, 16 % of the users,
+  // the "fifth" of scripts/nan_rows.py, and no matrix of the test suite has a table beyond 1 GiB -- and only their accesses with
+  // a NON-ZERO SGPR offset (chunks 1 ...; chunk 0 passed 0).  Vector offset >= 2^30 plus a scalar offset is treated as out of
+  // range (loads return 0, stores are dropped) although the sum is far below num_records; with the constant in the immediate
+  // field the same address is in range.  The rule kept here: row offsets beyond 2^30 never meet an SGPR offset.  The other user
+  // of the SGPR-offset form, als_wide.hip's BufF, works on per-wave bases with offsets of a few hundred KB and checks it.)
   __device__ __forceinline__ float4v ldb(uint32_t byte, int konst) const {
     static_assert(POL != 0, "byte offsets go through the buffer descriptor");
     return __builtin_bit_cast(float4v, __builtin_amdgcn_raw_buffer_load_b128(rs, byte + (uint32_t)konst, 0, AUXL));

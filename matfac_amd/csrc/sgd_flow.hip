@@ -66,7 +66,7 @@ struct FlowState {
   // owner assignment (owned rows -> queues, LDS slots), cached per train matrix: it depends on the rows' chain lengths only for
   // BALANCE, never for correctness, and the lists replayed over one matrix are permutations of its ratings
   uint64_t assign_gen = ~0ull;
-  int64_t assign_groups = -1, assign_nU = -1, assign_nI = -1;
+  int64_t assign_groups = -1, assign_nU = -1, assign_nI = -1, assign_count = -1;
   int assign_own_user = 0, assign_want = -2;
   int32_t assign_maxU = 0, assign_maxI = 0;
 };
@@ -1199,7 +1199,7 @@ int build_flow(mfx_ctx* ctx, int64_t first, int64_t count, int64_t groups, bool 
   // chain lengths of both sides in this list; the side with the longest chain is owned
   std::vector<int32_t> degU((size_t)ctx->nU, 0), degI((size_t)ctx->nI, 0);
   for (int64_t t = 0; t < count; t++) { degU[(size_t)S->hu[(size_t)t]]++; degI[(size_t)S->hi[(size_t)t]]++; }
-  const int32_t maxU = *std::max_element(degU.begin(), degU.end()), maxI = *std::max_element(degI.begin(), degI.end());
+  const int32_t maxU = degU.empty() ? 0 : *std::max_element(degU.begin(), degU.end()), maxI = degI.empty() ? 0 : *std::max_element(degI.begin(), degI.end());
   // owned side: as the device builder chooses it (user rows for a list that keeps a user's ratings together, else the longest chain)
   int own_user = maxU > maxI ? 1 : 0;
   if (const char* e = getenv("MFX_FLOW_OWN")) {
@@ -1484,15 +1484,18 @@ int build_flow_device(mfx_ctx* ctx, int64_t first, int64_t count, int64_t groups
     S->assign_gen = ~0ull;                 // the cached dealing by chain length is gone from downer
     S->assign_own_user = adj_own;
     S->assign_maxU = S->assign_maxI = 0;   // (not looked at on this path)
-  } else if (S->assign_gen != ctx->train_gen || S->assign_groups != groups || S->assign_nU != nU || S->assign_nI != nI || S->assign_want != want_own) {
+  } else if (S->assign_gen != ctx->train_gen || S->assign_groups != groups || S->assign_nU != nU || S->assign_nI != nI || S->assign_want != want_own ||
+             S->assign_count != count) {
+    // (keyed on the list length too: an assignment computed from a sub-range or from one round's list of trainSGDPar knows the chain
+    //  lengths of THAT list only; a later whole epoch gets its own.  Round-3 advice.)
     HIPCHK(hipMemsetAsync(S->degU, 0, sizeof(int32_t) * (size_t)(nU + nI), ctx->stream));
     hipLaunchKernelGGL(flow_degrees_kernel, dim3(grid), dim3(256), 0, ctx->stream, eu, ei, count, S->degU, S->degI);
     S->hdeg.resize((size_t)(nU + nI));
     HIPCHK(hipMemcpyAsync(S->hdeg.data(), S->degU, sizeof(int32_t) * (size_t)(nU + nI), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     const int32_t *hdU = S->hdeg.data(), *hdI = S->hdeg.data() + nU;
-    S->assign_maxU = *std::max_element(hdU, hdU + nU);
-    S->assign_maxI = *std::max_element(hdI, hdI + nI);
+    S->assign_maxU = nU > 0 ? *std::max_element(hdU, hdU + nU) : 0;
+    S->assign_maxI = nI > 0 ? *std::max_element(hdI, hdI + nI) : 0;
     S->assign_own_user = want_own >= 0 ? want_own : (S->assign_maxU > S->assign_maxI ? 1 : 0);
     S->assign_want = want_own;
     const int32_t* degOwn = S->assign_own_user ? hdU : hdI;
@@ -1514,9 +1517,19 @@ int build_flow_device(mfx_ctx* ctx, int64_t first, int64_t count, int64_t groups
       l.first += degOwn[r];
       heap.push(l);
     }
+    // rows this list does not visit: dealt round the queues, not piled onto queue 0 (another list replayed with this assignment
+    // -- same matrix, same length -- may visit them; ownership, not balance, is what correctness needs)
+    {
+      int64_t rr = 0;
+      for (int64_t r = 0; r < nOwnA; r++)
+        if (degOwn[r] == 0) {
+          const int32_t gq = (int32_t)(rr++ % groups);
+          S->owner[(size_t)r] = (int32_t)((uint32_t)gq | (uint32_t)(nrows[(size_t)gq]++ & 63) << FL_SLOT_SHIFT);
+        }
+    }
     HIPCHK(hipMemcpyAsync(S->downer, S->owner.data(), sizeof(int32_t) * (size_t)nOwnA, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));          // S->owner may be reassigned by the host builder
-    S->assign_gen = ctx->train_gen; S->assign_groups = groups; S->assign_nU = nU; S->assign_nI = nI;
+    S->assign_gen = ctx->train_gen; S->assign_groups = groups; S->assign_nU = nU; S->assign_nI = nI; S->assign_count = count;
   }
   const int own_user = S->assign_own_user;
   const int32_t maxU = S->assign_maxU, maxI = S->assign_maxI;

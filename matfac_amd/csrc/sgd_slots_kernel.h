@@ -566,13 +566,16 @@ static int launch_slots(mfx_ctx* ctx, SlotList* S, const mfx_sgd_opts* o, int bl
     const uint64_t ownb = (uint64_t)(OWN_U ? ctx->nU : ctx->nI) * ctx->ld * 4;
     const char* pe = getenv("MFX_SGD_PERSIST");
     if (S->active_waves == WG / 64 && ownb < (1ull << 32) && pe && pe[0] == '1' && !(o->flags & MFX_SGD_F_DRAIN_ONLY)) {
-      static int resident = -1;                          // per instantiation: workgroups of the persistent kernel the device holds
+      static int resident_dev[64];                       // per instantiation and device (+ 1; 0 = not asked yet): workgroups of the persistent kernel it holds
+      int& resident_p1 = resident_dev[ctx->device & 63];
+      int resident = resident_p1 - 1;
       if (resident < 0) {
         int per_cu = 0, dev = 0, cus = 0;
         HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sgd_slots_kernel<L, C, ARITH, false, OWN_U, VAR, true, true>, WG, 0));
         HIPCHK(hipGetDevice(&dev));
         HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         resident = std::max(0, per_cu) * std::max(0, cus);
+        resident_p1 = resident + 1;
       }
       int rc = 0;
       persist = blocks <= resident && mfx_xcc_ids_populated(ctx, blocks, &rc);
@@ -618,7 +621,8 @@ static int launch_slots(mfx_ctx* ctx, SlotList* S, const mfx_sgd_opts* o, int bl
     // the drain: one launch; the same diagonals keyed on the workgroup index (an item row keeps a single owner).  Its grid
     // barriers need every workgroup RESIDENT: the grid is what this device (or partition: a CPX / QPX partition has 32 - 64
     // CUs) holds of this kernel, a multiple of 8 (the diagonals are keyed on blockIdx & 7), at most DRAIN_WGS.
-    static int drain_wgs = 0;                          // per instantiation
+    static int drain_wgs_dev[64];                      // per instantiation and device (a process may drive a partitioned and a whole device)
+    int& drain_wgs = drain_wgs_dev[ctx->device & 63];
     if (drain_wgs == 0) {
       int per_cu = 0, dev = 0, cus = 0;
       HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sgd_slots_kernel<L, C, ARITH, true, OWN_U, VAR>, WG, 0));

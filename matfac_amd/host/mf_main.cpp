@@ -135,6 +135,8 @@ int main(int argc, char** argv) {
   try {
     return run_main(argc, argv);
   } catch (const MfxError& e) {          // the library classes throw; the driver ends like the reference's does
+    if (e.code == MFH_EXIT_OK) return 0;       // model.cpp:1481-1484: "No validation data", exit(0) (already printed)
+    if (e.code == MFH_EXIT_FAIL) return 255;   // exit(-1) (already printed)
     std::cerr << "\n" << e.what() << std::endl;
     return 254;                          // exit(-2)
   }

@@ -416,8 +416,10 @@ bool Model::terminateImpl(bool sing, Model& bestModel, const Data& data, int ite
     if (data.valMat) {
       currValRMSE = RMSE(data.valMat, invalidUsers, invalidItems);
     } else {
+      // model.cpp:1481-1484 prints this and calls exit(0); a library entered through the C API must not end its caller's process:
+      // MfxError(MFH_EXIT_OK) -- the CLI (mf_main.cpp) turns it back into the reference's exit status 0
       std::cerr << "\nNo validation data" << std::endl;
-      exit(0);
+      throw MfxError(MFH_EXIT_OK, "No validation data");
     }
   }
   if (currObj != currObj || currValRMSE != currValRMSE) {

@@ -50,6 +50,9 @@ struct DenseF32 {
 // What the library classes throw instead of calling exit(): a failed device call (code = mfx_status, what() = the text of
 // mfx_last_error) or a misuse of the class surface (code -100).  The `mf` driver catches it, prints it and exits like the
 // reference does; a program that embeds libmfhost.so decides for itself.
+// codes of MfxError that stand for the reference's exit() calls on the train path (never taken inside the library: the CLI maps them
+// back to the reference's exit status, mfh_* entry points of capi.cpp return them as error codes)
+enum { MFH_EXIT_OK = -101 /* model.cpp:1481-1484: exit(0) */, MFH_EXIT_FAIL = -102 /* unreadable matrix: GKlib aborts, exit(-1) */ };
 class MfxError : public std::runtime_error {
  public:
   int code;

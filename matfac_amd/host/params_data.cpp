@@ -1,4 +1,5 @@
 #include "params_data.h"
+#include "mf_model.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -78,7 +79,7 @@ Data::Data(const Params& params) {
     csr_t* m = csr_read_text(file, &err);
     if (!m) {  // GKlib aborts on unreadable files; so do we, loudly
       std::cerr << "\n" << err << std::endl;
-      exit(-1);
+      throw MfxError(MFH_EXIT_FAIL, err);        // (the CLI ends with status 255 = exit(-1); the C API returns the code)
     }
     return m;
   };
@@ -87,7 +88,7 @@ Data::Data(const Params& params) {
   valMat = load("val", params.valMatFile);
   if (!trainMat) {
     std::cerr << "\nNo train matrix" << std::endl;
-    exit(-1);
+    throw MfxError(MFH_EXIT_FAIL, "No train matrix");
   }
   finish();
   std::cout << "\ntrain nnz = " << trainNNZ << std::endl;
