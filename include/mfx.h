@@ -163,6 +163,15 @@ int mfx_sgd_set_order(mfx_ctx* ctx, const uint64_t* perm, int64_t n);
 /* the same list as 32-bit indices (half the bytes to shuffle on the host and to upload; the host classes use it for lists below
  * 2^32 entries)                                                                  */
 int mfx_sgd_set_order32(mfx_ctx* ctx, const uint32_t* perm, int64_t n);
+/* std::shuffle of that list ON THE DEVICE: the list of mfx_sgd_set_order32 (n entries) becomes what
+ *   for (i = 1; i < n; i++) swap(a[i], a[pos[i]]);        0 <= pos[i] <= i, pos[0] ignored
+ * leaves -- the plain loop libstdc++'s std::shuffle runs beyond 65 536 entries (modelMF.cpp:76-81: the reference
+ * shuffles the SAME vector every epoch) -- and stays the MFX_ORDER_HOST list.  The host only draws the positions
+ * (the generator's stream); the 20 M random swaps of an ML-20M epoch, 45 ms on a host core, take ~ 3 ms here.
+ * pos is copied when the call returns.                                            */
+int mfx_sgd_apply_swaps32(mfx_ctx* ctx, const uint32_t* pos, int64_t n);
+/* test hook: the 32-bit list the device holds (out == NULL queries n) */
+int mfx_debug_order32(mfx_ctx* ctx, uint32_t* out, int64_t cap, int64_t* n);
 int mfx_sgd_epoch(mfx_ctx* ctx, const mfx_sgd_opts* opts);
 /* test hook: the (u,i,r) list the last epoch visited, in visiting order */
 int mfx_debug_epoch_list(mfx_ctx* ctx, int32_t* u, int32_t* i, float* r, int64_t cap,

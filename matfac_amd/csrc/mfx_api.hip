@@ -459,6 +459,7 @@ extern "C" int mfx_sgd_set_order(mfx_ctx* ctx, const uint64_t* perm, int64_t n) 
   }
   if (n) HIPCHK(hipMemcpyAsync(ctx->order, perm, sizeof(uint64_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->order32_valid = false;
   ctx->order_n = n;
   return MFX_OK;
 }
@@ -491,6 +492,7 @@ extern "C" int mfx_sgd_set_order32(mfx_ctx* ctx, const uint32_t* perm, int64_t n
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));        // (the caller's buffer is free when this returns)
   ctx->order_n = n;
+  ctx->order32_valid = true;
   return MFX_OK;
 }
 

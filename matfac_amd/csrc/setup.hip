@@ -460,3 +460,114 @@ int mfx_slots_build_device(mfx_ctx* ctx, SlotList* S, int rows, int side, const 
   S->built = true;
   return MFX_OK;
 }
+
+
+// ---------------------------------------------------------------------------
+// std::shuffle's swaps applied on the device (mfx_sgd_apply_swaps32)
+// ---------------------------------------------------------------------------
+// The list a of mfx_sgd_set_order32 after  for i = 1 .. n-1: swap(a[i], a[pos[i]])  (0 <= pos[i] <= i: libstdc++'s std::shuffle beyond
+// 65 536 entries, modelMF.cpp:76-81), without walking the swaps one by one.  Step i moves TWO elements: the one that sat at i since the
+// start goes to pos[i], the one that sat at pos[i] comes to i (nothing moves when pos[i] == i).  So an element's way through the list is
+//     i  --(time i)-->  pos[i]  --(the next time t > i with pos[t] == pos[i])-->  t  --(the first time t' > t with pos[t'] == t)-->  t' ...
+// i.e. after its first hop it follows q -> head[q] := the first step AFTER q that hits position q, a forest whose edges all point
+// forward.  With the steps sorted stably by the position they hit (one radix sort of (pos[t], t)):  after[t] = the next step of t's group,
+// head[q] = the first step of group q other than q itself;  F[q] = the end of q's chain by pointer jumping (a handful of rounds: the
+// chains are O(log n) long);  the element of place i ends up at  after[i] == none ? pos[i] : F[after[i]].
+// Bit for bit the sequential swaps (tests/test_setup_gpu.py against a plain loop, and every exact-replay test through the host class).
+namespace {
+constexpr uint32_t SW_NONE = 0xffffffffu;
+__global__ void sw_iota_kernel(uint32_t* __restrict__ v, int64_t n, uint32_t* __restrict__ pos0) {
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) v[t] = (uint32_t)t;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && pos0) pos0[0] = 0u;          // (step 0 does not exist: a[0] "swaps with itself")
+}
+__global__ void sw_links_kernel(const uint32_t* __restrict__ ks, const uint32_t* __restrict__ vs, int64_t n, uint32_t* __restrict__ after,
+                                uint32_t* __restrict__ head) {
+  for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t q = ks[k], t = vs[k];
+    const uint32_t nxt = (k + 1 < n && ks[k + 1] == q) ? vs[k + 1] : SW_NONE;
+    after[t] = nxt;
+    if (k == 0 || ks[k - 1] != q) head[q] = t != q ? t : nxt;           // t == q: the step that hit its own place; it moved nothing
+  }
+}
+// F <- F o F where F[q] = q marks the end of a chain; *changed is raised when any entry moved
+__global__ void sw_jump_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int64_t n, unsigned* __restrict__ changed) {
+  bool ch = false;
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t a = in[q], b = in[a];
+    out[q] = b;
+    ch = ch || b != a;
+  }
+  if (__builtin_amdgcn_ballot_w64(ch) != 0ull && (threadIdx.x & 63) == 0) atomicOr(changed, 1u);
+}
+__global__ void sw_selfend_kernel(uint32_t* __restrict__ head, int64_t n) {
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x)
+    if (head[q] == SW_NONE) head[q] = (uint32_t)q;
+}
+__global__ void sw_scatter_kernel(const uint32_t* __restrict__ a, const uint32_t* __restrict__ pos, const uint32_t* __restrict__ after,
+                                  const uint32_t* __restrict__ F, int64_t n, uint32_t* __restrict__ out, uint64_t* __restrict__ wide) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t af = after[i];
+    const uint32_t dst = af == SW_NONE ? pos[i] : F[af];
+    const uint32_t v = a[i];
+    out[dst] = v;
+    wide[dst] = (uint64_t)v;
+  }
+}
+}  // namespace
+
+extern "C" int mfx_sgd_apply_swaps32(mfx_ctx* ctx, const uint32_t* pos, int64_t n) {
+  if (!ctx) return MFX_E_ARG;
+  NEED(pos && n >= 0 && n < ((int64_t)1 << 32), MFX_E_ARG, "mfx_sgd_apply_swaps32: pos NULL or n outside [0, 2^32)");
+  NEED(ctx->order32 && ctx->order32_valid && ctx->order && ctx->order_n == n && ctx->order32_cap >= n, MFX_E_STATE,
+       "mfx_sgd_apply_swaps32: the list to shuffle is the one of mfx_sgd_set_order32 with the same length (have %lld, swaps for %lld)",
+       (long long)ctx->order_n, (long long)n);
+  if (n < 2) return MFX_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  int rc;
+  Scratch sc;
+  uint32_t *dpos, *ks, *v0, *vs, *after, *f0, *f1, *out;
+  unsigned* changed;
+  if ((rc = sc.get(ctx, &dpos, (size_t)n)) || (rc = sc.get(ctx, &ks, (size_t)n)) || (rc = sc.get(ctx, &v0, (size_t)n)) || (rc = sc.get(ctx, &vs, (size_t)n)) ||
+      (rc = sc.get(ctx, &after, (size_t)n)) || (rc = sc.get(ctx, &f0, (size_t)n)) || (rc = sc.get(ctx, &f1, (size_t)n)) || (rc = sc.get(ctx, &out, (size_t)n)) ||
+      (rc = sc.get(ctx, &changed, (size_t)1)))
+    return rc;
+  HIPCHK(hipMemcpyAsync(dpos, pos, sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice, st));
+  const int grid = grid_for(n);
+  hipLaunchKernelGGL(sw_iota_kernel, dim3(grid), dim3(TB), 0, st, v0, n, dpos);
+  if ((rc = sort_pairs(ctx, sc, dpos, ks, v0, vs, (size_t)n, bits_for((uint64_t)n)))) return rc;
+  HIPCHK(hipMemsetAsync(f0, 0xff, sizeof(uint32_t) * (size_t)n, st));
+  hipLaunchKernelGGL(sw_links_kernel, dim3(grid), dim3(TB), 0, st, (const uint32_t*)ks, (const uint32_t*)vs, n, after, f0);
+  hipLaunchKernelGGL(sw_selfend_kernel, dim3(grid), dim3(TB), 0, st, f0, n);
+  HIPCHK(hipGetLastError());
+  uint32_t *fin = f0, *fout = f1;
+  for (int round = 0; round < 40; round++) {
+    unsigned h = 0;
+    HIPCHK(hipMemsetAsync(changed, 0, sizeof(unsigned), st));
+    hipLaunchKernelGGL(sw_jump_kernel, dim3(grid), dim3(TB), 0, st, (const uint32_t*)fin, fout, n, changed);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(&h, changed, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));                  // (also: the caller's pos buffer is free from the first round on)
+    std::swap(fin, fout);
+    if (!h) break;
+    NEED(round < 39, MFX_E_STATE, "mfx_sgd_apply_swaps32: the chains of the swaps did not close in 2^40 hops (pos[i] > i somewhere?)");
+  }
+  hipLaunchKernelGGL(sw_scatter_kernel, dim3(grid), dim3(TB), 0, st, (const uint32_t*)ctx->order32, (const uint32_t*)dpos, (const uint32_t*)after,
+                     (const uint32_t*)fin, n, out, ctx->order);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(ctx->order32, out, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));                    // (the scratch buffers go with this scope)
+  return MFX_OK;
+}
+
+extern "C" int mfx_debug_order32(mfx_ctx* ctx, uint32_t* out, int64_t cap, int64_t* n) {
+  if (!ctx) return MFX_E_ARG;
+  NEED(n, MFX_E_ARG, "mfx_debug_order32: n NULL");
+  *n = (ctx->order32 && ctx->order32_valid) ? ctx->order_n : 0;
+  if (!out) return MFX_OK;
+  NEED(cap >= *n, MFX_E_ARG, "mfx_debug_order32: cap too small");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (*n) HIPCHK(hipMemcpy(out, ctx->order32, sizeof(uint32_t) * (size_t)*n, hipMemcpyDeviceToHost));
+  return MFX_OK;
+}

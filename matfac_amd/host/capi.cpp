@@ -253,6 +253,34 @@ extern "C" int mfh_shuffle_check(int64_t n, uint32_t seed, double* secs) {
   }
 }
 
+extern "C" int mfh_shuffle_positions_check(int64_t n, uint32_t seed, uint32_t* pos, double* secs) {
+  try {
+    if (n < 0 || n >= ((int64_t)1 << 32)) return -1;
+    std::vector<size_t> x((size_t)n);
+    std::iota(x.begin(), x.end(), (size_t)0);
+    std::mt19937 g1(seed), g2(seed);
+    g1.discard(seed % 700); g2.discard(seed % 700);
+    std::vector<uint32_t> p;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (!mfhShufflePositions(p, (size_t)n, g2)) return 2;
+    if (secs) secs[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::shuffle(x.begin(), x.end(), g1);
+    std::vector<uint32_t> y((size_t)n);
+    std::iota(y.begin(), y.end(), 0u);
+    for (size_t i = 1; i < (size_t)n; i++) {
+      if (p[i] > i) return 0;
+      std::swap(y[i], y[p[i]]);
+    }
+    if (pos) std::memcpy(pos, p.data(), sizeof(uint32_t) * (size_t)n);
+    if (!(g1 == g2)) return 0;
+    for (size_t k = 0; k < x.size(); k++)
+      if (x[k] != (size_t)y[k]) return 0;
+    return 1;
+  } catch (...) {
+    return -1;
+  }
+}
+
 extern "C" int mfh_shuffle_check32(int64_t n, uint32_t seed, double* secs) {
   try {
     if (n < 0 || n >= ((int64_t)1 << 32)) return -1;

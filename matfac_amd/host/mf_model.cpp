@@ -694,6 +694,67 @@ bool shuffleAheadTriple(std::vector<T>& a, std::mt19937& g, size_t block) {
   if (!last.store(g)) throw std::runtime_error("mfhShuffle: the generator state could not be handed back");
   return true;
 }
+// The POSITIONS of std::shuffle alone: pos[i] = d(g, param_type(0, i)) for i = 1 .. n - 1 (pos[0] = 0), what the loop
+// `for i: swap(a[i], a[pos[i]])` of bits/stl_algo.h draws for a list of n entries, and the generator left where that loop leaves it.
+// Two threads: one twists and tempers the generator's blocks ahead, this one scales them (Lemire's multiply-shift with its rejection,
+// as shuffleAheadTriple).  The swaps themselves -- random accesses into the list, the slowest of the three stages on a host core --
+// run on the device (mfx_sgd_apply_swaps32).  false: not applicable (short list: the library pairs two positions per draw there).
+bool shufflePositions(std::vector<uint32_t>& pos, size_t n, std::mt19937& g) {
+  const uint64_t urngrange = (uint64_t)g.max() - (uint64_t)g.min();
+  if (n < 2 || urngrange / n >= n || n >= ((size_t)1 << 32)) return false;
+  constexpr size_t RAWS = 16;
+  std::vector<MtBulk> raw(RAWS);
+  pos.resize(n);
+  if (!raw[0].load(g)) return false;
+  std::atomic<size_t> rawProduced(1), rawReleased(0);
+  std::atomic<bool> stop(false);
+  std::thread gen([&] {
+    for (size_t b = 1;; b++) {
+      while (b - rawReleased.load(std::memory_order_acquire) >= RAWS) {
+        if (stop.load(std::memory_order_acquire)) return;
+        std::this_thread::yield();
+      }
+      if (stop.load(std::memory_order_acquire)) return;
+      MtBulk& nx = raw[b % RAWS];
+      std::memcpy(nx.x, raw[(b - 1) % RAWS].x, sizeof nx.x);
+      nx.twist();
+      rawProduced.store(b + 1, std::memory_order_release);
+    }
+  });
+  size_t rb = 0, idx = raw[0].p;
+  const uint32_t* out = raw[0].out;
+  auto nextRaw = [&]() -> uint32_t {
+    if (idx >= 624) {
+      rawReleased.store(rb + 1, std::memory_order_release);
+      rb++;
+      while (rawProduced.load(std::memory_order_acquire) <= rb) std::this_thread::yield();
+      out = raw[rb % RAWS].out;
+      idx = 0;
+    }
+    return out[idx++];
+  };
+  uint32_t* j = pos.data();
+  j[0] = 0;
+  for (size_t i = 1; i < n; i++) {
+    const uint32_t range = (uint32_t)(i + 1);
+    uint64_t product = (uint64_t)nextRaw() * (uint64_t)range;
+    uint32_t low = (uint32_t)product;
+    if (low < range) {
+      const uint32_t threshold = (0u - range) % range;
+      while (low < threshold) {
+        product = (uint64_t)nextRaw() * (uint64_t)range;
+        low = (uint32_t)product;
+      }
+    }
+    j[i] = (uint32_t)(product >> 32);
+  }
+  stop.store(true, std::memory_order_release);
+  gen.join();
+  MtBulk& last = raw[rb % RAWS];
+  last.p = idx;
+  if (!last.store(g)) throw std::runtime_error("mfhShufflePositions: the generator state could not be handed back");
+  return true;
+}
 bool shuffleAheadIsStd() {
   static const bool ok = [] {
     std::vector<size_t> x(70001), y, z;
@@ -766,6 +827,13 @@ void mfhShuffleT(std::vector<T>& a, std::mt19937& g) {
   }
 }
 }  // namespace
+// the swap positions of std::shuffle(a.begin(), a.end(), g) for a list of n entries (see shufflePositions); false when the list is
+// short or this standard library's generator / distribution are not the restated ones: the caller shuffles on the host then
+bool mfhShufflePositions(std::vector<uint32_t>& pos, size_t n, std::mt19937& g) {
+  static const bool off = getenv("MFX_STD_SHUFFLE") && atoi(getenv("MFX_STD_SHUFFLE")) != 0;
+  if (off || n < ((size_t)1 << 20) || !shuffleAheadIsStd() || !shuffleFastIsStd()) return false;
+  return shufflePositions(pos, n, g);
+}
 void mfhShuffle(std::vector<size_t>& a, std::mt19937& g) { mfhShuffleT(a, g); }
 void mfhShuffle(std::vector<uint32_t>& a, std::mt19937& g) { mfhShuffleT(a, g); }
 
@@ -1011,6 +1079,16 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
   const bool order32 = nRatings < ((int64_t)1 << 32) && !(getenv("MFX_ORDER64") && atoi(getenv("MFX_ORDER64")) != 0);
   // (the list of K_SGD / K_HOG / K_IFW is allocated and numbered by the thread that shuffles it: orderThread, below)
   const bool listOfAll = (kind == K_SGD || kind == K_HOG || kind == K_IFW) && exact;
+  // (MFX_DEVICE_SHUFFLE=0: the swaps of the epoch's std::shuffle on the host, as in round 3)
+  std::vector<uint32_t> swapPos;
+  bool devShuffleOk = true;
+  bool devShuffle = false;
+  if (listOfAll && order32 && nRatings >= ((int64_t)1 << 20) && !(getenv("MFX_DEVICE_SHUFFLE") && atoi(getenv("MFX_DEVICE_SHUFFLE")) == 0) &&
+      replayMode == MFX_SGD_LEVELS) {
+    std::mt19937 probe(1);
+    std::vector<uint32_t> pp;
+    devShuffle = mfhShufflePositions(pp, (size_t)1 << 20, probe);     // (the self-checks of the restated generator pass on this library)
+  }
   Strata strata;
   if (kind == K_SGDPAR && exact) {
     // modelMF.cpp:191-265: valid users / items shuffled with mt and dealt into T = omp_get_max_threads() parts
@@ -1109,10 +1187,18 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
         if (exact) {
           // modelMF.cpp:76-81: std::shuffle every epoch on one thread (parBlockShuffle with one
           // OpenMP thread is a plain std::shuffle; the reference is only reproducible that way)
-          if (order32) orderOfEpoch([&ratingInds32, &mt] { mfhShuffle(ratingInds32, mt); });
+          // Long lists (round 4): the host draws only the POSITIONS of the shuffle -- the generator's stream, a thread ahead -- and the
+          // device applies the swaps to the list it keeps from epoch to epoch (mfx_sgd_apply_swaps32: the same list, bit for bit);
+          // the random swaps were the slowest stage of mfhShuffle (45 ms of a 53 ms iteration at the ML-20M shape).
+          if (order32 && devShuffle) orderOfEpoch([&swapPos, &mt, nRatings, &devShuffleOk] { devShuffleOk = mfhShufflePositions(swapPos, (size_t)nRatings, mt); });
+          else if (order32) orderOfEpoch([&ratingInds32, &mt] { mfhShuffle(ratingInds32, mt); });
           else orderOfEpoch([&uiRatingInds, &mt] { mfhShuffle(uiRatingInds, mt); });
           const auto u0 = std::chrono::steady_clock::now();
-          if (order32) dev->check(mfx_sgd_set_order32(dev->ctx, ratingInds32.data(), nRatings), "set_order32");   // (copied when it returns)
+          if (order32 && devShuffle) {
+            if (!devShuffleOk) throw MfxError(-100, "ModelMF::train: the positions form of the shuffle stopped applying in the middle of a run");
+            if (iter == 0) dev->check(mfx_sgd_set_order32(dev->ctx, ratingInds32.data(), nRatings), "set_order32");   // 0 .. n-1, once
+            dev->check(mfx_sgd_apply_swaps32(dev->ctx, swapPos.data(), nRatings), "apply_swaps32");                    // (copied when it returns)
+          } else if (order32) dev->check(mfx_sgd_set_order32(dev->ctx, ratingInds32.data(), nRatings), "set_order32");   // (copied when it returns)
           else dev->check(mfx_sgd_set_order(dev->ctx, (const uint64_t*)uiRatingInds.data(), nRatings), "set_order");
           const auto u1 = std::chrono::steady_clock::now();
           o.mode = replayMode; o.order = MFX_ORDER_HOST;

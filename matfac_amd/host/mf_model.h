@@ -19,6 +19,9 @@
 // ahead so that their cache lines are on the way when the swaps follow (mf_model.cpp)
 void mfhShuffle(std::vector<size_t>& a, std::mt19937& g);
 void mfhShuffle(std::vector<uint32_t>& a, std::mt19937& g);      // the same swaps on a list of 32-bit entries (half the bytes)
+// the positions std::shuffle would swap with for a list of n entries (pos[i] <= i, pos[0] = 0), the generator advanced like the library's
+// loop: the swaps themselves then run on the device (mfx_sgd_apply_swaps32).  false: short list or another standard library.
+bool mfhShufflePositions(std::vector<uint32_t>& pos, size_t n, std::mt19937& g);
 int mfhShuffleForm();      // 0: the library call, 1: block-ahead, 2: block-ahead with the restated generator (self-checks passed)
 
 // constants of const.h:4-12 / modelMF.h:16-17

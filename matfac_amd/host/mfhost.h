@@ -54,6 +54,10 @@ int mfh_mat_read(const char* path, float* data, int32_t n, int32_t k);
 int mfh_shuffle_check(int64_t n, uint32_t seed, double* secs);
 /* the same with mfhShuffle working on a list of 32-bit entries (what ModelMF::train shuffles below 2^32 ratings) */
 int mfh_shuffle_check32(int64_t n, uint32_t seed, double* secs);
+/* test hook: the swap positions mfhShufflePositions draws for a list of n entries (what the device applies with mfx_sgd_apply_swaps32):
+ * 1 when `for i: swap(a[i], a[pos[i]])` on 0 .. n-1 gives std::shuffle's list and the generator ends in the same state, 0 when not, 2 when
+ * the positions form does not apply (short list / another standard library); pos (may be NULL) receives the n positions; secs[0] = seconds */
+int mfh_shuffle_positions_check(int64_t n, uint32_t seed, uint32_t* pos, double* secs);
 
 #ifdef __cplusplus
 }

@@ -142,6 +142,18 @@ class Ctx:
         k = _p(perm, np.uint32)
         self._chk(self.lib.mfx_sgd_set_order32(self.h, k[1], C.c_int64(k[0].size)))
 
+    def sgd_apply_swaps32(self, pos):
+        """std::shuffle's swaps on the device: for i = 1 .. n-1: swap(a[i], a[pos[i]]) on the list of sgd_set_order32"""
+        k = _p(pos, np.uint32)
+        self._chk(self.lib.mfx_sgd_apply_swaps32(self.h, k[1], C.c_int64(k[0].size)))
+
+    def debug_order32(self):
+        n = C.c_int64(0)
+        self._chk(self.lib.mfx_debug_order32(self.h, None, C.c_int64(0), C.byref(n)))
+        out = np.empty(n.value, np.uint32)
+        self._chk(self.lib.mfx_debug_order32(self.h, out.ctypes.data_as(C.c_void_p), C.c_int64(out.size), C.byref(n)))
+        return out
+
     def sgd_epoch(self, lr, uReg, iReg, mode=SGD_HOGWILD, order=ORDER_DEVICE, arith=ARITH_F32, seed=1,
                   epoch=0, first=0, count=0, blocks=0, own=0, flags=0, item_part=0):
         o = SgdOpts(mode, order, arith, lr, uReg, iReg, seed, epoch, blocks, own, first, count, flags, item_part)

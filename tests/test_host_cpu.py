@@ -253,3 +253,18 @@ def test_epoch_shuffle_is_std_shuffle_bit_for_bit(n):
     # this image's libstdc++ (GCC 11) is the one the restated generator + distribution were written against: from 2^20 entries on a
     # second thread swaps while the first draws with them (form 2); another library would fail the self-check and report 0 or 1
     assert secs[2] == 2.0
+
+
+@pytest.mark.parametrize("n", [1 << 20, (1 << 20) + 12345, 3_000_017])
+def test_positions_of_the_epoch_shuffle_are_std_shuffles(n):
+    """Round 4: for long lists the host draws only the POSITIONS of std::shuffle (mfhShufflePositions: the generator's stream on two
+    threads) and the device applies the swaps (mfx_sgd_apply_swaps32, tests/test_setup_gpu.py).  Applied one by one on the host they
+    must give std::shuffle's list and leave the generator in std::shuffle's state; below 2^20 entries the form does not apply."""
+    lib = synth._host()
+    lib.mfh_shuffle_positions_check.argtypes = [C.c_int64, C.c_uint32, C.c_void_p, C.POINTER(C.c_double)]
+    for seed in (1, 4242):
+        secs = (C.c_double * 1)()
+        pos = np.empty(n, np.uint32)
+        assert lib.mfh_shuffle_positions_check(n, seed, pos.ctypes.data_as(C.c_void_p), secs) == 1
+        assert pos[0] == 0 and np.all(pos <= np.arange(n, dtype=np.uint32))
+    assert lib.mfh_shuffle_positions_check(70001, 1, None, None) == 2
