@@ -110,7 +110,7 @@ void mfx_destroy(mfx_ctx* ctx) {
   mfx_segs_free_internal(ctx);
   for (auto& m : ctx->mat) free_csr(m);
   free_model(ctx);
-  dev_free(ctx->eu); dev_free(ctx->ei); dev_free(ctx->er); dev_free(ctx->order); dev_free(ctx->order32);
+  dev_free(ctx->eu); dev_free(ctx->ei); dev_free(ctx->er); dev_free(ctx->order); dev_free(ctx->order32); dev_free(ctx->sw_buf); dev_free(ctx->sw_tmp);
   mfx_slots_free_internal(ctx);
   mfx_levels_free_internal(ctx);
   mfx_flow_free_internal(ctx);

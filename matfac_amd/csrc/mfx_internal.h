@@ -74,6 +74,10 @@ struct mfx_ctx {
   int64_t order_n = 0, order_cap = 0;
   uint32_t* order32 = nullptr;   // staging of mfx_sgd_set_order32
   int64_t order32_cap = 0;
+  uint32_t* sw_buf = nullptr;    // mfx_sgd_apply_swaps32: eight arrays of order_n entries + the sort's workspace, kept between epochs
+  size_t sw_cap = 0;             // entries per array
+  char* sw_tmp = nullptr;
+  size_t sw_tmp_bytes = 0;
   bool order32_valid = false;    // order32 holds the same list as order (mfx_sgd_set_order32 / mfx_sgd_apply_swaps32; not after the 64-bit call)
   int32_t* ulist = nullptr;  // user list for MFX_SGD_USERS
   int64_t ulist_cap = 0;

@@ -513,6 +513,30 @@ __global__ void sw_scatter_kernel(const uint32_t* __restrict__ a, const uint32_t
     wide[dst] = (uint64_t)v;
   }
 }
+// The same without the jumping rounds: every element walks its own chain (head[q] == q ends it).  For positions drawn by a generator the
+// chains are a hop or two long -- a place q is hit again with probability 1 - (q + 1) / n -- and six rounds of F o F over 20 M entries
+// (two random gathers each: 6.9 ms at the ML-20M size) cost five times the walks.  A chain longer than 64 hops raises *over and
+// the caller takes the jumping rounds (any pos[i] <= i is handled, e.g. "every step hits its left neighbour": one chain of n hops).
+__global__ void sw_walk_scatter_kernel(const uint32_t* __restrict__ a, const uint32_t* __restrict__ pos, const uint32_t* __restrict__ after,
+                                       const uint32_t* __restrict__ head, int64_t n, uint32_t* __restrict__ out, uint64_t* __restrict__ wide,
+                                       unsigned* __restrict__ over) {
+  bool ov = false;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t af = after[i];
+    uint32_t dst = pos[i];
+    if (af != SW_NONE) {
+      uint32_t q = af, h = head[q];
+      int hops = 0;
+      while (h != q && hops < 64) { q = h; h = head[q]; hops++; }
+      ov = ov || h != q;
+      dst = q;
+    }
+    const uint32_t v = a[i];
+    out[dst] = v;
+    wide[dst] = (uint64_t)v;
+  }
+  if (__builtin_amdgcn_ballot_w64(ov) != 0ull && (threadIdx.x & 63) == 0) atomicOr(over, 1u);
+}
 }  // namespace
 
 extern "C" int mfx_sgd_apply_swaps32(mfx_ctx* ctx, const uint32_t* pos, int64_t n) {
@@ -525,38 +549,72 @@ extern "C" int mfx_sgd_apply_swaps32(mfx_ctx* ctx, const uint32_t* pos, int64_t 
   HIPCHK(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   int rc;
-  Scratch sc;
-  uint32_t *dpos, *ks, *v0, *vs, *after, *f0, *f1, *out;
-  unsigned* changed;
-  if ((rc = sc.get(ctx, &dpos, (size_t)n)) || (rc = sc.get(ctx, &ks, (size_t)n)) || (rc = sc.get(ctx, &v0, (size_t)n)) || (rc = sc.get(ctx, &vs, (size_t)n)) ||
-      (rc = sc.get(ctx, &after, (size_t)n)) || (rc = sc.get(ctx, &f0, (size_t)n)) || (rc = sc.get(ctx, &f1, (size_t)n)) || (rc = sc.get(ctx, &out, (size_t)n)) ||
-      (rc = sc.get(ctx, &changed, (size_t)1)))
-    return rc;
+  // eight arrays of n entries (+ one flag word) and the sort's workspace, allocated once per list length: an epoch of an ML-20M run
+  // must not pay nine hipMalloc / hipFree pairs of 80 MB (measured: 12 ms per call with them, most of it allocation)
+  const size_t per = ((size_t)n + 63) / 64 * 64;
+  if (ctx->sw_cap < per || !ctx->sw_buf) {
+    dev_free(ctx->sw_buf);
+    ctx->sw_cap = 0;
+    if ((rc = dev_alloc(ctx, &ctx->sw_buf, 8 * per + 64))) return rc;
+    ctx->sw_cap = per;
+  }
+  uint32_t* B = ctx->sw_buf;
+  const size_t cp = ctx->sw_cap;
+  uint32_t *dpos = B, *ks = B + cp, *v0 = B + 2 * cp, *vs = B + 3 * cp, *after = B + 4 * cp, *f0 = B + 5 * cp, *f1 = B + 6 * cp, *out = B + 7 * cp;
+  unsigned* changed = (unsigned*)(B + 8 * cp);
   HIPCHK(hipMemcpyAsync(dpos, pos, sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice, st));
   const int grid = grid_for(n);
   hipLaunchKernelGGL(sw_iota_kernel, dim3(grid), dim3(TB), 0, st, v0, n, dpos);
-  if ((rc = sort_pairs(ctx, sc, dpos, ks, v0, vs, (size_t)n, bits_for((uint64_t)n)))) return rc;
+  {
+    const int bits = bits_for((uint64_t)n);
+    size_t bytes = 0;
+    HIPCHK(rocprim::radix_sort_pairs(nullptr, bytes, dpos, ks, v0, vs, (size_t)n, 0, bits, st));
+    if (ctx->sw_tmp_bytes < bytes || !ctx->sw_tmp) {
+      dev_free(ctx->sw_tmp);
+      ctx->sw_tmp_bytes = 0;
+      if ((rc = dev_alloc(ctx, &ctx->sw_tmp, bytes))) return rc;
+      ctx->sw_tmp_bytes = bytes;
+    }
+    size_t have = ctx->sw_tmp_bytes;
+    HIPCHK(rocprim::radix_sort_pairs(ctx->sw_tmp, have, dpos, ks, v0, vs, (size_t)n, 0, bits, st));
+  }
   HIPCHK(hipMemsetAsync(f0, 0xff, sizeof(uint32_t) * (size_t)n, st));
   hipLaunchKernelGGL(sw_links_kernel, dim3(grid), dim3(TB), 0, st, (const uint32_t*)ks, (const uint32_t*)vs, n, after, f0);
   hipLaunchKernelGGL(sw_selfend_kernel, dim3(grid), dim3(TB), 0, st, f0, n);
   HIPCHK(hipGetLastError());
-  uint32_t *fin = f0, *fout = f1;
-  for (int round = 0; round < 40; round++) {
+  // first the walks (see sw_walk_scatter_kernel); `out` is a scratch list, so a second attempt simply writes it again
+  {
     unsigned h = 0;
     HIPCHK(hipMemsetAsync(changed, 0, sizeof(unsigned), st));
-    hipLaunchKernelGGL(sw_jump_kernel, dim3(grid), dim3(TB), 0, st, (const uint32_t*)fin, fout, n, changed);
+    hipLaunchKernelGGL(sw_walk_scatter_kernel, dim3(grid), dim3(TB), 0, st, (const uint32_t*)ctx->order32, (const uint32_t*)dpos, (const uint32_t*)after,
+                       (const uint32_t*)f0, n, out, ctx->order, changed);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(&h, changed, sizeof(unsigned), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));                  // (also: the caller's pos buffer is free from the first round on)
-    std::swap(fin, fout);
+    HIPCHK(hipStreamSynchronize(st));                  // (also: the caller's pos buffer is free from here on)
+    if (!h) {
+      HIPCHK(hipMemcpyAsync(ctx->order32, out, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, st));
+      return MFX_OK;
+    }
+  }
+  uint32_t *fin = f0, *fout = f1;
+  for (int round = 0; round < 40; round++) {
+    // F <- F o F; the flag is that of the LAST of three rounds (a round that changes nothing is followed by rounds that change nothing)
+    unsigned h = 0;
+    for (int k = 0; k < 3; k++) {
+      HIPCHK(hipMemsetAsync(changed, 0, sizeof(unsigned), st));
+      hipLaunchKernelGGL(sw_jump_kernel, dim3(grid), dim3(TB), 0, st, (const uint32_t*)fin, fout, n, changed);
+      std::swap(fin, fout);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(&h, changed, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));                  // (also: the caller's pos buffer is free from here on)
     if (!h) break;
-    NEED(round < 39, MFX_E_STATE, "mfx_sgd_apply_swaps32: the chains of the swaps did not close in 2^40 hops (pos[i] > i somewhere?)");
+    NEED(round < 39, MFX_E_STATE, "mfx_sgd_apply_swaps32: the chains of the swaps did not close (pos[i] > i somewhere?)");
   }
   hipLaunchKernelGGL(sw_scatter_kernel, dim3(grid), dim3(TB), 0, st, (const uint32_t*)ctx->order32, (const uint32_t*)dpos, (const uint32_t*)after,
                      (const uint32_t*)fin, n, out, ctx->order);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(ctx->order32, out, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, st));
-  HIPCHK(hipStreamSynchronize(st));                    // (the scratch buffers go with this scope)
   return MFX_OK;
 }
 

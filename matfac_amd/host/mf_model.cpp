@@ -702,55 +702,95 @@ bool shuffleAheadTriple(std::vector<T>& a, std::mt19937& g, size_t block) {
 bool shufflePositions(std::vector<uint32_t>& pos, size_t n, std::mt19937& g) {
   const uint64_t urngrange = (uint64_t)g.max() - (uint64_t)g.min();
   if (n < 2 || urngrange / n >= n || n >= ((size_t)1 << 32)) return false;
-  constexpr size_t RAWS = 16;
-  std::vector<MtBulk> raw(RAWS);
+  // The generating thread hands the stream over in CHUNKS of 64 blocks of 624 words (a hand-off per block -- 32 000 per ML-20M epoch, each a
+  // spin on an atomic with sched_yield -- cost more than the twists: twisting and tempering 20 M words takes 6 ms, scaling them 15 ms, the
+  // block-by-block pipeline took 29 - 43 ms).  A chunk remembers the generator state in front of its first block, so that the state
+  // behind the last word used can be rebuilt without keeping 32 000 states.
+  constexpr size_t CH = 64, NCH = 8;
+  struct Chunk { uint32_t startX[624]; uint32_t out[CH * 624]; };
+  std::vector<Chunk> ring(NCH);
+  MtBulk first;
   pos.resize(n);
-  if (!raw[0].load(g)) return false;
-  std::atomic<size_t> rawProduced(1), rawReleased(0);
+  if (!first.load(g)) return false;
+  std::atomic<size_t> produced(0), released(0);       // chunks
   std::atomic<bool> stop(false);
   std::thread gen([&] {
-    for (size_t b = 1;; b++) {
-      while (b - rawReleased.load(std::memory_order_acquire) >= RAWS) {
+    MtBulk cur;
+    std::memcpy(cur.x, first.x, sizeof cur.x);
+    for (size_t c = 0;; c++) {
+      while (c - released.load(std::memory_order_acquire) >= NCH) {
         if (stop.load(std::memory_order_acquire)) return;
         std::this_thread::yield();
       }
       if (stop.load(std::memory_order_acquire)) return;
-      MtBulk& nx = raw[b % RAWS];
-      std::memcpy(nx.x, raw[(b - 1) % RAWS].x, sizeof nx.x);
-      nx.twist();
-      rawProduced.store(b + 1, std::memory_order_release);
+      Chunk& k = ring[c % NCH];
+      std::memcpy(k.startX, cur.x, sizeof cur.x);
+      for (size_t b = 0; b < CH; b++) {
+        cur.twist();
+        std::memcpy(k.out + b * 624, cur.out, sizeof cur.out);
+      }
+      produced.store(c + 1, std::memory_order_release);
     }
   });
-  size_t rb = 0, idx = raw[0].p;
-  const uint32_t* out = raw[0].out;
-  auto nextRaw = [&]() -> uint32_t {
-    if (idx >= 624) {
-      rawReleased.store(rb + 1, std::memory_order_release);
-      rb++;
-      while (rawProduced.load(std::memory_order_acquire) <= rb) std::this_thread::yield();
-      out = raw[rb % RAWS].out;
-      idx = 0;
-    }
-    return out[idx++];
+  // the next raw word: block cb of the stream (0 = what is left of the generator's current block, block b >= 1 = word range
+  // [(b - 1) % CH * 624, + 624) of chunk (b - 1) / CH), word idx of it
+  size_t cb = 0, idx = first.p;
+  const uint32_t* out = first.out;
+  auto nextBlock = [&] {
+    if (cb >= 1 && cb % CH == 0) released.store(cb / CH, std::memory_order_release);     // the chunk that held blocks cb - CH + 1 .. cb is used up
+    cb++;
+    const size_t c = (cb - 1) / CH;
+    while (produced.load(std::memory_order_acquire) <= c) std::this_thread::yield();
+    out = ring[c % NCH].out + ((cb - 1) % CH) * 624;
+    idx = 0;
   };
   uint32_t* j = pos.data();
   j[0] = 0;
-  for (size_t i = 1; i < n; i++) {
+  size_t i = 1;
+  // eight positions at a time while their raw words lie in the current block and none of them needs a second look (low < range, the
+  // door to the rejection test, opens for range / 2^32 of the draws: < 0.5 % at 20 M entries): a loop the compiler vectorises
+  for (;;) {
+    while (i + 8 <= n && idx + 8 <= 624) {
+      uint64_t prod[8];
+      uint32_t any = 0;
+      for (int k = 0; k < 8; k++) {
+        const uint32_t range = (uint32_t)(i + k + 1);
+        prod[k] = (uint64_t)out[idx + k] * (uint64_t)range;
+        any |= (uint32_t)((uint32_t)prod[k] < range);
+      }
+      if (any) break;
+      for (int k = 0; k < 8; k++) j[i + k] = (uint32_t)(prod[k] >> 32);
+      i += 8;
+      idx += 8;
+    }
+    if (i >= n) break;
+    // one position the careful way (also the block's last words and the list's last entries): d(g, param_type(0, i)) of
+    // bits/uniform_int_dist.h, see MtBulk::below
     const uint32_t range = (uint32_t)(i + 1);
-    uint64_t product = (uint64_t)nextRaw() * (uint64_t)range;
+    if (idx >= 624) nextBlock();
+    uint64_t product = (uint64_t)out[idx++] * (uint64_t)range;
     uint32_t low = (uint32_t)product;
     if (low < range) {
       const uint32_t threshold = (0u - range) % range;
       while (low < threshold) {
-        product = (uint64_t)nextRaw() * (uint64_t)range;
+        if (idx >= 624) nextBlock();
+        product = (uint64_t)out[idx++] * (uint64_t)range;
         low = (uint32_t)product;
       }
     }
     j[i] = (uint32_t)(product >> 32);
+    i++;
   }
   stop.store(true, std::memory_order_release);
   gen.join();
-  MtBulk& last = raw[rb % RAWS];
+  // the generator as std::shuffle leaves it: the state of block cb with idx words taken
+  MtBulk last;
+  if (cb == 0) {
+    std::memcpy(last.x, first.x, sizeof last.x);
+  } else {
+    std::memcpy(last.x, ring[((cb - 1) / CH) % NCH].startX, sizeof last.x);
+    for (size_t b = 0; b <= (cb - 1) % CH; b++) last.twist();
+  }
   last.p = idx;
   if (!last.store(g)) throw std::runtime_error("mfhShufflePositions: the generator state could not be handed back");
   return true;
@@ -1080,7 +1120,8 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
   // (the list of K_SGD / K_HOG / K_IFW is allocated and numbered by the thread that shuffles it: orderThread, below)
   const bool listOfAll = (kind == K_SGD || kind == K_HOG || kind == K_IFW) && exact;
   // (MFX_DEVICE_SHUFFLE=0: the swaps of the epoch's std::shuffle on the host, as in round 3)
-  std::vector<uint32_t> swapPos;
+  std::vector<uint32_t> swapPos[2];      // the positions of this epoch's and of the next epoch's swaps
+  int swapMake = 0, swapMade = 0;
   bool devShuffleOk = true;
   bool devShuffle = false;
   if (listOfAll && order32 && nRatings >= ((int64_t)1 << 20) && !(getenv("MFX_DEVICE_SHUFFLE") && atoi(getenv("MFX_DEVICE_SHUFFLE")) == 0) &&
@@ -1190,19 +1231,26 @@ void ModelMF::run(Kind kind, const char* name, const Data& data, Model& bestMode
           // Long lists (round 4): the host draws only the POSITIONS of the shuffle -- the generator's stream, a thread ahead -- and the
           // device applies the swaps to the list it keeps from epoch to epoch (mfx_sgd_apply_swaps32: the same list, bit for bit);
           // the random swaps were the slowest stage of mfhShuffle (45 ms of a 53 ms iteration at the ML-20M shape).
-          if (order32 && devShuffle) orderOfEpoch([&swapPos, &mt, nRatings, &devShuffleOk] { devShuffleOk = mfhShufflePositions(swapPos, (size_t)nRatings, mt); });
+          if (order32 && devShuffle)
+            orderOfEpoch([&swapPos, &swapMake, &swapMade, &mt, nRatings, &devShuffleOk] {
+              devShuffleOk = mfhShufflePositions(swapPos[swapMake], (size_t)nRatings, mt);
+              swapMade = swapMake;
+              swapMake ^= 1;
+            });
           else if (order32) orderOfEpoch([&ratingInds32, &mt] { mfhShuffle(ratingInds32, mt); });
           else orderOfEpoch([&uiRatingInds, &mt] { mfhShuffle(uiRatingInds, mt); });
           const auto u0 = std::chrono::steady_clock::now();
           if (order32 && devShuffle) {
             if (!devShuffleOk) throw MfxError(-100, "ModelMF::train: the positions form of the shuffle stopped applying in the middle of a run");
+            const int cur = swapMade;
+            orderAhead();                     // the next epoch's positions go into the OTHER buffer while the device applies these
             if (iter == 0) dev->check(mfx_sgd_set_order32(dev->ctx, ratingInds32.data(), nRatings), "set_order32");   // 0 .. n-1, once
-            dev->check(mfx_sgd_apply_swaps32(dev->ctx, swapPos.data(), nRatings), "apply_swaps32");                    // (copied when it returns)
+            dev->check(mfx_sgd_apply_swaps32(dev->ctx, swapPos[cur].data(), nRatings), "apply_swaps32");
           } else if (order32) dev->check(mfx_sgd_set_order32(dev->ctx, ratingInds32.data(), nRatings), "set_order32");   // (copied when it returns)
           else dev->check(mfx_sgd_set_order(dev->ctx, (const uint64_t*)uiRatingInds.data(), nRatings), "set_order");
           const auto u1 = std::chrono::steady_clock::now();
           o.mode = replayMode; o.order = MFX_ORDER_HOST;
-          orderAhead();
+          if (!(order32 && devShuffle)) orderAhead();
           dev->check(mfx_sgd_epoch(dev->ctx, &o), "mfx_sgd_epoch");
           if (timeLoop)
             fprintf(stderr, "[mfh] iteration %d: order upload %.1f ms, replay call %.1f ms\n", iter,
