@@ -61,6 +61,14 @@ struct FlowState {
   // tagged schedule (sgd_flow_tag_kernel): granule copy {value, tag} of the other side's table; LDS slot of every owned row
   float* tagbuf = nullptr;
   int64_t tag_cap = 0;                // floats
+  // hybrid ownership (sgd_flow_wide_kernel<.., HYB>): granule copy of the OWNED side's table too, rank | pub of every queue record,
+  // the number of item queues (heavy users' queues follow them)
+  float* tagbuf2 = nullptr;
+  int64_t tag2_cap = 0;
+  uint32_t* qa = nullptr;
+  int64_t qa_cap = 0;
+  int g_item = 0, n_heavy = 0;
+  bool hybrid = false;
   std::vector<uint8_t> oslot;
   bool tagged = false;                // the queues of the last build carry the LDS slot of the owned row in .y
   // owner assignment (owned rows -> queues, LDS slots), cached per train matrix: it depends on the rows' chain lengths only for
@@ -341,7 +349,7 @@ struct F2 {
   static constexpr int LA = C <= 2 ? 4 : 2;        // rows of the other side in flight (queue positions ahead of the head)
   static constexpr int QR = C <= 2 ? 32 : 16;      // owned rows kept in LDS per queue
   static constexpr int NB = 64;                    // records per register block
-  static constexpr int WS = QR * LD * 4 + QR * 4;  // LDS bytes per wave: QR rows | their row ids
+  static constexpr int WS = QR * LD * 4 + QR * 8;  // LDS bytes per wave: QR rows | their row ids | their versions (hybrid ownership)
   static constexpr int LDS = WS * (FL_WG / 64);
   static constexpr int WGS = C <= 1 ? 4 : 2;       // workgroups per CU (registers: launch bounds; LDS: LDS * WGS <= 160 KiB)
   static constexpr int NSTEP = 4 * C;              // vector-memory instructions of a step: 2 C tagged stores, 2 C row requests
@@ -351,7 +359,8 @@ struct F2 {
 template <int L, int C, int ARITH>
 __global__ __launch_bounds__(FL_WG, (F2<L, C>::WGS)) void sgd_flow_tag_kernel(const int4* __restrict__ q, const int64_t* __restrict__ qoff,
                                                                               uint32_t qbytes, float* T, uint32_t tbytes, float* O, uint32_t obytes,
-                                                                              int own_flags, float lr, float uReg, float iReg, unsigned* flag) {
+                                                                              int own_flags, float lr, float uReg, float iReg, unsigned* flag,
+                                                                              const uint32_t* /*qa: hybrid ownership, wide kernel only*/, int /*g_item*/) {
   typedef F2<L, C> P;
   const int own_user = own_flags & 1;
   constexpr int LD = P::LD, LA = P::LA, QR = P::QR, NB = P::NB;
@@ -589,7 +598,7 @@ struct FW {
   static constexpr int LA = 4;                     // rows of the other side in flight (2 C landing registers each)
   static constexpr int QR = C <= 2 ? 32 : 16;      // owned rows kept in LDS per queue
   static constexpr int NB = 64;
-  static constexpr int WS = QR * LD * 4 + QR * 4;
+  static constexpr int WS = QR * LD * 4 + QR * 8;
   static constexpr int LDS = WS * (FL_WG / 64);
   static constexpr int WGS = C <= 1 ? 4 : 2;
   static constexpr int NSTEP = 2 * C;              // vector-memory instructions of a step: C tagged stores, C row requests
@@ -779,24 +788,38 @@ __device__ __forceinline__ void pole_axpys(float (&p)[C], float (&q)[C], float r
   }
 }
 
-template <int C, int ARITH>
+// HYB (round 4, MFX_FLOW_HYBRID): HYBRID OWNERSHIP.  Queues 0 .. g_item - 1 own item rows as before; queue g_item + h owns ONE heavy
+// user's row and holds ALL of that user's ratings -- the rows whose hand-off chains ended the launch (the busiest user's 10 717
+// ratings were 10 717 hand-offs between item queues; in a queue of its own they are 10 717 steps of a pole).  An item row is then
+// visited from two kinds of queues, so BOTH factor tables are in granule form for the launch (T = users', O = items'), every row
+// carries its version (visits received) as its tag, and an owner treats its rows as a CACHE of the table: a row that is not in
+// registers / LDS is read from the table by polling for the version this visit expects (qa = rank of the visit in the owned row's
+// chain << 1 | pub), a displaced row is written back with its version, and a row whose NEXT visit lies in another queue (pub) is
+// written back behind its visit and dropped from the cache -- the queue builder's pub bit also ends the block, so publishing happens
+// at block ends only.  The other side of a visit is handled exactly as before (tagged load LA positions ahead, tagged store).
+template <int C, int ARITH, bool HYB = false>
 __global__ __launch_bounds__(FL_WG, (FW<C>::WGS)) void sgd_flow_wide_kernel(const int4* __restrict__ q, const int64_t* __restrict__ qoff,
                                                                            uint32_t qbytes, float* T, uint32_t tbytes, float* O, uint32_t obytes,
-                                                                           int own_flags, float lr, float uReg, float iReg, unsigned* flag) {
+                                                                           int own_flags, float lr, float uReg, float iReg, unsigned* flag,
+                                                                           const uint32_t* __restrict__ qa, int g_item) {
   typedef FW<C> P;
   constexpr int LD = P::LD, LA = P::LA, QR = P::QR, NB = P::NB;
   extern __shared__ __attribute__((aligned(16))) char fl_smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float* qv = (float*)(fl_smem + (size_t)wv * P::WS);              // [QR][C][64]
   int* qt = (int*)(fl_smem + (size_t)wv * P::WS + QR * LD * 4);    // [QR]
+  uint32_t* qver = (uint32_t*)(qt + QR);                           // [QR] hybrid: version of the cached row
   const int64_t grp = (int64_t)blockIdx.x * (FL_WG / 64) + __builtin_amdgcn_readfirstlane(wv);
   uint32_t pos = (uint32_t)qoff[grp];
   const uint32_t end = (uint32_t)qoff[grp + 1];
-  const int own_user = own_flags & 1;
+  const int own_user = HYB ? (grp >= (int64_t)g_item ? 1 : 0) : (own_flags & 1);
   const int pollfull = (own_flags >> 8) & 0xffff;      // pole path: tries of a stalled head that read the whole row (MFX_FLOW_POLLFULL)
   fl_prio(own_flags, end - pos, qoff);
   if (lane < QR) qt[lane] = -1;
-  const desc4 dq = fl_desc(q, qbytes), dt = fl_desc(T, tbytes), dob = fl_desc(O, obytes);
+  // dt: the table of the OTHER side of this queue's visits (granule form); dob: the owned side's (plain floats, or granule form when HYB)
+  const desc4 dq = fl_desc(q, qbytes), dt = (HYB && own_user) ? fl_desc(O, obytes) : fl_desc(T, tbytes),
+              dob = (HYB && own_user) ? fl_desc(T, tbytes) : fl_desc(O, obytes), dqa = fl_desc(qa, HYB ? qbytes / 4u : 0u);
+  uint32_t cur_ver = 0;                                 // hybrid: version of the row held in registers (visits it has received)
   // this lane's granule inside a 512-byte chunk of the granule copy, and its float inside a 256-byte chunk of the owned table
   const uint32_t g_off = (uint32_t)(((lane >> 1) & 1) * 256 + (lane >> 2) * 16 + (lane & 1) * 8), o_off = (uint32_t)lane * 4u;
   // the landing registers: one 64-bit INTEGER {tag : value} per pipeline slot and chunk.  (As an array of two-element vectors
@@ -813,6 +836,79 @@ __global__ __launch_bounds__(FL_WG, (FW<C>::WGS)) void sgd_flow_wide_kernel(cons
   int cur_row = -1, cur_slot = 0;
   bool aborted = false;
 
+  // ---- the owned side's table.  Plain mode: rows of floats (fw_load1 / fw_store1).  HYB: granule form with the row's version as
+  // its tag -- OWN_FETCH polls until every granule of row ROW carries version VER, OWN_PUT writes VALS with version VER.
+#define OWN_PUT(ROW, VER, VALS)                                                                                       \
+  {                                                                                                                   \
+    if constexpr (HYB) {                                                                                              \
+      const uint32_t wb_ = (uint32_t)(ROW) * (uint32_t)(8 * LD) + g_off;                                              \
+      _Pragma("unroll") for (int c = 0; c < C; c++) fw_store2(dob, wb_ + (uint32_t)(c * 512), uint2v{__float_as_uint(VALS(c)), (uint32_t)(VER)}); \
+    } else {                                                                                                          \
+      _Pragma("unroll") for (int c = 0; c < C; c++)                                                                   \
+          fw_store1(dob, (uint32_t)(ROW) * (uint32_t)(4 * LD) + (uint32_t)(c * 256) + o_off, __float_as_uint(VALS(c))); \
+    }                                                                                                                 \
+  }
+#define OWN_FETCH(ROW, VER)                                                                                           \
+  {                                                                                                                   \
+    if constexpr (HYB) {                                                                                              \
+      const uint32_t fb_ = (uint32_t)(ROW) * (uint32_t)(8 * LD) + g_off;                                              \
+      long long t_f_ = wall_clock64();                                                                                \
+      int sp_ = 0;                                                                                                    \
+      for (;;) {                                                                                                      \
+        unsigned long long g_[C];                                                                                     \
+        _Pragma("unroll") for (int c = 0; c < C; c++) { g_[c] = 0ull; fw_load2(g_[c], dob, fb_ + (uint32_t)(c * 512)); } \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                              \
+        bool t_ = true;                                                                                               \
+        _Pragma("unroll") for (int c = 0; c < C; c++) { asm volatile("" : "+v"(g_[c])); t_ = t_ && (uint32_t)(g_[c] >> 32) == (uint32_t)(VER); } \
+        if (__builtin_amdgcn_ballot_w64(t_) == ~0ull) {                                                               \
+          _Pragma("unroll") for (int c = 0; c < C; c++) ov[c] = __uint_as_float((uint32_t)g_[c]);                     \
+          break;                                                                                                      \
+        }                                                                                                             \
+        if ((++sp_ & 63) == 0) {                                                                                      \
+          if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { aborted = true; break; }         \
+          if (wall_clock64() - t_f_ > 200000000LL) {                                                                  \
+            __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                                 \
+            aborted = true;                                                                                           \
+            break;                                                                                                    \
+          }                                                                                                           \
+        }                                                                                                             \
+      }                                                                                                               \
+    } else {                                                                                                          \
+      uint32_t in_[C];                                                                                                \
+      _Pragma("unroll") for (int c = 0; c < C; c++)                                                                   \
+          in_[c] = fw_load1(dob, (uint32_t)(ROW) * (uint32_t)(4 * LD) + (uint32_t)(c * 256) + o_off);                 \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                \
+      _Pragma("unroll") for (int c = 0; c < C; c++) {                                                                 \
+        asm volatile("" : "+v"(in_[c]));                                                                              \
+        ov[c] = __uint_as_float(in_[c]);                                                                              \
+      }                                                                                                               \
+    }                                                                                                                 \
+  }
+  // the owned row of the next visit: ROWY = the record's .y, KA = its rank in that row's chain (hybrid).  The held row goes to its LDS
+  // slot, the wanted one comes from its slot, or from the table (where the slot's occupant goes first).
+#define OWN_SWITCH(ROWY, KA)                                                                                          \
+  {                                                                                                                   \
+    const int orow_ = (ROWY) & FL_ROW_MASK, slot_ = (int)((uint32_t)(ROWY) >> FL_SLOT_SHIFT) & (QR - 1);              \
+    if (orow_ != cur_row) {                                                                                           \
+      if (cur_row >= 0) {                                                                                             \
+        _Pragma("unroll") for (int c = 0; c < C; c++) qv[(cur_slot * C + c) * 64 + lane] = ov[c];                     \
+        if (HYB && lane == 0) qver[cur_slot] = cur_ver;                                                               \
+      }                                                                                                               \
+      const int have_ = __builtin_amdgcn_readfirstlane(qt[slot_]);                                                    \
+      if (have_ == orow_) {                                                                                           \
+        _Pragma("unroll") for (int c = 0; c < C; c++) ov[c] = qv[(slot_ * C + c) * 64 + lane];                        \
+      } else {                                                                                                        \
+        if (have_ >= 0) {                                                                                             \
+          const uint32_t hv_ = HYB ? (uint32_t)__builtin_amdgcn_readfirstlane((int)qver[slot_]) : 0u;                 \
+          OWN_PUT(have_, hv_, [&](int c) { return qv[(slot_ * C + c) * 64 + lane]; })                                 \
+        }                                                                                                             \
+        OWN_FETCH(orow_, KA)                                                                                          \
+        if (lane == 0) qt[slot_] = orow_;                                                                             \
+      }                                                                                                               \
+      cur_row = orow_;                                                                                                \
+      cur_slot = slot_;                                                                                               \
+    }                                                                                                                 \
+  }
 #define FW_REQUEST(K, ROWX, LIVE)                                                                                     \
   {                                                                                                                   \
     const uint32_t rb_ = (LIVE) ? (uint32_t)(ROWX) * (uint32_t)(8 * LD) + g_off : FL_OOB;                             \
@@ -830,33 +926,9 @@ __global__ __launch_bounds__(FL_WG, (FW<C>::WGS)) void sgd_flow_wide_kernel(cons
       const int rx_ = __builtin_amdgcn_readlane(rec.x, sl_), ry_ = __builtin_amdgcn_readlane(rec.y, sl_);             \
       const int rz_ = __builtin_amdgcn_readlane(rec.z, sl_);                                                          \
       const uint32_t exp_ = (uint32_t)__builtin_amdgcn_readlane(rec.w, sl_);                                          \
-      const int orow_ = ry_ & FL_ROW_MASK, slot_ = (int)((uint32_t)ry_ >> FL_SLOT_SHIFT) & (QR - 1);                  \
-      if (orow_ != cur_row) {               /* another owned row: the held one goes to its LDS slot, this one comes in */ \
-        if (cur_row >= 0) {                                                                                           \
-          _Pragma("unroll") for (int c = 0; c < C; c++) qv[(cur_slot * C + c) * 64 + lane] = ov[c];                   \
-        }                                                                                                             \
-        const int have_ = __builtin_amdgcn_readfirstlane(qt[slot_]);                                                  \
-        if (have_ == orow_) {                                                                                         \
-          _Pragma("unroll") for (int c = 0; c < C; c++) ov[c] = qv[(slot_ * C + c) * 64 + lane];                      \
-        } else {                            /* not in LDS: the slot's row goes back to the table, this one is loaded */ \
-          if (have_ >= 0) {                                                                                           \
-            _Pragma("unroll") for (int c = 0; c < C; c++)                                                             \
-                fw_store1(dob, (uint32_t)have_ * (uint32_t)(4 * LD) + (uint32_t)(c * 256) + o_off,                    \
-                          __float_as_uint(qv[(slot_ * C + c) * 64 + lane]));                                          \
-          }                                                                                                           \
-          uint32_t in_[C];                                                                                            \
-          _Pragma("unroll") for (int c = 0; c < C; c++)                                                               \
-              in_[c] = fw_load1(dob, (uint32_t)orow_ * (uint32_t)(4 * LD) + (uint32_t)(c * 256) + o_off);             \
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                            \
-          _Pragma("unroll") for (int c = 0; c < C; c++) {                                                             \
-            asm volatile("" : "+v"(in_[c]));                                                                          \
-            ov[c] = __uint_as_float(in_[c]);                                                                          \
-          }                                                                                                           \
-          if (lane == 0) qt[slot_] = orow_;                                                                           \
-        }                                                                                                             \
-        cur_row = orow_;                                                                                              \
-        cur_slot = slot_;                                                                                             \
-      }                                                                                                               \
+      const uint32_t ka_ = HYB ? (uint32_t)__builtin_amdgcn_readlane((int)qav, sl_) >> 1 : 0u;                        \
+      OWN_SWITCH(ry_, ka_)                                                                                            \
+      cur_ver = ka_ + 1u;                                                                                             \
       /* the row of the other side: requested LA positions ago */                                                     \
       asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NWAIT) : "memory");                                                    \
       _Pragma("unroll") for (int c = 0; c < C; c++) asm volatile("" : "+v"(Tr[K][c]));                                \
@@ -1056,44 +1128,29 @@ __global__ __launch_bounds__(FL_WG, (FW<C>::WGS)) void sgd_flow_wide_kernel(cons
   }
 
   while (pos < end && !aborted) {
-    const int nb = (int)min((uint32_t)NB, end - pos);
+    int nb = (int)min((uint32_t)NB, end - pos);
     uint4v rb = fl_load<false>(dq, lane < nb ? (pos + (uint32_t)lane) * 16u : FL_OOB);
-    { FLW_T0 asm volatile("s_waitcnt vmcnt(0)" : "+v"(rb)::"memory"); FLW_T1(4) }
+    uint32_t qav = 0u;                                   // hybrid: rank of the visit in its owned row's chain << 1 | pub
+    if constexpr (HYB) qav = fw_load1(dqa, lane < nb ? (pos + (uint32_t)lane) * 4u : FL_OOB);
+    { FLW_T0 asm volatile("s_waitcnt vmcnt(0)" : "+v"(rb), "+v"(qav)::"memory"); FLW_T1(4) }
     const int4 rec = make_int4((int)rb.x, (int)rb.y, (int)rb.z, (int)rb.w);
+    bool pub_end = false;
+    if constexpr (HYB) {                                 // the block ends behind the first record that publishes its row
+      const unsigned long long pm = __builtin_amdgcn_ballot_w64(lane < nb && (qav & 1u));
+      if (pm) { nb = min(nb, (int)__builtin_ctzll(pm) + 1); pub_end = true; }
+    }
     // a pole block: 64 records, one owned row (nothing of it touches the landing registers Tr of the generic steps)
     const int ry0 = __builtin_amdgcn_readfirstlane(rec.y);
     if ((own_flags & 4) && nb == NB && __builtin_amdgcn_ballot_w64(rec.y == ry0) == ~0ull) {
-      const int orow_ = ry0 & FL_ROW_MASK, slot_ = (int)((uint32_t)ry0 >> FL_SLOT_SHIFT) & (QR - 1);
-      if (orow_ != cur_row) {               // the owned-row switch of FW_STEP, once for the block
-        if (cur_row >= 0) {
-#pragma unroll
-          for (int c = 0; c < C; c++) qv[(cur_slot * C + c) * 64 + lane] = ov[c];
-        }
-        const int have_ = __builtin_amdgcn_readfirstlane(qt[slot_]);
-        if (have_ == orow_) {
-#pragma unroll
-          for (int c = 0; c < C; c++) ov[c] = qv[(slot_ * C + c) * 64 + lane];
-        } else {
-          if (have_ >= 0) {
-#pragma unroll
-            for (int c = 0; c < C; c++)
-              fw_store1(dob, (uint32_t)have_ * (uint32_t)(4 * LD) + (uint32_t)(c * 256) + o_off, __float_as_uint(qv[(slot_ * C + c) * 64 + lane]));
-          }
-          uint32_t in_[C];
-#pragma unroll
-          for (int c = 0; c < C; c++) in_[c] = fw_load1(dob, (uint32_t)orow_ * (uint32_t)(4 * LD) + (uint32_t)(c * 256) + o_off);
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-          for (int c = 0; c < C; c++) {
-            asm volatile("" : "+v"(in_[c]));
-            ov[c] = __uint_as_float(in_[c]);
-          }
-          if (lane == 0) qt[slot_] = orow_;
-        }
-        cur_row = orow_;
-        cur_slot = slot_;
-      }
+      const uint32_t ka0 = HYB ? (uint32_t)__builtin_amdgcn_readfirstlane((int)qav) >> 1 : 0u;
+      OWN_SWITCH(ry0, ka0)          // the owned-row switch of FW_STEP, once for the block
       if (own_user) FWP_BLOCK(true) else FWP_BLOCK(false)
+      cur_ver = ka0 + (uint32_t)NB;
+      if (HYB && pub_end && !aborted) {       // the row's next visit lies in another queue: written back with its version, dropped from the cache
+        OWN_PUT(cur_row, cur_ver, [&](int c) { return ov[c]; })
+        if (lane == 0) qt[cur_slot] = -1;
+        cur_row = -1;
+      }
       pos += (uint32_t)nb;
       continue;
     }
@@ -1119,6 +1176,11 @@ __global__ __launch_bounds__(FL_WG, (FW<C>::WGS)) void sgd_flow_wide_kernel(cons
     for (int k = 0; k < LA; k++)
 #pragma unroll
       for (int c = 0; c < C; c++) asm volatile("" : "+v"(Tr[k][c]));
+    if (HYB && pub_end && !aborted && cur_row >= 0) {     // (the block's last record publishes the row it visited: the one in registers)
+      OWN_PUT(cur_row, cur_ver, [&](int c) { return ov[c]; })
+      if (lane == 0) qt[cur_slot] = -1;
+      cur_row = -1;
+    }
     pos += (uint32_t)nb;
   }
 #undef FW_STEP
@@ -1137,14 +1199,23 @@ __global__ __launch_bounds__(FL_WG, (FW<C>::WGS)) void sgd_flow_wide_kernel(cons
   if (cur_row >= 0) {
 #pragma unroll
     for (int c = 0; c < C; c++) qv[(cur_slot * C + c) * 64 + lane] = ov[c];
+    if (HYB && lane == 0) { qver[cur_slot] = cur_ver; qt[cur_slot] = cur_row; }
   }
   for (int sI = 0; sI < QR; sI++) {
     const int have = __builtin_amdgcn_readfirstlane(qt[sI]);
     if (have >= 0) {
+      if constexpr (HYB) {
+        const uint32_t hv = (uint32_t)__builtin_amdgcn_readfirstlane((int)qver[sI]);
+        OWN_PUT(have, hv, [&](int c) { return qv[(sI * C + c) * 64 + lane]; })
+      } else {
 #pragma unroll
-      for (int c = 0; c < C; c++) O[(int64_t)have * LD + c * 64 + lane] = qv[(sI * C + c) * 64 + lane];
+        for (int c = 0; c < C; c++) O[(int64_t)have * LD + c * 64 + lane] = qv[(sI * C + c) * 64 + lane];
+      }
     }
   }
+#undef OWN_PUT
+#undef OWN_FETCH
+#undef OWN_SWITCH
 }
 
 // granule copy of a factor table and back: row r, chunk c, lane j, half h (elements 4j+2h, 4j+2h+1 of the chunk) at byte
@@ -1285,6 +1356,141 @@ int build_flow(mfx_ctx* ctx, int64_t first, int64_t count, int64_t groups, bool 
     fprintf(stderr, "[mfx] dataflow replay: %lld ratings on %lld groups (%s rows owned), longest queue %lld, longest chains %d users / %d items, "
             "host preparation %.1f ms\n", (long long)count, (long long)groups, own_user ? "user" : "item", (long long)longest, maxU, maxI,
             S->prep_ms);
+  return MFX_OK;
+}
+
+// ---- hybrid ownership, host statement (sgd_flow_wide_kernel<.., HYB>).  The H busiest users (at most `heavy_max`, each with at least
+// `heavy_min` ratings in the list) get a queue of their own holding ALL their ratings; every other rating is visited in its item's
+// queue as before.  Per record: .x the other side's row, .y the owned row | LDS slot << 26, .z the rating, .w the rank of the visit
+// in the OTHER row's chain (its expected version), qa = rank in the OWNED row's chain << 1 | pub, pub = "the owned row's next visit
+// lies in another queue (or there is none)": the kernel writes the row back behind that visit and ends its block there.
+// Returns 1 (nothing built) for a list that keeps a user's ratings together or has no user heavy enough: the caller builds the
+// ordinary queues.
+int build_flow_hybrid_host(mfx_ctx* ctx, int64_t first, int64_t count, int64_t groups, int heavy_max, int heavy_min) {
+  FlowState* S = fl(ctx);
+  const auto t0 = std::chrono::steady_clock::now();
+  int rc;
+  const int64_t nU = ctx->nU, nI = ctx->nI;
+  std::vector<int32_t> hu((size_t)count), hi((size_t)count);
+  std::vector<float> hr((size_t)count);
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpy(hu.data(), ctx->eu + first, sizeof(int32_t) * (size_t)count, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(hi.data(), ctx->ei + first, sizeof(int32_t) * (size_t)count, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(hr.data(), ctx->er + first, sizeof(float) * (size_t)count, hipMemcpyDeviceToHost));
+  std::vector<int32_t> degU((size_t)nU, 0), degI((size_t)nI, 0);
+  int64_t au = 0;
+  for (int64_t t = 0; t < count; t++) {
+    degU[(size_t)hu[(size_t)t]]++; degI[(size_t)hi[(size_t)t]]++;
+    if (t + 1 < count) au += hu[(size_t)t] == hu[(size_t)t + 1];
+  }
+  if (2 * au > count) return 1;                              // a user-ordered list: user rows are owned there
+  // the heavy users: busiest first
+  std::vector<int32_t> heavy;
+  for (int64_t u = 0; u < nU; u++)
+    if (degU[(size_t)u] >= heavy_min) heavy.push_back((int32_t)u);
+  std::sort(heavy.begin(), heavy.end(), [&](int32_t a, int32_t b) { return degU[a] != degU[b] ? degU[a] > degU[b] : a < b; });
+  if ((int64_t)heavy.size() > heavy_max) heavy.resize((size_t)heavy_max);
+  const int H = (int)std::min<int64_t>((int64_t)heavy.size(), groups / 2);
+  if (H == 0) return 1;
+  heavy.resize((size_t)H);
+  const int64_t g_item = groups - H;
+  std::vector<int32_t> uq((size_t)nU, -1);
+  for (int h = 0; h < H; h++) uq[(size_t)heavy[(size_t)h]] = h;
+  // items -> item queues by the ratings that stay with them, longest first onto the lightest queue; LDS slots as in build_flow
+  std::vector<int32_t> degL((size_t)nI, 0);
+  for (int64_t t = 0; t < count; t++)
+    if (uq[(size_t)hu[(size_t)t]] < 0) degL[(size_t)hi[(size_t)t]]++;
+  std::vector<int32_t> owner((size_t)nI, 0);
+  std::vector<uint8_t> oslot((size_t)nI, 0);
+  {
+    std::vector<int32_t> rows;
+    for (int64_t r = 0; r < nI; r++)
+      if (degI[(size_t)r] > 0) rows.push_back((int32_t)r);
+    std::sort(rows.begin(), rows.end(), [&](int32_t a, int32_t b) { return degL[a] != degL[b] ? degL[a] > degL[b] : a < b; });
+    typedef std::pair<int64_t, int32_t> Load;
+    std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap;
+    for (int64_t gI = 0; gI < g_item; gI++) heap.push(Load(0, (int32_t)gI));
+    std::vector<int32_t> nrows((size_t)g_item, 0);
+    for (int32_t r : rows) {
+      Load l = heap.top();
+      heap.pop();
+      owner[(size_t)r] = l.second;
+      oslot[(size_t)r] = (uint8_t)(nrows[(size_t)l.second]++ & 31);
+      l.first += degL[(size_t)r];
+      heap.push(l);
+    }
+  }
+  // queue of every rating, queue offsets, ranks in both chains, the "next visit of the item lies elsewhere" flags
+  std::vector<int64_t> off((size_t)groups + 1, 0);
+  std::vector<int32_t> qof((size_t)count);
+  for (int64_t t = 0; t < count; t++) {
+    const int32_t h = uq[(size_t)hu[(size_t)t]];
+    qof[(size_t)t] = h >= 0 ? (int32_t)(g_item + h) : owner[(size_t)hi[(size_t)t]];
+    off[(size_t)qof[(size_t)t] + 1]++;
+  }
+  int64_t longest = 0;
+  for (int64_t gI = 0; gI < groups; gI++) { longest = std::max(longest, off[(size_t)gI + 1]); off[(size_t)gI + 1] += off[(size_t)gI]; }
+  std::vector<int4> rec((size_t)count);
+  std::vector<uint32_t> qa((size_t)count);
+  {
+    std::vector<int64_t> cur(off.begin(), off.end() - 1);
+    std::vector<int32_t> cu((size_t)nU, 0), ci((size_t)nI, 0);
+    std::vector<int64_t> lastOfItem((size_t)nI, -1);        // queue slot of the item's previous visit when that was in its own queue
+    for (int64_t t = 0; t < count; t++) {
+      const int32_t u = hu[(size_t)t], it = hi[(size_t)t];
+      const bool hv = uq[(size_t)u] >= 0;
+      const int64_t slot = cur[(size_t)qof[(size_t)t]]++;
+      const uint32_t ru = (uint32_t)cu[(size_t)u]++, ri = (uint32_t)ci[(size_t)it]++;
+      int rbits;
+      memcpy(&rbits, &hr[(size_t)t], 4);
+      if (hv) {
+        // the heavy user's queue: user row owned (slot 0), item row through its tags; published behind the user's last rating
+        rec[(size_t)slot] = make_int4(it, u, rbits, (int)ri);
+        qa[(size_t)slot] = ru << 1 | (ru + 1 == (uint32_t)degU[(size_t)u] ? 1u : 0u);
+        // the item's previous visit, if it was in the item's own queue, must publish: this visit reads the row from the table
+        if (lastOfItem[(size_t)it] >= 0) { qa[(size_t)lastOfItem[(size_t)it]] |= 1u; lastOfItem[(size_t)it] = -1; }
+      } else {
+        rec[(size_t)slot] = make_int4(u, (int)((uint32_t)it | (uint32_t)oslot[(size_t)it] << FL_SLOT_SHIFT), rbits, (int)ru);
+        qa[(size_t)slot] = ri << 1 | (ri + 1 == (uint32_t)degI[(size_t)it] ? 1u : 0u);
+        lastOfItem[(size_t)it] = slot;
+      }
+    }
+  }
+  // device copies
+  if (S->cap < count) {
+    dev_free(S->q); dev_free(S->lpos); dev_free(S->vexp);
+    S->cap = 0;
+    if ((rc = dev_alloc(ctx, &S->q, (size_t)count)) || (rc = dev_alloc(ctx, &S->lpos, (size_t)count)) || (rc = dev_alloc(ctx, &S->vexp, (size_t)count)))
+      return rc;
+    S->cap = count;
+  }
+  if (S->qa_cap < count) {
+    dev_free(S->qa);
+    S->qa_cap = 0;
+    if ((rc = dev_alloc(ctx, &S->qa, (size_t)count))) return rc;
+    S->qa_cap = count;
+  }
+  if (S->goff_cap < groups + 1) {
+    dev_free(S->qoff);
+    S->goff_cap = 0;
+    if ((rc = dev_alloc(ctx, &S->qoff, (size_t)groups + 1))) return rc;
+    S->goff_cap = groups + 1;
+  }
+  if (!S->flag && (rc = dev_alloc(ctx, &S->flag, (size_t)1))) return rc;
+  HIPCHK(hipMemsetAsync(S->flag, 0, sizeof(unsigned), ctx->stream));
+  HIPCHK(hipMemcpyAsync(S->qoff, off.data(), sizeof(int64_t) * ((size_t)groups + 1), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(S->q, rec.data(), sizeof(int4) * (size_t)count, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(S->qa, qa.data(), sizeof(uint32_t) * (size_t)count, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  S->hoff.assign(off.begin(), off.end());
+  S->assign_gen = ~0ull;
+  S->groups = groups; S->longest = longest; S->own_user = 0; S->tagged = true;
+  S->hybrid = true; S->g_item = (int)g_item; S->n_heavy = H;
+  S->prep_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (getenv("MFX_DEBUG"))
+    fprintf(stderr, "[mfx] dataflow replay, hybrid ownership: %lld ratings, %lld item queues + %d heavy users' queues (busiest %d, lightest %d ratings), "
+            "longest queue %lld, host preparation %.1f ms\n", (long long)count, (long long)g_item, H, degU[(size_t)heavy[0]], degU[(size_t)heavy[(size_t)H - 1]],
+            (long long)longest, S->prep_ms);
   return MFX_OK;
 }
 
@@ -1621,15 +1827,19 @@ int launch_flow_tag_lca(mfx_ctx* ctx, const mfx_sgd_opts* o, int blocks) {
   float* X = S->own_user ? ctx->V : ctx->U;          // the other side: read and written through its granule copy
   float* O = S->own_user ? ctx->U : ctx->V;          // the owned side
   // rows of 64 C floats: one element per lane and chunk (sgd_flow_wide_kernel; MFX_FLOW_WIDE=0 keeps the 16-lane kernel, the cross-check)
-  typedef void (*FlowKern)(const int4*, const int64_t*, uint32_t, float*, uint32_t, float*, uint32_t, int, float, float, float, unsigned*);
+  typedef void (*FlowKern)(const int4*, const int64_t*, uint32_t, float*, uint32_t, float*, uint32_t, int, float, float, float, unsigned*,
+                           const uint32_t*, int);
   FlowKern kern = sgd_flow_tag_kernel<L, C, ARITH>;
   int which = 0;
   if constexpr (L == 16) {
     static_assert(FW<C>::LDS == P::LDS && FW<C>::WGS == P::WGS && FW<C>::QR == P::QR, "the two tagged kernels share the launch shape");
     const char* we = getenv("MFX_FLOW_WIDE");
     if (!(we && we[0] == '0')) { kern = sgd_flow_wide_kernel<C, ARITH>; which = 1; }
+    if (S->hybrid) { kern = sgd_flow_wide_kernel<C, ARITH, true>; which = 2; }
+  } else {
+    NEED(!S->hybrid, MFX_E_STATE, "sgd dataflow: hybrid ownership runs on the wide kernel (ranks above 32)");
   }
-  static bool attr_done[2] = {false, false};         // per instantiation
+  static bool attr_done[3] = {false, false, false};  // per instantiation
   if (!attr_done[which]) {
     HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, P::LDS));
     attr_done[which] = true;
@@ -1648,11 +1858,33 @@ int launch_flow_tag_lca(mfx_ctx* ctx, const mfx_sgd_opts* o, int blocks) {
   const int pollfull = pf_ ? std::max(0, std::min(65535, atoi(pf_))) : 0;
   const int64_t total = nOth * L * C;
   const int tgrid = (int)std::min<int64_t>((total + 255) / 256, 8192);
+  if (S->hybrid) {
+    // both tables in granule form for the launch (users' = S->tagbuf, items' = S->tagbuf2), both copied back behind it
+    const int64_t need2 = (int64_t)ctx->nI * 2 * P::LD;
+    if (S->tag2_cap < need2) {
+      dev_free(S->tagbuf2);
+      S->tag2_cap = 0;
+      int rc = dev_alloc(ctx, &S->tagbuf2, (size_t)need2);
+      if (rc) return rc;
+      S->tag2_cap = need2;
+    }
+    const int t2grid = (int)std::min<int64_t>(((int64_t)ctx->nI * L * C + 255) / 256, 8192);
+    hipLaunchKernelGGL(flow_tag_kernel, dim3(tgrid), dim3(256), 0, ctx->stream, (const float*)ctx->U, (int64_t)ctx->nU, L, C, S->tagbuf);
+    hipLaunchKernelGGL(flow_tag_kernel, dim3(t2grid), dim3(256), 0, ctx->stream, (const float*)ctx->V, (int64_t)ctx->nI, L, C, S->tagbuf2);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(FL_WG), (size_t)P::LDS, ctx->stream, (const int4*)S->q, S->qoff,
+                       (uint32_t)((uint64_t)S->hoff.back() * 16u), S->tagbuf, (uint32_t)((uint64_t)ctx->nU * 8u * P::LD), S->tagbuf2,
+                       (uint32_t)((uint64_t)ctx->nI * 8u * P::LD), (prio ? 2 : 0) | (pole ? 4 : 0) | (pollfull << 8), o->learnRate, o->uReg, o->iReg,
+                       S->flag, (const uint32_t*)S->qa, S->g_item);
+    hipLaunchKernelGGL(flow_untag_kernel, dim3(tgrid), dim3(256), 0, ctx->stream, (const float*)S->tagbuf, (int64_t)ctx->nU, L, C, ctx->U);
+    hipLaunchKernelGGL(flow_untag_kernel, dim3(t2grid), dim3(256), 0, ctx->stream, (const float*)S->tagbuf2, (int64_t)ctx->nI, L, C, ctx->V);
+    HIPCHK(hipGetLastError());
+    return MFX_OK;
+  }
   hipLaunchKernelGGL(flow_tag_kernel, dim3(tgrid), dim3(256), 0, ctx->stream, (const float*)X, nOth, L, C, S->tagbuf);
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(FL_WG), (size_t)P::LDS, ctx->stream, (const int4*)S->q, S->qoff,
                      (uint32_t)((uint64_t)S->hoff.back() * 16u), S->tagbuf, (uint32_t)((uint64_t)nOth * 8u * P::LD), O,
                      (uint32_t)((uint64_t)(S->own_user ? ctx->nU : ctx->nI) * 4u * P::LD), (S->own_user ? 1 : 0) | (prio ? 2 : 0) | (pole ? 4 : 0) | (pollfull << 8), o->learnRate, o->uReg, o->iReg,
-                     S->flag);
+                     S->flag, (const uint32_t*)nullptr, 0);
   hipLaunchKernelGGL(flow_untag_kernel, dim3(tgrid), dim3(256), 0, ctx->stream, (const float*)S->tagbuf, nOth, L, C, X);
   HIPCHK(hipGetLastError());
   return MFX_OK;
@@ -1661,7 +1893,7 @@ template <int L, int C>
 int launch_flow_tag_lc(mfx_ctx* ctx, const mfx_sgd_opts* o, int blocks) {
   if constexpr (C <= 4) {
     FlowState* S = fl(ctx);
-    const int64_t need = (S->own_user ? (int64_t)ctx->nI : (int64_t)ctx->nU) * 2 * F2<L, C>::LD;
+    const int64_t need = (S->own_user ? (int64_t)ctx->nI : (int64_t)ctx->nU) * 2 * F2<L, C>::LD;      // (hybrid: own_user == 0, the users' table)
     if (S->tag_cap < need) {
       dev_free(S->tagbuf);
       S->tag_cap = 0;
@@ -1699,7 +1931,7 @@ void mfx_flow_free_internal(mfx_ctx* ctx) {
   if (!S) return;
   dev_free(S->q); dev_free(S->qoff); dev_free(S->lpos); dev_free(S->vexp); dev_free(S->ver); dev_free(S->flag);
   dev_free(S->k0); dev_free(S->k1); dev_free(S->v0); dev_free(S->v1); dev_free(S->pack); dev_free(S->sort_tmp);
-  dev_free(S->degU); dev_free(S->downer); dev_free(S->dstart); dev_free(S->tagbuf);
+  dev_free(S->degU); dev_free(S->downer); dev_free(S->dstart); dev_free(S->tagbuf); dev_free(S->tagbuf2); dev_free(S->qa);
   delete S;
   ctx->flow = nullptr;
 }
@@ -1729,7 +1961,23 @@ int mfx_launch_sgd_flow(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int6
   if (const char* e = getenv("MFX_FLOW_BLOCKS")) blocks = std::max(1, std::min(blocks, atoi(e)));   // test knob: few queues, many owned rows each
   const int64_t groups = (int64_t)blocks * per_block;
   // queues and versions are built on the device; MFX_FLOW_HOST=1 keeps the host statement of the same lists (the cross-check)
-  int rc = getenv("MFX_FLOW_HOST") ? build_flow(ctx, first, count, groups, tagged) : build_flow_device(ctx, first, count, groups, tagged);
+  // hybrid ownership (MFX_FLOW_HYBRID=1; wide kernel, plain update): the busiest users get queues of their own
+  int rc = 1;
+  fl(ctx)->hybrid = false;
+  {
+    const char* hy = getenv("MFX_FLOW_HYBRID");
+    if (hy && atoi(hy) != 0 && tagged && L == 16 && C <= 4 && !getenv("MFX_FLOW_OWN") && !(getenv("MFX_FLOW_WIDE") && getenv("MFX_FLOW_WIDE")[0] == '0') &&
+        (uint64_t)ctx->nI * ctx->ld * 8 < (1ull << 32)) {
+      const char* hm = getenv("MFX_FLOW_HEAVY");
+      const int heavy_max = hm ? std::max(0, atoi(hm)) : 128;
+      // a user is worth a queue when its chain is long next to a queue's share of the list (at 1.3 us per hand-off a chain of half an
+      // average queue already costs more than that queue's own work)
+      const int heavy_min = (int)std::max<int64_t>(256, count / (2 * std::max<int64_t>(groups, 1)));
+      if (heavy_max > 0) rc = build_flow_hybrid_host(ctx, first, count, groups, heavy_max, heavy_min);
+      if (rc < 0) return rc;
+    }
+  }
+  if (rc == 1) rc = getenv("MFX_FLOW_HOST") ? build_flow(ctx, first, count, groups, tagged) : build_flow_device(ctx, first, count, groups, tagged);
   if (rc) return rc;
 #define MFX_FLOW_GO(LL, CC) rc = tagged ? launch_flow_tag_lc<LL, CC>(ctx, o, blocks) : launch_flow_lc<LL, CC>(ctx, o, blocks)
   if (L == 4) MFX_FLOW_GO(4, 1);

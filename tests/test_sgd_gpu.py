@@ -408,6 +408,63 @@ def test_pole_blocks_of_the_tagged_replay_are_the_sequential_loop_bit_for_bit(K,
         assert np.array_equal(got[pole][0], Uo) and np.array_equal(got[pole][1], Vo), pole
 
 
+def _heavy_both_matrix(seed):
+    """popular items AND busy users: 4 items rated by ~80 % of 5 000 users, 5 users who rated ~70 % of 3 000 items, 5 random ratings
+    for everybody else"""
+    rng = np.random.default_rng(seed)
+    nU, nI = 5000, 3000
+    pairs = set()
+    for it in range(4):
+        for u in np.nonzero(rng.random(nU) < 0.8)[0]:
+            pairs.add((int(u), it))
+    for u in range(5):
+        for it in np.nonzero(rng.random(nI) < 0.7)[0]:
+            pairs.add((u, int(it)))
+    for u in range(nU):
+        for it in rng.integers(0, nI, 5):
+            pairs.add((u, int(it)))
+    a = np.array(sorted(pairs), dtype=np.int64)
+    rowptr = np.zeros(nU + 1, np.int64)
+    np.add.at(rowptr, a[:, 0] + 1, 1)
+    rowptr = np.cumsum(rowptr)
+    vals = (rng.integers(1, 11, len(a)) * 0.5).astype(np.float32)
+    return synth.CSR(nU, nI, rowptr, a[:, 1].astype(np.int32), vals)
+
+
+@pytest.mark.parametrize("K", [40, 64, 128, 256])
+@pytest.mark.parametrize("arith", ARITHS)
+def test_hybrid_ownership_is_the_sequential_loop_bit_for_bit(K, arith, monkeypatch):
+    """MFX_FLOW_HYBRID=1 (sgd_flow.hip, round 4): the busiest users get queues of their own that hold all their ratings, both factor
+    tables are in granule form with the row's version as its tag, and an item row moves between its owner's cache and the table
+    whenever a busy user's queue visits it in between.  Same bits as the oracle's sequential pass over three epochs of fresh
+    shuffled orders, with the pole path and without, for few (MFX_FLOW_HEAVY=2) and all qualifying busy users."""
+    tr = _heavy_both_matrix(seed=K)
+    nU, nI = tr.nrows, tr.ncols
+    rng = np.random.default_rng(11 + K)
+    U0 = rng.normal(0, 0.25 * np.sqrt(40.0 / K), (nU, K)).astype(np.float32)
+    V0 = rng.normal(0, 0.25 * np.sqrt(40.0 / K), (nI, K)).astype(np.float32)
+    ru = tr.rowids()
+    orders = [rng.permutation(tr.nnz).astype(np.uint64) for _ in range(3)]
+    Uo, Vo = U0.copy(), V0.copy()
+    for o in orders:
+        orc.sgd_pass(Uo, Vo, ru, tr.rowind, tr.rowval, o, 0.002, 0.01, 0.02, arith[1], orc.DOT_TREE)
+    assert np.isfinite(Uo).all() and np.isfinite(Vo).all() and np.abs(Vo - V0).max() > 1e-2
+    monkeypatch.setenv("MFX_FLOW_HYBRID", "1")
+    monkeypatch.setenv("MFX_DEBUG", "1")
+    for heavy, pole in (("128", "1"), ("2", "1"), ("128", "0")):
+        monkeypatch.setenv("MFX_FLOW_HEAVY", heavy)
+        monkeypatch.setenv("MFX_FLOW_POLE", pole)
+        with Ctx(0) as ctx:
+            ctx.set_csr(mfx.MAT_TRAIN, nU, nI, tr.rowptr, tr.rowind, tr.rowval)
+            ctx.set_model(nU, nI, K)
+            ctx.set_factors(U0, V0)
+            for o in orders:
+                ctx.sgd_set_order(o)
+                ctx.sgd_epoch(0.002, 0.01, 0.02, mode=mfx.SGD_LEVELS, order=mfx.ORDER_HOST, arith=arith[0])
+            U, V = ctx.get_factors()
+        assert np.array_equal(U, Uo) and np.array_equal(V, Vo), (heavy, pole)
+
+
 @pytest.mark.parametrize("K", [10, 64, 128, 200])
 @pytest.mark.parametrize("tagged", ["1", "0"])
 def test_dataflow_with_many_owned_rows_per_queue(K, tagged, monkeypatch):
