@@ -420,7 +420,7 @@ def main():
     exact = None
     if rank == 0 and solo and not args.no_exact:
         try:
-            exact = exact_replay(np, ctx, mfx, tr, U0, V0, lr, ureg, ireg)
+            exact = exact_replay(np, ctx, mfx, tr, U0, V0, lr, ureg, ireg, hybrid_too=True)
         except Exception as e:                  # noqa: BLE001 -- reported, the bench line does not depend on it
             exact = {"error": str(e)}
     if multi:
@@ -459,7 +459,7 @@ def main():
         print(json.dumps(out), flush=True)
 
 
-def exact_replay(np, ctx, mfx, tr, U0, V0, lr, ureg, ireg, epochs=3):
+def exact_replay(np, ctx, mfx, tr, U0, V0, lr, ureg, ireg, epochs=3, hybrid_too=False):
     """The path that IS the reference's sequential loop (ModelMF::train, modelMF.cpp:83-105): the same workload, one full-list
     permutation per epoch (what std::shuffle hands the loop), the reference's double bracket, replayed bit for bit by the
     tagged dataflow schedule (sgd_flow.hip; np.array_equal with the oracle at this size in tests/test_fullsize_gpu.py).
@@ -485,13 +485,39 @@ def exact_replay(np, ctx, mfx, tr, U0, V0, lr, ureg, ireg, epochs=3):
         info, _ = ctx.debug_levels_info()
     ctx.prof_enable(False)
     call_s, kern_s = float(np.median(calls)), float(np.median(kernels))
-    return {"path": "MFX_SGD_LEVELS, tagged dataflow schedule (order replay of ModelMF::train, double bracket): bit-identical to the "
+    hybrid = None
+    if hybrid_too:
+        # the same epochs with hybrid ownership (MFX_FLOW_HYBRID=1: the busiest users get queues of their own; queues built on the host, so
+        # only the kernel time is comparable -- DESIGN.md section 8)
+        try:
+            os.environ["MFX_FLOW_HYBRID"] = "1"
+            ctx.set_factors(U0, V0)
+            ctx.prof_enable(True)
+            hk = []
+            for ep in range(2):
+                ctx.sgd_set_order(rng.permutation(tr.nnz).astype(np.uint64))
+                ctx.synchronize()
+                ctx.prof_reset()
+                ctx.sgd_epoch(lr, ureg, ireg, mode=mfx.SGD_LEVELS, order=mfx.ORDER_HOST, arith=mfx.ARITH_REF64)
+                ctx.synchronize()
+                hk.append(ctx.prof_get(mfx.K_SGD)[0] * 1e-3)
+            ctx.prof_enable(False)
+            hinfo, _ = ctx.debug_levels_info()
+            hybrid = {"kernel_ms_per_epoch": float(min(hk)) * 1e3, "kernel_updates_per_s": tr.nnz / float(min(hk)), "longest_queue": int(hinfo[1]),
+                      "note": "MFX_FLOW_HYBRID=1, opt-in: bit-identical (tests/test_sgd_gpu.py); queues built on the host (0.4 s per epoch), not the default"}
+        except Exception as e:                  # noqa: BLE001
+            hybrid = {"error": str(e)}
+        finally:
+            os.environ.pop("MFX_FLOW_HYBRID", None)
+    return {"hybrid_ownership": hybrid,
+            "path": "MFX_SGD_LEVELS, tagged dataflow schedule (order replay of ModelMF::train, double bracket): bit-identical to the "
                     "sequential loop", "updates_per_s": tr.nnz / call_s, "ms_per_epoch": call_s * 1e3,
             "kernel_updates_per_s": tr.nnz / kern_s, "kernel_ms_per_epoch": kern_s * 1e3, "epochs": epochs,
             "longest_queue": int(info[1]), "queues": int(info[2]),
             "frac_of_hbm_roofline_model": (16 * U0.shape[1] + 12) * tr.nnz / call_s / 1e9 / HBM_PEAK_GBS,
-            "bound": "the longest chain of the list (the most popular item's ratings are sequentially dependent): longest_queue visits x "
-                     "the latency of one visit, not bandwidth",
+            "bound": "hand-off chains: at C2 the busiest user's 10 717 ratings are 10 717 hand-offs between item queues at ~ 1.3 us (DESIGN.md 3.1.2, "
+                     "scripts/flow_model.py); with those users in queues of their own (hybrid_ownership) the most popular item's queue: longest_queue "
+                     "visits x the step of one visit -- latency, not bandwidth",
             "test_rmse_vs_reference": "rmse_parity.*.gpu_default_path_* (whole training loops against the fixture's seed-1 row)"}
 
 
