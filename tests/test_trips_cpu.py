@@ -168,7 +168,7 @@ def test_landing_registers_of_the_tagged_replay_are_never_copied():
                     if q and regs(q.group(1)) & touched:
                         ok = False
                         break
-                assert ok, (l[:70], n, b.strip())
+                assert ok is not False, (l[:70], n, b.strip())      # (None: the kernel's first instructions, nothing requested yet)
             # the pole path: accumulation registers only inside asm statements, LAP x C landing pairs, no scratch
             joined = "\n".join(body)
             outside = re.sub(r";;#ASMSTART\n.*?;;#ASMEND", "", joined, flags=re.S)
