@@ -948,9 +948,9 @@ def host_loop_ms(np, d, K, lr, ureg, ireg):
         return {"error": "the loops ended after %d and %d iterations" % (t[3][1], t[9][1])}
     ms = (t[9][0] - t[3][0]) / (t[9][1] - t[3][1]) * 1e3
     nnz = d["train"].nnz
-    return {"trainer": "ModelMF::train (order replay, the default up to 32 M train ratings)", "ms_per_iteration": ms,
-            "updates_per_s": nnz / (ms * 1e-3), "includes": "host shuffle of the epoch's order (a thread ahead), upload of the order, "
-            "replay, objective + validation RMSE and the termination rule of every iteration"}
+    return {"trainer": "ModelMF::train (order replay, the default up to 128 M train ratings)", "ms_per_iteration": ms,
+            "updates_per_s": nnz / (ms * 1e-3), "includes": "the positions of the epoch's std::shuffle drawn on the host (a thread ahead), their "
+            "upload, the swaps applied on the device, the replay, objective + validation RMSE and the termination rule of every iteration"}
 
 
 def host_train_rmse(C, np, synth, d, cfg, env):
