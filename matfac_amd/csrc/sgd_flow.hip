@@ -1046,7 +1046,7 @@ __global__ __launch_bounds__(FL_WG, (FW<C>::WGS)) void sgd_flow_wide_kernel(cons
     const uint32_t exp_n = (uint32_t)__builtin_amdgcn_readlane(rec.w, s1_);                                           \
     bool okn_ = true;                                                                                                 \
     _Pragma("unroll") for (int c = 0; c < C; c++) okn_ = okn_ && tn_[c] == exp_n;                                     \
-    const bool needn_ = (S) + 1 < NB && __builtin_amdgcn_ballot_w64(okn_) != ~0ull;                                   \
+    const bool needn_ = (S) + 1 < nbp && __builtin_amdgcn_ballot_w64(okn_) != ~0ull;                                  \
     /* (2) the visit: other side's row gathered per quad, the chain, the reference's bracket */                      \
     float g_[C][4];                                                                                                   \
     _Pragma("unroll") for (int c = 0; c < C; c++) {                                                                   \
@@ -1063,10 +1063,10 @@ __global__ __launch_bounds__(FL_WG, (FW<C>::WGS)) void sgd_flow_wide_kernel(cons
           fw_store2(dt, stb_ + (uint32_t)(c * 512), uint2v{__float_as_uint(tvc[c]), exp_c + 1u});                     \
       const int sn_ = (S) + LAP;                                                                                      \
       const int rxq_ = __builtin_amdgcn_readlane(rec.x, sn_ & 63);                                                    \
-      fwa_request<K, C>(dt, sn_ < NB ? (uint32_t)rxq_ * (uint32_t)(8 * LD) + g_off : FL_OOB);                         \
+      fwa_request<K, C>(dt, sn_ < nbp ? (uint32_t)rxq_ * (uint32_t)(8 * LD) + g_off : FL_OOB);                        \
     }                                                                                                                 \
     /* (5) */                                                                                                         \
-    if (needn_ && !aborted) { FL_STAT(1, 1); FLW_T0 FWP_POLL(K1, rx_n, exp_n, vn_) FLW_T1(6) }                        \
+    if (__builtin_expect(needn_ && !aborted, 0)) { FL_STAT(1, 1); FLW_T0 FWP_POLL(K1, rx_n, exp_n, vn_) FLW_T1(6) }   \
     _Pragma("unroll") for (int c = 0; c < C; c++) tvc[c] = __uint_as_float(vn_[c]);                                   \
     rx_c = rx_n; rz_c = rz_n; exp_c = exp_n;                                                                          \
   }
@@ -1122,7 +1122,7 @@ __global__ __launch_bounds__(FL_WG, (FW<C>::WGS)) void sgd_flow_wide_kernel(cons
     if (!aborted) {                                                                                                   \
       FWP_ROUND(0, true)                                                                                              \
       _Pragma("clang loop unroll(disable)")                                                                           \
-      for (int s0 = LAP; s0 < NB && !aborted; s0 += LAP) FWP_ROUND(s0, false)                                         \
+      for (int s0 = LAP; s0 < nbp && !aborted; s0 += LAP) FWP_ROUND(s0, false)                                        \
     }                                                                                                                 \
     { FLW_T0 asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); FLW_T1(7) }   /* nothing in flight into a0 .. a31 when the block is left */ \
   }
@@ -1139,19 +1139,22 @@ __global__ __launch_bounds__(FL_WG, (FW<C>::WGS)) void sgd_flow_wide_kernel(cons
       const unsigned long long pm = __builtin_amdgcn_ballot_w64(lane < nb && (qav & 1u));
       if (pm) { nb = min(nb, (int)__builtin_ctzll(pm) + 1); pub_end = true; }
     }
-    // a pole block: 64 records, one owned row (nothing of it touches the landing registers Tr of the generic steps)
+    // a pole block: records that all visit ONE owned row, as many of them as whole rounds of LAP steps (the rest of a block that a
+    // publication or the queue's end cut short follows as a block of its own through the generic steps); nothing of it touches the
+    // landing registers Tr of the generic steps
     const int ry0 = __builtin_amdgcn_readfirstlane(rec.y);
-    if ((own_flags & 4) && nb == NB && __builtin_amdgcn_ballot_w64(rec.y == ry0) == ~0ull) {
+    const int nbp = nb / LAP * LAP;
+    if ((own_flags & 4) && nbp >= LAP && __builtin_amdgcn_ballot_w64(lane >= nbp || rec.y == ry0) == ~0ull) {
       const uint32_t ka0 = HYB ? (uint32_t)__builtin_amdgcn_readfirstlane((int)qav) >> 1 : 0u;
       OWN_SWITCH(ry0, ka0)          // the owned-row switch of FW_STEP, once for the block
       if (own_user) FWP_BLOCK(true) else FWP_BLOCK(false)
-      cur_ver = ka0 + (uint32_t)NB;
-      if (HYB && pub_end && !aborted) {       // the row's next visit lies in another queue: written back with its version, dropped from the cache
+      cur_ver = ka0 + (uint32_t)nbp;
+      if (HYB && pub_end && nbp == nb && !aborted) {     // the row's next visit lies in another queue: written back with its version, dropped from the cache
         OWN_PUT(cur_row, cur_ver, [&](int c) { return ov[c]; })
         if (lane == 0) qt[cur_slot] = -1;
         cur_row = -1;
       }
-      pos += (uint32_t)nb;
+      pos += (uint32_t)nbp;
       continue;
     }
 #pragma unroll

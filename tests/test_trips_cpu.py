@@ -172,7 +172,11 @@ def test_landing_registers_of_the_tagged_replay_are_never_copied():
             # the pole path: accumulation registers only inside asm statements, LAP x C landing pairs, no scratch
             joined = "\n".join(body)
             outside = re.sub(r";;#ASMSTART\n.*?;;#ASMEND", "", joined, flags=re.S)
-            assert not [x for x in outside.split("\n") if re.search(r"\ba\d+\b|\ba\[\d+", x) and not x.strip().startswith(";")], l[:70]
+            # (the compiler may park values of its own in accumulation registers ABOVE the landing ones: a32.. in the hybrid C = 4 kernel)
+            nland = 2 * lap * C
+            mine = [x for x in outside.split("\n") if not x.strip().startswith(";")
+                    and any(int(a) < nland for a in re.findall(r"\ba\[?(\d+)", x))]
+            assert not mine, (l[:70], mine[:4])
             pairs = set(re.findall(r"buffer_load_dwordx2 (a\[\d+:\d+\])", joined))
             assert len(pairs) == lap * C, (l[:70], sorted(pairs))
             assert "scratch_" not in joined
