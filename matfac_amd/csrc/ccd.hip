@@ -17,15 +17,17 @@
 // is staged in LDS.
 #include <algorithm>
 
-#include "mfx_internal.h"
+#include "ccd_blocks.h"
 
 void mfx_ccd_free_internal(mfx_ctx* ctx) {
   dev_free(ctx->res_row); dev_free(ctx->res_col); dev_free(ctx->uk); dev_free(ctx->vk);
   dev_free(ctx->uk_pend); dev_free(ctx->vk_pend);
   ctx->ccd_pending = false;
-  dev_free(ctx->ccd_part); dev_free(ctx->colid); dev_free(ctx->ccd_ind16); mfx_trips_free(ctx->ccd_trips); dev_free(ctx->ccd_gptr); dev_free(ctx->ccd_single);
-  ctx->ccd_nsingle = 0;
-  ctx->ccd_ngroups = 0;
+  dev_free(ctx->ccd_part); dev_free(ctx->colid); dev_free(ctx->ccd_ind16); dev_free(ctx->ccd_ind32); dev_free(ctx->ccd_rowid); dev_free(ctx->ccd_rpos);
+  dev_free(ctx->ccd_rfirst); dev_free(ctx->ccd_rcnt); dev_free(ctx->ccd_lrow);
+  mfx_blocks_free(ctx->ccd_blocks);
+  ctx->ccd_nnzp = 0;
+  ctx->ccd_nlrow = 0;
   mfx_ccd_cols_free(ctx);
   ctx->ccd_part_cap = 0;
   ctx->ccd_active = false;
@@ -57,7 +59,7 @@ __global__ void store_col_kernel(float* __restrict__ X, int32_t n, float* __rest
   else if (t - n < m) Y[(t - n) * ld + k] = yk[t - n];
 }
 
-// res[e] (+/-)= a[rowOf[e]] * b[colOf[e]]   -- float product, then float add/sub.
+// res[e] (+/-)= a[rowOf[e]] * b[colOf[e]]   -- float product, then float add/sub.  ia: the row of every EIGHT entries of the padded view.
 // Streaming: 16 bytes per lane per array (4 ratings per thread), the two factor vectors are L2 resident.
 // LDSB: the vector b (v_k in the row view) is first staged in LDS -- a 4-byte gather from L2 moves a whole
 // 128-byte line, which made these kernels L2-bandwidth-bound; from LDS the gather is free.
@@ -77,23 +79,43 @@ __device__ __forceinline__ void stage_vector(const float* __restrict__ v, int n)
 // the streaming kernels move 2 instead of 4 bytes per entry for them (ctx->ccd_ind16, made once by mfx_ccdpp_begin).
 template <bool LDS> struct ItemIdx { typedef int32_t type; };
 template <> struct ItemIdx<true> { typedef uint16_t type; };
-__global__ void narrow_ids_kernel(const int32_t* __restrict__ src, int64_t n, uint16_t* __restrict__ dst) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) dst[t] = (uint16_t)src[t];
+// The padded row view (ccd_blocks.h): row r copied to [rpos[r], rpos[r+1]), the padding entries behind it with residual 0 and the id
+// `zero_id` (the +0.0 slot behind v_k); then the tail of the last trip and the slack the pass loop may read.  rowid holds the row of
+// every EIGHT entries (rows start on multiples of 8): the residual kernels read 0.5 instead of 4 bytes of it per entry.
+template <typename IdxT>
+__global__ __launch_bounds__(256) void rowview_build_kernel(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ rowind,
+                                                            const float* __restrict__ rowval, const int64_t* __restrict__ rpos,
+                                                            int32_t nrows, int zero_id, int64_t nnzp, int64_t nalloc,
+                                                            float* __restrict__ res, IdxT* __restrict__ ids, int32_t* __restrict__ rowid) {
+  const int j = threadIdx.x & 15;
+  const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
+  for (int64_t r = grp; r < nrows; r += ngrp) {
+    const int64_t src = rowptr[r], n = rowptr[r + 1] - src, d = rpos[r], np = rpos[r + 1] - d;
+    for (int64_t t = j; t < np; t += 16) {
+      const bool real = t < n;
+      res[d + t] = real ? rowval[src + t] : 0.0f;
+      ids[d + t] = (IdxT)(real ? rowind[src + t] : zero_id);
+      if ((t & 7) == 0) rowid[(d + t) >> 3] = (int32_t)r;
+    }
+  }
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = rpos[nrows] + tid; t < nalloc; t += nth) {
+    res[t] = 0.0f;
+    ids[t] = (IdxT)zero_id;
+    if (t < nnzp && (t & 7) == 0) rowid[t >> 3] = nrows > 0 ? nrows - 1 : 0;
+  }
 }
-
-// a[x[0..3]] for four CONSECUTIVE entries of the row view: their rows ascend, and with ~200 entries per row a quad almost always
-// lies in one row or two.  Two gathers (first and last entry) serve it then; an entry whose row is neither (rows of one or two
-// entries) takes its own.  (A 4-byte gather occupies the vector memory pipe like a 16-byte load: four of them per quad were
-// half of this kernel's memory instructions.)
-typedef int mfx_i4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void gather_sorted4(const float* __restrict__ a, mfx_i4 x, float (&o)[4]) {
-  o[0] = a[x[0]];
-  o[3] = a[x[3]];
-  o[1] = x[1] == x[0] ? o[0] : o[3];
-  o[2] = x[2] == x[0] ? o[0] : o[3];
-  if (x[1] != x[0] && x[1] != x[3]) o[1] = a[x[1]];
-  if (x[2] != x[0] && x[2] != x[3]) o[2] = a[x[2]];
+// test hook: the padded residuals back in CSR order
+__global__ __launch_bounds__(256) void rowview_export_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict__ rpos, int32_t nrows,
+                                                             const float* __restrict__ res, float* __restrict__ out) {
+  const int j = threadIdx.x & 15;
+  const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
+  for (int64_t r = grp; r < nrows; r += ngrp) {
+    const int64_t src = rowptr[r], n = rowptr[r + 1] - src, d = rpos[r];
+    for (int64_t t = j; t < n; t += 16) out[src + t] = res[d + t];
+  }
 }
 
 template <int SIGN, bool LDSB>
@@ -107,21 +129,16 @@ __global__ __launch_bounds__(1024) void resid_update_kernel(float* __restrict__ 
   const float* b = LDSB ? ccd_lds : bg;
   const int64_t n4 = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride) {
-    const i4 x = ((const i4*)ia)[q], y = MfxCcdTrip::load4(ib + 4 * q);
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride) {     // (n is a multiple of 128)
+    const i4 y = MfxCcdTrip::load4(ib + 4 * q);
     f4 r = ((const f4*)res)[q];
-    float au[4];
-    gather_sorted4(a, x, au);
+    const float au = a[ia[q >> 1]];          // four consecutive entries of the padded view lie in ONE row
 #pragma unroll
     for (int e = 0; e < 4; e++) {
-      const float prod = au[e] * b[y[e]];
+      const float prod = au * b[y[e]];
       r[e] = SIGN > 0 ? r[e] + prod : r[e] - prod;
     }
     ((f4*)res)[q] = r;
-  }
-  for (int64_t e = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
-    const float prod = a[ia[e]] * b[ib[e]];
-    res[e] = SIGN > 0 ? res[e] + prod : res[e] - prod;
   }
 }
 
@@ -135,103 +152,103 @@ __global__ __launch_bounds__(1024) void resid_fused_kernel(float* __restrict__ r
                                                            int nb, int64_t n) {
   typedef float f4 __attribute__((ext_vector_type(4)));
   typedef int i4 __attribute__((ext_vector_type(4)));
+  const int nbs = (nb + 4) & ~3;            // stride of the two staged vectors: nb values and the +0.0 the padding entries gather
   if (LDSB) {
     const int n4 = nb >> 2;
     for (int q = threadIdx.x; q < n4; q += blockDim.x) {
       ((f4*)ccd_lds)[q] = ((const f4*)b0g)[q];
-      ((f4*)(ccd_lds + ((nb + 3) & ~3)))[q] = ((const f4*)b1g)[q];
+      ((f4*)(ccd_lds + nbs))[q] = ((const f4*)b1g)[q];
     }
     for (int q = (n4 << 2) + threadIdx.x; q < nb; q += blockDim.x) {
       ccd_lds[q] = b0g[q];
-      ccd_lds[((nb + 3) & ~3) + q] = b1g[q];
+      ccd_lds[nbs + q] = b1g[q];
     }
+    if (threadIdx.x == 0) { ccd_lds[nb] = 0.0f; ccd_lds[nbs + nb] = 0.0f; }
     __syncthreads();
   }
   const float* b0 = LDSB ? ccd_lds : b0g;
-  const float* b1 = LDSB ? ccd_lds + ((nb + 3) & ~3) : b1g;
+  const float* b1 = LDSB ? ccd_lds + nbs : b1g;
   const int64_t n4 = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride) {
-    const i4 x = ((const i4*)ia)[q], y = MfxCcdTrip::load4(ib + 4 * q);
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride) {     // (n is a multiple of 128)
+    const i4 y = MfxCcdTrip::load4(ib + 4 * q);
     f4 r = ((const f4*)res)[q];
-    float au0[4], au1[4];
-    gather_sorted4(a0, x, au0);
-    gather_sorted4(a1, x, au1);
+    const int row = ia[q >> 1];              // four consecutive entries of the padded view lie in ONE row
+    const float au0 = a0[row], au1 = a1[row];
 #pragma unroll
     for (int e = 0; e < 4; e++) {
-      const float p0 = au0[e] * b0[y[e]];
-      const float p1 = au1[e] * b1[y[e]];
+      const float p0 = au0 * b0[y[e]];
+      const float p1 = au1 * b1[y[e]];
       r[e] = (r[e] - p0) + p1;
     }
     ((f4*)res)[q] = r;
   }
-  for (int64_t e = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride)
-    res[e] = (res[e] - a0[ia[e]] * b0[ib[e]]) + a1[ia[e]] * b1[ib[e]];
 }
 
 __device__ __forceinline__ double group16_sum(double v) { return mfx_row16_sum(v); }
 
-// Row pass: one 16-lane group per range of the trip list (mfx_ccd_trip_loop).  meta of a trip = the slot of the segment's
-// (num, den) pair: rows with several segments first (RowSegs::seg_slab), then one slot per single-segment row.  The quotient
-// is taken by the finishing kernels: a double division is ~35 instructions, and with four groups per wavefront three steps out
-// of four end a segment somewhere in the wave -- it was a quarter of the pass.  (trainCCDPPFreqAdap's rule applies to items
-// only: modelMF.cpp:1336-1342 -- the row pass never sees a threshold.)
-constexpr int ROW_TRIP_E = 128;      // entries per trip of the row view: 8 per lane (mfx_internal.h)
-template <bool LDSO, bool BUF>
-__global__ __launch_bounds__(1024) void ccd_pass_kernel(const MfxTrips trips, const int32_t* __restrict__ gptr, int ngroups,
-                                                       const float* __restrict__ res,
-                                                       const typename ItemIdx<LDSO>::type* __restrict__ ind, uint32_t res_bytes,
-                                                       const float* __restrict__ otherg, int nother, double* __restrict__ part) {
+// Row pass: workgroup w works through window w of the padded row view (ccd_blocks.h), v_k staged in LDS when it fits.  The quotient
+// is taken by the finishing kernel: a double division is ~35 instructions.  (trainCCDPPFreqAdap's rule applies to items only:
+// modelMF.cpp:1336-1342 -- the row pass never sees a threshold.)
+template <bool LDSO>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void ccd_pass_kernel(const int2* __restrict__ rec, const int32_t* __restrict__ wg_t0,
+                                                       const int32_t* __restrict__ wg_n, const int64_t* __restrict__ wg_rec,
+                                                       const int32_t* __restrict__ wg_stride, const float* __restrict__ res,
+                                                       const typename ItemIdx<LDSO>::type* __restrict__ ind,
+                                                       const float* __restrict__ otherg, int nother, double* __restrict__ part,
+                                                       uint32_t part_bytes) {
   if (LDSO) stage_vector(otherg, nother);
-  const float* other = LDSO ? ccd_lds : otherg;
-  const int j = threadIdx.x & 15;
-  const int grp = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
-  if (grp >= ngroups) return;
-  // (the global vectors of a CCD++ session carry one more element, +0.0: mfx_ccdpp_begin)
-  mfx_ccd_trip_loop<BUF, ROW_TRIP_E / 16>(trips, gptr[grp], gptr[grp + 1], res, ind, res_bytes, other, nother, j, part);
+  const float* other = LDSO ? ccd_lds : otherg;   // (the global vectors of a CCD++ session carry one more element, +0.0: mfx_ccdpp_begin)
+  const int j = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int w = blockIdx.x, wn = wg_n[w];
+  const int64_t e0 = (int64_t)wg_t0[w] * MFX_BLK_E;
+  mfx_ccd_block_loop<typename ItemIdx<LDSO>::type>(rec + wg_rec[w], wn, wg_stride[w], g, res + e0, ind + e0, other, j, part, part_bytes);
 }
 
-// The quotients of a row pass, ONE launch: the first `dblocks` workgroups take the single-segment rows (u_k[row] = num / (reg +
-// den) from the row's slot, one thread each); the others the rows with several segments -- partials summed by a 16-lane
-// group, lane-strided in segment order then a fixed butterfly (a single thread walking ~100 partials made this 57 us launch
-// 13 % of a factor).
-__global__ __launch_bounds__(256) void ccd_finish_kernel(const int32_t* __restrict__ single, int64_t nsingle, const double* __restrict__ spart,
-                                                         int dblocks, const int32_t* __restrict__ mrow,
-                                                         const int32_t* __restrict__ mrow_first,
-                                                         const int32_t* __restrict__ mrow_n, int64_t nmrow,
-                                                         const double* __restrict__ part, float reg,
-                                                         float* __restrict__ mine, const int64_t* __restrict__ ptr,
-                                                         float freq_thresh, int k) {
+// The quotients of a row pass, ONE launch: the first `dblocks` workgroups one thread per row -- u_k[row] = num / (reg + den) over the
+// row's pieces in order (at most 32: 4 096 entries) --, the others one 16-lane group per LONG row: pieces lane-strided in order, then
+// a fixed butterfly (a single thread walking ~400 partials of a 50 k-rating row was 13 % of a factor in round 1).
+__global__ __launch_bounds__(256) void ccd_finish_kernel(const int32_t* __restrict__ rfirst, const int32_t* __restrict__ rcnt, int32_t nrows,
+                                                         int dblocks, const int32_t* __restrict__ lrow, int64_t nlrow,
+                                                         const double* __restrict__ part, float reg, float* __restrict__ mine) {
   if ((int)blockIdx.x < dblocks) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nsingle) mine[single[i]] = (float)(spart[2 * i] / ((double)reg + spart[2 * i + 1]));
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    const int n = rcnt[r];
+    if (n == 0 || n > 32) return;           // a row without ratings keeps uFac(r, k) (modelMF.cpp:1063-1065)
+    const double* p = part + 2 * (int64_t)rfirst[r];
+    double num = p[0], den = p[1];
+    for (int s = 1; s < n; s++) { num += p[2 * s]; den += p[2 * s + 1]; }
+    mine[r] = (float)(num / ((double)reg + den));
     return;
   }
   const int j = threadIdx.x & 15;
   const int64_t m = ((int64_t)((int)blockIdx.x - dblocks) * blockDim.x + threadIdx.x) >> 4;
-  if (m >= nmrow) return;
+  if (m >= nlrow) return;
+  const int row = lrow[m];
   double num = 0.0, den = 0.0;
-  const int first = mrow_first[m], n = mrow_n[m];
+  const int first = rfirst[row], n = rcnt[row];
   for (int s = j; s < n; s += 16) {
     num += part[2 * (int64_t)(first + s)];
     den += part[2 * (int64_t)(first + s) + 1];
   }
   num = group16_sum(num);
   den = group16_sum(den);
-  if (j != 0) return;
-  const int row = mrow[m];
-  float v = (float)(num / ((double)reg + den));
-  if (freq_thresh >= 0.0f) {
-    const double freq = (double)(ptr[row + 1] - ptr[row]);
-    if (freq < (double)freq_thresh && k > 0) v = 0.0f;
-  }
-  mine[row] = v;
+  if (j == 0) mine[row] = (float)(num / ((double)reg + den));
 }
 
 constexpr size_t LDS_BUDGET = 160 * 1024;
 static bool lds_fits(size_t bytes) { return bytes > 0 && bytes <= 150 * 1024; }
 static hipError_t set_lds(mfx_ctx*, const void* fn, size_t bytes) {
   return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+template <typename T>
+static int up_vec(mfx_ctx* ctx, T** dst, const std::vector<T>& v) {
+  int rc = dev_alloc(ctx, dst, v.size());
+  if (rc) return rc;
+  if (!v.empty()) HIPCHK(hipMemcpy(*dst, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
+  return MFX_OK;
 }
 
 extern "C" int mfx_ccdpp_begin(mfx_ctx* ctx) {
@@ -243,8 +260,6 @@ extern "C" int mfx_ccdpp_begin(mfx_ctx* ctx) {
   HIPCHK(hipSetDevice(ctx->device));
   mfx_ccd_free_internal(ctx);
   int rc;
-  const size_t nnz = (size_t)m.nnz;
-  if ((rc = dev_alloc(ctx, &ctx->res_row, nnz))) return rc;
   // u_k, v_k and the pending pair: one more element each, +0.0, which masked entries of the pass loop gather
   if ((rc = dev_alloc(ctx, &ctx->uk, (size_t)ctx->nU + 1))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->vk, (size_t)ctx->nI + 1))) return rc;
@@ -254,75 +269,65 @@ extern "C" int mfx_ccdpp_begin(mfx_ctx* ctx) {
   HIPCHK(hipMemsetAsync(ctx->vk + ctx->nI, 0, sizeof(float), ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->uk_pend + ctx->nU, 0, sizeof(float), ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->vk_pend + ctx->nI, 0, sizeof(float), ctx->stream));
-  // res = gk_csr_Dup(trainMat) (modelMF.cpp:1013): both value arrays
-  if (nnz) {
-    HIPCHK(hipMemcpyAsync(ctx->res_row, m.rowval, sizeof(float) * nnz, hipMemcpyDeviceToDevice, ctx->stream));
+  // res = gk_csr_Dup(trainMat) (modelMF.cpp:1013): both value arrays.  The row view is PADDED (ccd_blocks.h): every row starts on
+  // a multiple of 8 entries, the view ends on a multiple of 128 and has MFX_BLK_SLACK readable entries behind it.
+  std::vector<int64_t> rowptr((size_t)m.nrows + 1, 0), rpos((size_t)m.nrows + 1, 0);
+  if (m.nrows > 0) HIPCHK(hipMemcpy(rowptr.data(), m.rowptr, sizeof(int64_t) * rowptr.size(), hipMemcpyDeviceToHost));
+  std::vector<MfxPiece> pieces;
+  std::vector<int32_t> prow;
+  pieces.reserve((size_t)m.nrows);
+  prow.reserve((size_t)m.nrows);
+  for (int32_t r = 0; r < m.nrows; r++) {
+    const int64_t n = rowptr[(size_t)r + 1] - rowptr[(size_t)r];
+    rpos[(size_t)r + 1] = rpos[(size_t)r] + ((n + MFX_BLK_EPL - 1) & ~(int64_t)(MFX_BLK_EPL - 1));
+    if (n > 0) { pieces.push_back(MfxPiece{rpos[(size_t)r], rpos[(size_t)r + 1]}); prow.push_back(r); }
   }
-  HIPCHK(hipMemsetAsync(ctx->res_row + nnz, 0, MFX_ALLOC_PAD, ctx->stream));   // the pad behind the residuals is read (masked) by the pass loop: finite
-  if (nnz && lds_fits(((size_t)ctx->nI + 1) * sizeof(float))) {
-    if ((rc = dev_alloc(ctx, &ctx->ccd_ind16, nnz))) return rc;
-    hipLaunchKernelGGL(narrow_ids_kernel, dim3(2048), dim3(256), 0, ctx->stream, m.rowind, (int64_t)nnz, ctx->ccd_ind16);
-    HIPCHK(hipGetLastError());
-  }
+  const int64_t nnzp = (rpos[(size_t)m.nrows] + MFX_BLK_E - 1) / MFX_BLK_E * MFX_BLK_E, nalloc = nnzp + MFX_BLK_SLACK;
+  ctx->ccd_nnzp = nnzp;
+  NEED(nnzp / MFX_BLK_E < ((int64_t)1 << 31), MFX_E_ARG, "mfx_ccdpp_begin: too many trips");
+  const bool ids16 = lds_fits(((size_t)ctx->nI + 1) * sizeof(float)) && ctx->nI < 65536;
+  if ((rc = dev_alloc(ctx, &ctx->res_row, (size_t)nalloc))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->ccd_rowid, (size_t)(nnzp / MFX_BLK_EPL)))) return rc;
+  if ((rc = up_vec(ctx, &ctx->ccd_rpos, rpos))) return rc;
+  if (ids16) { if ((rc = dev_alloc(ctx, &ctx->ccd_ind16, (size_t)nalloc))) return rc; }
+  else if ((rc = dev_alloc(ctx, &ctx->ccd_ind32, (size_t)nalloc))) return rc;
+  if (ids16)
+    hipLaunchKernelGGL(rowview_build_kernel<uint16_t>, dim3(2048), dim3(256), 0, ctx->stream, m.rowptr, m.rowind, m.rowval, ctx->ccd_rpos, m.nrows,
+                       ctx->nI, nnzp, nalloc, ctx->res_row, ctx->ccd_ind16, ctx->ccd_rowid);
+  else
+    hipLaunchKernelGGL(rowview_build_kernel<int32_t>, dim3(2048), dim3(256), 0, ctx->stream, m.rowptr, m.rowind, m.rowval, ctx->ccd_rpos, m.nrows,
+                       ctx->nI, nnzp, nalloc, ctx->res_row, ctx->ccd_ind32, ctx->ccd_rowid);
+  HIPCHK(hipGetLastError());
   // the column view (res->colval) lives in user-strip-major order: ccd_cols.hip
   if ((rc = mfx_ccd_cols_build(ctx))) return rc;
   // uFac.fill(0) (modelMF.cpp:1020)
   HIPCHK(hipMemsetAsync(ctx->U, 0, sizeof(float) * (size_t)ctx->nU * ctx->ld, ctx->stream));
-  RowSegs* sg;
-  if ((rc = mfx_get_segments(ctx, 0, &sg))) return rc;
-  // the row view's trip list: segments in memory order (a trip's aligned 128 entries overlap its neighbours' -- adjacent in
-  // time they hit in L2), cut into one range per group of the launch
-  if (sg->nseg > 0) {
-    std::vector<int64_t> sb((size_t)sg->nseg), se((size_t)sg->nseg);
-    std::vector<int32_t> srow((size_t)sg->nseg), sslab((size_t)sg->nseg);
-    HIPCHK(hipMemcpyAsync(sb.data(), sg->seg_beg, sizeof(int64_t) * sb.size(), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(se.data(), sg->seg_end, sizeof(int64_t) * se.size(), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(srow.data(), sg->seg_row, sizeof(int32_t) * srow.size(), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(sslab.data(), sg->seg_slab, sizeof(int32_t) * sslab.size(), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    std::vector<int32_t> order((size_t)sg->nseg);
-    for (size_t q = 0; q < order.size(); q++) order[q] = (int32_t)q;
-    std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return sb[x] < sb[y]; });
-    std::vector<int4> trips;
-    std::vector<int32_t> gptr, single;
-    std::vector<MfxSeg> segs;
-    segs.reserve(order.size());
-    int64_t ntrips = 0;
-    for (int32_t q : order) {
-      NEED(se[q] - sb[q] <= MFX_SEG, MFX_E_STATE, "mfx_ccdpp_begin: a segment longer than %d", MFX_SEG);
-      int32_t slot = sslab[q];
-      if (slot < 0) { slot = (int32_t)(sg->nslab + (int64_t)single.size()); single.push_back(srow[q]); }
-      segs.push_back(MfxSeg{sb[q], se[q], slot});
-      ntrips += mfx_seg_trips(segs.back(), ROW_TRIP_E);
-    }
-    NEED(sg->nslab + (int64_t)single.size() < ((int64_t)1 << 31), MFX_E_ARG, "mfx_ccdpp_begin: too many segments");
-    if ((rc = dev_alloc(ctx, &ctx->ccd_single, single.size()))) return rc;
-    if (!single.empty()) HIPCHK(hipMemcpy(ctx->ccd_single, single.data(), sizeof(int32_t) * single.size(), hipMemcpyHostToDevice));
-    ctx->ccd_nsingle = (int64_t)single.size();
-    if (sg->nslab + ctx->ccd_nsingle > ctx->ccd_part_cap) {
-      dev_free(ctx->ccd_part);
-      if ((rc = dev_alloc(ctx, &ctx->ccd_part, (size_t)(sg->nslab + ctx->ccd_nsingle) * 2))) return rc;
-      ctx->ccd_part_cap = sg->nslab + ctx->ccd_nsingle;
-    }
-    NEED(ntrips < ((int64_t)1 << 31), MFX_E_ARG, "mfx_ccdpp_begin: too many trips");
+  // the row pass: windows of the padded view, at least eight steps per group
+  {
+    MfxBlockPlan plan;
+    std::vector<int32_t> first(pieces.size()), cnt(pieces.size());
+    const int64_t ntr = nnzp / MFX_BLK_E;
     const char* we = getenv("MFX_CCD_ROW_WGS");
     const int max_wg = we && atoi(we) > 0 ? atoi(we) : 512;
-    const int nwg = (int)std::max<int64_t>(1, std::min<int64_t>((ntrips + 8 * 64 - 1) / (8 * 64), max_wg));   // at least eight trips per group
-    const int ng = nwg * 64;
-    trips.reserve((size_t)ntrips);
-    int64_t max_end = 0;
-    mfx_trips_layout(segs, 0, segs.size(), nwg, 64, ROW_TRIP_E, trips, gptr, &max_end);
-    gptr.push_back((int32_t)trips.size());
-    // whole trips are loaded from the residuals (4 bytes per entry) and from the ids (2 or 4): they must lie inside the allocations
-    static_assert((ROW_TRIP_E - 1) * sizeof(float) <= MFX_ALLOC_PAD, "a row-view trip must fit the allocation pad");
-    NEED(mfx_trips_fit(max_end, m.nnz, sizeof(float)) && mfx_trips_fit(max_end, m.nnz, sizeof(int32_t)), MFX_E_STATE,
-         "mfx_ccdpp_begin: a trip of the row view reads %lld entries behind the %lld of its arrays (allocation pad %zu bytes)",
-         (long long)(max_end - m.nnz), (long long)m.nnz, MFX_ALLOC_PAD);
-    if ((rc = mfx_trips_upload(ctx, trips, &ctx->ccd_trips))) return rc;
-    if ((rc = dev_alloc(ctx, &ctx->ccd_gptr, gptr.size()))) return rc;
-    HIPCHK(hipMemcpy(ctx->ccd_gptr, gptr.data(), sizeof(int32_t) * gptr.size(), hipMemcpyHostToDevice));
-    ctx->ccd_ngroups = ng;
+    const int nwg = (int)std::max<int64_t>(1, std::min<int64_t>((ntr + 8 * MFX_BLK_GPW - 1) / (8 * MFX_BLK_GPW), max_wg));
+    NEED(mfx_blocks_region(pieces.data(), pieces.size(), 0, nnzp, nwg, 0, plan, first.data(), cnt.data()), MFX_E_STATE,
+         "mfx_ccdpp_begin: the padded row view does not lay out (%lld entries, %zu rows with ratings)", (long long)nnzp, pieces.size());
+    std::vector<int32_t> rfirst((size_t)m.nrows, 0), rcnt((size_t)m.nrows, 0), lrow;
+    for (size_t k = 0; k < pieces.size(); k++) {
+      rfirst[(size_t)prow[k]] = first[k];
+      rcnt[(size_t)prow[k]] = cnt[k];
+      if (cnt[k] > 32) lrow.push_back(prow[k]);
+    }
+    if ((rc = mfx_blocks_upload(ctx, plan, &ctx->ccd_blocks))) return rc;
+    if ((rc = up_vec(ctx, &ctx->ccd_rfirst, rfirst)) || (rc = up_vec(ctx, &ctx->ccd_rcnt, rcnt)) || (rc = up_vec(ctx, &ctx->ccd_lrow, lrow))) return rc;
+    ctx->ccd_nlrow = (int64_t)lrow.size();
+    if (plan.nslots > ctx->ccd_part_cap) {
+      dev_free(ctx->ccd_part);
+      if ((rc = dev_alloc(ctx, &ctx->ccd_part, (size_t)plan.nslots * 2))) return rc;
+      ctx->ccd_part_cap = plan.nslots;
+    }
   }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   ctx->ccd_active = true;
   return MFX_OK;
 }
@@ -331,66 +336,56 @@ extern "C" int mfx_ccdpp_begin(mfx_ctx* ctx) {
 static int run_pass(mfx_ctx* ctx, int side, float reg, float freq_thresh, int k) {
   if (side == 1) return mfx_ccd_cols_pass(ctx, ctx->uk, ctx->vk, reg, freq_thresh, k);
   const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
-  RowSegs* sg;
-  int rc = mfx_get_segments(ctx, side, &sg);
-  if (rc) return rc;
-  const float* res = side == 0 ? ctx->res_row : ctx->res_col;
-  const int32_t* ind = side == 0 ? m.rowind : m.colind;
-  const float* other = side == 0 ? ctx->vk : ctx->uk;
-  float* mine = side == 0 ? ctx->uk : ctx->vk;
-  const int64_t* ptr = side == 0 ? m.rowptr : m.colptr;
-  const int nother = side == 0 ? ctx->nI : ctx->nU;
-  if (sg->nseg > 0) {
+  const MfxBlocks& B = ctx->ccd_blocks;
+  if (B.nwg > 0) {
     ProfScope ps(ctx, MFX_K_CCD_ROW);
-    const size_t lds = ((size_t)nother + 1) * sizeof(float);
-    const int blocks = (ctx->ccd_ngroups + 63) / 64;
-    const uint64_t rbytes = ((uint64_t)m.nnz + 64) * 4;             // buffer loads (lanes outside a segment skip their access) below 4 GB
-    const bool buf = rbytes < ((uint64_t)1 << 32) && !getenv("MFX_CCD_NOBUF");
-#define MFX_ROWPASS(LD, BF, LDSB, IND)                                                                                          \
-  hipLaunchKernelGGL((ccd_pass_kernel<LD, BF>), dim3(blocks), dim3(1024), LDSB, ctx->stream, ctx->ccd_trips, ctx->ccd_gptr, ctx->ccd_ngroups, \
-                     res, IND, (uint32_t)rbytes, other, nother, ctx->ccd_part)
-    if (lds_fits(lds)) {   // the gathered vector fits in LDS (items: C2 107 KB, C4 71 KB)
-      HIPCHK(set_lds(ctx, (const void*)ccd_pass_kernel<true, true>, lds));
-      HIPCHK(set_lds(ctx, (const void*)ccd_pass_kernel<true, false>, lds));
-      if (buf) MFX_ROWPASS(true, true, lds, (const uint16_t*)ctx->ccd_ind16);
-      else MFX_ROWPASS(true, false, lds, (const uint16_t*)ctx->ccd_ind16);
+    const size_t lds = ((size_t)ctx->nI + 1) * sizeof(float);
+    const uint32_t pbytes = (uint32_t)(B.nslots * 16);
+    if (ctx->ccd_ind16) {   // the gathered vector fits in LDS (items: C2 107 KB, C4 71 KB)
+      HIPCHK(set_lds(ctx, (const void*)ccd_pass_kernel<true>, lds));
+      hipLaunchKernelGGL(ccd_pass_kernel<true>, dim3(B.nwg), dim3(1024), lds, ctx->stream, B.rec, B.wg_t0, B.wg_n, B.wg_rec, B.wg_stride, ctx->res_row,
+                         (const uint16_t*)ctx->ccd_ind16, ctx->vk, ctx->nI, ctx->ccd_part, pbytes);
     } else {
-      if (buf) MFX_ROWPASS(false, true, 0, ind);
-      else MFX_ROWPASS(false, false, 0, ind);
+      hipLaunchKernelGGL(ccd_pass_kernel<false>, dim3(B.nwg), dim3(1024), 0, ctx->stream, B.rec, B.wg_t0, B.wg_n, B.wg_rec, B.wg_stride, ctx->res_row,
+                         (const int32_t*)ctx->ccd_ind32, ctx->vk, ctx->nI, ctx->ccd_part, pbytes);
     }
-#undef MFX_ROWPASS
+    HIPCHK(hipGetLastError());
+    const int dblocks = (m.nrows + 255) / 256;
+    const int fblocks = (int)((ctx->ccd_nlrow * 16 + 255) / 256);
+    hipLaunchKernelGGL(ccd_finish_kernel, dim3((unsigned)(dblocks + fblocks)), dim3(256), 0, ctx->stream, ctx->ccd_rfirst, ctx->ccd_rcnt, m.nrows,
+                       dblocks, ctx->ccd_lrow, ctx->ccd_nlrow, ctx->ccd_part, reg, ctx->uk);
     HIPCHK(hipGetLastError());
   }
-  if (ctx->ccd_nsingle > 0 || sg->nmrow > 0) {
-    const int dblocks = (int)((ctx->ccd_nsingle + 255) / 256);
-    const int fblocks = (int)((sg->nmrow * 16 + 255) / 256);
-    hipLaunchKernelGGL(ccd_finish_kernel, dim3((unsigned)(dblocks + fblocks)), dim3(256), 0, ctx->stream, ctx->ccd_single, ctx->ccd_nsingle,
-                       ctx->ccd_part + 2 * sg->nslab, dblocks, sg->mrow, sg->mrow_first, sg->mrow_n, sg->nmrow, ctx->ccd_part, reg, mine, ptr,
-                       freq_thresh, k);
-    HIPCHK(hipGetLastError());
-  }
+  (void)freq_thresh; (void)k;
   return MFX_OK;
 }
 
+template <int SIGN>
+static int run_resid_rows(mfx_ctx* ctx, const float* uk, const float* vk) {
+  const int64_t nnzp = ctx->ccd_nnzp;                     // the padded row view: its padding entries gather the +0.0 behind v_k and stay 0
+  const int blocks = (int)std::min<int64_t>((nnzp / 4 + 1023) / 1024 + 1, 256 * 2);
+  // row view: res_row[e] +-= u_k[rowid[e]] * v_k[rowind[e]] (v_k gathered: staged in LDS when it fits);
+  // column view: res_col[e] +-= u_k[colind[e]] * v_k[colid[e]] (u_k gathered from L2)
+  const size_t lds = ((size_t)ctx->nI + 1) * sizeof(float);
+  if (ctx->ccd_ind16) {
+    const int per_cu = (int)std::min<size_t>(2, LDS_BUDGET / lds);
+    HIPCHK(set_lds(ctx, (const void*)resid_update_kernel<SIGN, true>, lds));
+    hipLaunchKernelGGL((resid_update_kernel<SIGN, true>), dim3(std::min(blocks, 256 * per_cu)), dim3(1024), lds,
+                       ctx->stream, ctx->res_row, ctx->ccd_rowid, (const uint16_t*)ctx->ccd_ind16, uk, vk, ctx->nI, nnzp);
+  } else {
+    hipLaunchKernelGGL((resid_update_kernel<SIGN, false>), dim3(blocks), dim3(1024), 0, ctx->stream, ctx->res_row,
+                       ctx->ccd_rowid, ctx->ccd_ind32, uk, vk, ctx->nI, nnzp);
+  }
+  HIPCHK(hipGetLastError());
+  return MFX_OK;
+}
 template <int SIGN>
 static int run_resid(mfx_ctx* ctx, const float* uk, const float* vk) {
   const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
   if (m.nnz == 0) return MFX_OK;
   ProfScope ps(ctx, MFX_K_CCD_RESID);
-  const int blocks = (int)std::min<int64_t>((m.nnz / 4 + 1023) / 1024 + 1, 256 * 2);
-  // row view: res_row[e] +-= u_k[rowid[e]] * v_k[rowind[e]] (v_k gathered: staged in LDS when it fits);
-  // column view: res_col[e] +-= u_k[colind[e]] * v_k[colid[e]] (u_k gathered from L2)
-  const size_t lds = ((size_t)ctx->nI + 1) * sizeof(float);
-  if (lds_fits(lds)) {
-    const int per_cu = (int)std::min<size_t>(2, LDS_BUDGET / lds);
-    HIPCHK(set_lds(ctx, (const void*)resid_update_kernel<SIGN, true>, lds));
-    hipLaunchKernelGGL((resid_update_kernel<SIGN, true>), dim3(std::min(blocks, 256 * per_cu)), dim3(1024), lds,
-                       ctx->stream, ctx->res_row, m.rowid, (const uint16_t*)ctx->ccd_ind16, uk, vk, ctx->nI, m.nnz);
-  } else {
-    hipLaunchKernelGGL((resid_update_kernel<SIGN, false>), dim3(blocks), dim3(1024), 0, ctx->stream, ctx->res_row,
-                       m.rowid, m.rowind, uk, vk, ctx->nI, m.nnz);
-  }
-  HIPCHK(hipGetLastError());
+  int rc = run_resid_rows<SIGN>(ctx, uk, vk);
+  if (rc) return rc;
   return mfx_ccd_cols_resid(ctx, SIGN, uk, vk, nullptr, nullptr);
 }
 
@@ -399,15 +394,20 @@ static int run_resid_fused(mfx_ctx* ctx, const float* uk0, const float* vk0, con
   const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
   if (m.nnz == 0) return MFX_OK;
   ProfScope ps(ctx, MFX_K_CCD_RESID);
-  const int blocks = (int)std::min<int64_t>((m.nnz / 4 + 1023) / 1024 + 1, 256 * 2);
-  const size_t lds = 2 * (((size_t)ctx->nI + 3) & ~(size_t)3) * sizeof(float);
-  if (lds_fits(lds)) {
+  const int64_t nnzp = ctx->ccd_nnzp;
+  const int blocks = (int)std::min<int64_t>((nnzp / 4 + 1023) / 1024 + 1, 256 * 2);
+  const size_t lds = 2 * (((size_t)ctx->nI + 4) & ~(size_t)3) * sizeof(float);     // two vectors, each with its +0.0 slot
+  if (ctx->ccd_ind16 && lds_fits(lds)) {
     HIPCHK(set_lds(ctx, (const void*)resid_fused_kernel<true>, lds));
     hipLaunchKernelGGL(resid_fused_kernel<true>, dim3(std::min(blocks, 256)), dim3(1024), lds, ctx->stream,
-                       ctx->res_row, m.rowid, (const uint16_t*)ctx->ccd_ind16, uk0, vk0, uk1, vk1, ctx->nI, m.nnz);
+                       ctx->res_row, ctx->ccd_rowid, (const uint16_t*)ctx->ccd_ind16, uk0, vk0, uk1, vk1, ctx->nI, nnzp);
+  } else if (ctx->ccd_ind16) {                                // two item vectors do not fit in LDS (C2: 2 x 107 KB): two sweeps, same roundings
+    int rc = run_resid_rows<-1>(ctx, uk0, vk0);
+    if (rc) return rc;
+    if ((rc = run_resid_rows<+1>(ctx, uk1, vk1))) return rc;
   } else {
-    hipLaunchKernelGGL(resid_fused_kernel<false>, dim3(blocks), dim3(1024), 0, ctx->stream, ctx->res_row, m.rowid,
-                       m.rowind, uk0, vk0, uk1, vk1, ctx->nI, m.nnz);
+    hipLaunchKernelGGL(resid_fused_kernel<false>, dim3(blocks), dim3(1024), 0, ctx->stream, ctx->res_row, ctx->ccd_rowid,
+                       ctx->ccd_ind32, uk0, vk0, uk1, vk1, ctx->nI, nnzp);
   }
   HIPCHK(hipGetLastError());
   return mfx_ccd_cols_resid(ctx, 2, uk0, vk0, uk1, vk1);
@@ -469,9 +469,19 @@ extern "C" int mfx_debug_residuals(mfx_ctx* ctx, float* res_row, float* res_col)
   HIPCHK(hipSetDevice(ctx->device));
   { int rc = ccd_flush(ctx); if (rc) return rc; }
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  const size_t nnz = (size_t)ctx->mat[MFX_MAT_TRAIN].nnz;
+  const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
+  const size_t nnz = (size_t)m.nnz;
   if (nnz == 0) return MFX_OK;
-  if (res_row) HIPCHK(hipMemcpy(res_row, ctx->res_row, sizeof(float) * nnz, hipMemcpyDeviceToHost));
+  if (res_row) {                      // the padded view back in CSR order
+    float* tmp = nullptr;
+    int rc = dev_alloc(ctx, &tmp, nnz);
+    if (rc) return rc;
+    hipLaunchKernelGGL(rowview_export_kernel, dim3(2048), dim3(256), 0, ctx->stream, m.rowptr, ctx->ccd_rpos, m.nrows, ctx->res_row, tmp);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(res_row, tmp, sizeof(float) * nnz, hipMemcpyDeviceToHost);
+    dev_free(tmp);
+    if (e != hipSuccess) return mfx_fail(ctx, MFX_E_HIP, "mfx_debug_residuals: %s", hipGetErrorString(e));
+  }
   if (res_col) return mfx_ccd_cols_export(ctx, res_col);
   return MFX_OK;
 }

@@ -22,47 +22,44 @@
 #include <cstdlib>
 #include <vector>
 
-#include "mfx_internal.h"
+#include "ccd_blocks.h"
 
 namespace {
 constexpr int UB = 8192;          // users per strip: 32 KB of u_k (two vectors fit for the fused update)
-constexpr int CSEG = 1024;        // entries per segment
 constexpr int LIGHT = 0;          // columns with at most this many entries are handled whole, outside the strips (MFX_CCD_LIGHT).
                                   // 0 since the trip lists: short (strip, column) pieces no longer cost per-segment latency, and the
                                   // light region's L2 gathers do (C4: 2.29 vs 2.40 ms per factor at 1024, C2 shape 0.86 vs 0.89)
-constexpr int GPW = 64;            // 16-lane groups per pass workgroup (1024 threads)
-constexpr int COL_TRIP_E = 64;     // entries per trip of the column view: 4 per lane (mfx_internal.h)
+constexpr int GPW = MFX_BLK_GPW;   // 16-lane groups per pass workgroup (1024 threads)
 constexpr int PASS_WGS = 1024;    // pass workgroups over all strips (two rounds of the 512 resident ones; MFX_CCD_PASS_WGS)
 constexpr int64_t ENT_PER_WG = 128 * 1024;
 
 struct ColState {
   int nb = 0;                       // strips
-  int64_t nnz = 0;
+  int64_t nnz = 0;                  // entries of the matrix
+  int64_t nnzp = 0;                 // entries of the PADDED strip-major view (ccd_blocks.h): every (strip, column) piece starts on a multiple
+                                    // of 8, every strip (and the light region) on a multiple of 128
   int32_t* off = nullptr;           // [nI][nb+1] CSC position where strip b starts inside column i (relative to colptr[i])
-  int64_t* dst = nullptr;           // [nb][nI] blocked position of segment (b,i)
+  int64_t* dst = nullptr;           // [nb][nI] padded position of piece (b,i)
+  int32_t* plen = nullptr;          // [nb][nI] its padded length (light columns: of the whole column, at strip 0; 0 elsewhere)
   // Index widths (the kernels stream these arrays, so their width is a share of the time): a strip-local user id is below
-  // UB = 8192 -> 16 bits, always; the column id is 16 bits when there are at most 65 536 columns; the light region keeps absolute
-  // 32-bit user ids in its own array (entry t of the blocked order sits at luser[t - (light0 & ~63)]: 16-byte loads stay aligned).
-  uint16_t* buser = nullptr;        // blocked, strips only: user - b*UB
+  // UB = 8192 -> 16 bits, always (padding entries: UB, the +0.0 slot behind the staged strip); the column id is 16 bits when there are
+  // at most 65 536 columns; the light region keeps absolute 32-bit user ids in its own array (entry t of the padded order sits at
+  // luser[t - light0]; padding entries: nU, the +0.0 behind u_k).
+  uint16_t* buser = nullptr;        // strips only: user - b*UB
   int32_t* luser = nullptr;         // light region: absolute user id
-  uint16_t* bcol16 = nullptr;       // blocked: column id (ncols <= 65536) ...
+  uint16_t* bcol16 = nullptr;       // column id of every EIGHT entries (pieces start on multiples of 8), 16-bit for ncols <= 65536 ...
   int32_t* bcol32 = nullptr;        // ... or 32-bit
-  float* res = nullptr;             // blocked residual (the reference's res->colval in strip-major order)
-  // pass segments
-  int64_t* seg_beg = nullptr; int64_t* seg_end = nullptr; int32_t* seg_col = nullptr;
-  int64_t nseg = 0;
-  double* part = nullptr;           // [nseg][2]
+  float* res = nullptr;             // residual (the reference's res->colval in padded strip-major order)
+  double* part = nullptr;           // [slots][2]
   double* sums = nullptr;           // sharded runs: [ncols][2] (num, den) for the all-reduce
-  int32_t* col_ptr = nullptr;       // [nI+1] column -> its segments (strip-major order)
+  int32_t* col_ptr = nullptr;       // [nI+1] column -> its slots (strip-major order)
   int32_t* col_seg = nullptr;
-  // pass: trip list (mfx_ccd_trip_loop), one range per group; the groups of the light region first, then the strips'
-  // workgroups (GPW groups each, one strip each)
-  MfxTrips trips; int32_t* gptr = nullptr;
-  int32_t* pw_blk = nullptr; int npw = 0;      // strip of each pass workgroup
-  int ngl = 0;                                 // groups of the light region (they come first, then the npw * GPW strip groups)
+  int32_t* fin_order = nullptr;     // the columns by team size of colfinish_kernel: n16 with at most 64 slots, n64 with at most 512, the rest
+  int fin_n16 = 0, fin_n64 = 0, fin_n256 = 0;
+  MfxBlocks blocks;                 // the pass: the light region's workgroups first (tag -1), then the strips' (tag = strip)
+  int nlw = 0;                      // workgroups of the light region
   int32_t* rw_blk = nullptr; int64_t* rw_e0 = nullptr; int64_t* rw_e1 = nullptr; int nrw = 0;       // residual
-  int64_t light0 = 0;               // blocked position where the light columns start (== nnz: none)
-  int32_t lseg0 = 0, nlseg = 0;     // their segments (one per column) in the segment tables
+  int64_t light0 = 0, light1 = 0;   // padded positions of the light region (light0 == light1: none)
 };
 ColState* st(mfx_ctx* ctx) { return (ColState*)ctx->ccd_cols; }
 
@@ -78,10 +75,10 @@ int up(mfx_ctx* ctx, T** dst, const std::vector<T>& v) {
 void mfx_ccd_cols_free(mfx_ctx* ctx) {
   ColState* s = st(ctx);
   if (!s) return;
-  dev_free(s->off); dev_free(s->dst); dev_free(s->buser); dev_free(s->luser); dev_free(s->bcol16); dev_free(s->bcol32); dev_free(s->res);
-  dev_free(s->seg_beg); dev_free(s->seg_end); dev_free(s->seg_col); dev_free(s->part); dev_free(s->sums);
-  dev_free(s->col_ptr); dev_free(s->col_seg);
-  dev_free(s->pw_blk); mfx_trips_free(s->trips); dev_free(s->gptr);
+  dev_free(s->off); dev_free(s->dst); dev_free(s->plen); dev_free(s->buser); dev_free(s->luser); dev_free(s->bcol16); dev_free(s->bcol32); dev_free(s->res);
+  dev_free(s->part); dev_free(s->sums);
+  dev_free(s->col_ptr); dev_free(s->col_seg); dev_free(s->fin_order);
+  mfx_blocks_free(s->blocks);
   dev_free(s->rw_blk); dev_free(s->rw_e0); dev_free(s->rw_e1);
   delete s;
   ctx->ccd_cols = nullptr;
@@ -103,14 +100,16 @@ __global__ void strip_offsets_kernel(const int64_t* __restrict__ colptr, const i
   off[t] = (int32_t)(lo - beg);
 }
 
-// copy the (strip, column) pieces into strip-major order
+// copy the (strip, column) pieces into the padded strip-major order; the padding entries behind a piece: residual 0, the piece's
+// column, and the user id that gathers +0.0 (UB in a strip, nU in the light region)
 template <typename ColT>
 __global__ __launch_bounds__(256) void strip_scatter_kernel(const int64_t* __restrict__ colptr,
                                                             const int32_t* __restrict__ colind,
                                                             const float* __restrict__ colval,
                                                             const int32_t* __restrict__ off,
-                                                            const int64_t* __restrict__ dst, int32_t ncols, int nb,
-                                                            int64_t light0, uint16_t* __restrict__ buser,
+                                                            const int64_t* __restrict__ dst, const int32_t* __restrict__ plen,
+                                                            int32_t ncols, int nb, int nU,
+                                                            int64_t light0, int64_t light1, uint16_t* __restrict__ buser,
                                                             int32_t* __restrict__ luser, ColT* __restrict__ bcol,
                                                             float* __restrict__ res) {
   const int j = threadIdx.x & 15;
@@ -121,14 +120,22 @@ __global__ __launch_bounds__(256) void strip_scatter_kernel(const int64_t* __res
     const int64_t src = colptr[i] + off[(int64_t)i * (nb + 1) + b];
     const int64_t n = off[(int64_t)i * (nb + 1) + b + 1] - off[(int64_t)i * (nb + 1) + b];
     const int64_t d = dst[(int64_t)b * ncols + i];
-    const bool is_light = d >= light0;                // light columns keep the absolute user id (u_k comes from L2)
-    for (int64_t t = j; t < n; t += 16) {
-      if (is_light) luser[d + t - (light0 & ~(int64_t)63)] = colind[src + t];
-      else buser[d + t] = (uint16_t)(colind[src + t] - b * UB);
-      bcol[d + t] = (ColT)i;
-      res[d + t] = colval[src + t];
+    const bool is_light = d >= light0 && d < light1;      // light columns keep the absolute user id (u_k comes from L2)
+    const int64_t np = plen[(int64_t)b * ncols + i];      // (light: the padding of the WHOLE column hangs on its last strip's piece)
+    for (int64_t t = j; t < (np > n ? np : n); t += 16) {
+      const bool real = t < n;
+      if (is_light) luser[d + t - light0] = real ? colind[src + t] : nU;
+      else buser[d + t] = (uint16_t)(real ? colind[src + t] - b * UB : UB);
+      if (((d + t) & 7) == 0) bcol[(d + t) >> 3] = (ColT)i;
+      res[d + t] = real ? colval[src + t] : 0.0f;
     }
   }
+}
+// p[a[g] .. b[g]) = value for a list of ranges: what no piece owns (the tails of the regions, the slack behind the view)
+template <typename T>
+__global__ void fill_ranges_kernel(T* __restrict__ p, const int64_t* __restrict__ a, const int64_t* __restrict__ b, int n, T value) {
+  for (int g = blockIdx.y; g < n; g += gridDim.y)
+    for (int64_t t = a[g] + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < b[g]; t += (int64_t)gridDim.x * blockDim.x) p[t] = value;
 }
 
 // inverse of the scatter for the test hook: strip-major residual -> CSC order
@@ -147,6 +154,23 @@ __global__ __launch_bounds__(256) void strip_gather_kernel(const int64_t* __rest
     for (int64_t t = j; t < n; t += 16) out[src + t] = res[d + t];
   }
 }
+
+namespace {
+struct Ranges { std::vector<int64_t> a, b; void add(int64_t x, int64_t y) { if (y > x) { a.push_back(x); b.push_back(y); } } };
+template <typename T>
+int fill_ranges(mfx_ctx* ctx, T* p, const Ranges& r, T value) {
+  if (r.a.empty()) return MFX_OK;
+  int64_t *da = nullptr, *db = nullptr;
+  int rc;
+  if ((rc = up(ctx, &da, r.a)) || (rc = up(ctx, &db, r.b))) { dev_free(da); dev_free(db); return rc; }
+  hipLaunchKernelGGL(fill_ranges_kernel<T>, dim3(64, (unsigned)std::min<size_t>(r.a.size(), 1024)), dim3(256), 0, ctx->stream, p, da, db, (int)r.a.size(), value);
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  dev_free(da); dev_free(db);
+  if (e != hipSuccess) return mfx_fail(ctx, MFX_E_HIP, "mfx_ccdpp_begin: %s", hipGetErrorString(e));
+  return MFX_OK;
+}
+int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+}  // namespace
 
 int mfx_ccd_cols_build(mfx_ctx* ctx) {
   const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
@@ -168,128 +192,156 @@ int mfx_ccd_cols_build(mfx_ctx* ctx) {
   std::vector<int32_t> off((size_t)nI * (nb + 1));
   HIPCHK(hipMemcpyAsync(off.data(), s->off, sizeof(int32_t) * off.size(), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  // strip-major positions, segments, per-column segment lists, workgroup tables
-  std::vector<int64_t> dst((size_t)nb * nI), seg_beg, seg_end, rw_e0, rw_e1;
-  std::vector<int32_t> seg_col, pw_blk, rw_blk, strip_seg0;
-  std::vector<int32_t> col_cnt((size_t)nI, 0);
+  // padded strip-major positions, the pieces of every region, per-column slot lists, workgroup tables
+  std::vector<int64_t> dst((size_t)nb * nI, 0), rw_e0, rw_e1;
+  std::vector<int32_t> plen((size_t)nb * nI, 0), rw_blk;
   std::vector<uint8_t> light((size_t)nI, 0);
   const char* le = getenv("MFX_CCD_LIGHT");        // experiment / test knob: the threshold (0: every column goes through the strips)
   const int light_max = le ? atoi(le) : LIGHT;
   for (int32_t i = 0; i < nI; i++) light[(size_t)i] = off[(size_t)i * (nb + 1) + nb] <= light_max;
+  struct Region { int64_t r0, r1; int tag; std::vector<MfxPiece> pc; std::vector<int32_t> col; };
+  std::vector<Region> regions;
+  Ranges tails;                                     // positions inside the view that no piece owns
   int64_t pos = 0;
   for (int b = 0; b < nb; b++) {
-    const int64_t ent0 = pos;
-    const int32_t sg0 = (int32_t)seg_col.size();
+    Region R;
+    R.r0 = pos;
+    R.tag = b;
     for (int32_t i = 0; i < nI; i++) {
       if (light[(size_t)i]) continue;
       const int64_t n = off[(size_t)i * (nb + 1) + b + 1] - off[(size_t)i * (nb + 1) + b];
+      const int64_t np = round_up(n, MFX_BLK_EPL);
       dst[(size_t)b * nI + i] = pos;
-      for (int64_t c = 0; c < n; c += CSEG) {
-        seg_beg.push_back(pos + c);
-        seg_end.push_back(pos + std::min<int64_t>(n, c + CSEG));
-        seg_col.push_back(i);
-        col_cnt[i]++;
-      }
-      pos += n;
+      plen[(size_t)b * nI + i] = (int32_t)np;
+      if (n > 0) { R.pc.push_back(MfxPiece{pos, pos + np}); R.col.push_back(i); }
+      pos += np;
     }
-    const int32_t sg1 = (int32_t)seg_col.size();
-    strip_seg0.push_back(sg0);
-    (void)sg1;
-    for (int64_t a = ent0; a < pos; a += ENT_PER_WG) { rw_blk.push_back(b); rw_e0.push_back(a); rw_e1.push_back(std::min(pos, a + ENT_PER_WG)); }
+    R.r1 = round_up(pos, MFX_BLK_E);
+    tails.add(pos, R.r1);
+    for (int64_t a = R.r0; a < R.r1; a += ENT_PER_WG) { rw_blk.push_back(b); rw_e0.push_back(a); rw_e1.push_back(std::min(R.r1, a + ENT_PER_WG)); }
+    pos = R.r1;
+    regions.push_back(std::move(R));
   }
-  // the light columns behind the strips: whole columns, one segment each; piece (b, i) sits at its CSC offset
+  // the light columns behind the strips: whole columns, one piece each; piece (b, i) sits at its CSC offset inside the column
   s->light0 = pos;
-  s->lseg0 = (int32_t)seg_col.size();
-  for (int32_t i = 0; i < nI; i++) {
-    if (!light[(size_t)i]) continue;
-    const int64_t n = off[(size_t)i * (nb + 1) + nb];
-    for (int b = 0; b < nb; b++) dst[(size_t)b * nI + i] = pos + off[(size_t)i * (nb + 1) + b];
-    for (int64_t c = 0; c < n; c += CSEG) {        // (longer than CSEG only under MFX_CCD_LIGHT: a trip record holds 11 bits of length)
-      seg_beg.push_back(pos + c);
-      seg_end.push_back(pos + std::min<int64_t>(n, c + CSEG));
-      seg_col.push_back(i);
-      col_cnt[i]++;
-    }
-    pos += n;
-  }
-  s->nlseg = (int32_t)seg_col.size() - s->lseg0;
-  strip_seg0.push_back(s->lseg0);
-  // trips: strip by strip (workgroups of one strip each), then the light columns; meta = the segment
-  std::vector<int4> trips;
-  std::vector<int32_t> gptr;
   {
-    std::vector<MfxSeg> segs(seg_col.size());
-    std::vector<int64_t> cum(seg_col.size() + 1, 0);
-    for (size_t k = 0; k < seg_col.size(); k++) {
-      segs[k] = MfxSeg{seg_beg[k], seg_end[k], (int32_t)k};
-      cum[k + 1] = cum[k] + mfx_seg_trips(segs[k], COL_TRIP_E);
+    Region R;
+    R.r0 = pos;
+    R.tag = -1;
+    for (int32_t i = 0; i < nI; i++) {
+      if (!light[(size_t)i]) continue;
+      const int64_t n = off[(size_t)i * (nb + 1) + nb];
+      const int64_t np = round_up(n, MFX_BLK_EPL);
+      for (int b = 0; b < nb; b++) {
+        dst[(size_t)b * nI + i] = pos + off[(size_t)i * (nb + 1) + b];
+        plen[(size_t)b * nI + i] = off[(size_t)i * (nb + 1) + b + 1] - off[(size_t)i * (nb + 1) + b] + (b == nb - 1 ? (int32_t)(np - n) : 0);
+      }
+      if (n > 0) { R.pc.push_back(MfxPiece{pos, pos + np}); R.col.push_back(i); }
+      pos += np;
     }
-    if (cum.back() >= ((int64_t)1 << 31)) return mfx_fail(ctx, MFX_E_ARG, "mfx_ccdpp_begin: too many trips in the column view");
-    trips.reserve((size_t)cum.back());
+    R.r1 = round_up(pos, MFX_BLK_E);
+    tails.add(pos, R.r1);
+    pos = R.r1;
+    s->light1 = pos;
+    regions.push_back(std::move(R));
+  }
+  const int64_t nnzp = pos, nalloc = nnzp + MFX_BLK_SLACK;
+  s->nnzp = nnzp;
+  if (nnzp / MFX_BLK_E >= ((int64_t)1 << 31)) return mfx_fail(ctx, MFX_E_ARG, "mfx_ccdpp_begin: too many trips in the column view");
+  // the pass: the light region's workgroups first (latency-bound: u_k from L2), then the strips' in proportion to their trips
+  MfxBlockPlan plan;
+  std::vector<int32_t> col_cnt((size_t)nI, 0);
+  std::vector<std::vector<int32_t>> pfirst(regions.size()), pcnt(regions.size());
+  {
     const char* pe = getenv("MFX_CCD_PASS_WGS");
     const int want_wgs = pe && atoi(pe) > 0 ? atoi(pe) : PASS_WGS;
-    const int64_t strip_trips = cum[(size_t)s->lseg0];
+    const int64_t strip_trips = s->light0 / MFX_BLK_E;
     const int64_t per_wg = std::max<int64_t>(8 * GPW, (strip_trips + want_wgs - 1) / want_wgs);     // at least eight trips per group
-    const int64_t light_trips = cum.back() - strip_trips;
-    const int lwg = (int)std::min<int64_t>((light_trips + 8 * GPW - 1) / (8 * GPW), 512);
-    s->ngl = lwg * GPW;
-    int64_t strip_end = 0, light_end = 0;      // positions behind the last entry the trips of the two regions load
-    if (lwg > 0) mfx_trips_layout(segs, (size_t)s->lseg0, seg_col.size(), lwg, GPW, COL_TRIP_E, trips, gptr, &light_end);
-    for (int b = 0; b < nb; b++) {
-      const size_t k0 = (size_t)strip_seg0[(size_t)b], k1 = (size_t)strip_seg0[(size_t)b + 1];
-      const int64_t tb = cum[k1] - cum[k0];
-      if (tb == 0) continue;
-      const int nw = (int)std::max<int64_t>(1, (tb + per_wg / 2) / per_wg);
-      mfx_trips_layout(segs, k0, k1, nw, GPW, COL_TRIP_E, trips, gptr, &strip_end);
-      for (int w = 0; w < nw; w++) pw_blk.push_back(b);
+    auto lay = [&](size_t q, int nw) {
+      Region& R = regions[q];
+      pfirst[q].resize(R.pc.size());
+      pcnt[q].resize(R.pc.size());
+      return mfx_blocks_region(R.pc.data(), R.pc.size(), R.r0, R.r1, nw, R.tag, plan, pfirst[q].data(), pcnt[q].data());
+    };
+    const int64_t light_trips = (s->light1 - s->light0) / MFX_BLK_E;
+    if (light_trips > 0) {
+      if (!lay(regions.size() - 1, (int)std::min<int64_t>((light_trips + 8 * GPW - 1) / (8 * GPW), 512)))
+        return mfx_fail(ctx, MFX_E_STATE, "mfx_ccdpp_begin: the light region of the column view does not lay out");
     }
-    gptr.push_back((int32_t)trips.size());
-    // whole trips are loaded: strips from res (float[nnz]) and buser (uint16[light0 + 4]), the light region from res and
-    // luser (int32, shifted by light0 & ~63): every one of them must lie inside its allocation (mfx_trips_fit)
-    static_assert((COL_TRIP_E - 1) * sizeof(float) <= MFX_ALLOC_PAD, "a column-view trip must fit the allocation pad");
-    if (!(mfx_trips_fit(std::max(strip_end, light_end), m.nnz, sizeof(float)) && mfx_trips_fit(strip_end, s->light0 + 4, sizeof(uint16_t)) &&
-          mfx_trips_fit(light_end, m.nnz + 4, sizeof(int32_t))))
-      return mfx_fail(ctx, MFX_E_STATE, "mfx_ccdpp_begin: a trip of the column view reads behind its arrays (strips to %lld of %lld, light "
-                      "columns to %lld of %lld; allocation pad %zu bytes)", (long long)strip_end, (long long)s->light0, (long long)light_end,
-                      (long long)m.nnz, MFX_ALLOC_PAD);
+    s->nlw = (int)plan.wg_t0.size();
+    for (size_t q = 0; q + 1 < regions.size(); q++) {
+      const int64_t tb = (regions[q].r1 - regions[q].r0) / MFX_BLK_E;
+      if (tb == 0) continue;
+      if (!lay(q, (int)std::max<int64_t>(1, (tb + per_wg / 2) / per_wg)))
+        return mfx_fail(ctx, MFX_E_STATE, "mfx_ccdpp_begin: strip %zu of the column view does not lay out", q);
+    }
   }
-  std::vector<int32_t> col_ptr((size_t)nI + 1, 0), col_seg(seg_col.size());
-  for (int32_t i = 0; i < nI; i++) col_ptr[i + 1] = col_ptr[i] + col_cnt[i];
+  // the slots of a column, strip-major (the light region last: a column lies in one or the other)
+  for (size_t q = 0; q < regions.size(); q++)
+    for (size_t k = 0; k < regions[q].pc.size(); k++) col_cnt[(size_t)regions[q].col[k]] += pcnt[q][k];
+  std::vector<int32_t> col_ptr((size_t)nI + 1, 0);
+  for (int32_t i = 0; i < nI; i++) col_ptr[(size_t)i + 1] = col_ptr[(size_t)i] + col_cnt[(size_t)i];
+  std::vector<int32_t> col_seg((size_t)col_ptr[(size_t)nI]);
   {
     std::vector<int32_t> w(col_ptr.begin(), col_ptr.end() - 1);
-    for (size_t k = 0; k < seg_col.size(); k++) col_seg[w[seg_col[k]]++] = (int32_t)k;   // strip-major inside a column
+    for (size_t q = 0; q < regions.size(); q++)
+      for (size_t k = 0; k < regions[q].pc.size(); k++)
+        for (int32_t c = 0; c < pcnt[q][k]; c++) col_seg[(size_t)w[(size_t)regions[q].col[k]]++] = pfirst[q][k] + c;
   }
+  std::vector<int32_t> fin_order;
+  fin_order.reserve((size_t)nI);
+  for (int pass = 0; pass < 3; pass++) {
+    for (int32_t i = 0; i < nI; i++) {
+      const int c = col_cnt[(size_t)i], cls = c <= 64 ? 0 : c <= 512 ? 1 : 2;
+      if (cls == pass) fin_order.push_back(i);
+    }
+    if (pass == 0) s->fin_n16 = (int)fin_order.size();
+    else if (pass == 1) s->fin_n64 = (int)fin_order.size() - s->fin_n16;
+    else s->fin_n256 = (int)fin_order.size() - s->fin_n16 - s->fin_n64;
+  }
+  if ((rc = up(ctx, &s->fin_order, fin_order))) return rc;
   if ((rc = up(ctx, &s->dst, dst))) return rc;
-  if ((rc = up(ctx, &s->seg_beg, seg_beg))) return rc;
-  if ((rc = up(ctx, &s->seg_end, seg_end))) return rc;
-  if ((rc = up(ctx, &s->seg_col, seg_col))) return rc;
+  if ((rc = up(ctx, &s->plen, plen))) return rc;
   if ((rc = up(ctx, &s->col_ptr, col_ptr))) return rc;
   if ((rc = up(ctx, &s->col_seg, col_seg))) return rc;
-  if ((rc = up(ctx, &s->pw_blk, pw_blk))) return rc;
-  if ((rc = mfx_trips_upload(ctx, trips, &s->trips))) return rc;
-  if ((rc = up(ctx, &s->gptr, gptr))) return rc;
+  if ((rc = mfx_blocks_upload(ctx, plan, &s->blocks))) return rc;
   if ((rc = up(ctx, &s->rw_blk, rw_blk))) return rc;
   if ((rc = up(ctx, &s->rw_e0, rw_e0))) return rc;
   if ((rc = up(ctx, &s->rw_e1, rw_e1))) return rc;
-  s->nseg = (int64_t)seg_col.size();
-  s->npw = (int)pw_blk.size();
   s->nrw = (int)rw_blk.size();
-  if ((rc = dev_alloc(ctx, &s->part, (size_t)s->nseg * 2))) return rc;
+  if ((rc = dev_alloc(ctx, &s->part, (size_t)plan.nslots * 2))) return rc;
   const bool col16 = nI <= 65536;
-  if ((rc = dev_alloc(ctx, &s->buser, (size_t)s->light0 + 4))) return rc;      // (+ MFX_ALLOC_PAD: the last strip trips run past light0)
-  if ((rc = dev_alloc(ctx, &s->luser, (size_t)(m.nnz - (s->light0 & ~(int64_t)63)) + 4))) return rc;
-  if (col16) { if ((rc = dev_alloc(ctx, &s->bcol16, (size_t)m.nnz + 4))) return rc; }
-  else if ((rc = dev_alloc(ctx, &s->bcol32, (size_t)m.nnz + 4))) return rc;
-  if ((rc = dev_alloc(ctx, &s->res, (size_t)m.nnz))) return rc;
-  HIPCHK(hipMemsetAsync(s->res + m.nnz, 0, MFX_ALLOC_PAD, ctx->stream));    // read (masked) by the pass loop: finite
+  const bool has_light = s->light1 > s->light0;
+  // buser serves the strips (and what their last workgroup reads behind them); luser the light region and the slack behind it
+  if ((rc = dev_alloc(ctx, &s->buser, (size_t)(s->light0 + MFX_BLK_SLACK)))) return rc;
+  if ((rc = dev_alloc(ctx, &s->luser, (size_t)(has_light ? nalloc - s->light0 : 1)))) return rc;
+  if (col16) { if ((rc = dev_alloc(ctx, &s->bcol16, (size_t)(nnzp / MFX_BLK_EPL)))) return rc; }
+  else if ((rc = dev_alloc(ctx, &s->bcol32, (size_t)(nnzp / MFX_BLK_EPL)))) return rc;
+  if ((rc = dev_alloc(ctx, &s->res, (size_t)nalloc))) return rc;
   if (m.nnz > 0) {
     if (col16)
       hipLaunchKernelGGL(strip_scatter_kernel<uint16_t>, dim3(2048), dim3(256), 0, ctx->stream, m.colptr, m.colind, m.colval,
-                         s->off, s->dst, nI, nb, s->light0, s->buser, s->luser, s->bcol16, s->res);
+                         s->off, s->dst, s->plen, nI, nb, ctx->nU, s->light0, s->light1, s->buser, s->luser, s->bcol16, s->res);
     else
       hipLaunchKernelGGL(strip_scatter_kernel<int32_t>, dim3(2048), dim3(256), 0, ctx->stream, m.colptr, m.colind, m.colval,
-                         s->off, s->dst, nI, nb, s->light0, s->buser, s->luser, s->bcol32, s->res);
+                         s->off, s->dst, s->plen, nI, nb, ctx->nU, s->light0, s->light1, s->buser, s->luser, s->bcol32, s->res);
     HIPCHK(hipGetLastError());
+  }
+  {
+    Ranges rres = tails, rbu, rlu, rbc;
+    for (size_t q = 0; q < tails.a.size(); q++) rbc.add(tails.a[q] / MFX_BLK_EPL, tails.b[q] / MFX_BLK_EPL);
+    rres.add(nnzp, nalloc);
+    for (size_t q = 0; q < tails.a.size(); q++) {
+      if (tails.a[q] < s->light0) rbu.add(tails.a[q], tails.b[q]);
+      else rlu.add(tails.a[q] - s->light0, tails.b[q] - s->light0);
+    }
+    rbu.add(s->light0, s->light0 + MFX_BLK_SLACK);
+    if (has_light) rlu.add(nnzp - s->light0, nalloc - s->light0);
+    if ((rc = fill_ranges(ctx, s->res, rres, 0.0f))) return rc;
+    if ((rc = fill_ranges(ctx, s->buser, rbu, (uint16_t)UB))) return rc;
+    if ((rc = fill_ranges(ctx, s->luser, rlu, (int32_t)ctx->nU))) return rc;
+    if (col16) { if ((rc = fill_ranges(ctx, s->bcol16, rbc, (uint16_t)0))) return rc; }
+    else if ((rc = fill_ranges(ctx, s->bcol32, rbc, (int32_t)0))) return rc;
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return MFX_OK;
@@ -305,28 +357,28 @@ __device__ __forceinline__ void stage_strip(float* lds, const float* __restrict_
 
 __device__ __forceinline__ double g16_sum(double v) { return mfx_row16_sum(v); }
 
-// column pass: one 16-lane group per range of the trip list.  Workgroups [0, nlw): the light columns, u_k gathered from L2 by
-// the absolute user id; the others: one strip each, the strip of u_k in LDS and strip-local 16-bit user ids.  ONE launch, the
-// latency-bound light part (4 % of the entries, but 42 us on its own at C4) first, so that it runs under the strips.
-template <bool BUF>
-__global__ __launch_bounds__(1024) void colpass_kernel(const MfxTrips trips, const int32_t* __restrict__ gptr,
-                                                       const int32_t* __restrict__ pw_blk, int nlw, int g_count,
-                                                       const float* __restrict__ res, uint32_t res_bytes, const uint16_t* __restrict__ buser,
+// column pass: workgroup w works through window w of the padded view (ccd_blocks.h).  Workgroups [0, nlw): the light columns, u_k
+// gathered from L2 by the absolute user id; the others: one strip each, the strip of u_k in LDS and strip-local 16-bit user ids.
+// ONE launch, the latency-bound light part first, so that it runs under the strips.
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void colpass_kernel(const int2* __restrict__ rec, const int32_t* __restrict__ wg_t0,
+                                                       const int32_t* __restrict__ wg_n, const int64_t* __restrict__ wg_rec,
+                                                       const int32_t* __restrict__ wg_tag, const int32_t* __restrict__ wg_stride,
+                                                       const float* __restrict__ res, const uint16_t* __restrict__ buser,
                                                        const int32_t* __restrict__ luser, const float* __restrict__ uk, int nU_strips,
-                                                       int nU, double* __restrict__ part) {
+                                                       double* __restrict__ part, uint32_t part_bytes) {
   __shared__ __attribute__((aligned(16))) float su[UB + 4];
-  const bool strip = (int)blockIdx.x >= nlw;       // the light workgroups come first: they start first and run under the strips
-  if (strip) {
-    const int b = pw_blk[(int)blockIdx.x - nlw];
+  const int w = blockIdx.x, b = wg_tag[w];
+  if (b >= 0) {
     stage_strip(su, uk, b * UB, min(UB, nU_strips - b * UB));
-    if (threadIdx.x == 0) su[UB] = 0.0f;          // what masked entries gather
+    if (threadIdx.x == 0) su[UB] = 0.0f;          // what the padding entries gather
     __syncthreads();
   }
-  const int j = threadIdx.x & 15;
-  const int g = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
-  if (g >= g_count) return;
-  if (strip) mfx_ccd_trip_loop<BUF, COL_TRIP_E / 16>(trips, gptr[g], gptr[g + 1], res, buser, res_bytes, su, UB, j, part);
-  else mfx_ccd_trip_loop<BUF, COL_TRIP_E / 16>(trips, gptr[g], gptr[g + 1], res, luser, res_bytes, uk, nU, j, part);      // uk[nU] = +0.0 (mfx_ccdpp_begin)
+  const int j = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int wn = wg_n[w];
+  const int2* r = rec + wg_rec[w];
+  const int64_t e0 = (int64_t)wg_t0[w] * MFX_BLK_E;
+  if (b >= 0) mfx_ccd_block_loop<uint16_t>(r, wn, wg_stride[w], g, res + e0, buser + e0, su, j, part, part_bytes);
+  else mfx_ccd_block_loop<int32_t>(r, wn, wg_stride[w], g, res + e0, luser + e0, uk, j, part, part_bytes);      // uk[nU] = +0.0 (mfx_ccdpp_begin)
 }
 
 // residual update of the light region (MODE as colresid_kernel): u_k from L2
@@ -337,7 +389,7 @@ __global__ __launch_bounds__(256) void colresid_light_kernel(int64_t e0, int64_t
                                                              const float* __restrict__ vk1) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t t = e0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < e1; t += stride) {
-    const int u = luser[t - lshift], c = (int)bcol[t];
+    const int u = luser[t - lshift], c = (int)bcol[t >> 3];
     const float p0 = uk0[u] * vk0[c];
     float r = res[t];
     if (MODE == 1) r = r + p0;
@@ -347,30 +399,57 @@ __global__ __launch_bounds__(256) void colresid_light_kernel(int64_t e0, int64_t
   }
 }
 
-// v_k[i] from the column's segment partials in strip-major order; one 16-lane group per column.
+// v_k[i] from the column's slots in strip-major order.  A column is summed by a TEAM of 16, 64 or 256 lanes by the number of its
+// slots (C4: 1.9 M slots over 17 770 columns, the most popular one 2 600): lane-strided in list order, a fixed butterfly over the
+// rows of 16, the rows in order, the waves in order -- a fixed association.  (One 16-lane group per column, as for the segment lists of
+// rounds 2 and 3, made this launch 90 us: the longest column's 160 dependent index -> slot reads in one group.)
+// ONE launch: blocks [0, b16) take 16 columns each from order[0, n16), blocks [b16, b16 + b64) four each from order[n16, n16 + n64),
+// the others one each.
 // SUMS (sharded runs): only emit (num, den) of this rank's users; coldivide_kernel finishes after the all-reduce.
 template <bool SUMS>
-__global__ __launch_bounds__(256) void colfinish_kernel(const int32_t* __restrict__ col_ptr,
+__global__ __launch_bounds__(256) void colfinish_kernel(const int32_t* __restrict__ order, int n16, int n64, int b16, int b64,
+                                                        const int32_t* __restrict__ col_ptr,
                                                         const int32_t* __restrict__ col_seg,
                                                         const double* __restrict__ part, int32_t ncols, float reg,
                                                         float* __restrict__ vk, const int64_t* __restrict__ colptr,
                                                         float freq_thresh, int k, double* __restrict__ sums) {
-  const int j = threadIdx.x & 15;
-  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-  if (i >= ncols) return;
+  __shared__ double sh[2 * 4 * 4];
+  const int bx = blockIdx.x;
+  int team, slot_in_block, idx;
+  if (bx < b16) { team = 16; slot_in_block = threadIdx.x >> 4; idx = bx * 16 + slot_in_block; if (idx >= n16) return; }
+  else if (bx < b16 + b64) { team = 64; slot_in_block = threadIdx.x >> 6; idx = n16 + (bx - b16) * 4 + slot_in_block; if (idx >= n16 + n64) return; }
+  else { team = 256; slot_in_block = 0; idx = n16 + n64 + (bx - b16 - b64); }
+  const int i = order[idx];
+  const int lane = threadIdx.x & (team - 1);
   const int a = col_ptr[i], e = col_ptr[i + 1];
   if (a == e) {         // an item without train ratings is invalid: v_k keeps iFac(i,k) (modelMF.cpp:1079-1081)
-    if (SUMS && j == 0) { sums[2 * i] = 0.0; sums[2 * i + 1] = 0.0; }
+    if (SUMS && lane == 0) { sums[2 * i] = 0.0; sums[2 * i + 1] = 0.0; }
     return;
   }
   double num = 0.0, den = 0.0;
-  for (int t = a + j; t < e; t += 16) {   // lane-strided in list order, then a fixed butterfly
+  for (int t = a + lane; t < e; t += team) {
     num += part[2 * (int64_t)col_seg[t]];
     den += part[2 * (int64_t)col_seg[t] + 1];
   }
   num = g16_sum(num);
   den = g16_sum(den);
-  if (j == 0) {
+  if (team >= 64) {      // the four rows of a wave, in order
+    double n4 = 0.0, d4 = 0.0;
+    for (int r = 0; r < 4; r++) {
+      n4 += __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(num), 16 * r), __builtin_amdgcn_readlane(__double2loint(num), 16 * r));
+      d4 += __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(den), 16 * r), __builtin_amdgcn_readlane(__double2loint(den), 16 * r));
+    }
+    num = n4;
+    den = d4;
+  }
+  if (team == 256) {     // the four waves of the block, in order (block-uniform branch: such a block holds one column)
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[2 * wv] = num; sh[2 * wv + 1] = den; }
+    __syncthreads();
+    num = ((sh[0] + sh[2]) + sh[4]) + sh[6];
+    den = ((sh[1] + sh[3]) + sh[5]) + sh[7];
+  }
+  if (lane == 0) {
     if (SUMS) { sums[2 * i] = num; sums[2 * i + 1] = den; return; }
     float v = (float)(num / ((double)reg + den));
     if (freq_thresh >= 0.0f) {  // modelMF.cpp:1336-1342
@@ -401,11 +480,13 @@ __global__ __launch_bounds__(1024) void colresid_kernel(const int32_t* __restric
                                                         const float* __restrict__ uk0, const float* __restrict__ vk0,
                                                         const float* __restrict__ uk1, const float* __restrict__ vk1,
                                                         int nU) {
-  __shared__ __attribute__((aligned(16))) float su[(MODE == 2 ? 2 : 1) * UB];
+  constexpr int UBS = UB + 4;                     // a staged strip and the +0.0 the padding entries (user id UB) gather
+  __shared__ __attribute__((aligned(16))) float su[(MODE == 2 ? 2 : 1) * UBS];
   const int b = rw_blk[blockIdx.x];
   const int n = min(UB, nU - b * UB);
   stage_strip(su, uk0, b * UB, n);
-  if (MODE == 2) stage_strip(su + UB, uk1, b * UB, n);
+  if (MODE == 2) stage_strip(su + UBS, uk1, b * UB, n);
+  if (threadIdx.x == 0) { su[UB] = 0.0f; if (MODE == 2) su[UBS + UB] = 0.0f; }
   __syncthreads();
   // 16 aligned bytes per lane and array (4 entries); the entries of a neighbouring workgroup's range are left alone
   typedef float f4 __attribute__((ext_vector_type(4)));
@@ -413,39 +494,28 @@ __global__ __launch_bounds__(1024) void colresid_kernel(const int32_t* __restric
   const int64_t e0 = rw_e0[blockIdx.x], e1 = rw_e1[blockIdx.x];
   for (int64_t t = (e0 & ~(int64_t)3) + 4 * (int64_t)threadIdx.x; t < e1; t += 4 * (int64_t)blockDim.x) {
     if (t >= e0 && t + 4 <= e1) {
-      const i4 lu = MfxCcdTrip::load4(buser + t), c = MfxCcdTrip::load4(bcol + t);
+      const i4 lu = MfxCcdTrip::load4(buser + t);
+      const int c = (int)bcol[t >> 3];        // four consecutive entries of the padded view lie in ONE column
       f4 r = *(const f4*)(res + t);
-      // the column ids of four consecutive entries ascend (column by column inside a strip): two gathers serve a quad that
-      // lies in one column or two, an entry in a third column takes its own (see gather_sorted4 in ccd.hip)
-      float v0[4], v1[4];
-      v0[0] = vk0[c[0]]; v0[3] = vk0[c[3]];
-      v0[1] = c[1] == c[0] ? v0[0] : v0[3]; v0[2] = c[2] == c[0] ? v0[0] : v0[3];
-      if (c[1] != c[0] && c[1] != c[3]) v0[1] = vk0[c[1]];
-      if (c[2] != c[0] && c[2] != c[3]) v0[2] = vk0[c[2]];
-      if (MODE == 2) {
-        v1[0] = vk1[c[0]]; v1[3] = vk1[c[3]];
-        v1[1] = c[1] == c[0] ? v1[0] : v1[3]; v1[2] = c[2] == c[0] ? v1[0] : v1[3];
-        if (c[1] != c[0] && c[1] != c[3]) v1[1] = vk1[c[1]];
-        if (c[2] != c[0] && c[2] != c[3]) v1[2] = vk1[c[2]];
-      }
+      const float v0 = vk0[c], v1 = MODE == 2 ? vk1[c] : 0.0f;
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        const float p0 = su[lu[q]] * v0[q];   // u_k(u)*v_k(item): float product (modelMF.cpp:1053, :1114)
+        const float p0 = su[lu[q]] * v0;      // u_k(u)*v_k(item): float product (modelMF.cpp:1053, :1114)
         if (MODE == 1) r[q] = r[q] + p0;
         else r[q] = r[q] - p0;
-        if (MODE == 2) r[q] = r[q] + su[UB + lu[q]] * v1[q];
+        if (MODE == 2) r[q] = r[q] + su[UBS + lu[q]] * v1;
       }
       *(f4*)(res + t) = r;
     } else {
       for (int q = 0; q < 4; q++) {
         const int64_t tt = t + q;
         if (tt < e0 || tt >= e1) continue;
-        const int lu = (int)buser[tt], c = (int)bcol[tt];
+        const int lu = (int)buser[tt], c = (int)bcol[tt >> 3];
         const float p0 = su[lu] * vk0[c];
         float r = res[tt];
         if (MODE == 1) r = r + p0;
         else r = r - p0;
-        if (MODE == 2) r = r + su[UB + lu] * vk1[c];
+        if (MODE == 2) r = r + su[UBS + lu] * vk1[c];
         res[tt] = r;
       }
     }
@@ -455,20 +525,18 @@ __global__ __launch_bounds__(1024) void colresid_kernel(const int32_t* __restric
 int mfx_ccd_cols_pass(mfx_ctx* ctx, const float* uk, float* vk, float reg, float freq_thresh, int k) {
   ColState* s = st(ctx);
   const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
-  if (s->npw > 0 || s->ngl > 0) {
+  const bool any = s->blocks.nwg > 0;
+  if (any) {
     ProfScope ps(ctx, MFX_K_CCD_COL);
-    // entry t of the blocked order sits at luser[t - (light0 & ~63)]
-    const uint64_t rbytes = ((uint64_t)s->nnz + 64) * 4;
-#define MFX_COLPASS(BF)                                                                                                              \
-  hipLaunchKernelGGL(colpass_kernel<BF>, dim3(s->npw + s->ngl / GPW), dim3(16 * GPW), 0, ctx->stream, s->trips, s->gptr, s->pw_blk, s->ngl / GPW, \
-                     s->npw * GPW + s->ngl, s->res, (uint32_t)rbytes, (const uint16_t*)s->buser,                                      \
-                     (const int32_t*)(s->luser - (s->light0 & ~(int64_t)63)), uk, m.nrows, ctx->nU, s->part)
-    if (rbytes < ((uint64_t)1 << 32) && !getenv("MFX_CCD_NOBUF")) MFX_COLPASS(true); else MFX_COLPASS(false);
-#undef MFX_COLPASS
-    const unsigned fb = (unsigned)(((int64_t)m.ncols * 16 + 255) / 256);
+    const MfxBlocks& B = s->blocks;
+    // entry t of the padded order sits at luser[t - light0]
+    hipLaunchKernelGGL(colpass_kernel, dim3(B.nwg), dim3(16 * GPW), 0, ctx->stream, B.rec, B.wg_t0, B.wg_n, B.wg_rec, B.wg_tag, B.wg_stride, s->res,
+                       (const uint16_t*)s->buser, (const int32_t*)(s->luser - s->light0), uk, m.nrows, s->part, (uint32_t)(B.nslots * 16));
+    HIPCHK(hipGetLastError());
     if (!mfx_sharded(ctx)) {
-      hipLaunchKernelGGL(colfinish_kernel<false>, dim3(fb), dim3(256), 0, ctx->stream, s->col_ptr, s->col_seg, s->part,
-                         m.ncols, reg, vk, m.colptr, freq_thresh, k, (double*)nullptr);
+      const int b16 = (s->fin_n16 + 15) / 16, b64 = (s->fin_n64 + 3) / 4;
+      hipLaunchKernelGGL(colfinish_kernel<false>, dim3((unsigned)(b16 + b64 + s->fin_n256)), dim3(256), 0, ctx->stream, s->fin_order, s->fin_n16,
+                         s->fin_n64, b16, b64, s->col_ptr, s->col_seg, s->part, m.ncols, reg, vk, m.colptr, freq_thresh, k, (double*)nullptr);
       HIPCHK(hipGetLastError());
       return MFX_OK;
     }
@@ -479,9 +547,10 @@ int mfx_ccd_cols_pass(mfx_ctx* ctx, const float* uk, float* vk, float reg, float
     if (!s->sums && (rc = dev_alloc(ctx, &s->sums, (size_t)m.ncols * 2))) return rc;
     const double* gcol;
     if ((rc = mfx_comm_global_col_counts(ctx, &gcol))) return rc;
-    if (s->npw > 0 || s->nlseg > 0) {
-      hipLaunchKernelGGL(colfinish_kernel<true>, dim3((unsigned)(((int64_t)m.ncols * 16 + 255) / 256)), dim3(256), 0, ctx->stream,
-                         s->col_ptr, s->col_seg, s->part, m.ncols, reg, vk, m.colptr, freq_thresh, k, s->sums);
+    if (any) {
+      const int b16 = (s->fin_n16 + 15) / 16, b64 = (s->fin_n64 + 3) / 4;
+      hipLaunchKernelGGL(colfinish_kernel<true>, dim3((unsigned)(b16 + b64 + s->fin_n256)), dim3(256), 0, ctx->stream, s->fin_order, s->fin_n16,
+                         s->fin_n64, b16, b64, s->col_ptr, s->col_seg, s->part, m.ncols, reg, vk, m.colptr, freq_thresh, k, s->sums);
       HIPCHK(hipGetLastError());
     } else {
       HIPCHK(hipMemsetAsync(s->sums, 0, sizeof(double) * 2 * (size_t)m.ncols, ctx->stream));
@@ -511,16 +580,16 @@ int mfx_ccd_cols_resid(mfx_ctx* ctx, int mode, const float* uk0, const float* vk
     if (mode == 1) MFX_CR(1); else if (mode == 2) MFX_CR(2); else MFX_CR(-1);
 #undef MFX_CR
   }
-  if (s->light0 < s->nnz) {
-    const unsigned lb = (unsigned)std::min<int64_t>((s->nnz - s->light0 + 255) / 256, 4096);
-    const int64_t lsh = s->light0 & ~(int64_t)63;
+  if (s->light0 < s->light1) {
+    const unsigned lb = (unsigned)std::min<int64_t>((s->light1 - s->light0 + 255) / 256, 4096);
+    const int64_t lsh = s->light0;
 #define MFX_CL(MD)                                                                                                                \
   do {                                                                                                                            \
     if (s->bcol16)                                                                                                                \
-      hipLaunchKernelGGL((colresid_light_kernel<MD, uint16_t>), dim3(lb), dim3(256), 0, ctx->stream, s->light0, s->nnz, s->res,   \
+      hipLaunchKernelGGL((colresid_light_kernel<MD, uint16_t>), dim3(lb), dim3(256), 0, ctx->stream, s->light0, s->light1, s->res,\
                          s->luser, lsh, s->bcol16, uk0, vk0, uk1, vk1);                                                           \
     else                                                                                                                          \
-      hipLaunchKernelGGL((colresid_light_kernel<MD, int32_t>), dim3(lb), dim3(256), 0, ctx->stream, s->light0, s->nnz, s->res,    \
+      hipLaunchKernelGGL((colresid_light_kernel<MD, int32_t>), dim3(lb), dim3(256), 0, ctx->stream, s->light0, s->light1, s->res, \
                          s->luser, lsh, s->bcol32, uk0, vk0, uk1, vk1);                                                           \
   } while (0)
     if (mode == 1) MFX_CL(1); else if (mode == 2) MFX_CL(2); else MFX_CL(-1);

@@ -45,6 +45,17 @@ struct RowSegs {
 
 // trip list of a CCD++ pass (see mfx_ccd_trip_loop)
 struct MfxTrips { int32_t* q = nullptr; int32_t* pk = nullptr; int32_t* meta = nullptr; };
+// one pass launch over a padded view (ccd_blocks.h)
+struct MfxBlocks {
+  int2* rec = nullptr;             // [workgroup][group][step]: x = first slot of the trip's pieces (-1: no trip), y = end mask
+  int32_t* wg_t0 = nullptr;        // first trip of the workgroup's window (position / 128)
+  int32_t* wg_n = nullptr;         // trips in it
+  int32_t* wg_stride = nullptr;    // chunks of 64 trips from one step of the workgroup to its next (1: a contiguous window)
+  int64_t* wg_rec = nullptr;       // where its records start
+  int32_t* wg_tag = nullptr;       // the caller's tag (column view: the strip, -1 = the light region)
+  int nwg = 0;
+  int64_t nslots = 0;
+};
 
 struct ProfSlot {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
@@ -109,12 +120,17 @@ struct mfx_ctx {
   double* ccd_part = nullptr;
   int64_t ccd_part_cap = 0;
   int32_t* colid = nullptr;
-  uint16_t* ccd_ind16 = nullptr;   // rowind as 16-bit ids (CCD++ row view, when v_k fits LDS: at most 38 400 items)
-  MfxTrips ccd_trips;              // row view: trip list and the groups' ranges (mfx_ccd_trip_loop)
-  int32_t* ccd_gptr = nullptr;
-  int ccd_ngroups = 0;
-  int32_t* ccd_single = nullptr;   // rows with ONE segment; their (num, den) slot is nslab + position in this list
-  int64_t ccd_nsingle = 0;
+  // CCD++ row view, PADDED (ccd_blocks.h): row r at [ccd_rpos[r], ccd_rpos[r+1]), both multiples of 8; ccd_nnzp entries, a multiple of 128
+  int64_t ccd_nnzp = 0;
+  int64_t* ccd_rpos = nullptr;
+  uint16_t* ccd_ind16 = nullptr;   // item ids, 16-bit when v_k fits LDS (at most 38 400 items) ...
+  int32_t* ccd_ind32 = nullptr;    // ... else 32-bit; the padding entries carry nI (the +0.0 slot behind v_k)
+  int32_t* ccd_rowid = nullptr;    // row of every padded entry
+  MfxBlocks ccd_blocks;            // the row pass
+  int32_t* ccd_rfirst = nullptr;   // [nU] first (num, den) slot of a row's pieces
+  int32_t* ccd_rcnt = nullptr;     // [nU] how many (0: a row without ratings)
+  int32_t* ccd_lrow = nullptr;     // rows with more than 32 pieces (finished by a 16-lane group each)
+  int64_t ccd_nlrow = 0;
   void* ccd_cols = nullptr;   // strip-major column view (ccd_cols.hip owns the type)
   void* cd = nullptr;         // trainCCD state (cd.hip owns the type)
   void* als_wide = nullptr;   // ALS for K > 64 (als_wide.hip owns the type)
