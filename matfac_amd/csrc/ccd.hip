@@ -94,14 +94,14 @@ __global__ __launch_bounds__(256) void rowview_build_kernel(const int64_t* __res
     const int64_t src = rowptr[r], n = rowptr[r + 1] - src, d = rpos[r], np = rpos[r + 1] - d;
     for (int64_t t = j; t < np; t += 16) {
       const bool real = t < n;
-      res[d + t] = real ? rowval[src + t] : 0.0f;
+      res[mfx_blk_mem_of(d + t)] = real ? rowval[src + t] : 0.0f;
       ids[d + t] = (IdxT)(real ? rowind[src + t] : zero_id);
       if ((t & 7) == 0) rowid[(d + t) >> 3] = (int32_t)r;
     }
   }
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t t = rpos[nrows] + tid; t < nalloc; t += nth) {
-    res[t] = 0.0f;
+  for (int64_t t = rpos[nrows] + tid; t < nalloc; t += nth) {      // (nalloc is a whole number of trips: the image of [.., nalloc) is inside it)
+    res[mfx_blk_mem_of(t)] = 0.0f;
     ids[t] = (IdxT)zero_id;
     if (t < nnzp && (t & 7) == 0) rowid[t >> 3] = nrows > 0 ? nrows - 1 : 0;
   }
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void rowview_export_kernel(const int64_t* __re
   const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
   for (int64_t r = grp; r < nrows; r += ngrp) {
     const int64_t src = rowptr[r], n = rowptr[r + 1] - src, d = rpos[r];
-    for (int64_t t = j; t < n; t += 16) out[src + t] = res[d + t];
+    for (int64_t t = j; t < n; t += 16) out[src + t] = res[mfx_blk_mem_of(d + t)];
   }
 }
 
@@ -130,9 +130,10 @@ __global__ __launch_bounds__(1024) void resid_update_kernel(float* __restrict__ 
   const int64_t n4 = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride) {     // (n is a multiple of 128)
-    const i4 y = MfxCcdTrip::load4(ib + 4 * q);
+    const int64_t ql = (q & ~(int64_t)31) | ((q & 15) << 1) | ((q >> 4) & 1);     // residual quad q (memory order) holds entry quad ql (mfx_blk_entry_of)
+    const i4 y = MfxCcdTrip::load4(ib + 4 * ql);
     f4 r = ((const f4*)res)[q];
-    const float au = a[ia[q >> 1]];          // four consecutive entries of the padded view lie in ONE row
+    const float au = a[ia[ql >> 1]];         // the four entries of a quad lie in ONE row
 #pragma unroll
     for (int e = 0; e < 4; e++) {
       const float prod = au * b[y[e]];
@@ -171,9 +172,10 @@ __global__ __launch_bounds__(1024) void resid_fused_kernel(float* __restrict__ r
   const int64_t n4 = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride) {     // (n is a multiple of 128)
-    const i4 y = MfxCcdTrip::load4(ib + 4 * q);
+    const int64_t ql = (q & ~(int64_t)31) | ((q & 15) << 1) | ((q >> 4) & 1);     // residual quad q (memory order) holds entry quad ql (mfx_blk_entry_of)
+    const i4 y = MfxCcdTrip::load4(ib + 4 * ql);
     f4 r = ((const f4*)res)[q];
-    const int row = ia[q >> 1];              // four consecutive entries of the padded view lie in ONE row
+    const int row = ia[ql >> 1];             // the four entries of a quad lie in ONE row
     const float au0 = a0[row], au1 = a1[row];
 #pragma unroll
     for (int e = 0; e < 4; e++) {

@@ -11,7 +11,7 @@
 //     +0.0 slot behind the gathered vector: they add exact zeros (C4: 2 % more entries in the row view, 4 % in the column view);
 //   * a region (the row view; one strip) is a whole number of 128-entry TRIPS, trip t = entries [128 t, 128 t + 128): sixteen lanes,
 //     two 16-byte residual loads and one 16-byte load of eight 16-bit ids each.  Every line is loaded once, by one instruction, with all
-//     lanes live, no compare and no select;
+//     lanes live, no compare and no select (the residuals of a trip are stored quad-interleaved for that: mfx_blk_mem_of);
 //   * piece boundaries fall BETWEEN lanes.  A trip's record is (first slot, 16-bit mask of the lanes that end a piece; lane 15 always
 //     set: what runs on into the next trip is a piece of its own).  The lane sums go through an inclusive scan over the sixteen lanes
 //     (4 DPP levels); an end lane takes the prefix of the previous end lane (ds_bpermute) and stores the difference to
@@ -36,6 +36,15 @@ constexpr int MFX_BLK_GPW = 64;                    // 16-lane groups per workgro
 // ahead and rounds a group's steps up to four, i.e. it reads at most 64 * 6 trips past the end of its window.
 constexpr int64_t MFX_BLK_SLACK = (int64_t)MFX_BLK_GPW * 6 * MFX_BLK_E;
 
+// Where the RESIDUAL of (logical) entry p of a padded view lies: inside every trip the sixteen lanes' first quads come first, then
+// their second quads, so that each of a lane's two 16-byte loads is part of 256 contiguous bytes of its group.  Ids stay in entry
+// order (a lane takes its eight with one load); the elementwise residual kernels walk the residuals in memory order and map back.
+__host__ __device__ static inline int64_t mfx_blk_mem_of(int64_t p) {
+  return (p & ~(int64_t)127) | (((p >> 2) & 1) << 6) | (((p >> 3) & 15) << 2) | (p & 3);
+}
+__host__ __device__ static inline int64_t mfx_blk_entry_of(int64_t t) {
+  return (t & ~(int64_t)127) | (((t >> 2) & 15) << 3) | (((t >> 6) & 1) << 2) | (t & 3);
+}
 static inline void mfx_blocks_free(MfxBlocks& b) { dev_free(b.rec); dev_free(b.wg_t0); dev_free(b.wg_n); dev_free(b.wg_rec); dev_free(b.wg_tag); dev_free(b.wg_stride); b.nwg = 0; b.nslots = 0; }
 
 struct MfxPiece { int64_t b, e; };               // padded positions [b, e): multiples of 8, ascending inside a region
@@ -133,7 +142,7 @@ template <typename IdxT> struct MfxIds8;
 template <> struct MfxIds8<uint16_t> {
   typedef unsigned u4 __attribute__((ext_vector_type(4)));
   struct raw { u4 a; };
-  static __device__ __forceinline__ raw load(const uint16_t* p) { return raw{*(const u4*)p}; }
+  static __device__ __forceinline__ raw load(const uint16_t* p) { return raw{__builtin_nontemporal_load((const u4*)p)}; }
   static __device__ __forceinline__ int get(const raw& v, int q) { return (int)((q & 1) ? (v.a[q >> 1] >> 16) : (v.a[q >> 1] & 0xffffu)); }
 };
 template <> struct MfxIds8<int32_t> {
@@ -201,8 +210,12 @@ __device__ __forceinline__ void mfx_ccd_block_loop(const int2* __restrict__ rec,
   const uint32_t eo_last = eo + STRIDE * (uint32_t)max((wn - g + MFX_BLK_GPW - 1) / MFX_BLK_GPW - 1, 0);
   auto data = [&]() {                                                 // the loads of the next step not yet requested
     Data d;
-    d.r0 = *(const f4*)((const char*)res + (size_t)(eo * 4u));
-    d.r1 = *(const f4*)((const char*)res + (size_t)(eo * 4u) + 16);
+    // the residuals of a trip are stored QUAD-INTERLEAVED (mfx_blk_mem_of): the lanes' first quads, then their second quads -- each
+    // load is 256 contiguous bytes per group.  (In entry order a lane's two quads are 32 bytes apart: both loads touched every
+    // line of the trip, half of it each -- measured 11 % of the pass.)  nt: a stream, nothing of it is read twice.
+    const uint32_t tb = (eo & ~127u) * 4u + 16u * (uint32_t)j;
+    d.r0 = __builtin_nontemporal_load((const f4*)((const char*)res + (size_t)tb));
+    d.r1 = __builtin_nontemporal_load((const f4*)((const char*)res + (size_t)tb + 256));
     d.x = MfxIds8<IdxT>::load((const IdxT*)((const char*)ind + (size_t)(eo * (uint32_t)sizeof(IdxT))));
     eo = min(eo + STRIDE, eo_last);
     return d;

@@ -30,7 +30,7 @@ constexpr int LIGHT = 0;          // columns with at most this many entries are 
                                   // 0 since the trip lists: short (strip, column) pieces no longer cost per-segment latency, and the
                                   // light region's L2 gathers do (C4: 2.29 vs 2.40 ms per factor at 1024, C2 shape 0.86 vs 0.89)
 constexpr int GPW = MFX_BLK_GPW;   // 16-lane groups per pass workgroup (1024 threads)
-constexpr int PASS_WGS = 1024;    // pass workgroups over all strips (two rounds of the 512 resident ones; MFX_CCD_PASS_WGS)
+constexpr int PASS_WGS = 512;     // pass workgroups over all strips: ONE round of the 512 resident ones (MFX_CCD_PASS_WGS)
 constexpr int64_t ENT_PER_WG = 128 * 1024;
 
 struct ColState {
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void strip_scatter_kernel(const int64_t* __res
       if (is_light) luser[d + t - light0] = real ? colind[src + t] : nU;
       else buser[d + t] = (uint16_t)(real ? colind[src + t] - b * UB : UB);
       if (((d + t) & 7) == 0) bcol[(d + t) >> 3] = (ColT)i;
-      res[d + t] = real ? colval[src + t] : 0.0f;
+      res[mfx_blk_mem_of(d + t)] = real ? colval[src + t] : 0.0f;
     }
   }
 }
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void strip_gather_kernel(const int64_t* __rest
     const int64_t src = colptr[i] + off[(int64_t)i * (nb + 1) + b];
     const int64_t n = off[(int64_t)i * (nb + 1) + b + 1] - off[(int64_t)i * (nb + 1) + b];
     const int64_t d = dst[(int64_t)b * ncols + i];
-    for (int64_t t = j; t < n; t += 16) out[src + t] = res[d + t];
+    for (int64_t t = j; t < n; t += 16) out[src + t] = res[mfx_blk_mem_of(d + t)];
   }
 }
 
@@ -269,10 +269,28 @@ int mfx_ccd_cols_build(mfx_ctx* ctx) {
         return mfx_fail(ctx, MFX_E_STATE, "mfx_ccdpp_begin: the light region of the column view does not lay out");
     }
     s->nlw = (int)plan.wg_t0.size();
+    // the strips share want_wgs workgroups in proportion to their trips (largest remainders first), at least eight steps per group:
+    // the total is what was asked for -- 59 strips rounded one by one came to 531 workgroups for 512, i.e. a second round of 19
+    std::vector<int> nw(regions.size() - 1, 0);
+    {
+      const int64_t total = std::max<int64_t>(1, strip_trips);
+      const int64_t budget = std::max<int64_t>(1, std::min<int64_t>(want_wgs, total / (8 * GPW)));
+      std::vector<std::pair<int64_t, size_t>> frac;
+      int64_t used = 0;
+      for (size_t q = 0; q + 1 < regions.size(); q++) {
+        const int64_t tb = (regions[q].r1 - regions[q].r0) / MFX_BLK_E;
+        if (tb == 0) continue;
+        nw[q] = (int)std::max<int64_t>(1, tb * budget / total);
+        used += nw[q];
+        frac.push_back({-(tb * budget % total), q});
+      }
+      std::sort(frac.begin(), frac.end());
+      for (size_t k = 0; k < frac.size() && used < budget; k++, used++) nw[frac[k].second]++;
+    }
+    (void)per_wg;
     for (size_t q = 0; q + 1 < regions.size(); q++) {
-      const int64_t tb = (regions[q].r1 - regions[q].r0) / MFX_BLK_E;
-      if (tb == 0) continue;
-      if (!lay(q, (int)std::max<int64_t>(1, (tb + per_wg / 2) / per_wg)))
+      if (nw[q] == 0) continue;
+      if (!lay(q, nw[q]))
         return mfx_fail(ctx, MFX_E_STATE, "mfx_ccdpp_begin: strip %zu of the column view does not lay out", q);
     }
   }
@@ -318,6 +336,8 @@ int mfx_ccd_cols_build(mfx_ctx* ctx) {
   if (col16) { if ((rc = dev_alloc(ctx, &s->bcol16, (size_t)(nnzp / MFX_BLK_EPL)))) return rc; }
   else if ((rc = dev_alloc(ctx, &s->bcol32, (size_t)(nnzp / MFX_BLK_EPL)))) return rc;
   if ((rc = dev_alloc(ctx, &s->res, (size_t)nalloc))) return rc;
+  // (the residuals are stored quad-interleaved inside a trip: what no piece owns is not a contiguous range of them -- all zero first)
+  HIPCHK(hipMemsetAsync(s->res, 0, sizeof(float) * (size_t)nalloc, ctx->stream));
   if (m.nnz > 0) {
     if (col16)
       hipLaunchKernelGGL(strip_scatter_kernel<uint16_t>, dim3(2048), dim3(256), 0, ctx->stream, m.colptr, m.colind, m.colval,
@@ -328,16 +348,14 @@ int mfx_ccd_cols_build(mfx_ctx* ctx) {
     HIPCHK(hipGetLastError());
   }
   {
-    Ranges rres = tails, rbu, rlu, rbc;
+    Ranges rbu, rlu, rbc;
     for (size_t q = 0; q < tails.a.size(); q++) rbc.add(tails.a[q] / MFX_BLK_EPL, tails.b[q] / MFX_BLK_EPL);
-    rres.add(nnzp, nalloc);
     for (size_t q = 0; q < tails.a.size(); q++) {
       if (tails.a[q] < s->light0) rbu.add(tails.a[q], tails.b[q]);
       else rlu.add(tails.a[q] - s->light0, tails.b[q] - s->light0);
     }
     rbu.add(s->light0, s->light0 + MFX_BLK_SLACK);
     if (has_light) rlu.add(nnzp - s->light0, nalloc - s->light0);
-    if ((rc = fill_ranges(ctx, s->res, rres, 0.0f))) return rc;
     if ((rc = fill_ranges(ctx, s->buser, rbu, (uint16_t)UB))) return rc;
     if ((rc = fill_ranges(ctx, s->luser, rlu, (int32_t)ctx->nU))) return rc;
     if (col16) { if ((rc = fill_ranges(ctx, s->bcol16, rbc, (uint16_t)0))) return rc; }
@@ -389,7 +407,8 @@ __global__ __launch_bounds__(256) void colresid_light_kernel(int64_t e0, int64_t
                                                              const float* __restrict__ vk1) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t t = e0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < e1; t += stride) {
-    const int u = luser[t - lshift], c = (int)bcol[t >> 3];
+    const int64_t tl = mfx_blk_entry_of(t);          // residual t (memory order) is entry tl
+    const int u = luser[tl - lshift], c = (int)bcol[tl >> 3];
     const float p0 = uk0[u] * vk0[c];
     float r = res[t];
     if (MODE == 1) r = r + p0;
@@ -492,33 +511,20 @@ __global__ __launch_bounds__(1024) void colresid_kernel(const int32_t* __restric
   typedef float f4 __attribute__((ext_vector_type(4)));
   typedef int i4 __attribute__((ext_vector_type(4)));
   const int64_t e0 = rw_e0[blockIdx.x], e1 = rw_e1[blockIdx.x];
-  for (int64_t t = (e0 & ~(int64_t)3) + 4 * (int64_t)threadIdx.x; t < e1; t += 4 * (int64_t)blockDim.x) {
-    if (t >= e0 && t + 4 <= e1) {
-      const i4 lu = MfxCcdTrip::load4(buser + t);
-      const int c = (int)bcol[t >> 3];        // four consecutive entries of the padded view lie in ONE column
-      f4 r = *(const f4*)(res + t);
-      const float v0 = vk0[c], v1 = MODE == 2 ? vk1[c] : 0.0f;
+  for (int64_t t = e0 + 4 * (int64_t)threadIdx.x; t < e1; t += 4 * (int64_t)blockDim.x) {      // (e0, e1: multiples of 128)
+    const int64_t tl = mfx_blk_entry_of(t);   // the residual quad at t (memory order) holds the entries tl .. tl + 3
+    const i4 lu = MfxCcdTrip::load4(buser + tl);
+    const int c = (int)bcol[tl >> 3];         // the four entries of a quad lie in ONE column
+    f4 r = *(const f4*)(res + t);
+    const float v0 = vk0[c], v1 = MODE == 2 ? vk1[c] : 0.0f;
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const float p0 = su[lu[q]] * v0;      // u_k(u)*v_k(item): float product (modelMF.cpp:1053, :1114)
-        if (MODE == 1) r[q] = r[q] + p0;
-        else r[q] = r[q] - p0;
-        if (MODE == 2) r[q] = r[q] + su[UBS + lu[q]] * v1;
-      }
-      *(f4*)(res + t) = r;
-    } else {
-      for (int q = 0; q < 4; q++) {
-        const int64_t tt = t + q;
-        if (tt < e0 || tt >= e1) continue;
-        const int lu = (int)buser[tt], c = (int)bcol[tt >> 3];
-        const float p0 = su[lu] * vk0[c];
-        float r = res[tt];
-        if (MODE == 1) r = r + p0;
-        else r = r - p0;
-        if (MODE == 2) r = r + su[UBS + lu] * vk1[c];
-        res[tt] = r;
-      }
+    for (int q = 0; q < 4; q++) {
+      const float p0 = su[lu[q]] * v0;        // u_k(u)*v_k(item): float product (modelMF.cpp:1053, :1114)
+      if (MODE == 1) r[q] = r[q] + p0;
+      else r[q] = r[q] - p0;
+      if (MODE == 2) r[q] = r[q] + su[UBS + lu[q]] * v1;
     }
+    *(f4*)(res + t) = r;
   }
 }
 
