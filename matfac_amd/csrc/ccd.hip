@@ -8,13 +8,12 @@
 //   col pass   v_k[i] = sum_u res_ui u_k[u] / (iReg + sum_u u_k[u]^2)   (:1078-1090)
 //   residual   res_ui +-= u_k[u] v_k[i] on both views                   (:1032-1056, :1095-1116)
 // Arithmetic as in the reference: the products are float*float, num/denom accumulate
-// in double, the quotient is rounded to float once.  A 16-lane group reduces one row
-// segment (<= MFX_SEG ratings) at a time, working through its range of the TRIP LIST
-// (mfx_internal.h: mfx_ccd_trip_loop -- 128-entry trips, records fetched four at a time,
-// data prefetched two trips ahead, whole trips loaded and masked); the sums of a segment
-// go to a slot and the quotients are taken by the finishing kernels in a fixed order, so
-// every sum has a fixed association (reproducible).  Item ids are 16 bits wherever v_k
-// is staged in LDS.
+// in double, the quotient is rounded to float once.  Both views are PADDED (ccd_blocks.h:
+// every row / (strip, column) piece starts on a multiple of 8 entries, the view is whole
+// 128-entry trips); a pass is a segmented reduction over the trips -- a 16-lane group per
+// trip, the sums of the pieces inside it to consecutive slots -- and the finishing kernels
+// add a row's slots in order and take the quotient, so every sum has a fixed association
+// (reproducible).  Item ids are 16 bits wherever v_k is staged in LDS.
 #include <algorithm>
 
 #include "ccd_blocks.h"

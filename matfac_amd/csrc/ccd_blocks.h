@@ -25,6 +25,7 @@
 #define MFX_CCD_BLOCKS_H_
 
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "mfx_internal.h"
@@ -88,7 +89,7 @@ static inline bool mfx_blocks_region(const MfxPiece* pc, size_t np, int64_t r0, 
   // contiguous windows.
   const int64_t nch = (ntr + MFX_BLK_GPW - 1) / MFX_BLK_GPW;
   nwg = (int)std::max<int64_t>(1, std::min<int64_t>(nwg, nch));
-  const bool interleave = (r1 - r0) + MFX_BLK_SLACK < ((int64_t)1 << 30);
+  const bool interleave = (r1 - r0) + MFX_BLK_SLACK < ((int64_t)1 << 30) && !getenv("MFX_CCD_CONTIG");      // (the knob: tests)
   for (int w = 0; w < nwg; w++) {
     int64_t c0, nc, stride;             // first chunk, chunks, chunks between steps
     if (interleave) { c0 = w; nc = (nch - w + nwg - 1) / nwg; stride = nwg; }

@@ -7,16 +7,17 @@
 // LDS (C4: 1.9 MB), so the column view is stored in USER-BLOCK-major order: block b holds, column by
 // column, the entries whose user lies in [b*UB, (b+1)*UB), users ascending -- i.e. the reference's
 // colind/colval (gk_csr_CreateIndex order) cut into UB-user strips.  A workgroup stages u_k[b*UB ...] (32 KB)
-// in LDS and works on entries of that strip only.  Column sums are formed per (strip, column) segment of <= 1024
-// entries and finished per column in a fixed order (strip-major), so every sum has a fixed association.
+// in LDS and works on entries of that strip only.  The view is PADDED (ccd_blocks.h: every (strip, column) piece starts on a
+// multiple of 8 entries, every strip on a multiple of 128); column sums are formed per piece and 128-entry trip and finished per
+// column in a fixed order (strip-major), so every sum has a fixed association.
 //
 // LIGHT columns (at most LIGHT entries in the whole column: at the Netflix shape two thirds of the items, 4 % of the
 // entries, and two thirds of the 1 M (strip, column) segments, each 1..16 entries long -- the pass spent its time on
 // per-segment latency, not on bytes) stay OUT of the strip scheme: their entries are kept contiguous behind the strips,
 // users ascending (the reference's CSC order), one segment per column, and u_k is gathered from L2 for them.
-// (That was round 2's first answer to the short pieces; with the trip lists the strips handle them better, and the default
+// (That was round 2's first answer to the short pieces; the strips handle them better since, and the default
 // threshold is 0 -- every column goes through the strips.  The region stays as the MFX_CCD_LIGHT knob and in the tests.)
-// Both regions are worked through as trip lists (mfx_internal.h) by ONE launch: the light workgroups first, then the
+// Both regions are worked through by ONE launch of the block loop (ccd_blocks.h): the light workgroups first, then the
 // strips' workgroups in proportion to their trips.
 #include <algorithm>
 #include <cstdlib>

@@ -127,14 +127,15 @@ def test_column_view_strips_and_light_columns_agree(light, monkeypatch):
 
 
 
-@pytest.mark.parametrize("nobuf", ["", "1"])
+@pytest.mark.parametrize("contig", ["", "1"])
 @pytest.mark.parametrize("nI", [500, 70000])
-def test_wide_item_axis_and_plain_load_paths(nI, nobuf, monkeypatch):
-    """The pass kernels have two index widths and two load paths.  70 000 items: v_k does not fit in LDS (gathered from L2),
-    item and column ids are 32 bits; 500 items: 16-bit ids, v_k in LDS.  MFX_CCD_NOBUF=1 takes the plain global loads that
-    matrices of 2^30 ratings and more use (no per-lane skip outside a segment).  Same tolerances as above on all four."""
-    if nobuf:
-        monkeypatch.setenv("MFX_CCD_NOBUF", nobuf)
+def test_wide_item_axis_and_both_window_layouts(nI, contig, monkeypatch):
+    """The pass kernels have two index widths and the block plan two ways of dealing the trips.  70 000 items: v_k does not fit in
+    LDS (gathered from L2), item and column ids are 32 bits; 500 items: 16-bit ids, v_k in LDS.  MFX_CCD_CONTIG=1 gives every
+    workgroup one contiguous window, what regions of 2^30 entries and more use (the loop addresses a region with 32-bit byte
+    offsets), instead of chunks dealt round-robin.  Same tolerances as above on all four."""
+    if contig:
+        monkeypatch.setenv("MFX_CCD_CONTIG", contig)
     K = 8
     d, tr, (cp, ci, cv), U0, V0 = _setup(12000, nI, 200000, K, seed=5 + nI)
     nU, nIt = d["nUsers"], d["nItems"]
