@@ -756,7 +756,7 @@ def bench_ccd(np, with_cpu):
            "row_pass_ms": r_ms / max(r_n, 1), "col_pass_ms": c_ms / max(c_n, 1), "resid_update_ms": x_ms / max(x_n, 1),
            "roofline": {"bound": "hbm", "achieved": bytes_per_k / per_k / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": bytes_per_k / per_k / 1e9 / HBM_PEAK_GBS, "bytes_per_factor": bytes_per_k, "traffic": None,
-                        "kernel": "ccd_pass_kernel / ccd_cols pass / resid_update_kernel (whole rank-one step, wall clock)"}}
+                        "kernel": "ccd_pass_kernel / colpass_kernel (segmented reduction over padded 128-entry trips) / resid_fused_kernel / colresid_kernel (whole rank-one step, wall clock)"}}
     rec["exact_replay_of_ModelMF_train_at_this_size"] = replay
     # memory-side bytes of one rank-one step from the committed counter passes (scripts/pmc_c4.sh), time from this run
     try:

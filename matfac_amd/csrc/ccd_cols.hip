@@ -32,7 +32,6 @@ constexpr int LIGHT = 0;          // columns with at most this many entries are 
                                   // light region's L2 gathers do (C4: 2.29 vs 2.40 ms per factor at 1024, C2 shape 0.86 vs 0.89)
 constexpr int GPW = MFX_BLK_GPW;   // 16-lane groups per pass workgroup (1024 threads)
 constexpr int PASS_WGS = 512;     // pass workgroups over all strips: ONE round of the 512 resident ones (MFX_CCD_PASS_WGS)
-constexpr int64_t ENT_PER_WG = 128 * 1024;
 
 struct ColState {
   int nb = 0;                       // strips
@@ -59,7 +58,7 @@ struct ColState {
   int fin_n16 = 0, fin_n64 = 0, fin_n256 = 0;
   MfxBlocks blocks;                 // the pass: the light region's workgroups first (tag -1), then the strips' (tag = strip)
   int nlw = 0;                      // workgroups of the light region
-  int32_t* rw_blk = nullptr; int64_t* rw_e0 = nullptr; int64_t* rw_e1 = nullptr; int nrw = 0;       // residual
+  int32_t* rw_blk = nullptr; int64_t* rw_e0 = nullptr; int64_t* rw_e1 = nullptr; int64_t* rw_stride = nullptr; int nrw = 0;       // residual: strip, first piece, end of the strip, entries to the workgroup's next piece
   int64_t light0 = 0, light1 = 0;   // padded positions of the light region (light0 == light1: none)
 };
 ColState* st(mfx_ctx* ctx) { return (ColState*)ctx->ccd_cols; }
@@ -80,7 +79,7 @@ void mfx_ccd_cols_free(mfx_ctx* ctx) {
   dev_free(s->part); dev_free(s->sums);
   dev_free(s->col_ptr); dev_free(s->col_seg); dev_free(s->fin_order);
   mfx_blocks_free(s->blocks);
-  dev_free(s->rw_blk); dev_free(s->rw_e0); dev_free(s->rw_e1);
+  dev_free(s->rw_blk); dev_free(s->rw_e0); dev_free(s->rw_e1); dev_free(s->rw_stride);
   delete s;
   ctx->ccd_cols = nullptr;
 }
@@ -194,12 +193,23 @@ int mfx_ccd_cols_build(mfx_ctx* ctx) {
   HIPCHK(hipMemcpyAsync(off.data(), s->off, sizeof(int32_t) * off.size(), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   // padded strip-major positions, the pieces of every region, per-column slot lists, workgroup tables
-  std::vector<int64_t> dst((size_t)nb * nI, 0), rw_e0, rw_e1;
+  std::vector<int64_t> dst((size_t)nb * nI, 0), rw_e0, rw_e1, rw_stride;
   std::vector<int32_t> plen((size_t)nb * nI, 0), rw_blk;
   std::vector<uint8_t> light((size_t)nI, 0);
   const char* le = getenv("MFX_CCD_LIGHT");        // experiment / test knob: the threshold (0: every column goes through the strips)
   const int light_max = le ? atoi(le) : LIGHT;
   for (int32_t i = 0; i < nI; i++) light[(size_t)i] = off[(size_t)i * (nb + 1) + nb] <= light_max;
+  // residual update: a workgroup works on ONE strip (it stages that strip of u_k), the workgroups of a strip take its 4 096-entry
+  // pieces round-robin.  About ONE workgroup per CU over all strips (MFX_CCD_RESID_WGS, default 256): measured at C4 per launch of
+  // colresid_kernel<2> -- 128: 385 us, 192: 250, 256: 215, 320: 275, 512: 234, 1 024 / 2 048: 240; the 813 contiguous 128 K-entry
+  // ranges of rounds 2 and 3: 245)
+  int64_t ent_per_wg = 128 * 1024;
+  {
+    const char* re = getenv("MFX_CCD_RESID_WGS");
+    const int64_t slots = re && atoi(re) > 0 ? atoi(re) : 256;
+    const int64_t est = m.nnz + 8 * (int64_t)nI * nb / 2 + 128 * (int64_t)nb;          // entries with their padding, roughly
+    if (slots > nb) ent_per_wg = std::max<int64_t>(ent_per_wg, round_up((est + (slots - nb) - 1) / (slots - nb), 4096));
+  }
   struct Region { int64_t r0, r1; int tag; std::vector<MfxPiece> pc; std::vector<int32_t> col; };
   std::vector<Region> regions;
   Ranges tails;                                     // positions inside the view that no piece owns
@@ -219,7 +229,10 @@ int mfx_ccd_cols_build(mfx_ctx* ctx) {
     }
     R.r1 = round_up(pos, MFX_BLK_E);
     tails.add(pos, R.r1);
-    for (int64_t a = R.r0; a < R.r1; a += ENT_PER_WG) { rw_blk.push_back(b); rw_e0.push_back(a); rw_e1.push_back(std::min(R.r1, a + ENT_PER_WG)); }
+    {   // the strip's workgroups take its 4 096-entry pieces (one trip of a workgroup's loop) round-robin: one front per strip
+      const int64_t nwb = (R.r1 - R.r0 + ent_per_wg - 1) / ent_per_wg;
+      for (int64_t k = 0; k < nwb; k++) { rw_blk.push_back(b); rw_e0.push_back(R.r0 + 4096 * k); rw_e1.push_back(R.r1); rw_stride.push_back(4096 * nwb); }
+    }
     pos = R.r1;
     regions.push_back(std::move(R));
   }
@@ -327,6 +340,7 @@ int mfx_ccd_cols_build(mfx_ctx* ctx) {
   if ((rc = up(ctx, &s->rw_blk, rw_blk))) return rc;
   if ((rc = up(ctx, &s->rw_e0, rw_e0))) return rc;
   if ((rc = up(ctx, &s->rw_e1, rw_e1))) return rc;
+  if ((rc = up(ctx, &s->rw_stride, rw_stride))) return rc;
   s->nrw = (int)rw_blk.size();
   if ((rc = dev_alloc(ctx, &s->part, (size_t)plan.nslots * 2))) return rc;
   const bool col16 = nI <= 65536;
@@ -494,7 +508,8 @@ __global__ void coldivide_kernel(const double* __restrict__ sums, const double* 
 template <int MODE, typename ColT>
 __global__ __launch_bounds__(1024) void colresid_kernel(const int32_t* __restrict__ rw_blk,
                                                         const int64_t* __restrict__ rw_e0,
-                                                        const int64_t* __restrict__ rw_e1, float* __restrict__ res,
+                                                        const int64_t* __restrict__ rw_e1, const int64_t* __restrict__ rw_stride,
+                                                        float* __restrict__ res,
                                                         const uint16_t* __restrict__ buser,
                                                         const ColT* __restrict__ bcol,
                                                         const float* __restrict__ uk0, const float* __restrict__ vk0,
@@ -511,8 +526,8 @@ __global__ __launch_bounds__(1024) void colresid_kernel(const int32_t* __restric
   // 16 aligned bytes per lane and array (4 entries); the entries of a neighbouring workgroup's range are left alone
   typedef float f4 __attribute__((ext_vector_type(4)));
   typedef int i4 __attribute__((ext_vector_type(4)));
-  const int64_t e0 = rw_e0[blockIdx.x], e1 = rw_e1[blockIdx.x];
-  for (int64_t t = e0 + 4 * (int64_t)threadIdx.x; t < e1; t += 4 * (int64_t)blockDim.x) {      // (e0, e1: multiples of 128)
+  const int64_t e0 = rw_e0[blockIdx.x], e1 = rw_e1[blockIdx.x], stride = rw_stride[blockIdx.x];
+  for (int64_t t = e0 + 4 * (int64_t)threadIdx.x; t < e1; t += stride) {      // (e0, e1: multiples of 128; a piece = 4 x 1 024 entries)
     const int64_t tl = mfx_blk_entry_of(t);   // the residual quad at t (memory order) holds the entries tl .. tl + 3
     const i4 lu = MfxCcdTrip::load4(buser + tl);
     const int c = (int)bcol[tl >> 3];         // the four entries of a quad lie in ONE column
@@ -578,10 +593,10 @@ int mfx_ccd_cols_resid(mfx_ctx* ctx, int mode, const float* uk0, const float* vk
 #define MFX_CR(MD)                                                                                                                 \
   do {                                                                                                                             \
     if (s->bcol16)                                                                                                                 \
-      hipLaunchKernelGGL((colresid_kernel<MD, uint16_t>), dim3(s->nrw), dim3(1024), 0, ctx->stream, s->rw_blk, s->rw_e0, s->rw_e1, \
+      hipLaunchKernelGGL((colresid_kernel<MD, uint16_t>), dim3(s->nrw), dim3(1024), 0, ctx->stream, s->rw_blk, s->rw_e0, s->rw_e1, s->rw_stride, \
                          s->res, s->buser, s->bcol16, uk0, vk0, uk1, vk1, m.nrows);                                                \
     else                                                                                                                           \
-      hipLaunchKernelGGL((colresid_kernel<MD, int32_t>), dim3(s->nrw), dim3(1024), 0, ctx->stream, s->rw_blk, s->rw_e0, s->rw_e1,  \
+      hipLaunchKernelGGL((colresid_kernel<MD, int32_t>), dim3(s->nrw), dim3(1024), 0, ctx->stream, s->rw_blk, s->rw_e0, s->rw_e1, s->rw_stride, \
                          s->res, s->buser, s->bcol32, uk0, vk0, uk1, vk1, m.nrows);                                                \
   } while (0)
     if (mode == 1) MFX_CR(1); else if (mode == 2) MFX_CR(2); else MFX_CR(-1);
