@@ -487,10 +487,10 @@ def exact_replay(np, ctx, mfx, tr, U0, V0, lr, ureg, ireg, epochs=3, hybrid_too=
     call_s, kern_s = float(np.median(calls)), float(np.median(kernels))
     hybrid = None
     if hybrid_too:
-        # the same epochs with hybrid ownership (MFX_FLOW_HYBRID=1: the busiest users get queues of their own; queues built on the host, so
-        # only the kernel time is comparable -- DESIGN.md section 8)
+        # the same epochs with the item rows owned throughout (MFX_FLOW_HYBRID=0: what rounds 2 and 3 ran; the default since round 4 gives
+        # the busiest users queues of their own -- DESIGN.md section 3.1.2)
         try:
-            os.environ["MFX_FLOW_HYBRID"] = "1"
+            os.environ["MFX_FLOW_HYBRID"] = "0"
             ctx.set_factors(U0, V0)
             ctx.prof_enable(True)
             hk = []
@@ -504,20 +504,20 @@ def exact_replay(np, ctx, mfx, tr, U0, V0, lr, ureg, ireg, epochs=3, hybrid_too=
             ctx.prof_enable(False)
             hinfo, _ = ctx.debug_levels_info()
             hybrid = {"kernel_ms_per_epoch": float(min(hk)) * 1e3, "kernel_updates_per_s": tr.nnz / float(min(hk)), "longest_queue": int(hinfo[1]),
-                      "note": "MFX_FLOW_HYBRID=1, opt-in: bit-identical (tests/test_sgd_gpu.py); queues built on the host (0.4 s per epoch), not the default"}
+                      "note": "MFX_FLOW_HYBRID=0: item rows owned throughout, every visit of a busy user a hand-off between item queues (the schedule of rounds 2 and 3)"}
         except Exception as e:                  # noqa: BLE001
             hybrid = {"error": str(e)}
         finally:
             os.environ.pop("MFX_FLOW_HYBRID", None)
-    return {"hybrid_ownership": hybrid,
+    return {"item_rows_owned_throughout": hybrid,
             "path": "MFX_SGD_LEVELS, tagged dataflow schedule (order replay of ModelMF::train, double bracket): bit-identical to the "
                     "sequential loop", "updates_per_s": tr.nnz / call_s, "ms_per_epoch": call_s * 1e3,
             "kernel_updates_per_s": tr.nnz / kern_s, "kernel_ms_per_epoch": kern_s * 1e3, "epochs": epochs,
             "longest_queue": int(info[1]), "queues": int(info[2]),
             "frac_of_hbm_roofline_model": (16 * U0.shape[1] + 12) * tr.nnz / call_s / 1e9 / HBM_PEAK_GBS,
-            "bound": "hand-off chains: at C2 the busiest user's 10 717 ratings are 10 717 hand-offs between item queues at ~ 1.3 us (DESIGN.md 3.1.2, "
-                     "scripts/flow_model.py); with those users in queues of their own (hybrid_ownership) the most popular item's queue: longest_queue "
-                     "visits x the step of one visit -- latency, not bandwidth",
+            "bound": "the most popular item's queue: longest_queue visits x the step of one visit (the busiest users have queues of their own: hybrid "
+                     "ownership, DESIGN.md 3.1.2; with the item rows owned throughout the busiest user's 10 717 ratings are 10 717 hand-offs between "
+                     "item queues at ~ 1.3 us, scripts/flow_model.py) -- latency, not bandwidth",
             "test_rmse_vs_reference": "rmse_parity.*.gpu_default_path_* (whole training loops against the fixture's seed-1 row)"}
 
 

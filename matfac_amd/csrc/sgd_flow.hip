@@ -69,6 +69,14 @@ struct FlowState {
   int64_t qa_cap = 0;
   int g_item = 0, n_heavy = 0;
   bool hybrid = false;
+  // ... built on the device (build_flow_hybrid_device): queue of every user (-1: not heavy), rank << 1 | pub of every list position in
+  // its item's chain and of its queue record; the heavy set and the item queues are cached per train matrix like the assignment below
+  int32_t* duq = nullptr;
+  uint32_t *hy_ri = nullptr, *hy_qa = nullptr;
+  int64_t hy_cap = 0, duq_cap = 0;
+  uint64_t hy_gen = ~0ull;
+  int64_t hy_groups = -1, hy_nU = -1, hy_nI = -1, hy_count = -1;
+  int hy_heavy_max = -1, hy_heavy_min = -1, hy_H = 0;
   std::vector<uint8_t> oslot;
   bool tagged = false;                // the queues of the last build carry the LDS slot of the owned row in .y
   // owner assignment (owned rows -> queues, LDS slots), cached per train matrix: it depends on the rows' chain lengths only for
@@ -1596,9 +1604,9 @@ static int bits_for(uint64_t n) {
   return b;
 }
 
-int build_flow_device(mfx_ctx* ctx, int64_t first, int64_t count, int64_t groups, bool tagged) {
+// the buffers of the device-side constructions (build_flow_device, build_flow_hybrid_device)
+static int flow_device_buffers(mfx_ctx* ctx, int64_t count, int64_t groups) {
   FlowState* S = fl(ctx);
-  const auto t0 = std::chrono::steady_clock::now();
   int rc;
   const int64_t nU = ctx->nU, nI = ctx->nI;
   if (S->cap < count) {
@@ -1642,6 +1650,15 @@ int build_flow_device(mfx_ctx* ctx, int64_t first, int64_t count, int64_t groups
     S->goff_cap = groups + 1;
   }
   if (!S->flag && (rc = dev_alloc(ctx, &S->flag, (size_t)1))) return rc;
+  return MFX_OK;
+}
+
+int build_flow_device(mfx_ctx* ctx, int64_t first, int64_t count, int64_t groups, bool tagged) {
+  FlowState* S = fl(ctx);
+  const auto t0 = std::chrono::steady_clock::now();
+  int rc;
+  const int64_t nU = ctx->nU, nI = ctx->nI;
+  if ((rc = flow_device_buffers(ctx, count, groups))) return rc;
   const int32_t *eu = ctx->eu + first, *ei = ctx->ei + first;
   const float* er = ctx->er + first;
   const int grid = (int)std::min<int64_t>((count + 255) / 256, 8192);
@@ -1691,6 +1708,7 @@ int build_flow_device(mfx_ctx* ctx, int64_t first, int64_t count, int64_t groups
     hipLaunchKernelGGL(flow_deal_kernel, dim3(rgrid), dim3(256), 0, ctx->stream, S->k1, S->v1, nOwnD, groups, S->downer);
     HIPCHK(hipGetLastError());
     S->assign_gen = ~0ull;                 // the cached dealing by chain length is gone from downer
+    S->hy_gen = ~0ull;
     S->assign_own_user = adj_own;
     S->assign_maxU = S->assign_maxI = 0;   // (not looked at on this path)
   } else if (S->assign_gen != ctx->train_gen || S->assign_groups != groups || S->assign_nU != nU || S->assign_nI != nI || S->assign_want != want_own ||
@@ -1739,6 +1757,7 @@ int build_flow_device(mfx_ctx* ctx, int64_t first, int64_t count, int64_t groups
     HIPCHK(hipMemcpyAsync(S->downer, S->owner.data(), sizeof(int32_t) * (size_t)nOwnA, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));          // S->owner may be reassigned by the host builder
     S->assign_gen = ctx->train_gen; S->assign_groups = groups; S->assign_nU = nU; S->assign_nI = nI; S->assign_count = count;
+    S->hy_gen = ~0ull;                     // (downer is shared with the hybrid builder's item queues)
   }
   const int own_user = S->assign_own_user;
   const int32_t maxU = S->assign_maxU, maxI = S->assign_maxI;
@@ -1782,6 +1801,197 @@ int build_flow_device(mfx_ctx* ctx, int64_t first, int64_t count, int64_t groups
     fprintf(stderr, "[mfx] dataflow replay (device construction): %lld ratings on %lld queues (%s rows owned), longest queue %lld, longest chains "
             "%d users / %d items, preparation %.1f ms\n", (long long)count, (long long)groups, own_user ? "user" : "item", (long long)longest, maxU,
             maxI, S->prep_ms);
+  return MFX_OK;
+}
+
+// ---- hybrid ownership built on the device (the default; MFX_FLOW_HYBRID=host keeps build_flow_hybrid_host as the cross-check) ----
+// ratings per item that stay in the item's queue (their user is not heavy)
+__global__ void hy_light_degrees_kernel(const int32_t* __restrict__ eu, const int32_t* __restrict__ ei, int64_t n, const int32_t* __restrict__ uq,
+                                        int32_t* __restrict__ degL) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride)
+    if (uq[eu[t]] < 0) atomicAdd(degL + ei[t], 1);
+}
+// sorted by user (stable): rank of list position v1[k] in its user's chain
+__global__ void hy_user_rank_kernel(const uint32_t* __restrict__ k1, const uint32_t* __restrict__ v1, const int64_t* __restrict__ start, int64_t n,
+                                    uint32_t* __restrict__ ru) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) ru[v1[k]] = (uint32_t)(k - start[k1[k]]);
+}
+// sorted by item (stable): rank in the item's chain << 1 | "the item's next visit lies in another queue (a heavy user's), or there is none"
+__global__ void hy_item_rank_kernel(const uint32_t* __restrict__ k1, const uint32_t* __restrict__ v1, const int64_t* __restrict__ start, int64_t n,
+                                    const int32_t* __restrict__ eu, const int32_t* __restrict__ uq, uint32_t* __restrict__ ri) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+    const uint32_t it = k1[k];
+    const bool next_same = k + 1 < n && k1[k + 1] == it;
+    const bool pub = !next_same || uq[eu[v1[k + 1]]] >= 0;
+    ri[v1[k]] = (uint32_t)(k - start[it]) << 1 | (pub ? 1u : 0u);
+  }
+}
+// the queue record, rank | pub and queue of every list position (list order)
+__global__ void hy_pack_kernel(const int32_t* __restrict__ eu, const int32_t* __restrict__ ei, const float* __restrict__ er, int64_t n,
+                               const int32_t* __restrict__ uq, const int32_t* __restrict__ owner, const int32_t* __restrict__ degU,
+                               const uint32_t* __restrict__ ru, const uint32_t* __restrict__ ri, int g_item, int4* __restrict__ pack,
+                               uint32_t* __restrict__ qa, uint32_t* __restrict__ key, uint32_t* __restrict__ val) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
+    const int u = eu[t], it = ei[t];
+    const int h = uq[u];
+    const uint32_t a = ru[t], b = ri[t];
+    if (h >= 0) {      // the heavy user's queue: user row owned, the item row through its tags; published behind the user's last rating
+      pack[t] = make_int4(it, u, __float_as_int(er[t]), (int)(b >> 1));
+      qa[t] = a << 1 | (a + 1 == (uint32_t)degU[u] ? 1u : 0u);
+      key[t] = (uint32_t)(g_item + h);
+    } else {
+      const uint32_t ow = (uint32_t)owner[it];
+      pack[t] = make_int4(u, (int)((uint32_t)it | (ow >> FL_SLOT_SHIFT) << FL_SLOT_SHIFT), __float_as_int(er[t]), (int)a);
+      qa[t] = b;
+      key[t] = ow & (uint32_t)FL_ROW_MASK;
+    }
+    val[t] = (uint32_t)t;
+  }
+}
+__global__ void hy_gather_kernel(const uint32_t* __restrict__ lpos, const int4* __restrict__ pack, const uint32_t* __restrict__ qa_list, int64_t n,
+                                 int4* __restrict__ q, uint32_t* __restrict__ qa) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) { q[t] = pack[lpos[t]]; qa[t] = qa_list[lpos[t]]; }
+}
+
+// Same lists as build_flow_hybrid_host.  Cached per train matrix, queue count and list length: the heavy users (uq), the item queues and
+// LDS slots (downer) -- they follow from the chain lengths, which a permutation of the same ratings does not change.  Per call: three
+// stable radix sorts (by user: ranks in the users' chains; by item: ranks in the items' chains and the publish flags; by queue).
+// Returns 1 (nothing built) for a user-ordered list or when no user is heavy enough.
+int build_flow_hybrid_device(mfx_ctx* ctx, int64_t first, int64_t count, int64_t groups, int heavy_max, int heavy_min) {
+  FlowState* S = fl(ctx);
+  const auto t0 = std::chrono::steady_clock::now();
+  int rc;
+  const int64_t nU = ctx->nU, nI = ctx->nI;
+  NEED(count < ((int64_t)1 << 31), MFX_E_ARG, "sgd dataflow (hybrid): list of %lld ratings", (long long)count);
+  if ((rc = flow_device_buffers(ctx, count, groups))) return rc;
+  if (S->hy_cap < count) {
+    dev_free(S->hy_ri); dev_free(S->hy_qa);
+    S->hy_cap = 0;
+    if ((rc = dev_alloc(ctx, &S->hy_ri, (size_t)count)) || (rc = dev_alloc(ctx, &S->hy_qa, (size_t)count))) return rc;
+    S->hy_cap = count;
+  }
+  if (S->qa_cap < count) {
+    dev_free(S->qa);
+    S->qa_cap = 0;
+    if ((rc = dev_alloc(ctx, &S->qa, (size_t)count))) return rc;
+    S->qa_cap = count;
+  }
+  if (S->duq_cap < nU) {
+    dev_free(S->duq);
+    S->duq_cap = 0; S->hy_gen = ~0ull;
+    if ((rc = dev_alloc(ctx, &S->duq, (size_t)nU))) return rc;
+    S->duq_cap = nU;
+  }
+  const int32_t *eu = ctx->eu + first, *ei = ctx->ei + first;
+  const float* er = ctx->er + first;
+  const int grid = (int)std::min<int64_t>((count + 255) / 256, 8192);
+  if (count > 1) {          // a user-ordered list: user rows are owned there (the ordinary queues)
+    unsigned long long* adj = (unsigned long long*)S->dstart;
+    unsigned long long hadj[2] = {0, 0};
+    HIPCHK(hipMemsetAsync(adj, 0, sizeof hadj, ctx->stream));
+    hipLaunchKernelGGL(flow_adjacent_kernel, dim3(std::min(grid, 1024)), dim3(256), 0, ctx->stream, eu, ei, count, adj);
+    HIPCHK(hipMemcpyAsync(hadj, adj, sizeof hadj, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (2 * hadj[0] > (unsigned long long)count) return 1;
+  }
+  if (S->hy_gen != ctx->train_gen || S->hy_groups != groups || S->hy_nU != nU || S->hy_nI != nI || S->hy_count != count ||
+      S->hy_heavy_max != heavy_max || S->hy_heavy_min != heavy_min) {
+    HIPCHK(hipMemsetAsync(S->degU, 0, sizeof(int32_t) * (size_t)(nU + nI), ctx->stream));
+    hipLaunchKernelGGL(flow_degrees_kernel, dim3(grid), dim3(256), 0, ctx->stream, eu, ei, count, S->degU, S->degI);
+    S->hdeg.resize((size_t)(nU + nI));
+    HIPCHK(hipMemcpyAsync(S->hdeg.data(), S->degU, sizeof(int32_t) * (size_t)(nU + nI), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const int32_t *degU = S->hdeg.data(), *degI = S->hdeg.data() + nU;
+    std::vector<int32_t> heavy;
+    for (int64_t u = 0; u < nU; u++)
+      if (degU[u] >= heavy_min) heavy.push_back((int32_t)u);
+    std::sort(heavy.begin(), heavy.end(), [&](int32_t a, int32_t b) { return degU[a] != degU[b] ? degU[a] > degU[b] : a < b; });
+    if ((int64_t)heavy.size() > heavy_max) heavy.resize((size_t)heavy_max);
+    const int H = (int)std::min<int64_t>((int64_t)heavy.size(), groups / 2);
+    S->hy_gen = ~0ull;
+    if (H == 0) {                          // remembered: the next call over this matrix asks no more than the key
+      S->hy_gen = ctx->train_gen; S->hy_groups = groups; S->hy_nU = nU; S->hy_nI = nI; S->hy_count = count;
+      S->hy_heavy_max = heavy_max; S->hy_heavy_min = heavy_min; S->hy_H = 0;
+      return 1;
+    }
+    S->assign_gen = ~0ull;                 // downer no longer holds the ordinary assignment
+    heavy.resize((size_t)H);
+    const int64_t g_item = groups - H;
+    std::vector<int32_t> uq((size_t)nU, -1);
+    for (int h = 0; h < H; h++) uq[(size_t)heavy[(size_t)h]] = h;
+    HIPCHK(hipMemcpyAsync(S->duq, uq.data(), sizeof(int32_t) * (size_t)nU, hipMemcpyHostToDevice, ctx->stream));
+    // items -> item queues by the ratings that stay with them (longest first onto the lightest queue), LDS slots as the host statement
+    int32_t* degL = (int32_t*)S->k0;       // (scratch: the sort buffers are written further down)
+    HIPCHK(hipMemsetAsync(degL, 0, sizeof(int32_t) * (size_t)nI, ctx->stream));
+    hipLaunchKernelGGL(hy_light_degrees_kernel, dim3(grid), dim3(256), 0, ctx->stream, eu, ei, count, (const int32_t*)S->duq, degL);
+    std::vector<int32_t> hdegL((size_t)nI);
+    HIPCHK(hipMemcpyAsync(hdegL.data(), degL, sizeof(int32_t) * (size_t)nI, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    S->hpacked.assign((size_t)nI, 0);
+    {
+      std::vector<int32_t> rows;
+      for (int64_t r = 0; r < nI; r++)
+        if (degI[r] > 0) rows.push_back((int32_t)r);
+      std::sort(rows.begin(), rows.end(), [&](int32_t a, int32_t b) { return hdegL[a] != hdegL[b] ? hdegL[a] > hdegL[b] : a < b; });
+      typedef std::pair<int64_t, int32_t> Load;
+      std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap;
+      for (int64_t gI = 0; gI < g_item; gI++) heap.push(Load(0, (int32_t)gI));
+      std::vector<int32_t> nrows((size_t)g_item, 0);
+      for (int32_t r : rows) {
+        Load l = heap.top();
+        heap.pop();
+        S->hpacked[(size_t)r] = (int32_t)((uint32_t)l.second | (uint32_t)(nrows[(size_t)l.second]++ & 31) << FL_SLOT_SHIFT);
+        l.first += hdegL[(size_t)r];
+        heap.push(l);
+      }
+    }
+    HIPCHK(hipMemcpyAsync(S->downer, S->hpacked.data(), sizeof(int32_t) * (size_t)nI, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    S->hy_gen = ctx->train_gen; S->hy_groups = groups; S->hy_nU = nU; S->hy_nI = nI; S->hy_count = count;
+    S->hy_heavy_max = heavy_max; S->hy_heavy_min = heavy_min; S->hy_H = H;
+  }
+  const int H = S->hy_H;
+  if (H == 0) return 1;
+  const int64_t g_item = groups - H;
+  HIPCHK(hipMemsetAsync(S->flag, 0, sizeof(unsigned), ctx->stream));
+  size_t bytes;
+  // ranks in the users' chains
+  hipLaunchKernelGGL(flow_keys_kernel, dim3(grid), dim3(256), 0, ctx->stream, eu, (const int32_t*)nullptr, count, S->k0, S->v0);
+  bytes = S->sort_tmp_bytes;
+  HIPCHK(rocprim::radix_sort_pairs(S->sort_tmp, bytes, S->k0, S->k1, S->v0, S->v1, (size_t)count, 0, bits_for((uint64_t)nU), ctx->stream));
+  hipLaunchKernelGGL(flow_bounds32_kernel, dim3((unsigned)std::min<int64_t>((nU + 256) / 256, 4096)), dim3(256), 0, ctx->stream, S->k1, count, nU + 1, S->dstart);
+  hipLaunchKernelGGL(hy_user_rank_kernel, dim3(grid), dim3(256), 0, ctx->stream, S->k1, S->v1, S->dstart, count, S->vexp);
+  // ranks in the items' chains and the publish flags of the visits that stay in the item queues
+  hipLaunchKernelGGL(flow_keys_kernel, dim3(grid), dim3(256), 0, ctx->stream, ei, (const int32_t*)nullptr, count, S->k0, S->v0);
+  bytes = S->sort_tmp_bytes;
+  HIPCHK(rocprim::radix_sort_pairs(S->sort_tmp, bytes, S->k0, S->k1, S->v0, S->v1, (size_t)count, 0, bits_for((uint64_t)nI), ctx->stream));
+  hipLaunchKernelGGL(flow_bounds32_kernel, dim3((unsigned)std::min<int64_t>((nI + 256) / 256, 4096)), dim3(256), 0, ctx->stream, S->k1, count, nI + 1, S->dstart);
+  hipLaunchKernelGGL(hy_item_rank_kernel, dim3(grid), dim3(256), 0, ctx->stream, S->k1, S->v1, S->dstart, count, eu, (const int32_t*)S->duq, S->hy_ri);
+  // records, queues, queue order
+  hipLaunchKernelGGL(hy_pack_kernel, dim3(grid), dim3(256), 0, ctx->stream, eu, ei, er, count, (const int32_t*)S->duq, (const int32_t*)S->downer,
+                     (const int32_t*)S->degU, (const uint32_t*)S->vexp, (const uint32_t*)S->hy_ri, (int)g_item, S->pack, S->hy_qa, S->k0, S->v0);
+  bytes = S->sort_tmp_bytes;
+  HIPCHK(rocprim::radix_sort_pairs(S->sort_tmp, bytes, S->k0, S->k1, S->v0, S->lpos, (size_t)count, 0, bits_for((uint64_t)groups), ctx->stream));
+  hipLaunchKernelGGL(flow_bounds_kernel, dim3((unsigned)std::min<int64_t>((groups + 256) / 256, 4096)), dim3(256), 0, ctx->stream, S->k1, count,
+                     groups + 1, S->qoff);
+  hipLaunchKernelGGL(hy_gather_kernel, dim3(grid), dim3(256), 0, ctx->stream, S->lpos, (const int4*)S->pack, (const uint32_t*)S->hy_qa, count, S->q, S->qa);
+  HIPCHK(hipGetLastError());
+  S->hoff.resize((size_t)groups + 1);
+  HIPCHK(hipMemcpyAsync(S->hoff.data(), S->qoff, sizeof(int64_t) * ((size_t)groups + 1), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  int64_t longest = 0;
+  for (int64_t gI = 0; gI < groups; gI++) longest = std::max(longest, S->hoff[(size_t)gI + 1] - S->hoff[(size_t)gI]);
+  S->groups = groups; S->longest = longest; S->own_user = 0; S->tagged = true;
+  S->hybrid = true; S->g_item = (int)g_item; S->n_heavy = H;
+  S->prep_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (getenv("MFX_DEBUG"))
+    fprintf(stderr, "[mfx] dataflow replay, hybrid ownership (device construction): %lld ratings, %lld item queues + %d heavy users' queues, longest queue "
+            "%lld, preparation %.1f ms\n", (long long)count, (long long)g_item, H, (long long)longest, S->prep_ms);
   return MFX_OK;
 }
 
@@ -1933,6 +2143,7 @@ void mfx_flow_free_internal(mfx_ctx* ctx) {
   FlowState* S = fl(ctx);
   if (!S) return;
   dev_free(S->q); dev_free(S->qoff); dev_free(S->lpos); dev_free(S->vexp); dev_free(S->ver); dev_free(S->flag);
+  dev_free(S->duq); dev_free(S->hy_ri); dev_free(S->hy_qa);
   dev_free(S->k0); dev_free(S->k1); dev_free(S->v0); dev_free(S->v1); dev_free(S->pack); dev_free(S->sort_tmp);
   dev_free(S->degU); dev_free(S->downer); dev_free(S->dstart); dev_free(S->tagbuf); dev_free(S->tagbuf2); dev_free(S->qa);
   delete S;
@@ -1964,19 +2175,23 @@ int mfx_launch_sgd_flow(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int6
   if (const char* e = getenv("MFX_FLOW_BLOCKS")) blocks = std::max(1, std::min(blocks, atoi(e)));   // test knob: few queues, many owned rows each
   const int64_t groups = (int64_t)blocks * per_block;
   // queues and versions are built on the device; MFX_FLOW_HOST=1 keeps the host statement of the same lists (the cross-check)
-  // hybrid ownership (MFX_FLOW_HYBRID=1; wide kernel, plain update): the busiest users get queues of their own
+  // hybrid ownership (wide kernel, plain update): the busiest users get queues of their own.  Built on the device by default;
+  // MFX_FLOW_HYBRID=host: the host statement of the same lists (the cross-check), MFX_FLOW_HYBRID=0: item rows owned throughout.
   int rc = 1;
   fl(ctx)->hybrid = false;
   {
     const char* hy = getenv("MFX_FLOW_HYBRID");
-    if (hy && atoi(hy) != 0 && tagged && L == 16 && C <= 4 && !getenv("MFX_FLOW_OWN") && !(getenv("MFX_FLOW_WIDE") && getenv("MFX_FLOW_WIDE")[0] == '0') &&
-        (uint64_t)ctx->nI * ctx->ld * 8 < (1ull << 32)) {
+    const bool off = hy && hy[0] == '0';
+    if (!off && tagged && L == 16 && C <= 4 && !getenv("MFX_FLOW_OWN") && !getenv("MFX_FLOW_HOST") &&
+        !(getenv("MFX_FLOW_WIDE") && getenv("MFX_FLOW_WIDE")[0] == '0') && (uint64_t)ctx->nI * ctx->ld * 8 < (1ull << 32)) {
       const char* hm = getenv("MFX_FLOW_HEAVY");
       const int heavy_max = hm ? std::max(0, atoi(hm)) : 128;
       // a user is worth a queue when its chain is long next to a queue's share of the list (at 1.3 us per hand-off a chain of half an
       // average queue already costs more than that queue's own work)
       const int heavy_min = (int)std::max<int64_t>(256, count / (2 * std::max<int64_t>(groups, 1)));
-      if (heavy_max > 0) rc = build_flow_hybrid_host(ctx, first, count, groups, heavy_max, heavy_min);
+      const bool host = (hy && hy[0] == 'h') || ctx->nI > count || ctx->nU > count;      // (the device statement borrows list-sized buffers for per-row tables)
+      if (heavy_max > 0) rc = host ? build_flow_hybrid_host(ctx, first, count, groups, heavy_max, heavy_min)
+                                   : build_flow_hybrid_device(ctx, first, count, groups, heavy_max, heavy_min);
       if (rc < 0) return rc;
     }
   }

@@ -434,10 +434,11 @@ def _heavy_both_matrix(seed):
 @pytest.mark.parametrize("K", [40, 64, 128, 256])
 @pytest.mark.parametrize("arith", ARITHS)
 def test_hybrid_ownership_is_the_sequential_loop_bit_for_bit(K, arith, monkeypatch):
-    """MFX_FLOW_HYBRID=1 (sgd_flow.hip, round 4): the busiest users get queues of their own that hold all their ratings, both factor
-    tables are in granule form with the row's version as its tag, and an item row moves between its owner's cache and the table
-    whenever a busy user's queue visits it in between.  Same bits as the oracle's sequential pass over three epochs of fresh
-    shuffled orders, with the pole path and without, for few (MFX_FLOW_HEAVY=2) and all qualifying busy users."""
+    """Hybrid ownership (sgd_flow.hip, round 4; the default of the exact replay for ranks above 32): the busiest users get queues of
+    their own that hold all their ratings, both factor tables are in granule form with the row's version as its tag, and an item row
+    moves between its owner's cache and the table whenever a busy user's queue visits it in between.  Same bits as the oracle's
+    sequential pass over three epochs of fresh shuffled orders, with the pole path and without, for few (MFX_FLOW_HEAVY=2) and all
+    qualifying busy users, with the queues built on the device (default) and by the host statement (MFX_FLOW_HYBRID=host)."""
     tr = _heavy_both_matrix(seed=K)
     nU, nI = tr.nrows, tr.ncols
     rng = np.random.default_rng(11 + K)
@@ -449,11 +450,13 @@ def test_hybrid_ownership_is_the_sequential_loop_bit_for_bit(K, arith, monkeypat
     for o in orders:
         orc.sgd_pass(Uo, Vo, ru, tr.rowind, tr.rowval, o, 0.002, 0.01, 0.02, arith[1], orc.DOT_TREE)
     assert np.isfinite(Uo).all() and np.isfinite(Vo).all() and np.abs(Vo - V0).max() > 1e-2
-    monkeypatch.setenv("MFX_FLOW_HYBRID", "1")
-    monkeypatch.setenv("MFX_DEBUG", "1")
-    for heavy, pole in (("128", "1"), ("2", "1"), ("128", "0")):
+    for heavy, pole, builder in (("128", "1", ""), ("2", "1", ""), ("128", "0", ""), ("128", "1", "host"), ("2", "0", "host")):
         monkeypatch.setenv("MFX_FLOW_HEAVY", heavy)
         monkeypatch.setenv("MFX_FLOW_POLE", pole)
+        if builder:
+            monkeypatch.setenv("MFX_FLOW_HYBRID", builder)
+        else:
+            monkeypatch.delenv("MFX_FLOW_HYBRID", raising=False)
         with Ctx(0) as ctx:
             ctx.set_csr(mfx.MAT_TRAIN, nU, nI, tr.rowptr, tr.rowind, tr.rowval)
             ctx.set_model(nU, nI, K)
@@ -461,8 +464,9 @@ def test_hybrid_ownership_is_the_sequential_loop_bit_for_bit(K, arith, monkeypat
             for o in orders:
                 ctx.sgd_set_order(o)
                 ctx.sgd_epoch(0.002, 0.01, 0.02, mode=mfx.SGD_LEVELS, order=mfx.ORDER_HOST, arith=arith[0])
+            info, _ = ctx.debug_levels_info()
             U, V = ctx.get_factors()
-        assert np.array_equal(U, Uo) and np.array_equal(V, Vo), (heavy, pole)
+        assert np.array_equal(U, Uo) and np.array_equal(V, Vo), (heavy, pole, builder)
 
 
 @pytest.mark.parametrize("K", [10, 64, 128, 200])
