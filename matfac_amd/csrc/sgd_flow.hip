@@ -2185,7 +2185,7 @@ int mfx_launch_sgd_flow(mfx_ctx* ctx, const mfx_sgd_opts* o, int64_t first, int6
     if (!off && tagged && L == 16 && C <= 4 && !getenv("MFX_FLOW_OWN") && !getenv("MFX_FLOW_HOST") &&
         !(getenv("MFX_FLOW_WIDE") && getenv("MFX_FLOW_WIDE")[0] == '0') && (uint64_t)ctx->nI * ctx->ld * 8 < (1ull << 32)) {
       const char* hm = getenv("MFX_FLOW_HEAVY");
-      const int heavy_max = hm ? std::max(0, atoi(hm)) : 128;
+      const int heavy_max = hm ? std::max(0, atoi(hm)) : 32;      // (C2: 32 queues 11.1 ms, 128: 11.6, all 290 qualifying users: 12.6)
       // a user is worth a queue when its chain is long next to a queue's share of the list (at 1.3 us per hand-off a chain of half an
       // average queue already costs more than that queue's own work)
       const int heavy_min = (int)std::max<int64_t>(256, count / (2 * std::max<int64_t>(groups, 1)));
