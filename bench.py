@@ -753,10 +753,11 @@ def bench_ccd(np, with_cpu):
     rec = {"config": "C4: Netflix-shape %dx%d, train nnz=%d, rank=%d, CCD++ (5 inner sweeps per factor), reg=%.1f" % (nU, nI, tr.nnz, K, reg),
            "metric": "rating-factor updates/sec", "value": tr.nnz / per_k, "ms_per_factor": per_k * 1e3,
            "s_per_outer_iteration": per_k * K, "steps": nk, "datagen_s": gen,
-           "row_pass_ms": r_ms / max(r_n, 1), "col_pass_ms": c_ms / max(c_n, 1), "resid_update_ms": x_ms / max(x_n, 1),
+           "row_pass_ms": r_ms / max(r_n, 1), "col_pass_ms": c_ms / max(c_n, 1),
+           "resid_update_ms": (x_ms / x_n) if x_n else None,    # None: the update rides on each factor's first sweep (fused pass kernels), inside row/col_pass_ms
            "roofline": {"bound": "hbm", "achieved": bytes_per_k / per_k / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": bytes_per_k / per_k / 1e9 / HBM_PEAK_GBS, "bytes_per_factor": bytes_per_k, "traffic": None,
-                        "kernel": "ccd_pass_kernel / colpass_kernel (segmented reduction over padded 128-entry trips) / resid_fused_kernel / colresid_kernel (whole rank-one step, wall clock)"}}
+                        "kernel": "ccd_pass_kernel / colpass_kernel (segmented reduction over padded 128-entry trips; the first sweep of a factor as ccd_pass_fused_kernel / colpass_fused_kernel with the residual update on the way) (whole rank-one step, wall clock)"}}
     rec["exact_replay_of_ModelMF_train_at_this_size"] = replay
     # memory-side bytes of one rank-one step from the committed counter passes (scripts/pmc_c4.sh), time from this run
     try:

@@ -20,7 +20,7 @@
 
 void mfx_ccd_free_internal(mfx_ctx* ctx) {
   dev_free(ctx->res_row); dev_free(ctx->res_col); dev_free(ctx->uk); dev_free(ctx->vk);
-  dev_free(ctx->uk_pend); dev_free(ctx->vk_pend);
+  dev_free(ctx->uk_pend); dev_free(ctx->vk_pend); dev_free(ctx->uk_init); dev_free(ctx->ccd_rpair);
   ctx->ccd_pending = false;
   dev_free(ctx->ccd_part); dev_free(ctx->colid); dev_free(ctx->ccd_ind16); dev_free(ctx->ccd_ind32); dev_free(ctx->ccd_rowid); dev_free(ctx->ccd_rpos);
   dev_free(ctx->ccd_rfirst); dev_free(ctx->ccd_rcnt); dev_free(ctx->ccd_lrow);
@@ -206,6 +206,51 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
   mfx_ccd_block_loop<typename ItemIdx<LDSO>::type>(rec + wg_rec[w], wn, wg_stride[w], g, res + e0, ind + e0, other, j, part, part_bytes);
 }
 
+// The FIRST row sweep of a factor with the residual update on the way (ccd_blocks.h, FUSE): both item vectors of the update in LDS
+// (the finished factor's v and the new one's, which is also what the sums gather), the users' pair per eight entries from rpair.
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void ccd_pass_fused_kernel(
+    const int2* __restrict__ rec, const int32_t* __restrict__ wg_t0, const int32_t* __restrict__ wg_n, const int64_t* __restrict__ wg_rec,
+    const int32_t* __restrict__ wg_stride, float* __restrict__ res, const uint16_t* __restrict__ ind, const float* __restrict__ v0g,
+    const float* __restrict__ v1g, int nother, const float2* __restrict__ rpair, double* __restrict__ part, uint32_t part_bytes) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int nbs = (nother + 4) & ~3;
+  {
+    const int n4 = nother >> 2;
+    for (int q = threadIdx.x; q < n4; q += blockDim.x) {
+      ((f4*)ccd_lds)[q] = ((const f4*)v0g)[q];
+      ((f4*)(ccd_lds + nbs))[q] = ((const f4*)v1g)[q];
+    }
+    for (int q = (n4 << 2) + threadIdx.x; q < nother; q += blockDim.x) {
+      ccd_lds[q] = v0g[q];
+      ccd_lds[nbs + q] = v1g[q];
+    }
+    if (threadIdx.x == 0) { ccd_lds[nother] = 0.0f; ccd_lds[nbs + nother] = 0.0f; }
+    __syncthreads();
+  }
+  const float *b0 = ccd_lds, *b1 = ccd_lds + nbs;
+  const int j = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int w = blockIdx.x, wn = wg_n[w];
+  const int64_t e0 = (int64_t)wg_t0[w] * MFX_BLK_E;
+  mfx_ccd_block_loop<uint16_t, true>(rec + wg_rec[w], wn, wg_stride[w], g, res + e0, ind + e0, b1, j, part, part_bytes, b0, b1, rpair + e0 / MFX_BLK_EPL);
+}
+// (a0[id[l]], a1[id[l]]) for every eight entries l of a padded view
+template <typename IdT>
+__global__ void ccd_pairs_kernel(const IdT* __restrict__ id8, int64_t n8, const float* __restrict__ a0, const float* __restrict__ a1,
+                                 float2* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; l < n8; l += stride) {
+    const int r = (int)id8[l];
+    out[l] = make_float2(a0[r], a1[r]);
+  }
+}
+int mfx_ccd_pairs(mfx_ctx* ctx, const void* id8, bool ids16, int64_t n8, const float* a0, const float* a1, float2* out) {
+  const unsigned blocks = (unsigned)std::min<int64_t>((n8 + 255) / 256, 8192);
+  if (ids16) hipLaunchKernelGGL(ccd_pairs_kernel<uint16_t>, dim3(blocks), dim3(256), 0, ctx->stream, (const uint16_t*)id8, n8, a0, a1, out);
+  else hipLaunchKernelGGL(ccd_pairs_kernel<int32_t>, dim3(blocks), dim3(256), 0, ctx->stream, (const int32_t*)id8, n8, a0, a1, out);
+  HIPCHK(hipGetLastError());
+  return MFX_OK;
+}
+
 // The quotients of a row pass, ONE launch: the first `dblocks` workgroups one thread per row -- u_k[row] = num / (reg + den) over the
 // row's pieces in order (at most 32: 4 096 entries) --, the others one 16-lane group per LONG row: pieces lane-strided in order, then
 // a fixed butterfly (a single thread walking ~400 partials of a 50 k-rating row was 13 % of a factor in round 1).
@@ -309,7 +354,7 @@ extern "C" int mfx_ccdpp_begin(mfx_ctx* ctx) {
     std::vector<int32_t> first(pieces.size()), cnt(pieces.size());
     const int64_t ntr = nnzp / MFX_BLK_E;
     const char* we = getenv("MFX_CCD_ROW_WGS");
-    const int max_wg = we && atoi(we) > 0 ? atoi(we) : 512;
+    const int max_wg = we && atoi(we) > 0 ? atoi(we) : 256;      // one per CU: as fast as two for the plain sweep, one round for the fused one (142 KB of LDS)
     const int nwg = (int)std::max<int64_t>(1, std::min<int64_t>((ntr + 8 * MFX_BLK_GPW - 1) / (8 * MFX_BLK_GPW), max_wg));
     NEED(mfx_blocks_region(pieces.data(), pieces.size(), 0, nnzp, nwg, 0, plan, first.data(), cnt.data()), MFX_E_STATE,
          "mfx_ccdpp_begin: the padded row view does not lay out (%lld entries, %zu rows with ratings)", (long long)nnzp, pieces.size());
@@ -414,6 +459,40 @@ static int run_resid_fused(mfx_ctx* ctx, const float* uk0, const float* vk0, con
   return mfx_ccd_cols_resid(ctx, 2, uk0, vk0, uk1, vk1);
 }
 
+// The fused first sweep needs: 16-bit ids and BOTH item vectors in LDS (row view), no light region and no sharding (column view:
+// ccd_cols.hip).  MFX_CCD_FUSE=0 keeps the separate update (the cross-check of the tests).
+static bool can_fuse_first_sweep(mfx_ctx* ctx) {
+  const char* e = getenv("MFX_CCD_FUSE");
+  if (e && e[0] == '0') return false;
+  const size_t lds = 2 * (((size_t)ctx->nI + 4) & ~(size_t)3) * sizeof(float);
+  return ctx->ccd_ind16 && lds_fits(lds) && ctx->ccd_blocks.nwg > 0 && !mfx_sharded(ctx) && mfx_ccd_cols_can_fuse(ctx);
+}
+static int run_first_sweep_fused(mfx_ctx* ctx, float uReg, float iReg, float freq_thresh, int k) {
+  const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
+  const MfxBlocks& B = ctx->ccd_blocks;
+  int rc;
+  const int64_t n8 = ctx->ccd_nnzp / MFX_BLK_EPL;
+  if (!ctx->uk_init && (rc = dev_alloc(ctx, &ctx->uk_init, (size_t)ctx->nU + 1))) return rc;
+  if (!ctx->ccd_rpair && (rc = dev_alloc(ctx, &ctx->ccd_rpair, (size_t)n8 + (size_t)(MFX_BLK_SLACK / MFX_BLK_EPL)))) return rc;
+  HIPCHK(hipMemcpyAsync(ctx->uk_init, ctx->uk, sizeof(float) * ((size_t)ctx->nU + 1), hipMemcpyDeviceToDevice, ctx->stream));
+  {
+    ProfScope ps(ctx, MFX_K_CCD_ROW);
+    if ((rc = mfx_ccd_pairs(ctx, ctx->ccd_rowid, false, n8, ctx->uk_pend, ctx->uk, ctx->ccd_rpair))) return rc;
+    const size_t lds = 2 * (((size_t)ctx->nI + 4) & ~(size_t)3) * sizeof(float);
+    HIPCHK(set_lds(ctx, (const void*)ccd_pass_fused_kernel, lds));
+    hipLaunchKernelGGL(ccd_pass_fused_kernel, dim3(B.nwg), dim3(1024), lds, ctx->stream, B.rec, B.wg_t0, B.wg_n, B.wg_rec, B.wg_stride, ctx->res_row,
+                       (const uint16_t*)ctx->ccd_ind16, ctx->vk_pend, ctx->vk, ctx->nI, (const float2*)ctx->ccd_rpair, ctx->ccd_part,
+                       (uint32_t)(B.nslots * 16));
+    HIPCHK(hipGetLastError());
+    const int dblocks = (m.nrows + 255) / 256;
+    const int fblocks = (int)((ctx->ccd_nlrow * 16 + 255) / 256);
+    hipLaunchKernelGGL(ccd_finish_kernel, dim3((unsigned)(dblocks + fblocks)), dim3(256), 0, ctx->stream, ctx->ccd_rfirst, ctx->ccd_rcnt, m.nrows,
+                       dblocks, ctx->ccd_lrow, ctx->ccd_nlrow, ctx->ccd_part, uReg, ctx->uk);
+    HIPCHK(hipGetLastError());
+  }
+  return mfx_ccd_cols_pass_fused(ctx, ctx->uk_pend, ctx->vk_pend, ctx->uk_init, ctx->vk, ctx->uk, ctx->vk, iReg, freq_thresh, k);
+}
+
 // The subtract of a finished factor is deferred so that it can share a sweep with the next add-back;
 // anything that looks at the residuals (or ends the session) flushes it first.
 static int ccd_flush(mfx_ctx* ctx) {
@@ -434,14 +513,21 @@ extern "C" int mfx_ccdpp_rank1(mfx_ctx* ctx, int32_t k, int32_t inner, float uRe
   hipLaunchKernelGGL(extract_col_kernel, dim3(bui), dim3(256), 0, ctx->stream, ctx->U, ctx->nU, ctx->V, ctx->nI, ctx->ld, k, ctx->uk, ctx->vk);
   HIPCHK(hipGetLastError());
   int rc;
-  if (ctx->ccd_pending && add_back) {                       // previous factor's :1095-1116 + this one's :1032-1056
+  int it0 = 0;
+  if (ctx->ccd_pending && add_back && inner >= 1 && can_fuse_first_sweep(ctx)) {
+    // previous factor's :1095-1116 + this one's :1032-1056 applied ON THE WAY of the first sweep (:1058-1092, it = 0): each view is
+    // read once instead of twice.  The add-back takes u_k, v_k as extracted -- the row pass moves u_k on before the column view is updated.
+    ctx->ccd_pending = false;
+    if ((rc = run_first_sweep_fused(ctx, uReg, iReg, freq_thresh, k))) return rc;
+    it0 = 1;
+  } else if (ctx->ccd_pending && add_back) {                // previous factor's :1095-1116 + this one's :1032-1056
     ctx->ccd_pending = false;
     if ((rc = run_resid_fused(ctx, ctx->uk_pend, ctx->vk_pend, ctx->uk, ctx->vk))) return rc;
   } else {
     if ((rc = ccd_flush(ctx))) return rc;
     if (add_back && (rc = run_resid<+1>(ctx, ctx->uk, ctx->vk))) return rc;   // :1032-1056
   }
-  for (int it = 0; it < inner; it++) {                      // :1058-1092
+  for (int it = it0; it < inner; it++) {                    // :1058-1092
     if ((rc = run_pass(ctx, 0, uReg, -1.0f, k))) return rc;
     if ((rc = run_pass(ctx, 1, iReg, freq_thresh, k))) return rc;
   }

@@ -189,19 +189,30 @@ __device__ __forceinline__ void mfx_blk_store(mfx_desc4 rs, uint32_t off, double
   asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(off), "s"(rs) : "memory");
 }
 
+// the updated residuals of a lane (fused sweep), unseen by the compiler's counting like the store above
+__device__ __forceinline__ void mfx_blk_store_res(char* base, uint32_t off, float __attribute__((ext_vector_type(4))) a, float __attribute__((ext_vector_type(4))) b) {
+  asm volatile("global_store_dwordx4 %0, %1, %3\n\tglobal_store_dwordx4 %0, %2, %3 offset:256\n\ts_nop 1" ::"v"(off), "v"(a), "v"(b), "s"(base) : "memory");
+}
+
 // One 16-lane group (lane j) of a workgroup's window -- group g takes the window's trips g, g + 64, ...  rec: the WORKGROUP's records
 // (wave-uniform; group g's s4 records start at g * s4).
 // res / ind: the padded view AT THE WINDOW'S FIRST TRIP (wave-uniform pointers: the loads take the scalar-base + 32-bit-offset form;
 // a window is far below 4 GB); whole trips, MFX_BLK_SLACK valid entries behind the last.  other: the gathered vector with +0.0 at the
 // index the padding entries carry.  part: [nslots][2] doubles.
-template <typename IdxT>
+// FUSE (the first sweep of a factor, ccd.hip: mfx_ccdpp_rank1): the residual update res = (res - a0 * o0[id]) + a1 * o1[id] -- the
+// subtract of the finished factor and the add-back of the new one, modelMF.cpp:1095-1116 and :1032-1056, both roundings kept -- is
+// applied to the entries on the way: they are stored back and the sums are formed over the NEW values.  (a0, a1): the lane's pair of
+// pair[] (one per eight entries: a lane's entries lie in one row / column); o0, o1: the two gathered vectors of the update.  Saves
+// the update's own sweep over the view (C4: 0.6 GB read per view and factor).
+template <typename IdxT, bool FUSE = false>
 __device__ __forceinline__ void mfx_ccd_block_loop(const int2* __restrict__ rec, int wn, int wstride, int g, const float* __restrict__ res,
                                                    const IdxT* __restrict__ ind, const float* other, int j, double* __restrict__ part,
-                                                   uint32_t part_bytes) {
+                                                   uint32_t part_bytes, const float* o0 = nullptr, const float* o1 = nullptr,
+                                                   const float2* __restrict__ pair = nullptr) {
   const int steps = (wn + MFX_BLK_GPW - 1) / MFX_BLK_GPW, s4 = mfx_blk_steps4(wn);   // of the workgroup (its last one is empty for groups >= wn % 64)
   typedef float f4 __attribute__((ext_vector_type(4)));
   typedef typename MfxIds8<IdxT>::raw raw_t;
-  struct Data { f4 r0, r1; raw_t x; };
+  struct Data { f4 r0, r1; raw_t x; float2 ap; uint32_t tb; };
   const mfx_desc4 rs_part = mfx_blk_desc(part, part_bytes);
   uint32_t eo = (uint32_t)(g * MFX_BLK_E + MFX_BLK_EPL * j);          // entry offset inside the window
   const uint32_t STRIDE = (uint32_t)MFX_BLK_GPW * MFX_BLK_E * (uint32_t)wstride;   // entries from one step of a group to its next
@@ -218,6 +229,12 @@ __device__ __forceinline__ void mfx_ccd_block_loop(const int2* __restrict__ rec,
     d.r0 = __builtin_nontemporal_load((const f4*)((const char*)res + (size_t)tb));
     d.r1 = __builtin_nontemporal_load((const f4*)((const char*)res + (size_t)tb + 256));
     d.x = MfxIds8<IdxT>::load((const IdxT*)((const char*)ind + (size_t)(eo * (uint32_t)sizeof(IdxT))));
+    if (FUSE) {                                                       // (8 bytes per 8 entries)
+      typedef float f2 __attribute__((ext_vector_type(2)));
+      const f2 v = __builtin_nontemporal_load((const f2*)((const char*)pair + (size_t)eo));
+      d.ap = make_float2(v[0], v[1]);
+      d.tb = tb;
+    }
     eo = min(eo + STRIDE, eo_last);
     return d;
   };
@@ -233,6 +250,17 @@ __device__ __forceinline__ void mfx_ccd_block_loop(const int2* __restrict__ rec,
     const int base = __builtin_amdgcn_mov_dpp(ra.x, 0x150 + (S), 0xF, 0xF, true);                                             \
     const unsigned mask = (unsigned)__builtin_amdgcn_mov_dpp(ra.y, 0x150 + (S), 0xF, 0xF, true);                              \
     double num, den;                                                                                                          \
+    if (FUSE) {                                                                                                               \
+      f4 n0, n1;                                                                                                              \
+      _Pragma("unroll") for (int q = 0; q < 8; q++) {                                                                         \
+        const int id = MfxIds8<IdxT>::get(DC.x, q);                                                                           \
+        const float rq = q < 4 ? DC.r0[q] : DC.r1[q - 4];                                                                     \
+        const float nv = (rq - DC.ap.x * o0[id]) + DC.ap.y * o1[id];                                                          \
+        if (q < 4) n0[q] = nv; else n1[q - 4] = nv;                                                                           \
+      }                                                                                                                       \
+      if (base >= 0) mfx_blk_store_res((char*)res, DC.tb, n0, n1);      /* (a step past the group's last trip holds that trip AGAIN) */ \
+      DC.r0 = n0; DC.r1 = n1;                                                                                                 \
+    }                                                                                                                         \
     {                                                                                                                         \
       float o[8];                                                                                                             \
       _Pragma("unroll") for (int q = 0; q < 8; q++) o[q] = (MFX_BLK_EXP & 1) ? __int_as_float(MfxIds8<IdxT>::get(DC.x, q) | 0x3f800000) : other[MfxIds8<IdxT>::get(DC.x, q)]; \

@@ -31,7 +31,7 @@ constexpr int LIGHT = 0;          // columns with at most this many entries are 
                                   // 0 since the trip lists: short (strip, column) pieces no longer cost per-segment latency, and the
                                   // light region's L2 gathers do (C4: 2.29 vs 2.40 ms per factor at 1024, C2 shape 0.86 vs 0.89)
 constexpr int GPW = MFX_BLK_GPW;   // 16-lane groups per pass workgroup (1024 threads)
-constexpr int PASS_WGS = 512;     // pass workgroups over all strips: ONE round of the 512 resident ones (MFX_CCD_PASS_WGS)
+constexpr int PASS_WGS = 256;     // pass workgroups over all strips (MFX_CCD_PASS_WGS): one per CU -- as fast as 512 for the plain sweep, one round for the fused one
 
 struct ColState {
   int nb = 0;                       // strips
@@ -54,6 +54,7 @@ struct ColState {
   double* sums = nullptr;           // sharded runs: [ncols][2] (num, den) for the all-reduce
   int32_t* col_ptr = nullptr;       // [nI+1] column -> its slots (strip-major order)
   int32_t* col_seg = nullptr;
+  float2* cpair = nullptr;          // fused first sweep: (v_pend[col], v_k[col]) per eight entries
   int32_t* fin_order = nullptr;     // the columns by team size of colfinish_kernel: n16 with at most 64 slots, n64 with at most 512, the rest
   int fin_n16 = 0, fin_n64 = 0, fin_n256 = 0;
   MfxBlocks blocks;                 // the pass: the light region's workgroups first (tag -1), then the strips' (tag = strip)
@@ -77,7 +78,7 @@ void mfx_ccd_cols_free(mfx_ctx* ctx) {
   if (!s) return;
   dev_free(s->off); dev_free(s->dst); dev_free(s->plen); dev_free(s->buser); dev_free(s->luser); dev_free(s->bcol16); dev_free(s->bcol32); dev_free(s->res);
   dev_free(s->part); dev_free(s->sums);
-  dev_free(s->col_ptr); dev_free(s->col_seg); dev_free(s->fin_order);
+  dev_free(s->col_ptr); dev_free(s->col_seg); dev_free(s->fin_order); dev_free(s->cpair);
   mfx_blocks_free(s->blocks);
   dev_free(s->rw_blk); dev_free(s->rw_e0); dev_free(s->rw_e1); dev_free(s->rw_stride);
   delete s;
@@ -414,6 +415,30 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
   else mfx_ccd_block_loop<int32_t>(r, wn, wg_stride[w], g, res + e0, luser + e0, uk, j, part, part_bytes);      // uk[nU] = +0.0 (mfx_ccdpp_begin)
 }
 
+// The FIRST column sweep of a factor with the residual update on the way (ccd_blocks.h, FUSE): three strips of user vectors in LDS --
+// the finished factor's u, the new factor's u as extracted (the add-back), and u_k after the row pass (what the sums gather) --, the
+// columns' pair per eight entries from cpair.  Strips only (no light region when this runs).
+extern __shared__ __attribute__((aligned(16))) float colfuse_lds[];
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void colpass_fused_kernel(
+    const int2* __restrict__ rec, const int32_t* __restrict__ wg_t0, const int32_t* __restrict__ wg_n, const int64_t* __restrict__ wg_rec,
+    const int32_t* __restrict__ wg_tag, const int32_t* __restrict__ wg_stride, float* __restrict__ res, const uint16_t* __restrict__ buser,
+    const float* __restrict__ uk0, const float* __restrict__ uk1, const float* __restrict__ uk, int nU_strips, const float2* __restrict__ cpair,
+    double* __restrict__ part, uint32_t part_bytes) {
+  constexpr int UBS = UB + 4;
+  float *s0 = colfuse_lds, *s1 = colfuse_lds + UBS, *s2 = colfuse_lds + 2 * UBS;
+  const int w = blockIdx.x, b = wg_tag[w];
+  const int n = min(UB, nU_strips - b * UB);
+  stage_strip(s0, uk0, b * UB, n);
+  stage_strip(s1, uk1, b * UB, n);
+  stage_strip(s2, uk, b * UB, n);
+  if (threadIdx.x == 0) { s0[UB] = 0.0f; s1[UB] = 0.0f; s2[UB] = 0.0f; }          // what the padding entries gather
+  __syncthreads();
+  const int j = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int wn = wg_n[w];
+  const int64_t e0 = (int64_t)wg_t0[w] * MFX_BLK_E;
+  mfx_ccd_block_loop<uint16_t, true>(rec + wg_rec[w], wn, wg_stride[w], g, res + e0, buser + e0, s2, j, part, part_bytes, s0, s1, cpair + e0 / MFX_BLK_EPL);
+}
+
 // residual update of the light region (MODE as colresid_kernel): u_k from L2
 template <int MODE, typename ColT>
 __global__ __launch_bounds__(256) void colresid_light_kernel(int64_t e0, int64_t e1, float* __restrict__ res, const int32_t* __restrict__ luser,
@@ -582,6 +607,32 @@ int mfx_ccd_cols_pass(mfx_ctx* ctx, const float* uk, float* vk, float reg, float
                        freq_thresh, k);
     HIPCHK(hipGetLastError());
   }
+  return MFX_OK;
+}
+
+bool mfx_ccd_cols_can_fuse(mfx_ctx* ctx) {
+  ColState* s = st(ctx);
+  return s && s->blocks.nwg > 0 && s->nlw == 0 && s->light0 == s->light1;
+}
+int mfx_ccd_cols_pass_fused(mfx_ctx* ctx, const float* uk0, const float* vk0, const float* uk1, const float* vk1, const float* uk, float* vk,
+                            float reg, float freq_thresh, int k) {
+  ColState* s = st(ctx);
+  const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
+  const MfxBlocks& B = s->blocks;
+  int rc;
+  const int64_t n8 = s->nnzp / MFX_BLK_EPL;
+  if (!s->cpair && (rc = dev_alloc(ctx, &s->cpair, (size_t)n8))) return rc;
+  ProfScope ps(ctx, MFX_K_CCD_COL);
+  if ((rc = mfx_ccd_pairs(ctx, s->bcol16 ? (const void*)s->bcol16 : (const void*)s->bcol32, s->bcol16 != nullptr, n8, vk0, vk1, s->cpair))) return rc;
+  const size_t lds = 3 * (size_t)(UB + 4) * sizeof(float);
+  HIPCHK(hipFuncSetAttribute((const void*)colpass_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(colpass_fused_kernel, dim3(B.nwg), dim3(16 * GPW), lds, ctx->stream, B.rec, B.wg_t0, B.wg_n, B.wg_rec, B.wg_tag, B.wg_stride,
+                     s->res, (const uint16_t*)s->buser, uk0, uk1, uk, m.nrows, (const float2*)s->cpair, s->part, (uint32_t)(B.nslots * 16));
+  HIPCHK(hipGetLastError());
+  const int b16 = (s->fin_n16 + 15) / 16, b64 = (s->fin_n64 + 3) / 4;
+  hipLaunchKernelGGL(colfinish_kernel<false>, dim3((unsigned)(b16 + b64 + s->fin_n256)), dim3(256), 0, ctx->stream, s->fin_order, s->fin_n16,
+                     s->fin_n64, b16, b64, s->col_ptr, s->col_seg, s->part, m.ncols, reg, vk, m.colptr, freq_thresh, k, (double*)nullptr);
+  HIPCHK(hipGetLastError());
   return MFX_OK;
 }
 

@@ -56,7 +56,7 @@ if "ccd" in what:
                           row_pass_ms=r_ms / max(r_n, 1), col_pass_ms=c_ms / max(c_n, 1), resid_ms=x_ms / max(x_n, 1),
                           algorithmic_GBs=bytes_per_k / per_k / 1e9, hbm_peak_GBs=8000,
                           row_pass_GBs=8 * tr.nnz / (r_ms / max(r_n, 1) * 1e-3) / 1e9,
-                          resid_GBs=2 * 12 * tr.nnz / (x_ms / max(x_n, 1) * 1e-3) / 1e9)), flush=True)
+                          resid_GBs=(2 * 12 * tr.nnz / (x_ms / max(x_n, 1) * 1e-3) / 1e9) if x_ms > 0 else None)), flush=True)   # (None: the update rides on the first sweep, MFX_CCD_FUSE)
     ctx.ccdpp_end(); ctx.close()
 if "cd" in what:      # trainCCD (a12) on the C2 matrix
     K = int(os.environ.get("CD_K", 64))

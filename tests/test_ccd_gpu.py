@@ -65,7 +65,13 @@ def test_rank1_steps_match_oracle(K, freq):
         assert np.all(V[:tr.ncols][cold, 1:min(K, 6)] == 0) and np.any(V[:tr.ncols][cold, 0] != 0)
 
 
-def test_ccdpp_outer_iterations_track_oracle_and_objective_decreases():
+@pytest.mark.parametrize("fuse", ["", "0"])
+def test_ccdpp_outer_iterations_track_oracle_and_objective_decreases(fuse, monkeypatch):
+    """Four outer iterations with the factors in shuffled order.  From the second factor on the deferred subtract and the add-back
+    ride on the first sweep of each factor (the fused pass kernels, default) or run as their own sweep (MFX_CCD_FUSE=0): the same
+    models either way -- both keep every rounding of modelMF.cpp:1032-1056 and :1095-1116."""
+    if fuse:
+        monkeypatch.setenv("MFX_CCD_FUSE", fuse)
     K, reg = 16, 0.5
     d, tr, (cp, ci, cv), U0, V0 = _setup(1000, 600, 40000, K, seed=7)
     va = d["val"]
@@ -90,7 +96,11 @@ def test_ccdpp_outer_iterations_track_oracle_and_objective_decreases():
             o_val, _, _ = orc.rmse(Uo, Vo, nU, nI, va.nrows, va.rowptr, va.rowind, va.rowval, invU, invI)
             assert abs(g_obj - o_obj) <= 1e-5 * o_obj and abs(g_val - o_val) <= 1e-6
             objs.append(g_obj)
+        U, V = ctx.get_factors()
+        grr, grc = ctx.debug_residuals(tr.nnz)
         ctx.ccdpp_end()
+    assert ulp_diff(U, Uo).max() <= 2 and ulp_diff(V, Vo).max() <= 2
+    assert np.abs(grr - rr).max() < 1e-5 and np.abs(grc - rc).max() < 1e-5
     assert all(b <= a * (1 + 1e-6) for a, b in zip(objs, objs[1:]))   # CCD++ never increases the objective
 
 
