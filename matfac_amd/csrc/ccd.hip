@@ -211,7 +211,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void ccd_pass_fused_kernel(
     const int2* __restrict__ rec, const int32_t* __restrict__ wg_t0, const int32_t* __restrict__ wg_n, const int64_t* __restrict__ wg_rec,
     const int32_t* __restrict__ wg_stride, float* __restrict__ res, const uint16_t* __restrict__ ind, const float* __restrict__ v0g,
-    const float* __restrict__ v1g, int nother, const float2* __restrict__ rpair, double* __restrict__ part, uint32_t part_bytes) {
+    const float* __restrict__ v1g, int nother, const int32_t* __restrict__ rowid8, const float2* __restrict__ rpair, double* __restrict__ part,
+    uint32_t part_bytes) {
   typedef float f4 __attribute__((ext_vector_type(4)));
   const int nbs = (nother + 4) & ~3;
   {
@@ -231,22 +232,16 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
   const int j = threadIdx.x & 15, g = threadIdx.x >> 4;
   const int w = blockIdx.x, wn = wg_n[w];
   const int64_t e0 = (int64_t)wg_t0[w] * MFX_BLK_E;
-  mfx_ccd_block_loop<uint16_t, true>(rec + wg_rec[w], wn, wg_stride[w], g, res + e0, ind + e0, b1, j, part, part_bytes, b0, b1, rpair + e0 / MFX_BLK_EPL);
+  mfx_ccd_block_loop<uint16_t, true, int32_t>(rec + wg_rec[w], wn, wg_stride[w], g, res + e0, ind + e0, b1, j, part, part_bytes, b0, b1,
+                                              rowid8 + e0 / MFX_BLK_EPL, rpair);
 }
-// (a0[id[l]], a1[id[l]]) for every eight entries l of a padded view
-template <typename IdT>
-__global__ void ccd_pairs_kernel(const IdT* __restrict__ id8, int64_t n8, const float* __restrict__ a0, const float* __restrict__ a1,
-                                 float2* __restrict__ out) {
+// (a0[r], a1[r]) side by side: what a lane of the fused sweep gathers for its row / column with ONE 8-byte load
+__global__ void ccd_pairs_kernel(int64_t n, const float* __restrict__ a0, const float* __restrict__ a1, float2* __restrict__ out) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; l < n8; l += stride) {
-    const int r = (int)id8[l];
-    out[l] = make_float2(a0[r], a1[r]);
-  }
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) out[r] = make_float2(a0[r], a1[r]);
 }
-int mfx_ccd_pairs(mfx_ctx* ctx, const void* id8, bool ids16, int64_t n8, const float* a0, const float* a1, float2* out) {
-  const unsigned blocks = (unsigned)std::min<int64_t>((n8 + 255) / 256, 8192);
-  if (ids16) hipLaunchKernelGGL(ccd_pairs_kernel<uint16_t>, dim3(blocks), dim3(256), 0, ctx->stream, (const uint16_t*)id8, n8, a0, a1, out);
-  else hipLaunchKernelGGL(ccd_pairs_kernel<int32_t>, dim3(blocks), dim3(256), 0, ctx->stream, (const int32_t*)id8, n8, a0, a1, out);
+int mfx_ccd_pairs(mfx_ctx* ctx, int64_t n, const float* a0, const float* a1, float2* out) {
+  hipLaunchKernelGGL(ccd_pairs_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, ctx->stream, n, a0, a1, out);
   HIPCHK(hipGetLastError());
   return MFX_OK;
 }
@@ -471,17 +466,16 @@ static int run_first_sweep_fused(mfx_ctx* ctx, float uReg, float iReg, float fre
   const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
   const MfxBlocks& B = ctx->ccd_blocks;
   int rc;
-  const int64_t n8 = ctx->ccd_nnzp / MFX_BLK_EPL;
   if (!ctx->uk_init && (rc = dev_alloc(ctx, &ctx->uk_init, (size_t)ctx->nU + 1))) return rc;
-  if (!ctx->ccd_rpair && (rc = dev_alloc(ctx, &ctx->ccd_rpair, (size_t)n8 + (size_t)(MFX_BLK_SLACK / MFX_BLK_EPL)))) return rc;
+  if (!ctx->ccd_rpair && (rc = dev_alloc(ctx, &ctx->ccd_rpair, (size_t)ctx->nU + 1))) return rc;
   HIPCHK(hipMemcpyAsync(ctx->uk_init, ctx->uk, sizeof(float) * ((size_t)ctx->nU + 1), hipMemcpyDeviceToDevice, ctx->stream));
   {
     ProfScope ps(ctx, MFX_K_CCD_ROW);
-    if ((rc = mfx_ccd_pairs(ctx, ctx->ccd_rowid, false, n8, ctx->uk_pend, ctx->uk, ctx->ccd_rpair))) return rc;
+    if ((rc = mfx_ccd_pairs(ctx, (int64_t)ctx->nU, ctx->uk_pend, ctx->uk, ctx->ccd_rpair))) return rc;
     const size_t lds = 2 * (((size_t)ctx->nI + 4) & ~(size_t)3) * sizeof(float);
     HIPCHK(set_lds(ctx, (const void*)ccd_pass_fused_kernel, lds));
     hipLaunchKernelGGL(ccd_pass_fused_kernel, dim3(B.nwg), dim3(1024), lds, ctx->stream, B.rec, B.wg_t0, B.wg_n, B.wg_rec, B.wg_stride, ctx->res_row,
-                       (const uint16_t*)ctx->ccd_ind16, ctx->vk_pend, ctx->vk, ctx->nI, (const float2*)ctx->ccd_rpair, ctx->ccd_part,
+                       (const uint16_t*)ctx->ccd_ind16, ctx->vk_pend, ctx->vk, ctx->nI, (const int32_t*)ctx->ccd_rowid, (const float2*)ctx->ccd_rpair, ctx->ccd_part,
                        (uint32_t)(B.nslots * 16));
     HIPCHK(hipGetLastError());
     const int dblocks = (m.nrows + 255) / 256;

@@ -201,18 +201,20 @@ __device__ __forceinline__ void mfx_blk_store_res(char* base, uint32_t off, floa
 // index the padding entries carry.  part: [nslots][2] doubles.
 // FUSE (the first sweep of a factor, ccd.hip: mfx_ccdpp_rank1): the residual update res = (res - a0 * o0[id]) + a1 * o1[id] -- the
 // subtract of the finished factor and the add-back of the new one, modelMF.cpp:1095-1116 and :1032-1056, both roundings kept -- is
-// applied to the entries on the way: they are stored back and the sums are formed over the NEW values.  (a0, a1): the lane's pair of
-// pair[] (one per eight entries: a lane's entries lie in one row / column); o0, o1: the two gathered vectors of the update.  Saves
-// the update's own sweep over the view (C4: 0.6 GB read per view and factor).
-template <typename IdxT, bool FUSE = false>
+// applied to the entries on the way: they are stored back and the sums are formed over the NEW values.  (a0, a1) = pair[id8[lane]]: a
+// lane's eight entries lie in one row / column (id8: the view's id per eight entries, at the window like res), pair[] holds both
+// factors' values per row / column; the id is loaded two steps ahead with the data, the pair gathered one step ahead (a hit: ~26
+// consecutive lanes share a row).  o0, o1: the two gathered vectors of the update.  Saves the update's own sweep over the view
+// (C4: 0.6 GB read per view and factor).
+template <typename IdxT, bool FUSE = false, typename Id8T = int32_t>
 __device__ __forceinline__ void mfx_ccd_block_loop(const int2* __restrict__ rec, int wn, int wstride, int g, const float* __restrict__ res,
                                                    const IdxT* __restrict__ ind, const float* other, int j, double* __restrict__ part,
                                                    uint32_t part_bytes, const float* o0 = nullptr, const float* o1 = nullptr,
-                                                   const float2* __restrict__ pair = nullptr) {
+                                                   const Id8T* __restrict__ id8 = nullptr, const float2* __restrict__ pair = nullptr) {
   const int steps = (wn + MFX_BLK_GPW - 1) / MFX_BLK_GPW, s4 = mfx_blk_steps4(wn);   // of the workgroup (its last one is empty for groups >= wn % 64)
   typedef float f4 __attribute__((ext_vector_type(4)));
   typedef typename MfxIds8<IdxT>::raw raw_t;
-  struct Data { f4 r0, r1; raw_t x; float2 ap; uint32_t tb; };
+  struct Data { f4 r0, r1; raw_t x; float2 ap; uint32_t tb; int id; };
   const mfx_desc4 rs_part = mfx_blk_desc(part, part_bytes);
   uint32_t eo = (uint32_t)(g * MFX_BLK_E + MFX_BLK_EPL * j);          // entry offset inside the window
   const uint32_t STRIDE = (uint32_t)MFX_BLK_GPW * MFX_BLK_E * (uint32_t)wstride;   // entries from one step of a group to its next
@@ -222,6 +224,7 @@ __device__ __forceinline__ void mfx_ccd_block_loop(const int2* __restrict__ rec,
   const uint32_t eo_last = eo + STRIDE * (uint32_t)max((wn - g + MFX_BLK_GPW - 1) / MFX_BLK_GPW - 1, 0);
   auto data = [&]() {                                                 // the loads of the next step not yet requested
     Data d;
+    if (FUSE) d.id = (int)id8[eo >> 3];       // FIRST: the next step gathers with it while the rest of this trip is still on its way
     // the residuals of a trip are stored QUAD-INTERLEAVED (mfx_blk_mem_of): the lanes' first quads, then their second quads -- each
     // load is 256 contiguous bytes per group.  (In entry order a lane's two quads are 32 bytes apart: both loads touched every
     // line of the trip, half of it each -- measured 11 % of the pass.)  nt: a stream, nothing of it is read twice.
@@ -229,12 +232,7 @@ __device__ __forceinline__ void mfx_ccd_block_loop(const int2* __restrict__ rec,
     d.r0 = __builtin_nontemporal_load((const f4*)((const char*)res + (size_t)tb));
     d.r1 = __builtin_nontemporal_load((const f4*)((const char*)res + (size_t)tb + 256));
     d.x = MfxIds8<IdxT>::load((const IdxT*)((const char*)ind + (size_t)(eo * (uint32_t)sizeof(IdxT))));
-    if (FUSE) {                                                       // (8 bytes per 8 entries)
-      typedef float f2 __attribute__((ext_vector_type(2)));
-      const f2 v = __builtin_nontemporal_load((const f2*)((const char*)pair + (size_t)eo));
-      d.ap = make_float2(v[0], v[1]);
-      d.tb = tb;
-    }
+    if (FUSE) d.tb = tb;
     eo = min(eo + STRIDE, eo_last);
     return d;
   };
@@ -243,10 +241,11 @@ __device__ __forceinline__ void mfx_ccd_block_loop(const int2* __restrict__ rec,
   double pnum = 0.0, pden = 0.0;
   uint32_t poff = 0xfffffff0u;                                      // pending store (none)
   // records: lane j & 3 of the group loads the record of step base + (j & 3); a step takes its own with a DPP row_newbcast
-#define MFX_BLK_STEP(S, DC, DN)                                                                                               \
+#define MFX_BLK_STEP(S, DC, DM, DN)                                                                                           \
   {                                                                                                                           \
     if (poff != 0xfffffff0u) mfx_blk_store(rs_part, poff, pnum, pden);   /* (EXEC-masked: an all-lanes store of mostly dropped lanes costs the memory pipe a full one) */ \
     DN = data();                                                                                                              \
+    if (FUSE) DM.ap = pair[DM.id];                                      /* the NEXT step's pair: its id came in with the step before */ \
     const int base = __builtin_amdgcn_mov_dpp(ra.x, 0x150 + (S), 0xF, 0xF, true);                                             \
     const unsigned mask = (unsigned)__builtin_amdgcn_mov_dpp(ra.y, 0x150 + (S), 0xF, 0xF, true);                              \
     double num, den;                                                                                                          \
@@ -292,21 +291,22 @@ __device__ __forceinline__ void mfx_ccd_block_loop(const int2* __restrict__ rec,
   // the loads run ONE step ahead (two register sets): with eight waves per SIMD a wave's next step is ~4 000 cycles away, and two more
   // sets (two steps ahead, the first version) cost the eighth wave -- 65 and 82 registers, one workgroup per CU instead of two
   Data d0 = data(), d1 = data(), d2, d3;
+  if (FUSE) d0.ap = pair[d0.id];
   int n = 0;
   for (; n + 4 <= steps; n += 4) {
-    MFX_BLK_STEP(0, d0, d2)
-    MFX_BLK_STEP(1, d1, d3)
-    MFX_BLK_STEP(2, d2, d0)
+    MFX_BLK_STEP(0, d0, d1, d2)
+    MFX_BLK_STEP(1, d1, d2, d3)
+    MFX_BLK_STEP(2, d2, d3, d0)
     ro += n + 4 < s4 ? 4u : 0u;
     const int2 rn = rec[ro];                                      // the next four records: a step (and seven other waves) ahead of their use
-    MFX_BLK_STEP(3, d3, d1)
+    MFX_BLK_STEP(3, d3, d0, d1)
     ra = rn;
   }
   if (n < steps) {                                                // the last one to three steps (workgroup-uniform branches)
-    MFX_BLK_STEP(0, d0, d2)
+    MFX_BLK_STEP(0, d0, d1, d2)
     if (n + 1 < steps) {
-      MFX_BLK_STEP(1, d1, d3)
-      if (n + 2 < steps) MFX_BLK_STEP(2, d2, d0)
+      MFX_BLK_STEP(1, d1, d2, d3)
+      if (n + 2 < steps) MFX_BLK_STEP(2, d2, d3, d0)
     }
   }
   if (poff != 0xfffffff0u) mfx_blk_store(rs_part, poff, pnum, pden);

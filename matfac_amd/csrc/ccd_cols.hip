@@ -54,7 +54,7 @@ struct ColState {
   double* sums = nullptr;           // sharded runs: [ncols][2] (num, den) for the all-reduce
   int32_t* col_ptr = nullptr;       // [nI+1] column -> its slots (strip-major order)
   int32_t* col_seg = nullptr;
-  float2* cpair = nullptr;          // fused first sweep: (v_pend[col], v_k[col]) per eight entries
+  float2* cpair = nullptr;          // fused first sweep: (v_pend[i], v_k[i]) per item
   int32_t* fin_order = nullptr;     // the columns by team size of colfinish_kernel: n16 with at most 64 slots, n64 with at most 512, the rest
   int fin_n16 = 0, fin_n64 = 0, fin_n256 = 0;
   MfxBlocks blocks;                 // the pass: the light region's workgroups first (tag -1), then the strips' (tag = strip)
@@ -419,10 +419,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
 // the finished factor's u, the new factor's u as extracted (the add-back), and u_k after the row pass (what the sums gather) --, the
 // columns' pair per eight entries from cpair.  Strips only (no light region when this runs).
 extern __shared__ __attribute__((aligned(16))) float colfuse_lds[];
+template <typename ColT>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void colpass_fused_kernel(
     const int2* __restrict__ rec, const int32_t* __restrict__ wg_t0, const int32_t* __restrict__ wg_n, const int64_t* __restrict__ wg_rec,
     const int32_t* __restrict__ wg_tag, const int32_t* __restrict__ wg_stride, float* __restrict__ res, const uint16_t* __restrict__ buser,
-    const float* __restrict__ uk0, const float* __restrict__ uk1, const float* __restrict__ uk, int nU_strips, const float2* __restrict__ cpair,
+    const float* __restrict__ uk0, const float* __restrict__ uk1, const float* __restrict__ uk, int nU_strips, const ColT* __restrict__ bcol8,
+    const float2* __restrict__ cpair,
     double* __restrict__ part, uint32_t part_bytes) {
   constexpr int UBS = UB + 4;
   float *s0 = colfuse_lds, *s1 = colfuse_lds + UBS, *s2 = colfuse_lds + 2 * UBS;
@@ -436,7 +438,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
   const int j = threadIdx.x & 15, g = threadIdx.x >> 4;
   const int wn = wg_n[w];
   const int64_t e0 = (int64_t)wg_t0[w] * MFX_BLK_E;
-  mfx_ccd_block_loop<uint16_t, true>(rec + wg_rec[w], wn, wg_stride[w], g, res + e0, buser + e0, s2, j, part, part_bytes, s0, s1, cpair + e0 / MFX_BLK_EPL);
+  mfx_ccd_block_loop<uint16_t, true, ColT>(rec + wg_rec[w], wn, wg_stride[w], g, res + e0, buser + e0, s2, j, part, part_bytes, s0, s1,
+                                           bcol8 + e0 / MFX_BLK_EPL, cpair);
 }
 
 // residual update of the light region (MODE as colresid_kernel): u_k from L2
@@ -620,14 +623,19 @@ int mfx_ccd_cols_pass_fused(mfx_ctx* ctx, const float* uk0, const float* vk0, co
   const DevCSR& m = ctx->mat[MFX_MAT_TRAIN];
   const MfxBlocks& B = s->blocks;
   int rc;
-  const int64_t n8 = s->nnzp / MFX_BLK_EPL;
-  if (!s->cpair && (rc = dev_alloc(ctx, &s->cpair, (size_t)n8))) return rc;
+  if (!s->cpair && (rc = dev_alloc(ctx, &s->cpair, (size_t)ctx->nI + 1))) return rc;
   ProfScope ps(ctx, MFX_K_CCD_COL);
-  if ((rc = mfx_ccd_pairs(ctx, s->bcol16 ? (const void*)s->bcol16 : (const void*)s->bcol32, s->bcol16 != nullptr, n8, vk0, vk1, s->cpair))) return rc;
+  if ((rc = mfx_ccd_pairs(ctx, (int64_t)ctx->nI, vk0, vk1, s->cpair))) return rc;
   const size_t lds = 3 * (size_t)(UB + 4) * sizeof(float);
-  HIPCHK(hipFuncSetAttribute((const void*)colpass_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(colpass_fused_kernel, dim3(B.nwg), dim3(16 * GPW), lds, ctx->stream, B.rec, B.wg_t0, B.wg_n, B.wg_rec, B.wg_tag, B.wg_stride,
-                     s->res, (const uint16_t*)s->buser, uk0, uk1, uk, m.nrows, (const float2*)s->cpair, s->part, (uint32_t)(B.nslots * 16));
+#define MFX_COLFUSE(CT, BC)                                                                                                          \
+  do {                                                                                                                               \
+    HIPCHK(hipFuncSetAttribute((const void*)colpass_fused_kernel<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
+    hipLaunchKernelGGL(colpass_fused_kernel<CT>, dim3(B.nwg), dim3(16 * GPW), lds, ctx->stream, B.rec, B.wg_t0, B.wg_n, B.wg_rec, B.wg_tag, \
+                       B.wg_stride, s->res, (const uint16_t*)s->buser, uk0, uk1, uk, m.nrows, (const CT*)BC, (const float2*)s->cpair, s->part, \
+                       (uint32_t)(B.nslots * 16));                                                                                   \
+  } while (0)
+  if (s->bcol16) MFX_COLFUSE(uint16_t, s->bcol16); else MFX_COLFUSE(int32_t, s->bcol32);
+#undef MFX_COLFUSE
   HIPCHK(hipGetLastError());
   const int b16 = (s->fin_n16 + 15) / 16, b64 = (s->fin_n64 + 3) / 4;
   hipLaunchKernelGGL(colfinish_kernel<false>, dim3((unsigned)(b16 + b64 + s->fin_n256)), dim3(256), 0, ctx->stream, s->fin_order, s->fin_n16,

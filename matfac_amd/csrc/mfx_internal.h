@@ -109,7 +109,7 @@ struct mfx_ctx {
   float *res_row = nullptr, *res_col = nullptr, *uk = nullptr, *vk = nullptr;
   float *uk_pend = nullptr, *vk_pend = nullptr;   // factor whose residual subtract is deferred
   float* uk_init = nullptr;                       // u_k as extracted (the fused first sweep's add-back uses it after the row pass has moved u_k on)
-  float2* ccd_rpair = nullptr;                    // row view, per eight entries: (u_pend[row], u_k[row]) of the fused first sweep
+  float2* ccd_rpair = nullptr;                    // (u_pend[r], u_k[r]) per user: what a lane of the fused first sweep gathers for its row
   bool ccd_active = false, ccd_pending = false;
 
   RowSegs segs[2];
@@ -316,7 +316,7 @@ void mfx_ccd_cols_free(mfx_ctx* ctx);
 int mfx_ccd_cols_pass(mfx_ctx* ctx, const float* uk, float* vk, float reg, float freq_thresh, int k);
 // the first column sweep of a factor with the residual update on the way: res = (res - uk0 vk0) + uk1 vk1, sums over the new values with uk
 bool mfx_ccd_cols_can_fuse(mfx_ctx* ctx);
-int mfx_ccd_pairs(mfx_ctx* ctx, const void* id8, bool ids16, int64_t n8, const float* a0, const float* a1, float2* out);   // ccd.hip
+int mfx_ccd_pairs(mfx_ctx* ctx, int64_t n, const float* a0, const float* a1, float2* out);   // ccd.hip
 int mfx_ccd_cols_pass_fused(mfx_ctx* ctx, const float* uk0, const float* vk0, const float* uk1, const float* vk1, const float* uk, float* vk,
                             float reg, float freq_thresh, int k);
 int mfx_ccd_cols_resid(mfx_ctx* ctx, int mode, const float* uk0, const float* vk0, const float* uk1, const float* vk1);

@@ -18,7 +18,10 @@ for f in glob.glob(out + "/*/**/*counter_collection.csv", recursive=True):
         n = r["Kernel_Name"].split("(")[0].replace("void ", "")
         acc[n][r["Counter_Name"]].append(float(r["Counter_Value"]))
 # launches per rank-one step in steady state (add_back: the deferred subtract of the previous factor fused with the add-back)
-per_factor = {"ccd_pass_kernel": 5, "ccd_finish_kernel": 5, "colpass_kernel": 5, "colfinish_kernel": 5,
+# (round 4: the first sweep of a factor carries the residual update -- ccd_pass_fused_kernel / colpass_fused_kernel and the two pair builders)
+fused = any(n.startswith("ccd_pass_fused_kernel") for n in acc)
+per_factor = {"ccd_pass_kernel": 4 if fused else 5, "ccd_pass_fused_kernel": 1, "ccd_finish_kernel": 5, "colpass_kernel": 4 if fused else 5,
+              "colpass_fused_kernel": 1, "colfinish_kernel": 5, "ccd_pairs_kernel": 1,
               "resid_fused_kernel": 1, "colresid_kernel<2": 1, "colresid_light_kernel<2": 1, "extract_col_kernel": 1, "store_col_kernel": 1}
 kern, total = {}, 0.0
 for n, c in acc.items():
