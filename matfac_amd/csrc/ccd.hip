@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void rowview_build_kernel(const int64_t* __res
   for (int64_t t = rpos[nrows] + tid; t < nalloc; t += nth) {      // (nalloc is a whole number of trips: the image of [.., nalloc) is inside it)
     res[mfx_blk_mem_of(t)] = 0.0f;
     ids[t] = (IdxT)zero_id;
-    if (t < nnzp && (t & 7) == 0) rowid[t >> 3] = nrows > 0 ? nrows - 1 : 0;
+    if ((t & 7) == 0) rowid[t >> 3] = nrows > 0 ? nrows - 1 : 0;      // (the slack too: the fused sweep gathers with it)
   }
 }
 // test hook: the padded residuals back in CSR order
@@ -328,7 +328,7 @@ extern "C" int mfx_ccdpp_begin(mfx_ctx* ctx) {
   NEED(nnzp / MFX_BLK_E < ((int64_t)1 << 31), MFX_E_ARG, "mfx_ccdpp_begin: too many trips");
   const bool ids16 = lds_fits(((size_t)ctx->nI + 1) * sizeof(float)) && ctx->nI < 65536;
   if ((rc = dev_alloc(ctx, &ctx->res_row, (size_t)nalloc))) return rc;
-  if ((rc = dev_alloc(ctx, &ctx->ccd_rowid, (size_t)(nnzp / MFX_BLK_EPL)))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->ccd_rowid, (size_t)(nalloc / MFX_BLK_EPL)))) return rc;
   if ((rc = up_vec(ctx, &ctx->ccd_rpos, rpos))) return rc;
   if (ids16) { if ((rc = dev_alloc(ctx, &ctx->ccd_ind16, (size_t)nalloc))) return rc; }
   else if ((rc = dev_alloc(ctx, &ctx->ccd_ind32, (size_t)nalloc))) return rc;

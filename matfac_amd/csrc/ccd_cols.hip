@@ -349,8 +349,8 @@ int mfx_ccd_cols_build(mfx_ctx* ctx) {
   // buser serves the strips (and what their last workgroup reads behind them); luser the light region and the slack behind it
   if ((rc = dev_alloc(ctx, &s->buser, (size_t)(s->light0 + MFX_BLK_SLACK)))) return rc;
   if ((rc = dev_alloc(ctx, &s->luser, (size_t)(has_light ? nalloc - s->light0 : 1)))) return rc;
-  if (col16) { if ((rc = dev_alloc(ctx, &s->bcol16, (size_t)(nnzp / MFX_BLK_EPL)))) return rc; }
-  else if ((rc = dev_alloc(ctx, &s->bcol32, (size_t)(nnzp / MFX_BLK_EPL)))) return rc;
+  if (col16) { if ((rc = dev_alloc(ctx, &s->bcol16, (size_t)(nalloc / MFX_BLK_EPL)))) return rc; }      // (with the slack: the fused sweep gathers with it)
+  else if ((rc = dev_alloc(ctx, &s->bcol32, (size_t)(nalloc / MFX_BLK_EPL)))) return rc;
   if ((rc = dev_alloc(ctx, &s->res, (size_t)nalloc))) return rc;
   // (the residuals are stored quad-interleaved inside a trip: what no piece owns is not a contiguous range of them -- all zero first)
   HIPCHK(hipMemsetAsync(s->res, 0, sizeof(float) * (size_t)nalloc, ctx->stream));
@@ -366,6 +366,7 @@ int mfx_ccd_cols_build(mfx_ctx* ctx) {
   {
     Ranges rbu, rlu, rbc;
     for (size_t q = 0; q < tails.a.size(); q++) rbc.add(tails.a[q] / MFX_BLK_EPL, tails.b[q] / MFX_BLK_EPL);
+    rbc.add(nnzp / MFX_BLK_EPL, nalloc / MFX_BLK_EPL);
     for (size_t q = 0; q < tails.a.size(); q++) {
       if (tails.a[q] < s->light0) rbu.add(tails.a[q], tails.b[q]);
       else rlu.add(tails.a[q] - s->light0, tails.b[q] - s->light0);
