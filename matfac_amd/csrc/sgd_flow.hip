@@ -1818,15 +1818,25 @@ __global__ void hy_user_rank_kernel(const uint32_t* __restrict__ k1, const uint3
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) ru[v1[k]] = (uint32_t)(k - start[k1[k]]);
 }
+// key = item, value = list position | (its user is heavy) << 31: the item-sorted order then knows of every visit whether it lies in a
+// heavy user's queue without going back to the list
+__global__ void hy_item_keys_kernel(const int32_t* __restrict__ ei, const int32_t* __restrict__ eu, const int32_t* __restrict__ uq, int64_t n,
+                                    uint32_t* __restrict__ key, uint32_t* __restrict__ val) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
+    key[t] = (uint32_t)ei[t];
+    val[t] = (uint32_t)t | (uq[eu[t]] >= 0 ? 0x80000000u : 0u);
+  }
+}
 // sorted by item (stable): rank in the item's chain << 1 | "the item's next visit lies in another queue (a heavy user's), or there is none"
 __global__ void hy_item_rank_kernel(const uint32_t* __restrict__ k1, const uint32_t* __restrict__ v1, const int64_t* __restrict__ start, int64_t n,
-                                    const int32_t* __restrict__ eu, const int32_t* __restrict__ uq, uint32_t* __restrict__ ri) {
+                                    uint32_t* __restrict__ ri) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
     const uint32_t it = k1[k];
     const bool next_same = k + 1 < n && k1[k + 1] == it;
-    const bool pub = !next_same || uq[eu[v1[k + 1]]] >= 0;
-    ri[v1[k]] = (uint32_t)(k - start[it]) << 1 | (pub ? 1u : 0u);
+    const bool pub = !next_same || (v1[k + 1] >> 31) != 0u;
+    ri[v1[k] & 0x7fffffffu] = (uint32_t)(k - start[it]) << 1 | (pub ? 1u : 0u);
   }
 }
 // the queue record, rank | pub and queue of every list position (list order)
@@ -1967,11 +1977,11 @@ int build_flow_hybrid_device(mfx_ctx* ctx, int64_t first, int64_t count, int64_t
   hipLaunchKernelGGL(flow_bounds32_kernel, dim3((unsigned)std::min<int64_t>((nU + 256) / 256, 4096)), dim3(256), 0, ctx->stream, S->k1, count, nU + 1, S->dstart);
   hipLaunchKernelGGL(hy_user_rank_kernel, dim3(grid), dim3(256), 0, ctx->stream, S->k1, S->v1, S->dstart, count, S->vexp);
   // ranks in the items' chains and the publish flags of the visits that stay in the item queues
-  hipLaunchKernelGGL(flow_keys_kernel, dim3(grid), dim3(256), 0, ctx->stream, ei, (const int32_t*)nullptr, count, S->k0, S->v0);
+  hipLaunchKernelGGL(hy_item_keys_kernel, dim3(grid), dim3(256), 0, ctx->stream, ei, eu, (const int32_t*)S->duq, count, S->k0, S->v0);
   bytes = S->sort_tmp_bytes;
   HIPCHK(rocprim::radix_sort_pairs(S->sort_tmp, bytes, S->k0, S->k1, S->v0, S->v1, (size_t)count, 0, bits_for((uint64_t)nI), ctx->stream));
   hipLaunchKernelGGL(flow_bounds32_kernel, dim3((unsigned)std::min<int64_t>((nI + 256) / 256, 4096)), dim3(256), 0, ctx->stream, S->k1, count, nI + 1, S->dstart);
-  hipLaunchKernelGGL(hy_item_rank_kernel, dim3(grid), dim3(256), 0, ctx->stream, S->k1, S->v1, S->dstart, count, eu, (const int32_t*)S->duq, S->hy_ri);
+  hipLaunchKernelGGL(hy_item_rank_kernel, dim3(grid), dim3(256), 0, ctx->stream, S->k1, S->v1, S->dstart, count, S->hy_ri);
   // records, queues, queue order
   hipLaunchKernelGGL(hy_pack_kernel, dim3(grid), dim3(256), 0, ctx->stream, eu, ei, er, count, (const int32_t*)S->duq, (const int32_t*)S->downer,
                      (const int32_t*)S->degU, (const uint32_t*)S->vexp, (const uint32_t*)S->hy_ri, (int)g_item, S->pack, S->hy_qa, S->k0, S->v0);
