@@ -23,6 +23,10 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifndef MFX_ALS_LDS_SPLIT
+#define MFX_ALS_LDS_SPLIT 8      // eighths of a step's trailing pairs that stay on v_readlane before the rest comes through LDS (8 = 0 eighths:
+                                 // all through LDS, the default; 0: none through LDS, the round-3 solve; + 16: no sched_barrier between steps)
+#endif
 constexpr int GT_STRIDE = 36;   // row stride of the transposition tile in LDS (floats): 16-byte aligned rows, banks staggered
 
 namespace {
@@ -254,15 +258,41 @@ __device__ __forceinline__ float gram_solve(const GramAcc& g, int K, float reg, 
       const float lik = lv > k ? a[k >> 1][k & 1] * rk : 0.0f;
       if ((k & 1) == 0) a[k >> 1][1] = __builtin_fmaf(-lik, rdlane(a[k >> 1][1], k), a[k >> 1][1]);
       const f32x2 l2 = {lik, lik};
+#if MFX_ALS_LDS_SPLIT
+      // Part of the pivot row through LDS instead of v_readlane: by symmetry element (k, j) is lane j's a[k] -- ONE ds_write_b32 puts
+      // the whole row into tr, and the pairs from PL on read it back as broadcasts (two pairs per ds_read_b128) while the VALU does
+      // the readlanes of the pairs below PL.  (a_jk and a_kj agree to rounding, not bitwise: the factorisation stays an LU of A to
+      // eps.)
+      const int P0 = (k >> 1) + 1;                                           // (constants once the k loop is unrolled)
+      const int PL = (P0 + (32 - P0) * (MFX_ALS_LDS_SPLIT & 7) / 8 + 1) & ~1;   // even: a ds_read_b128 holds pairs PL, PL + 1 (8: all of them through LDS)
+      f32x4 lrow[16];
+      if (PL < 32) {
+        tr[lane] = a[k >> 1][k & 1];
+#pragma unroll
+        for (int q = PL; q < 32; q += 2) lrow[(q - PL) / 2] = *(const f32x4*)(tr + 2 * q);
+      }
+#pragma unroll
+      for (int p = P0; p < (PL < 32 ? PL : 32); p++) {
+        const f32x2 row = {rdlane(a[p][0], k), rdlane(a[p][1], k)};
+        a[p] = __builtin_elementwise_fma(-l2, row, a[p]);
+      }
+#pragma unroll
+      for (int q = PL; q < 32; q += 2) {
+        const f32x4 v = lrow[(q - PL) / 2];
+        a[q] = __builtin_elementwise_fma(-l2, f32x2{v[0], v[1]}, a[q]);
+        a[q + 1] = __builtin_elementwise_fma(-l2, f32x2{v[2], v[3]}, a[q + 1]);
+      }
+#else
 #pragma unroll
       for (int p = (k >> 1) + 1; p < 32; p++) {
         const f32x2 row = {rdlane(a[p][0], k), rdlane(a[p][1], k)};
         a[p] = __builtin_elementwise_fma(-l2, row, a[p]);   // v_pk_fma_f32 with the scalar pair as one source
       }
+#endif
       z = __builtin_fmaf(-lik, rdlane(z, k), z);
       a[k >> 1][k & 1] = lv > k ? lik : a[k >> 1][k & 1];
       d = lv == k ? dk : d;
-      __builtin_amdgcn_sched_barrier(0);   // keep the steps apart: interleaved, each column becomes one dependent chain
+      if (!(MFX_ALS_LDS_SPLIT & 16)) __builtin_amdgcn_sched_barrier(0);   // keep the steps apart: interleaved, each column becomes one dependent chain
     }
   }
   // L^T x = D^-1 y from the last row up: x_j is final in lane j; lanes k < j subtract (d_k l_jk) x_j before their division
