@@ -170,10 +170,13 @@ def test_wide_item_axis_and_both_window_layouts(nI, contig, monkeypatch):
     assert np.array_equal(grr[order], grc)
 
 
-def test_random_small_shapes_against_the_oracle():
-    """The trip lists, the masked whole-trip loads and the record batches on shapes that stress their edges: fewer ratings
-    than one trip, rows and columns without ratings, one-entry segments next to 1024-entry ones, a light region that is
-    empty or everything.  Twelve random shapes, three rank-one steps each, oracle tolerances as above."""
+def test_random_small_shapes_against_the_oracle(monkeypatch):
+    """The block plan, the padded views, the record batches and the fused first sweeps on shapes that stress their edges: fewer
+    ratings than one trip (most groups of the one workgroup have no trip at all), rows and columns without ratings, one-entry
+    pieces next to 1024-entry ones.  Twelve random shapes; three rank-one steps against the oracle at its tolerances, then three
+    more that add back -- from their second factor on the residual update rides on the first sweep -- against the oracle (errors of
+    1 ulp propagate through the later factors of a 70-rating matrix: relative 2e-6) and BIT FOR BIT against the same steps with the
+    update as a sweep of its own (MFX_CCD_FUSE=0)."""
     rng = np.random.default_rng(2024)
     shapes = [(3, 2, 4), (70, 9, 65), (200, 300, 700), (5000, 40, 30000), (40, 5000, 30000), (9000, 33, 9000)]
     shapes += [(int(rng.integers(50, 3000)), int(rng.integers(5, 900)), int(rng.integers(100, 40000))) for _ in range(6)]
@@ -182,19 +185,31 @@ def test_random_small_shapes_against_the_oracle():
         K = 4
         d, tr, (cp, ci, cv), U0, V0 = _setup(nU, nI, nnz, K, seed=nU + nI)
         nUs, nIs = d["nUsers"], d["nItems"]
+        shape = (nU, nI, tr.nnz)
         Uo, Vo = U0.copy(), V0.copy()
         Uo[:] = 0
         rr, rc = tr.rowval.copy(), cv.copy()
-        with Ctx(0) as ctx:
-            invU, invI = load_ctx(ctx, d, K, U0, V0)
-            ctx.ccdpp_begin()
-            for k in range(3):
-                ctx.ccdpp_rank1(k, 0.3, 0.2, add_back=False, inner=3)
-                orc.ccdpp_rank1(k, Uo, Vo, nUs, nIs, tr.ncols, tr.rowptr, tr.rowind, rr, cp, ci, rc, invU, invI, 0.3, 0.2, False, 3, -1.0,
-                                nthreads=2)
-            U, V = ctx.get_factors()
-            grr, grc = ctx.debug_residuals(tr.nnz)
-            ctx.ccdpp_end()
-        shape = (nU, nI, tr.nnz)
-        assert ulp_diff(U[:, :3], Uo[:, :3]).max() <= 2 and ulp_diff(V[:, :3], Vo[:, :3]).max() <= 2, shape
+        got = {}
+        for fuse in ("1", "0"):
+            monkeypatch.setenv("MFX_CCD_FUSE", fuse)
+            with Ctx(0) as ctx:
+                invU, invI = load_ctx(ctx, d, K, U0, V0)
+                ctx.ccdpp_begin()
+                for it in range(2):
+                    for k in range(3):
+                        ctx.ccdpp_rank1(k, 0.3, 0.2, add_back=it > 0, inner=3)
+                        if fuse == "1":
+                            orc.ccdpp_rank1(k, Uo, Vo, nUs, nIs, tr.ncols, tr.rowptr, tr.rowind, rr, cp, ci, rc, invU, invI, 0.3, 0.2, it > 0, 3,
+                                            -1.0, nthreads=2)
+                    if it == 0 and fuse == "1":
+                        U, V = ctx.get_factors()
+                        assert ulp_diff(U[:, :3], Uo[:, :3]).max() <= 2 and ulp_diff(V[:, :3], Vo[:, :3]).max() <= 2, shape
+                U, V = ctx.get_factors()
+                grr, grc = ctx.debug_residuals(tr.nnz)
+                ctx.ccdpp_end()
+            got[fuse] = (U, V, grr, grc)
+        U, V, grr, grc = got["1"]
+        assert np.allclose(U[:, :3], Uo[:, :3], rtol=2e-6, atol=1e-7) and np.allclose(V[:, :3], Vo[:, :3], rtol=2e-6, atol=1e-7), shape
         assert np.abs(grr - rr).max() < 1e-5 and np.abs(grc - rc).max() < 1e-5, shape
+        for x, y in zip(got["1"], got["0"]):
+            assert np.array_equal(x, y), shape
